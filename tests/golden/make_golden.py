@@ -1,0 +1,318 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/*.npz by IMPORTING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference; nothing else reads that path).
+The GPU box and the test-suite only ever see the .npz files written here.
+
+    python tests/golden/make_golden.py [--ref /root/reference]
+
+Import recipe: the reference's package __init__ files pull in packages that
+are absent here (tensorboard, wandb, mmcv, ...), so we register empty package shells with
+``__path__`` set, stub ``easydict``, ``torch_knnquery`` and ``torch._six`` and then import the
+hot-path modules directly.  No reference source is copied; only arrays are saved.
+"""
+import argparse
+import importlib
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def import_reference(ref_root: str):
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            for k, v in {**(d or {}), **kw}.items():
+                self[k] = v
+
+        def __setitem__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, EasyDict):
+                v = EasyDict(v)
+            super().__setitem__(k, v)
+
+        __setattr__ = __setitem__
+
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError as e:
+                raise AttributeError(k) from e
+
+    ed = types.ModuleType("easydict"); ed.EasyDict = EasyDict
+    sys.modules["easydict"] = ed
+    knn = types.ModuleType("torch_knnquery"); knn.VoxelGrid = type("VoxelGrid", (), {})
+    sys.modules["torch_knnquery"] = knn
+    six = types.ModuleType("torch._six"); six.string_classes = (str, bytes)
+    sys.modules["torch._six"] = six
+    for name, sub in (("npcd", "npcd"), ("npcd.utils", "npcd/utils"), ("npcd.models", "npcd/models")):
+        m = types.ModuleType(name); m.__path__ = [os.path.join(ref_root, sub)]
+        sys.modules[name] = m
+    util = importlib.import_module("npcd.utils.util")
+    for fn in ("normal_kl", "mean_flat", "discretized_gaussian_log_likelihood", "to_torch",
+               "get_torch_model_device", "split_num"):
+        setattr(sys.modules["npcd.utils"], fn, getattr(util, fn))
+    ref = types.SimpleNamespace()
+    ref.transformer = importlib.import_module("npcd.models.diffusion.denoisers.transformer")
+    ref.diffusion_model = importlib.import_module("npcd.models.diffusion.diffusion_model")
+    ref.gaussian = importlib.import_module("npcd.models.diffusion.diffusion_processes.gaussian_diffusion")
+    ref.fields = importlib.import_module("npcd.models.pointnerf.fields")
+    ref.renderers = importlib.import_module("npcd.models.pointnerf.renderers")
+    ref.util = util
+    ref.EasyDict = EasyDict
+    return ref
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez(path, **out)
+    print(f"  {name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+# --------------------------------------------------------------------------------------------
+def gen_attention(ref):
+    for tag, (B, n, H, d) in {"n513_h1_d64": (1, 513, 1, 64), "n130_h4_d64": (1, 130, 4, 64),
+                              "n17_h4_d32": (2, 17, 4, 32)}.items():
+        g = torch.Generator().manual_seed(100 + n)
+        qkv = torch.randn(B, n, 3 * H * d, generator=g, requires_grad=True)
+        gout = torch.randn(B, n, H * d, generator=g)
+        mod = ref.transformer.QKVMultiheadAttention(heads=H, use_flash_attn=False)
+        out = mod(qkv)
+        (out * gout).sum().backward()
+        save("attention_" + tag, qkv=qkv, gout=gout, out=out, dqkv=qkv.grad, heads=H)
+
+
+def gen_timestep(ref):
+    t = torch.tensor([0, 1, 500, 999], dtype=torch.int64)
+    save("timestep_embedding", t=t, dim128=ref.transformer.timestep_embedding(t, 128),
+         dim1024=ref.transformer.timestep_embedding(t, 1024), dim7=ref.transformer.timestep_embedding(t, 7))
+
+
+def gen_denoiser(ref):
+    for tag, (F, W, L, H, N, B) in {"f32_w64": (32, 64, 2, 1, 32, 2), "f128_w64": (128, 64, 1, 1, 16, 2)}.items():
+        torch.manual_seed(7 + F)
+        net = ref.transformer.NPCDTransformer(coords_dim=3, feats_dim=F, width=W, layers=L, heads=H,
+                                              use_flash_attn=False)
+        with torch.no_grad():                      # the reference zero-inits output_proj
+            net.output_proj.weight.normal_(0, 0.05)
+            net.output_proj.bias.normal_(0, 0.05)
+            for m in net.modules():                # non-trivial LN affine / biases
+                if isinstance(m, torch.nn.LayerNorm):
+                    m.weight.normal_(1, 0.1); m.bias.normal_(0, 0.1)
+                if isinstance(m, torch.nn.Linear):
+                    m.bias.normal_(0, 0.05)
+        g = torch.Generator().manual_seed(11)
+        coords = torch.randn(B, 3, N, generator=g)
+        feats = torch.randn(B, F, N, generator=g)
+        t = torch.tensor([3, 977][:B])
+        gc = torch.randn(B, 3, N, generator=g)
+        gf = torch.randn(B, F, N, generator=g)
+        ec, ef = net(coords, feats, t)
+        ((ec * gc).sum() + (ef * gf).sum()).backward()
+        arrays = {"coords": coords, "feats": feats, "t": t, "gc": gc, "gf": gf, "eps_coords": ec,
+                  "eps_feats": ef, "heads": H}
+        for k, v in net.state_dict().items():
+            arrays["w:" + k] = v
+        for k, v in net.named_parameters():
+            arrays["g:" + k] = v.grad
+        save("denoiser_" + tag, **arrays)
+
+
+def gen_diffusion(ref):
+    gd = ref.gaussian.GaussianDiffusion()
+    names = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_one_minus_betas", "sqrt_alphas_cumprod",
+             "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+             "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+             "posterior_mean_coef1", "posterior_mean_coef2"]
+    arrays = {"tab:" + n: getattr(gd, n) for n in names}
+    g = torch.Generator().manual_seed(5)
+    B, F, N = 3, 8, 16
+    c0, f0 = torch.randn(B, 3, N, generator=g), torch.randn(B, F, N, generator=g)
+    cn, fn = torch.randn(B, 3, N, generator=g), torch.randn(B, F, N, generator=g)
+    t = torch.tensor([0, 417, 999])
+    wc, wf = torch.randn(3, 3, generator=g) * 0.3, torch.randn(F, F, generator=g) * 0.3
+
+    def fake_denoiser(c, f, tt):            # any deterministic function of (x_t, t)
+        s = (tt.float() / 1000.0).reshape(-1, 1, 1)
+        return torch.einsum("ij,bjn->bin", wc, c) + s, torch.tanh(torch.einsum("ij,bjn->bin", wf, f)) - s
+
+    loss, sub, pw = gd.p_losses(fake_denoiser, c0, f0, t, coords_noise=cn, feats_noise=fn)
+    arrays.update(c0=c0, f0=f0, cn=cn, fn=fn, t=t, wc=wc, wf=wf, loss=loss, coords_loss=sub["00_coords_loss"],
+                  feats_loss=sub["01_feats_loss"], pw_coords=pw["pointwise_coords_loss"],
+                  pw_feats=pw["pointwise_feats_loss"], coords_t=gd.q_sample(c0, t, cn), feats_t=gd.q_sample(f0, t, fn))
+    # one reverse step (sampling path)
+    tt = torch.tensor([0, 417, 999])
+    torch.manual_seed(99)
+    eps_c, eps_f = fake_denoiser(c0, f0, tt)
+    clipc = (torch.tensor([-2.5]), torch.tensor([2.5]))
+    clipf = (torch.tensor([-1.0]), torch.tensor([1.0]))
+    torch.manual_seed(1234)
+    cn_next, crec, fn_next, frec = gd.p_sample(fake_denoiser, c0, f0, tt, coords_clip_range=clipc, feats_clipping_range=clipf)
+    torch.manual_seed(1234)
+    noise_c = torch.randn_like(c0); noise_f = torch.randn_like(f0)
+    arrays.update(ps_eps_c=eps_c, ps_eps_f=eps_f, ps_noise_c=noise_c, ps_noise_f=noise_f, ps_next_c=cn_next,
+                  ps_next_f=fn_next, ps_rec_c=crec, ps_rec_f=frec, ps_clipc=torch.cat(clipc), ps_clipf=torch.cat(clipf))
+    save("diffusion", **arrays)
+
+    # normalisers
+    g = torch.Generator().manual_seed(6)
+    data_c = torch.randn(3, 40, 16, generator=g) * torch.tensor([0.4, 0.2, 0.1]).reshape(3, 1, 1) + 0.05
+    data_f = torch.randn(F, 40, 16, generator=g) * 2.0 + 0.3
+    un = ref.diffusion_model.UnitGaussianNormalization(dim=3)
+    mm = ref.diffusion_model.MinusOneToOneNormalization(dim=F)
+    un.set_from_all_data(data_c); mm.set_from_all_data(data_f)
+    xc, xf = torch.randn(2, 3, 16, generator=g), torch.randn(2, F, 16, generator=g)
+    un.train(); mm.train()
+    ctrain, ftrain = un(xc), mm(xf)
+    un.eval(); mm.eval()
+    save("normalizers", data_c=data_c, data_f=data_f, xc=xc, xf=xf, c_train=ctrain, f_train=ftrain,
+         c_eval=un(xc), f_eval=mm(xf),
+         **{"un:" + k: v for k, v in un.state_dict().items()}, **{"mm:" + k: v for k, v in mm.state_dict().items()})
+
+
+# --------------------------------------------------------------------------------------------
+def build_field(ref, feats_dim, k=8, r=0.08, M=50, seed=0):
+    ED = ref.EasyDict
+    agg = ED(network="MLP", kwargs=ED(k=k, r=r, max_shading_pts=M, ray_subsamples=128, n_freqs=10, freq_mult=1,
+                                      out_dim=256, layers=[256, 256, 256, 256], activation="LeakyReLU",
+                                      layer_norm=False))
+    field = ref.fields.MLP(feats_dim, None, agg, feat_freqs=0, dir_freqs=8, channel_layers=[256, 256, 256, 256],
+                           shape_layers=[256], activation="LeakyReLU", layer_norm=False, use_dir=False, nerf=True)
+    # weights come from the oracle's deterministic initialiser (CPU torch.Generator), so the fixture
+    # only needs to carry a checksum instead of 2.4 MB of weights
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle.renderer import init_field_params
+    missing, unexpected = field.load_state_dict(init_field_params(feats_dim, seed=seed), strict=True)
+    return field.eval()
+
+
+def ellipsoid_cloud(n, F, seed):
+    g = torch.Generator().manual_seed(seed)
+    u = torch.randn(1, n, 3, generator=g)
+    u = u / u.norm(dim=-1, keepdim=True)
+    return u * torch.tensor([0.45, 0.20, 0.15]), torch.randn(1, n, F, generator=g)
+
+
+def gen_rays(ref, ref_root):
+    poses = torch.from_numpy(np.load(os.path.join(ref_root, "data/srncars_test_poses.npy")))[[0, 57, 200]]
+    intr = torch.from_numpy(np.load(os.path.join(ref_root, "data/srncars_test_intrinsics.npy")))[[0, 57, 200]].float()
+    skew = intr.clone(); skew[:, 0, 1] = 3.5; skew[:, 0, 0] = 120.0        # exercise the skew terms
+    rs = ref.renderers.ray_sampler.RaySampler()
+    arrays = {"extr": poses, "intr": intr, "intr_skew": skew}
+    for res in (8, 128):
+        o, d = rs(poses, intr, res)
+        arrays[f"o{res}"], arrays[f"d{res}"] = o[:, :: max(1, res * res // 512)], d[:, :: max(1, res * res // 512)]
+        arrays[f"stride{res}"] = max(1, res * res // 512)
+    o, d = rs(poses, skew, 8)
+    arrays["o8_skew"], arrays["d8_skew"] = o, d
+    # ray limits: normal view, a partial miss (camera close, wide fov) and an all-miss case
+    dummy = ref.renderers.VolumeRenderer(build_field(ref, 4), cube_scale=1.0, depth_resolution=16, white_back=True)
+    o8, d8 = rs(poses, intr, 8)
+    s, e = dummy.get_ray_limits(o8[None], d8[None])
+    arrays["lim_start"], arrays["lim_end"] = s, e
+    wide = intr.clone(); wide[:, 0, 0] = 20.0; wide[:, 1, 1] = 20.0
+    ow, dw = rs(poses, wide, 8)
+    s, e = dummy.get_ray_limits(ow[None], dw[None])
+    arrays.update(intr_wide=wide, limw_start=s, limw_end=e, ow=ow, dw=dw)
+    om = o8 + torch.tensor([0.0, 0.0, 50.0]); dm = d8.clone()
+    dm[..., :] = torch.nn.functional.normalize(torch.tensor([1.0, 0.2, 0.1]), dim=0)
+    s, e = dummy.get_ray_limits(om[None], dm[None])
+    arrays.update(om=om, dm=dm, limm_start=s, limm_end=e)
+    # depth samples (eval mode)
+    s8, e8 = arrays["lim_start"], arrays["lim_end"]
+    dep = dummy.sample(s8.flatten(0, 1), e8.flatten(0, 1))
+    arrays["depths16"] = dep
+    save("rays", **arrays)
+
+
+def gen_render(ref, ref_root):
+    poses = torch.from_numpy(np.load(os.path.join(ref_root, "data/srncars_test_poses.npy")))
+    intr = torch.from_numpy(np.load(os.path.join(ref_root, "data/srncars_test_intrinsics.npy"))).float()
+    F_, N, res, S, M, k, r = 32, 64, 16, 32, 12, 8, 0.08
+    field = build_field(ref, F_, k=k, r=r, M=M, seed=3)
+    coords, feats = ellipsoid_cloud(N, F_, seed=1)
+    K = intr[:1].clone(); K[:, 0, 0] = K[:, 1, 1] = 131.25 * res / 128; K[:, 0, 2] = K[:, 1, 2] = res / 2
+    ren = ref.renderers.VolumeRenderer(field, cube_scale=1.0, depth_resolution=S, white_back=True).eval()
+    extr = poses[[0, 100]][None]                          # [1,2,4,4]
+    Kb = K[None].expand(1, 2, 3, 3).contiguous()
+    with torch.no_grad():
+        # G8: brute-force query on the sample positions of this view
+        rs = ren.ray_sampler
+        o, d = rs(extr.flatten(0, 1), Kb.flatten(0, 1), res)
+        o, d = o.view(1, 2, -1, 3), d.view(1, 2, -1, 3)
+        start, end = ren.get_ray_limits(o, d)
+        dep = ren.sample(start.flatten(0, 1), end.flatten(0, 1)).view(1, 2, res * res, S, 1)
+        x = o.unsqueeze(-2) + dep * d.unsqueeze(-2)
+        nb, sp, mask = field.aggregator.query_keypoints(x, coords)
+        # exact fp64 distances so the test can discount radius-boundary / tie ambiguities
+        d64 = torch.cdist(x.reshape(1, -1, 3).double(), coords.double(), compute_mode="donot_use_mm_for_euclid_dist")
+        # G9: shading for the reference's own neighbour lists
+        agg = field.aggregator.get_local_feat(x, coords, feats, sample=False)
+        feat = field.aggregator.aggregate_local_feat(agg["local_feat"], agg["weights"], agg["shading_idx"], agg["num_valid_pts"])
+        sigma = field.shape_act(field.get_shape(feat))
+        rgb = torch.sigmoid(field.get_channels(feat, None))
+        # G11: end to end
+        out = ren(coords, feats, extr, Kb, res, sample=False)
+    arrays = {"coords": coords, "feats": feats, "extr": extr, "intr": Kb, "res": res, "S": S, "M": M, "k": k, "r": r,
+              "x": x, "nb_idx": nb, "shading_pts": sp, "mask": mask, "dist64_min": d64.min(dim=-1).values,
+              "agg_feat": feat, "sigma": sigma, "rgb": rgb, "out_mask": out["mask"], "out_depth": out["depth"],
+              "out_channels": out["channels"]}
+    # per-sample sorted fp64 distances to the 10 nearest points (tie / boundary diagnostics)
+    arrays["dist64_top"] = torch.sort(d64, dim=-1).values[..., :10].float()
+    arrays["field_seed"] = 3
+    arrays["field_checksum"] = np.array([float(sum(v.double().abs().sum() for v in field.state_dict().values())),
+                                         float(field.state_dict()["shape_net.0.weight"][17, 5])])
+    save("render_brute", **arrays)
+
+    # G10: depth-from-points + ray-march on hand-made dense inputs
+    g = torch.Generator().manual_seed(21)
+    Nr, Mm = 24, 10
+    o = torch.randn(1, 1, Nr, 3, generator=g) * 0.1 + torch.tensor([0.0, 0.0, -1.3])
+    dd = torch.nn.functional.normalize(torch.randn(1, 1, Nr, 3, generator=g) * 0.2 + torch.tensor([0.0, 0.0, 1.0]), dim=-1)
+    tt = torch.sort(torch.rand(1, 1, Nr, Mm, 1, generator=g) * 2.0 + 0.3, dim=-2).values
+    m = torch.rand(1, 1, Nr, Mm, 1, generator=g) > 0.35
+    m[0, 0, 0] = False                                    # an all-invalid ray
+    m[0, 0, 1] = True                                     # an all-valid ray
+    m[0, 0, 2, :3] = False                                # leading invalid slots
+    pts = (o.unsqueeze(-2) + tt * dd.unsqueeze(-2)) * m
+    ray_end = torch.full((1, 1, Nr, 1), 2.6)
+    sig = torch.rand(1, 1, Nr, Mm, 1, generator=g) * 30.0 * m
+    sig[0, 0, 3] = 0.0                                    # valid slots but zero density -> NaN depth path
+    dep = ren.get_depths_from_shading_pts(pts, m, None, o.unsqueeze(-2), dd.unsqueeze(-2), ray_end)
+    rgbc = torch.rand(int(m.sum()), 3, generator=g)
+    res_ = ren.ray_march(sig, dep, rgbc, None, m)
+    save("raymarch", o=o, d=dd, pts=pts, mask=m, ray_end=ray_end, sigma=sig, rgb_compact=rgbc, depths=dep,
+         out_mask=res_["mask"], out_depth=res_["depth"], out_channels=res_["channels"])
+
+    # G12: unflatten_pred
+    ch = torch.rand(2, 3, 16, 3, generator=g)
+    save("unflatten", channels=ch, image=ref.util.unflatten_pred(ch))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    args = ap.parse_args()
+    torch.set_num_threads(4)
+    ref = import_reference(args.ref)
+    print("writing fixtures to", HERE)
+    gen_attention(ref)
+    gen_timestep(ref)
+    gen_denoiser(ref)
+    gen_diffusion(ref)
+    gen_rays(ref, args.ref)
+    gen_render(ref, args.ref)
+
+
+if __name__ == "__main__":
+    main()
