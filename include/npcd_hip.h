@@ -1,0 +1,147 @@
+/*
+ * npcd_hip.h -- C ABI of libnpcd_hip.so, the MI355X (gfx950) implementation of the NPCD hot path.
+ *
+ * These entry points are what the reference's two native plug points bind to
+ * (paths relative to lmb-freiburg/neural-point-cloud-diffusion @ 2024_10_08):
+ *
+ *   flash_attn.flash_attn_func       called at npcd/models/diffusion/denoisers/transformer.py:75
+ *                                    (import :9-12)                     -> npcd_attn_fwd / npcd_attn_bwd
+ *   torch_knnquery.VoxelGrid         ctor  npcd/models/pointnerf/pointnerf.py:20,147-153
+ *     .set_pointset                  pointnerf.py:67-75,116-124        -> npcd_grid_build
+ *     .query                         fields/aggregators/aggregator.py:63 -> npcd_grid_query
+ *
+ * plus the fused replacements of the PyTorch op chains around them on the render path
+ * (ray generation, neighbour gather + positional encoding + MLP shading, ray marching) and the
+ * elementwise chains of the denoiser training step (LayerNorm, bias+GELU, q_sample/MSE, AdamW+EMA).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all buffers
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and never synchronise
+ *   - return value: 0 on success, a negative NPCD_ERR_* otherwise (no exceptions cross the ABI)
+ *   - strides are in ELEMENTS, the innermost (head_dim / channel) dimension is contiguous
+ *   - dtype codes: NPCD_BF16 = 0, NPCD_F16 = 1, NPCD_F32 = 2
+ */
+#ifndef NPCD_HIP_H
+#define NPCD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPCD_OK 0
+#define NPCD_ERR_ARG (-1)          /* bad argument (null pointer, misaligned, negative size) */
+#define NPCD_ERR_UNSUPPORTED (-2)  /* shape / dtype not implemented by the kernels           */
+#define NPCD_ERR_HIP (-3)          /* a HIP runtime call failed (see npcd_last_hip_error)     */
+
+#define NPCD_BF16 0
+#define NPCD_F16 1
+#define NPCD_F32 2
+
+int npcd_abi_version(void);
+const char* npcd_error_string(int code);
+const char* npcd_last_hip_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Attention over points: out = softmax(q k^T * scale) v, non-causal, no mask, no dropout.
+ * Replaces flash_attn_func(q, k, v, causal=False, dropout_p=0) (transformer.py:75) and its
+ * autograd backward.  q/k/v are [B, n, H, d] views (typically of one interleaved [B,n,H,3d]
+ * buffer, transformer.py:71-72) sharing the stride triple (sb, sn, sh); d must be 64.
+ * lse [B, H, n] fp32 receives log(sum_j exp(scale * <q_i, k_j>)).
+ * ------------------------------------------------------------------------------------------ */
+int npcd_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
+                  int B, int n, int H, int d,
+                  int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh,
+                  int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                  float scale, int dtype, void* stream);
+
+/* Backward of the above.  dq/dk/dv share (g_sb, g_sn, g_sh); out/dout share the out strides.
+ * delta [B, H, n] fp32 is scratch (rowsum(dout * out)), written by the call. */
+int npcd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                  const float* lse, void* dq, void* dk, void* dv, float* delta,
+                  int B, int n, int H, int d,
+                  int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh,
+                  int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                  int64_t g_sb, int64_t g_sn, int64_t g_sh,
+                  float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Voxel grid (torch_knnquery.VoxelGrid).  The grid description is passed by value.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct npcd_grid_params {
+    float voxel_size[3];     /* fine voxel edge lengths            (pointnerf.py:148) */
+    int32_t voxel_scale[3];  /* coarse cell = fine // voxel_scale  (:149)             */
+    int32_t kernel_size[3];  /* odd; dilation + candidate window   (:150)             */
+    int32_t max_points_per_voxel;        /* (:151) */
+    int32_t max_occ_voxels_per_example;  /* (:152) */
+    float range_min[3];      /* (:153) */
+    float range_max[3];
+    int32_t dims[3];         /* fine grid dimensions, computed by the host */
+    int32_t cdims[3];        /* coarse grid dimensions                      */
+} npcd_grid_params;
+
+/* bytes of device workspace npcd_grid_build needs for (B, N): per point {ix,iy,iz,kept} + the
+ * coarse occupancy bitmaps */
+int64_t npcd_grid_workspace_bytes(const npcd_grid_params* g, int B, int N);
+
+/* set_pointset: points [B,N,3] fp32, counts [B] int32 (points >= counts[b] are ignored). */
+int npcd_grid_build(const npcd_grid_params* g, const float* points, const int32_t* counts,
+                    int B, int N, void* workspace, void* stream);
+
+/* query, dense form: x is given implicitly as ray samples x = o + depth_s * d with
+ * depth_s = t0 + (s/(S-1)) * (t1 - t0) (renderer.py:49-77, volume_renderer.py:63-70), or
+ * explicitly through `x` [B,R,S,3] when x != NULL (then rays_o/rays_d/t0/t1 may be NULL).
+ *   mode 0 = voxel-grid semantics (DESIGN.md "VoxelGrid spec"), radius = r * max(voxel_size)
+ *   mode 1 = the reference's voxel_grid=None branch (aggregator.py:42-58), radius = r
+ * Outputs (dense, per ray): sample_idx [B,R,M,k] int32 (global index b*N+i sorted by
+ * (dist^2, i), -1 pad), sample_loc [B,R,M,3] fp32, slot_sample [B,R,M] int32 (depth-sample
+ * index of each slot, -1 = empty), nsel [B,R] int32 (selected slots per ray).            */
+int npcd_grid_query(const npcd_grid_params* g, const void* workspace, const float* points,
+                    int B, int N, int R, int S, int M, int k, float r, int mode,
+                    const float* x, const float* rays_o, const float* rays_d,
+                    const float* t0, const float* t1,
+                    int32_t* sample_idx, float* sample_loc, int32_t* slot_sample, int32_t* nsel,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Ray generation + box limits (ray_sampler.py:10-49, math_utils.py:46-97, renderer.py:36-47).
+ * extr [V,4,4] world2cam fp32, intr [V,3,3] fp32 -> rays_o/rays_d [V,res*res,3], t0/t1 [V,res*res].
+ * limits_ws: 4 floats of device scratch (global min start / max end, hit flag).
+ * ------------------------------------------------------------------------------------------ */
+int npcd_ray_gen(const float* extr, const float* intr, int V, int res, float box,
+                 float* rays_o, float* rays_d, float* t0, float* t1, float* limits_ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused shading of compact shading points (aggregators/mlp.py:36-125, fields/mlp.py:38-72,
+ * field.py:113-141): gather -> rel. position -> positional encoding -> 5-layer MLP ->
+ * inverse-distance aggregation -> density head (softplus(x-1)) and colour head (sigmoid).
+ * Weights are packed once by npcd_shade_pack_weights into `wpack`.
+ *   nb_idx [P,k] int32 (-1 pad), pts [P,3] fp32, kp_pos [B*N,3] fp32, kp_feat [B*N,F] fp32
+ *   -> sigma [P] fp32, rgb [P,3] fp32.  n_points_dev: device int32 holding P (so that P may be
+ *   produced on the device without a host round trip); max_points bounds the launch.
+ * ------------------------------------------------------------------------------------------ */
+int64_t npcd_shade_wpack_bytes(int feat_dim, int n_freqs, int hidden);
+int64_t npcd_shade_workspace_bytes(int max_points, int hidden);
+int npcd_shade_pack_weights(const float* const* weights_host, const float* const* biases_host,
+                            int feat_dim, int n_freqs, int hidden, void* wpack_host);
+int npcd_shade_points(const void* wpack, int feat_dim, int n_freqs, int hidden,
+                      const int32_t* nb_idx, const float* pts, const float* kp_pos, const float* kp_feat,
+                      const int32_t* n_points_dev, int max_points, int k,
+                      float* sigma, float* rgb, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Ray marching (renderer.py:96-110,120-185, volume_renderer.py:23-39) on the dense slot layout:
+ * sigma/rgb are COMPACT per valid slot (row-major over [ray, slot]); slot_valid [Nr,M] uint8,
+ * slot_loc [Nr,M,3], point_base [Nr] int32 = index of the ray's first compact point.
+ * -> mask [Nr], depth [Nr], channels [Nr,3].  depth_ws: 2 floats scratch (global min/max).
+ * ------------------------------------------------------------------------------------------ */
+int npcd_ray_march(const float* sigma, const float* rgb, const uint8_t* slot_valid, const float* slot_loc,
+                   const int32_t* point_base, const float* rays_o, const float* rays_d, const float* t1,
+                   int Nr, int M, int white_back, float* mask, float* depth, float* channels,
+                   float* depth_ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NPCD_HIP_H */

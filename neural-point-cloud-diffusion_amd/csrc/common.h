@@ -1,0 +1,76 @@
+// Shared device/host helpers for libnpcd_hip (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/npcd_hip.h"
+
+namespace npcd {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+constexpr int kWave = 64;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// ---- element traits: the 16-bit MFMA input types -------------------------------------------
+struct BF16 {
+    using elem = __bf16;
+    using vec8 = bf16x8;
+    using vec4 = bf16x4;
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+struct F16 {
+    using elem = _Float16;
+    using vec8 = f16x8;
+    using vec4 = f16x4;
+    static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+
+// Row r of a 32x32 MFMA accumulator register i on lane-half hh:  (i&3) + 8*(i>>2) + 4*hh
+__device__ __forceinline__ int acc_row(int i, int hh) { return (i & 3) + 8 * (i >> 2) + 4 * hh; }
+
+// Blocks b and b+8 share an XCD (round-robin dispatch, MI355X_MICROARCH.md).  Give each XCD one
+// contiguous chunk of the logical grid so that neighbouring work items share an L2.  Bijective
+// for any grid size.  Speed only: results never depend on the placement.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, rem = nblocks & 7, xcd = bid & 7, j = bid >> 3;
+    const int base = (xcd < rem) ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    return base + j;
+}
+
+// lanes l and l^32 exchange a value
+__device__ __forceinline__ float swap_half(float x) { return __shfl_xor(x, 32, 64); }
+
+// 64-wide tiles of 16-bit elements live in LDS as 128-byte rows; the 16-byte chunk index is
+// XOR-swizzled with (row>>1)&7 so that the 32 lanes (rows r..r+31, same logical chunk) of a
+// ds_read_b128 fragment read hit 16 distinct 16-byte slots per 16-lane group (conflict-free).
+__device__ __forceinline__ int tile_off(int row, int chunk) {
+    return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4);
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// host-side error latch
+void set_hip_error(hipError_t e);
+#define NPCD_HIP_CHECK(expr)                          \
+    do {                                              \
+        hipError_t _e = (expr);                       \
+        if (_e != hipSuccess) {                       \
+            ::npcd::set_hip_error(_e);                \
+            return NPCD_ERR_HIP;                      \
+        }                                             \
+    } while (0)
+
+}  // namespace npcd

@@ -1,0 +1,100 @@
+"""ctypes binding of libnpcd_hip.so (C ABI: include/npcd_hip.h).
+
+The library is built in-tree by ``csrc/build.py`` (``__graft_entry__.build()``).  Nothing in here
+falls back to PyTorch/CPU: if the shared object cannot be loaded, or an operator is handed a
+non-GPU tensor, a RuntimeError is raised.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libnpcd_hip.so")
+
+NPCD_BF16, NPCD_F16, NPCD_F32 = 0, 1, 2
+_DTYPE_CODE = {torch.bfloat16: NPCD_BF16, torch.float16: NPCD_F16, torch.float32: NPCD_F32}
+
+
+class GridParams(ctypes.Structure):
+    """struct npcd_grid_params (include/npcd_hip.h)."""
+    _fields_ = [("voxel_size", c_float * 3), ("voxel_scale", c_int32 * 3), ("kernel_size", c_int32 * 3),
+                ("max_points_per_voxel", c_int32), ("max_occ_voxels_per_example", c_int32),
+                ("range_min", c_float * 3), ("range_max", c_float * 3), ("dims", c_int32 * 3), ("cdims", c_int32 * 3)]
+
+
+_P = c_void_p
+# name -> (restype, argtypes); must list every symbol include/npcd_hip.h declares
+SIGNATURES = {
+    "npcd_abi_version": (c_int, []),
+    "npcd_error_string": (c_char_p, [c_int]),
+    "npcd_last_hip_error": (c_char_p, []),
+    "npcd_attn_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int] + [c_int64] * 6 + [c_float, c_int, _P]),
+    "npcd_attn_bwd": (c_int, [_P] * 10 + [c_int] * 4 + [c_int64] * 9 + [c_float, c_int, _P]),
+    "npcd_grid_workspace_bytes": (c_int64, [POINTER(GridParams), c_int, c_int]),
+    "npcd_grid_build": (c_int, [POINTER(GridParams), _P, _P, c_int, c_int, _P, _P]),
+    "npcd_grid_query": (c_int, [POINTER(GridParams), _P, _P] + [c_int] * 6 + [c_float, c_int] + [_P] * 9 + [_P]),
+    "npcd_ray_gen": (c_int, [_P, _P, c_int, c_int, c_float] + [_P] * 5 + [_P]),
+    "npcd_shade_wpack_bytes": (c_int64, [c_int, c_int, c_int]),
+    "npcd_shade_workspace_bytes": (c_int64, [c_int, c_int]),
+    "npcd_shade_pack_weights": (c_int, [POINTER(_P), POINTER(_P), c_int, c_int, c_int, _P]),
+    "npcd_shade_points": (c_int, [_P, c_int, c_int, c_int] + [_P] * 5 + [c_int, c_int] + [_P] * 3 + [_P]),
+    "npcd_ray_march": (c_int, [_P] * 8 + [c_int, c_int, c_int] + [_P] * 4 + [_P]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the native library; raise loudly if it is not there."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"libnpcd_hip.so not found at {LIB_PATH}: build it with "
+                f"`python neural-point-cloud-diffusion_amd/csrc/build.py` (or __graft_entry__.build()). "
+                f"There is no CPU / PyTorch fallback for the NPCD hot path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        missing = []
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                missing.append(name)
+                continue
+            fn.restype, fn.argtypes = res, args
+        handle.npcd_missing = tuple(missing)      # calling a missing symbol raises AttributeError
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        L = lib()
+        msg = L.npcd_error_string(rc).decode()
+        if rc == -3:
+            msg += ": " + L.npcd_last_hip_error().decode()
+        raise RuntimeError(f"{what} failed: {msg} (code {rc})")
+
+
+def require_gpu(*tensors: torch.Tensor):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("npcd.hip operators need GPU tensors (MI355X); got a tensor on "
+                               f"{t.device}. There is no CPU fallback in the product path.")
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DTYPE_CODE[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"unsupported dtype {t.dtype}") from None
+
+
+def ptr(t):
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

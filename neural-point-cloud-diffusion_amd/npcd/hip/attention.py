@@ -1,0 +1,109 @@
+"""Attention over points on the HIP kernels (csrc/attention.hip).
+
+`attention_qkvpacked` is what `QKVMultiheadAttention` calls: it consumes the per-head interleaved
+c_qkv output in place (transformer.py:71-72) and its backward writes one packed gradient buffer.
+`flash_attn_func` keeps the third-party signature the reference imports (transformer.py:9-12,75).
+"""
+import math
+
+import torch
+
+from . import check, dtype_code, lib, ptr, require_gpu, stream_ptr
+
+
+def _fwd(q, k, v, scale):
+    B, n, H, d = q.shape
+    out = torch.empty((B, n, H, d), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H, n), dtype=torch.float32, device=q.device)
+    assert q.stride() == k.stride() == v.stride() and q.stride(3) == 1
+    check(lib().npcd_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), B, n, H, d,
+                              q.stride(0), q.stride(1), q.stride(2), out.stride(0), out.stride(1), out.stride(2),
+                              scale, dtype_code(q), stream_ptr()), "npcd_attn_fwd")
+    return out, lse
+
+
+def _bwd(q, k, v, out, dout, lse, dq, dk, dv, scale):
+    B, n, H, d = q.shape
+    delta = torch.empty((B, H, n), dtype=torch.float32, device=q.device)
+    assert dq.stride() == dk.stride() == dv.stride() and dout.stride() == out.stride()
+    check(lib().npcd_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(dq), ptr(dk), ptr(dv),
+                              ptr(delta), B, n, H, d, q.stride(0), q.stride(1), q.stride(2),
+                              out.stride(0), out.stride(1), out.stride(2), dq.stride(0), dq.stride(1), dq.stride(2),
+                              scale, dtype_code(q), stream_ptr()), "npcd_attn_bwd")
+
+
+def _check_input(x):
+    require_gpu(x)
+    if x.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError(f"HIP attention computes in bf16/f16 (MFMA); got {x.dtype}. Run the denoiser under "
+                           "autocast(bfloat16) as train_diffusion.py does for --dtype bfloat16.")
+
+
+class _AttnPacked(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        B, n, w3 = qkv.shape
+        d = w3 // heads // 3
+        qkv = qkv.contiguous()
+        x = qkv.view(B, n, heads, 3 * d)
+        q, k, v = x[..., :d], x[..., d:2 * d], x[..., 2 * d:]
+        scale = 1.0 / math.sqrt(d)
+        out, lse = _fwd(q, k, v, scale)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.heads, ctx.scale = heads, scale
+        return out.view(B, n, heads * d)
+
+    @staticmethod
+    def backward(ctx, gout):
+        qkv, out, lse = ctx.saved_tensors
+        B, n, w3 = qkv.shape
+        H = ctx.heads
+        d = w3 // H // 3
+        x = qkv.view(B, n, H, 3 * d)
+        q, k, v = x[..., :d], x[..., d:2 * d], x[..., 2 * d:]
+        dqkv = torch.empty_like(qkv)
+        g = dqkv.view(B, n, H, 3 * d)
+        gout = gout.contiguous().view(B, n, H, d)
+        _bwd(q, k, v, out, gout, lse, g[..., :d], g[..., d:2 * d], g[..., 2 * d:], ctx.scale)
+        return dqkv, None
+
+
+def attention_qkvpacked(qkv: torch.Tensor, heads: int) -> torch.Tensor:
+    """qkv [B, n, 3W] with head h at columns [3d*h, 3d*(h+1)) = q|k|v  ->  [B, n, W]."""
+    _check_input(qkv)
+    return _AttnPacked.apply(qkv, heads)
+
+
+class _AttnQKV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        if not (q.stride() == k.stride() == v.stride() and q.stride(3) == 1
+                and all(s % 8 == 0 for s in q.stride()[:3]) and q.data_ptr() % 16 == 0
+                and k.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0):
+            q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out, lse = _fwd(q, k, v, scale)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        q, k, v, out, lse = ctx.saved_tensors
+        B, n, H, d = q.shape
+        g = torch.empty((B, n, H, 3 * d), dtype=q.dtype, device=q.device)
+        dq, dk, dv = g[..., :d], g[..., d:2 * d], g[..., 2 * d:]
+        _bwd(q, k, v, out, gout.contiguous(), lse, dq, dk, dv, ctx.scale)
+        return dq, dk, dv, None
+
+
+def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, **unused):
+    """Drop-in for flash_attn.flash_attn_func as the reference calls it (transformer.py:75):
+    q, k, v [B, n, H, d] (any strides with a contiguous last dim), non-causal, no dropout."""
+    if causal:
+        raise NotImplementedError("the NPCD denoiser attends non-causally; causal=True is not implemented")
+    if dropout_p:
+        raise NotImplementedError("dropout is 0 everywhere in the reference (transformer.py:56,93,123,146,182)")
+    for t in (q, k, v):
+        _check_input(t)
+    scale = 1.0 / math.sqrt(q.shape[-1]) if softmax_scale is None else float(softmax_scale)
+    return _AttnQKV.apply(q, k, v, scale)
