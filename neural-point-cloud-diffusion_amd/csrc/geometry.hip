@@ -1,0 +1,580 @@
+// Geometry kernels of the PointNeRF render path (gfx950): ray generation + box limits, voxel-grid
+// build, neighbour query, ray marching.  HBM-bound / latency-bound integer + fp32 work: no MFMA.
+//
+// This file is compiled with -ffp-contract=off: the integer outputs of the neighbour query must be
+// bit-exact against oracle/voxel_grid.py, which evaluates every fp32 step as a separately rounded
+// operation in a fixed order.
+//
+// Reference call sites replaced:
+//   ray generation      npcd/models/pointnerf/renderers/ray_sampler.py:10-49
+//   box limits          renderers/math_utils.py:46-97, renderers/renderer.py:36-47
+//   depth samples       renderers/renderer.py:49-77, math_utils.py:100-117
+//   VoxelGrid           torch_knnquery (pointnerf.py:20,67-75; aggregator.py:42-73)
+//   depth / ray march   renderers/renderer.py:96-110,120-185, volume_renderer.py:23-39
+#include <math.h>
+
+#include "common.h"
+
+namespace npcd {
+
+// monotone float <-> uint32 key (for atomicMin/atomicMax on floats of either sign)
+__device__ __forceinline__ uint32_t fkey(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// ============================================================================================
+// rays
+// ============================================================================================
+__global__ void limits_init_kernel(uint32_t* ws) {
+    ws[0] = 0xffffffffu;  // min start key
+    ws[1] = 0u;           // max end key
+    ws[2] = 0u;           // any ray hit the box
+    ws[3] = 0u;
+}
+
+__global__ __launch_bounds__(256) void ray_gen_kernel(const float* __restrict__ extr, const float* __restrict__ intr, int V, int res,
+                                                      float box, float* __restrict__ rays_o, float* __restrict__ rays_d,
+                                                      float* __restrict__ t0, float* __restrict__ t1, uint32_t* ws) {
+    const int R = res * res;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool hit = false;
+    float tmin = -1.f, tmax = -2.f;
+    if (gid < (int64_t)V * R) {
+        const int v = (int)(gid / R), ray = (int)(gid % R);
+        const float* E = extr + v * 16;
+        const float* K = intr + v * 9;
+        const float fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
+        const float x = (float)(ray % res) + 0.5f, y = (float)(ray / res) + 0.5f;
+        // ray_sampler.py:27-28
+        const float xl = (x - cx + cy * sk / fy - sk * y / fy) / fx;
+        const float yl = (y - cy) / fy;
+        // cam2world = [R^T | -R^T t]  (ray_sampler.py:35-39); world = cam2world * (xl, yl, 1, 1)
+        float o[3], w[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float r0 = E[0 * 4 + a], r1 = E[1 * 4 + a], r2 = E[2 * 4 + a];  // row a of R^T
+            o[a] = -(r0 * E[3] + r1 * E[7] + r2 * E[11]);
+            w[a] = r0 * xl + r1 * yl + r2 * 1.f + o[a] * 1.f;
+        }
+        float d[3] = {w[0] - o[0], w[1] - o[1], w[2] - o[2]};
+        const float nrm = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);  // F.normalize eps
+#pragma unroll
+        for (int a = 0; a < 3; ++a) d[a] = d[a] / nrm;
+        // slab test (math_utils.py:46-97)
+        float lo[3], hi[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float inv = 1.f / d[a];
+            const bool neg = inv < 0.f;
+            lo[a] = ((neg ? box : -box) - o[a]) * inv;
+            hi[a] = ((neg ? -box : box) - o[a]) * inv;
+        }
+        bool ok = true;
+        float a0 = lo[0], a1 = hi[0];
+        if (a0 > hi[1] || lo[1] > a1) ok = false;
+        a0 = fmaxf(a0, lo[1]);   // torch.max/min propagate NaN; NaN only arises for degenerate rays
+        a1 = fminf(a1, hi[1]);
+        if (a0 > hi[2] || lo[2] > a1) ok = false;
+        a0 = fmaxf(a0, lo[2]);
+        a1 = fminf(a1, hi[2]);
+        if (ok) { tmin = a0; tmax = a1; }
+        hit = tmax > tmin;
+        rays_o[gid * 3 + 0] = o[0]; rays_o[gid * 3 + 1] = o[1]; rays_o[gid * 3 + 2] = o[2];
+        rays_d[gid * 3 + 0] = d[0]; rays_d[gid * 3 + 1] = d[1]; rays_d[gid * 3 + 2] = d[2];
+        t0[gid] = tmin;
+        t1[gid] = tmax;
+    }
+    // global min(start) / max(end) over the rays that hit (renderer.py:40-43): wave reduce, one atomic per wave
+    uint32_t kmin = hit ? fkey(tmin) : 0xffffffffu, kmax = hit ? fkey(tmax) : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && kmax != 0u) {
+        atomicMin(&ws[0], kmin);
+        atomicMax(&ws[1], kmax);
+        atomicOr(&ws[2], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void ray_limits_fix_kernel(int64_t n, float* __restrict__ t0, float* __restrict__ t1, const uint32_t* ws) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n || ws[2] == 0u) return;
+    if (!(t1[gid] > t0[gid])) {
+        t0[gid] = fkey_inv(ws[0]);
+        t1[gid] = fkey_inv(ws[1]);
+    }
+}
+
+// ============================================================================================
+// voxel grid
+// ============================================================================================
+// packed point record: ix | iy<<10 | iz<<20 | kept<<30
+__device__ __forceinline__ int pack_coord(int ix, int iy, int iz, bool kept) { return ix | (iy << 10) | (iz << 20) | ((int)kept << 30); }
+
+struct FineCoord {
+    int c[3];
+    bool ok;
+};
+__device__ __forceinline__ FineCoord fine_coord(const npcd_grid_params& g, float x, float y, float z) {
+    FineCoord f;
+    const float p[3] = {x, y, z};
+    f.ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float q = floorf((p[a] - g.range_min[a]) / g.voxel_size[a]);
+        const bool in = (q >= 0.f) && (q < (float)g.dims[a]);  // NaN -> false
+        f.ok = f.ok && in;
+        f.c[a] = in ? (int)q : 0;
+    }
+    return f;
+}
+
+static inline int occ_words(const npcd_grid_params& g) { return (g.cdims[0] * g.cdims[1] * g.cdims[2] + 31) / 32; }
+
+// one workgroup per example.  LDS: lin[N] int32, flag[N] uint8-as-int, bitmap[occ_words]
+__global__ __launch_bounds__(256) void grid_build_kernel(npcd_grid_params g, const float* __restrict__ points, const int32_t* __restrict__ counts,
+                                                         int N, int nwords, int32_t* __restrict__ pcoord, uint32_t* __restrict__ occ) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+    int* lin = reinterpret_cast<int*>(dsmem);
+    int* first = lin + N;
+    uint32_t* bitmap = reinterpret_cast<uint32_t*>(first + N);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(counts ? counts[b] : N, N);
+    const float* P = points + (int64_t)b * N * 3;
+    for (int w = tid; w < nwords; w += blockDim.x) bitmap[w] = 0u;
+    for (int i = tid; i < N; i += blockDim.x) {
+        int l = -1;
+        if (i < n) {
+            const FineCoord f = fine_coord(g, P[i * 3 + 0], P[i * 3 + 1], P[i * 3 + 2]);
+            if (f.ok) l = (f.c[0] * g.dims[1] + f.c[1]) * g.dims[2] + f.c[2];
+        }
+        lin[i] = l;
+    }
+    __syncthreads();
+    // rank among the points of the same fine voxel, in ascending point index
+    for (int i = tid; i < N; i += blockDim.x) {
+        const int l = lin[i];
+        int rank = 0;
+        if (l >= 0)
+            for (int j = 0; j < i; ++j) rank += (lin[j] == l);
+        first[i] = (l >= 0) ? rank : -1;
+    }
+    __syncthreads();
+    const bool need_cap = n > g.max_occ_voxels_per_example;  // otherwise #occupied voxels <= n <= cap
+    for (int i = tid; i < N; i += blockDim.x) {
+        const int l = lin[i], rank = first[i];
+        bool kept = (l >= 0) && (rank < g.max_points_per_voxel);
+        if (kept && need_cap) {
+            int vrank = 0;  // number of distinct occupied voxels with a smaller linear id
+            for (int j = 0; j < N; ++j) vrank += (first[j] == 0 && lin[j] < l);
+            kept = vrank < g.max_occ_voxels_per_example;
+        }
+        int cz = 0, cy = 0, cx = 0;
+        if (l >= 0) {
+            cz = l % g.dims[2];
+            cy = (l / g.dims[2]) % g.dims[1];
+            cx = l / (g.dims[2] * g.dims[1]);
+        }
+        pcoord[(int64_t)b * N + i] = pack_coord(cx, cy, cz, kept);
+        if (kept) {
+            const int ccx = cx / g.voxel_scale[0], ccy = cy / g.voxel_scale[1], ccz = cz / g.voxel_scale[2];
+            const int hx = (g.kernel_size[0] - 1) / 2, hy = (g.kernel_size[1] - 1) / 2, hz = (g.kernel_size[2] - 1) / 2;
+            for (int dx = -hx; dx <= hx; ++dx)
+                for (int dy = -hy; dy <= hy; ++dy)
+                    for (int dz = -hz; dz <= hz; ++dz) {
+                        const int ox = ccx + dx, oy = ccy + dy, oz = ccz + dz;
+                        if (ox < 0 || oy < 0 || oz < 0 || ox >= g.cdims[0] || oy >= g.cdims[1] || oz >= g.cdims[2]) continue;
+                        const int bit = (ox * g.cdims[1] + oy) * g.cdims[2] + oz;
+                        atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+                    }
+        }
+    }
+    __syncthreads();
+    for (int w = tid; w < nwords; w += blockDim.x) occ[(int64_t)b * nwords + w] = bitmap[w];
+}
+
+// top-8 list kept sorted by (dist^2, index); candidates arrive in ascending index order, so a
+// strict '<' insertion keeps the lower index first on ties.
+struct Top8 {
+    float d[8];
+    int i[8];
+    __device__ __forceinline__ void init() {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { d[t] = INFINITY; i[t] = -1; }
+    }
+    __device__ __forceinline__ void insert(float dist, int idx) {
+        d[7] = dist;
+        i[7] = idx;
+#pragma unroll
+        for (int t = 7; t > 0; --t) {
+            if (d[t] < d[t - 1]) {
+                const float td = d[t]; d[t] = d[t - 1]; d[t - 1] = td;
+                const int ti = i[t]; i[t] = i[t - 1]; i[t - 1] = ti;
+            }
+        }
+    }
+};
+
+struct QueryArgs {
+    npcd_grid_params g;
+    const int32_t* pcoord;
+    const uint32_t* occ;
+    const float* points;
+    int B, N, R, S, M, k, nwords;
+    float r2;
+    const float *x, *rays_o, *rays_d, *t0, *t1;
+    int32_t* sample_idx;
+    float* sample_loc;
+    int32_t* slot_sample;
+    int32_t* nsel;
+};
+
+// position of depth sample s of a ray: renderer.py:49-77 (eval) + volume_renderer.py:70
+__device__ __forceinline__ void sample_pos(const QueryArgs& a, int64_t ray, int s, const float o[3], const float d[3], float t0, float t1, float p[3]) {
+    if (a.x) {
+        const float* xp = a.x + (ray * a.S + s) * 3;
+        p[0] = xp[0]; p[1] = xp[1]; p[2] = xp[2];
+    } else {
+        const float step = (float)s / (float)(a.S - 1);
+        const float depth = t0 + step * (t1 - t0);
+        p[0] = o[0] + depth * d[0];
+        p[1] = o[1] + depth * d[1];
+        p[2] = o[2] + depth * d[2];
+    }
+}
+
+// scan all points of the example (LDS resident, broadcast reads) for one query position
+template <bool GRID>
+__device__ __forceinline__ void scan_points(const QueryArgs& a, const float4* pts, const float p[3], const FineCoord& fc, Top8& top) {
+    const int hx = (a.g.kernel_size[0] - 1) / 2, hy = (a.g.kernel_size[1] - 1) / 2, hz = (a.g.kernel_size[2] - 1) / 2;
+    for (int j = 0; j < a.N; ++j) {
+        const float4 q = pts[j];
+        const float dx = p[0] - q.x, dy = p[1] - q.y, dz = p[2] - q.z;
+        const float d2 = (dx * dx + dy * dy) + dz * dz;
+        bool cand = d2 < a.r2;
+        if (GRID) {
+            const int pc = __float_as_int(q.w);
+            const int ix = pc & 1023, iy = (pc >> 10) & 1023, iz = (pc >> 20) & 1023;
+            cand = cand && ((pc >> 30) & 1) && (abs(ix - fc.c[0]) <= hx) && (abs(iy - fc.c[1]) <= hy) && (abs(iz - fc.c[2]) <= hz);
+        }
+        if (cand && d2 < top.d[7]) top.insert(d2, j);
+    }
+}
+
+// one wave per ray, 4 rays per workgroup (all of the same example when R % 4 == 0; otherwise the
+// workgroup reloads the point set per wave -- handled by making the grid per example).
+template <bool GRID>
+__global__ __launch_bounds__(256) void grid_query_kernel(QueryArgs a, int blocks_per_example) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+    float4* pts = reinterpret_cast<float4*>(dsmem);
+    uint32_t* bitmap = reinterpret_cast<uint32_t*>(pts + a.N);
+    int* sel = reinterpret_cast<int*>(bitmap + a.nwords);  // [4][64] selected sample ids per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / blocks_per_example;
+    const int rb = blockIdx.x % blocks_per_example;
+    for (int j = tid; j < a.N; j += blockDim.x) {
+        const float* P = a.points + ((int64_t)b * a.N + j) * 3;
+        pts[j] = make_float4(P[0], P[1], P[2], __int_as_float(GRID ? a.pcoord[(int64_t)b * a.N + j] : 0));
+    }
+    if (GRID)
+        for (int w = tid; w < a.nwords; w += blockDim.x) bitmap[w] = a.occ[(int64_t)b * a.nwords + w];
+    __syncthreads();
+    const int r = rb * 4 + wave;
+    if (r >= a.R) return;
+    const int64_t ray = (int64_t)b * a.R + r;
+    float o[3] = {0, 0, 0}, d[3] = {0, 0, 0}, t0 = 0, t1 = 0;
+    if (!a.x) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { o[c] = a.rays_o[ray * 3 + c]; d[c] = a.rays_d[ray * 3 + c]; }
+        t0 = a.t0[ray];
+        t1 = a.t1[ray];
+    }
+    int* mysel = sel + wave * 64;
+    int32_t* out_idx = a.sample_idx + ray * a.M * a.k;
+    float* out_loc = a.sample_loc + ray * a.M * 3;
+    int32_t* out_ss = a.slot_sample + ray * a.M;
+    int nsel = 0;
+
+    if (GRID) {
+        // pass A: occupancy of every depth sample, first M occupied samples -> slots
+        for (int s0 = 0; s0 < a.S && nsel < a.M; s0 += 64) {
+            const int s = s0 + lane;
+            bool occ = false;
+            if (s < a.S) {
+                float p[3];
+                sample_pos(a, ray, s, o, d, t0, t1, p);
+                const FineCoord fc = fine_coord(a.g, p[0], p[1], p[2]);
+                if (fc.ok) {
+                    const int bit = ((fc.c[0] / a.g.voxel_scale[0]) * a.g.cdims[1] + fc.c[1] / a.g.voxel_scale[1]) * a.g.cdims[2] + fc.c[2] / a.g.voxel_scale[2];
+                    occ = (bitmap[bit >> 5] >> (bit & 31)) & 1u;
+                }
+            }
+            const unsigned long long m = __ballot(occ);
+            const int slot = nsel + __popcll(m & ((1ull << lane) - 1ull));
+            if (occ && slot < a.M) mysel[slot] = s;
+            nsel = min(a.M, nsel + __popcll(m));
+        }
+        // pass B: lane j handles slot j
+        const bool active = lane < nsel;
+        Top8 top;
+        top.init();
+        float p[3] = {0, 0, 0};
+        int s = -1;
+        if (active) {
+            s = mysel[lane];
+            sample_pos(a, ray, s, o, d, t0, t1, p);
+            const FineCoord fc = fine_coord(a.g, p[0], p[1], p[2]);
+            scan_points<true>(a, pts, p, fc, top);
+        }
+        if (lane < a.M) {
+            const int gbase = b * a.N;
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (t < a.k) out_idx[lane * a.k + t] = (active && top.i[t] >= 0) ? gbase + top.i[t] : -1;
+            out_loc[lane * 3 + 0] = active ? p[0] : 0.f;
+            out_loc[lane * 3 + 1] = active ? p[1] : 0.f;
+            out_loc[lane * 3 + 2] = active ? p[2] : 0.f;
+            out_ss[lane] = s;
+        }
+    } else {
+        // brute-force branch: a sample is valid iff it has a neighbour within the radius; the first M
+        // valid samples fill slots 0.. (aggregator.py:42-58)
+        for (int s0 = 0; s0 < a.S && nsel < a.M; s0 += 64) {
+            const int s = s0 + lane;
+            Top8 top;
+            top.init();
+            float p[3] = {0, 0, 0};
+            if (s < a.S) {
+                sample_pos(a, ray, s, o, d, t0, t1, p);
+                FineCoord fc{};
+                scan_points<false>(a, pts, p, fc, top);
+            }
+            const bool valid = top.i[0] >= 0;
+            const unsigned long long m = __ballot(valid);
+            const int slot = nsel + __popcll(m & ((1ull << lane) - 1ull));
+            if (valid && slot < a.M) {
+                const int gbase = b * a.N;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+                    if (t < a.k) out_idx[slot * a.k + t] = (top.i[t] >= 0) ? gbase + top.i[t] : -1;
+                out_loc[slot * 3 + 0] = p[0]; out_loc[slot * 3 + 1] = p[1]; out_loc[slot * 3 + 2] = p[2];
+                out_ss[slot] = s;
+            }
+            nsel = min(a.M, nsel + __popcll(m));
+        }
+        for (int slot = nsel + lane; slot < a.M; slot += 64) {
+            for (int t = 0; t < a.k; ++t) out_idx[slot * a.k + t] = -1;
+            out_loc[slot * 3 + 0] = 0.f; out_loc[slot * 3 + 1] = 0.f; out_loc[slot * 3 + 2] = 0.f;
+            out_ss[slot] = -1;
+        }
+    }
+    if (lane == 0) a.nsel[ray] = nsel;
+}
+
+// ============================================================================================
+// ray march
+// ============================================================================================
+__global__ void march_init_kernel(uint32_t* ws) {
+    ws[0] = 0xffffffffu;  // min depth key
+    ws[1] = 0u;           // max depth key
+}
+
+__global__ __launch_bounds__(256) void ray_march_kernel(const float* __restrict__ sigma, const float* __restrict__ rgb, const uint8_t* __restrict__ slot_valid,
+                                                        const float* __restrict__ slot_loc, const int32_t* __restrict__ point_base,
+                                                        const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ t1,
+                                                        int Nr, int M, int white_back, float* __restrict__ mask, float* __restrict__ depth,
+                                                        float* __restrict__ channels, uint32_t* ws) {
+    const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+    if (ray < Nr) {
+        const float o[3] = {rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2]};
+        const float d[3] = {rays_d[ray * 3], rays_d[ray * 3 + 1], rays_d[ray * 3 + 2]};
+        const float ray_end = t1[ray];
+        const uint8_t* sv = slot_valid + (int64_t)ray * M;
+        const float* sl = slot_loc + (int64_t)ray * M * 3;
+        int cp = point_base[ray];
+        float run_max = -INFINITY;
+        float T = 1.f, total = 0.f, wd = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+        float pd = 0.f, ps = 0.f, pr = 0.f, pg = 0.f, pb = 0.f;  // previous slot
+        bool pv = false;
+        for (int j = 0; j < M; ++j) {
+            const bool valid = sv[j] != 0;
+            float sg = 0.f, r_ = 0.f, g_ = 0.f, b_ = 0.f;
+            if (valid) {
+                // depth = nanmean_xyz((p - o) / d)   (renderer.py:103)
+                float acc = 0.f;
+                int cnt = 0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float q = (sl[j * 3 + c] - o[c]) / d[c];
+                    if (q == q) { acc += q; ++cnt; }
+                }
+                const float dep = acc / (float)cnt;  // cnt == 0 -> NaN, like torch.nanmean
+                run_max = fmaxf(run_max, dep);
+                sg = sigma[cp]; r_ = rgb[cp * 3]; g_ = rgb[cp * 3 + 1]; b_ = rgb[cp * 3 + 2];
+                ++cp;
+            }
+            const float dj = (run_max == -INFINITY) ? ray_end : run_max;
+            kmin = min(kmin, fkey(dj));
+            kmax = max(kmax, fkey(dj));
+            if (j > 0) {
+                const float alpha = 1.f - expf(-(ps * (dj - pd)));
+                const float w = alpha * T;
+                total += w;
+                wd += w * pd;
+                if (pv) { cr += w * pr; cg += w * pg; cb += w * pb; }
+                T *= (1.f - alpha + 1e-10f);
+            }
+            pd = dj; ps = sg; pr = r_; pg = g_; pb = b_; pv = valid;
+        }
+        // the last slot has delta = 0 -> alpha = 0 -> contributes nothing (volume_renderer.py:35)
+        mask[ray] = total;
+        depth[ray] = wd / total;  // NaN when total == 0; fixed up by depth_clamp_kernel
+        const float bg = white_back ? 1.f - total : 0.f;
+        channels[ray * 3 + 0] = cr + bg;
+        channels[ray * 3 + 1] = cg + bg;
+        channels[ray * 3 + 2] = cb + bg;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && kmax != 0u) {
+        atomicMin(&ws[0], kmin);
+        atomicMax(&ws[1], kmax);
+    }
+}
+
+// nan -> +inf -> clamp to the global [min, max] of the per-slot depths (renderer.py:151-156)
+__global__ __launch_bounds__(256) void depth_clamp_kernel(int Nr, float* __restrict__ depth, const uint32_t* ws) {
+    const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= Nr) return;
+    const float lo = fkey_inv(ws[0]), hi = fkey_inv(ws[1]);
+    float x = depth[ray];
+    if (x != x) x = INFINITY;
+    depth[ray] = fminf(fmaxf(x, lo), hi);
+}
+
+}  // namespace npcd
+
+using namespace npcd;
+
+// --------------------------------------------------------------------------------------------
+extern "C" int npcd_ray_gen(const float* extr, const float* intr, int V, int res, float box, float* rays_o, float* rays_d,
+                            float* t0, float* t1, float* limits_ws, void* stream) {
+    if (!extr || !intr || !rays_o || !rays_d || !t0 || !t1 || !limits_ws || V <= 0 || res <= 0) return NPCD_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t n = (int64_t)V * res * res;
+    const int grid = (int)((n + 255) / 256);
+    uint32_t* ws = reinterpret_cast<uint32_t*>(limits_ws);
+    hipLaunchKernelGGL(limits_init_kernel, dim3(1), dim3(1), 0, st, ws);
+    hipLaunchKernelGGL(ray_gen_kernel, dim3(grid), dim3(256), 0, st, extr, intr, V, res, box, rays_o, rays_d, t0, t1, ws);
+    hipLaunchKernelGGL(ray_limits_fix_kernel, dim3(grid), dim3(256), 0, st, n, t0, t1, ws);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+static int grid_check(const npcd_grid_params* g, int B, int N) {
+    if (!g || B <= 0 || N <= 0) return NPCD_ERR_ARG;
+    for (int a = 0; a < 3; ++a) {
+        if (g->dims[a] <= 0 || g->dims[a] > 1023 || g->cdims[a] <= 0) return NPCD_ERR_UNSUPPORTED;
+        if (g->voxel_scale[a] <= 0 || g->kernel_size[a] <= 0 || (g->kernel_size[a] & 1) == 0) return NPCD_ERR_ARG;
+        if (!(g->voxel_size[a] > 0.f)) return NPCD_ERR_ARG;
+    }
+    if (N > 4096) return NPCD_ERR_UNSUPPORTED;                     // point set must fit LDS
+    if (occ_words(*g) * 4 > 65536) return NPCD_ERR_UNSUPPORTED;    // coarse bitmap must fit LDS
+    return NPCD_OK;
+}
+
+extern "C" int64_t npcd_grid_workspace_bytes(const npcd_grid_params* g, int B, int N) {
+    if (grid_check(g, B, N) != NPCD_OK) return -1;
+    return (int64_t)B * N * 4 + (int64_t)B * occ_words(*g) * 4;
+}
+
+extern "C" int npcd_grid_build(const npcd_grid_params* g, const float* points, const int32_t* counts, int B, int N,
+                               void* workspace, void* stream) {
+    int rc = grid_check(g, B, N);
+    if (rc != NPCD_OK) return rc;
+    if (!points || !workspace) return NPCD_ERR_ARG;
+    const int nwords = occ_words(*g);
+    int32_t* pcoord = static_cast<int32_t*>(workspace);
+    uint32_t* occ = reinterpret_cast<uint32_t*>(pcoord + (int64_t)B * N);
+    const size_t lds = (size_t)N * 8 + (size_t)nwords * 4;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static size_t lds_set = 0;
+    if (lds > 65536 && lds > lds_set) {
+        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    hipLaunchKernelGGL(grid_build_kernel, dim3(B), dim3(256), lds, st, *g, points, counts, N, nwords, pcoord, occ);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int npcd_grid_query(const npcd_grid_params* g, const void* workspace, const float* points, int B, int N, int R, int S,
+                               int M, int k, float r, int mode, const float* x, const float* rays_o, const float* rays_d,
+                               const float* t0, const float* t1, int32_t* sample_idx, float* sample_loc, int32_t* slot_sample,
+                               int32_t* nsel, void* stream) {
+    int rc = grid_check(g, B, N);
+    if (rc != NPCD_OK) return rc;
+    if (!points || !sample_idx || !sample_loc || !slot_sample || !nsel) return NPCD_ERR_ARG;
+    if (R <= 0 || S <= 1 || M <= 0 || k <= 0 || !(r > 0.f)) return NPCD_ERR_ARG;
+    if (M > 64 || k > 8) return NPCD_ERR_UNSUPPORTED;
+    if (!x && (!rays_o || !rays_d || !t0 || !t1)) return NPCD_ERR_ARG;
+    if (mode == 0 && !workspace) return NPCD_ERR_ARG;
+    if (mode != 0 && mode != 1) return NPCD_ERR_ARG;
+    QueryArgs a{};
+    a.g = *g;
+    a.pcoord = static_cast<const int32_t*>(workspace);
+    a.nwords = occ_words(*g);
+    a.occ = reinterpret_cast<const uint32_t*>(a.pcoord + (int64_t)B * N);
+    a.points = points;
+    a.B = B; a.N = N; a.R = R; a.S = S; a.M = M; a.k = k;
+    float radius = r;
+    if (mode == 0) {
+        float vmax = g->voxel_size[0];
+        if (g->voxel_size[1] > vmax) vmax = g->voxel_size[1];
+        if (g->voxel_size[2] > vmax) vmax = g->voxel_size[2];
+        radius = (float)((double)r * (double)vmax);   // aggregator.py:20, evaluated in float64 then rounded
+    }
+    a.r2 = radius * radius;
+    a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t0 = t0; a.t1 = t1;
+    a.sample_idx = sample_idx; a.sample_loc = sample_loc; a.slot_sample = slot_sample; a.nsel = nsel;
+    const int bpe = (R + 3) / 4;
+    const size_t lds = (size_t)N * 16 + (size_t)a.nwords * 4 + 4 * 64 * 4;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static size_t lds_set[2] = {0, 0};
+    if (lds > 65536 && lds > lds_set[mode]) {
+        const void* fn = mode == 0 ? reinterpret_cast<const void*>(grid_query_kernel<true>) : reinterpret_cast<const void*>(grid_query_kernel<false>);
+        NPCD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set[mode] = lds;
+    }
+    if (mode == 0) hipLaunchKernelGGL(grid_query_kernel<true>, dim3(B * bpe), dim3(256), lds, st, a, bpe);
+    else hipLaunchKernelGGL(grid_query_kernel<false>, dim3(B * bpe), dim3(256), lds, st, a, bpe);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int npcd_ray_march(const float* sigma, const float* rgb, const uint8_t* slot_valid, const float* slot_loc,
+                              const int32_t* point_base, const float* rays_o, const float* rays_d, const float* t1, int Nr, int M,
+                              int white_back, float* mask, float* depth, float* channels, float* depth_ws, void* stream) {
+    if (!sigma || !rgb || !slot_valid || !slot_loc || !point_base || !rays_o || !rays_d || !t1 || !mask || !depth || !channels || !depth_ws)
+        return NPCD_ERR_ARG;
+    if (Nr <= 0 || M <= 0) return NPCD_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint32_t* ws = reinterpret_cast<uint32_t*>(depth_ws);
+    const int grid = (Nr + 255) / 256;
+    hipLaunchKernelGGL(march_init_kernel, dim3(1), dim3(1), 0, st, ws);
+    hipLaunchKernelGGL(ray_march_kernel, dim3(grid), dim3(256), 0, st, sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1,
+                       Nr, M, white_back, mask, depth, channels, ws);
+    hipLaunchKernelGGL(depth_clamp_kernel, dim3(grid), dim3(256), 0, st, Nr, depth, ws);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}

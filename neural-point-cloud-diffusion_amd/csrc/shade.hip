@@ -1,0 +1,458 @@
+// Fused PointNeRF shading for gfx950: neighbour gather -> relative position -> positional encoding
+// -> per-pair MLP -> inverse-distance aggregation -> density / colour heads.
+//
+// Reference op chain replaced (one eager PyTorch kernel per line there):
+//   gather + x_rel + weights + posenc   npcd/models/pointnerf/fields/aggregators/mlp.py:62-88,
+//                                       aggregator.py:122-156, utils/positional_encoder.py:16-20
+//   local_field MLP (95->256x4->256)    aggregators/mlp.py:83-84, utils/model.py:22-36
+//   weighted aggregation (index_add_)   aggregators/mlp.py:102-125
+//   shape_net + softplus(x-1)           fields/mlp.py:38-51, field.py:30,126-128
+//   channel_net + sigmoid               fields/mlp.py:53-72, field.py:139-140
+//
+// Design.  Activations never leave the CU between layers: a 128-row tile lives in LDS as fp16
+// (64 KiB, XOR-swizzled 512-byte rows) and every 256x256 layer is a chain of 32x32x16 f16 MFMAs
+// with fp32 accumulation, oriented as  H_out^T[out][row] = W[out][in] . H_in^T[in][row]  so that
+//   * the WEIGHTS are the A operand, read straight from global/L2 in a pre-packed fragment order
+//     (1 KiB contiguous per wave-instruction, no LDS staging: all workgroups stream the same
+//     1.2 MB, which stays L2 resident),
+//   * the ACTIVATIONS are the B operand (ds_read_b128 of 8 consecutive input channels of one row),
+//   * each lane ends up owning 4 consecutive output channels of one row per accumulator group, so
+//     the epilogue (bias, LeakyReLU, fp16 convert) writes 8-byte packed values back in place.
+// The last aggregator layer is linear, so it commutes with the (normalised) weighted sum over a
+// point's neighbours: kernel A runs the four non-linear layers on the (point, neighbour) pairs and
+// aggregates; kernel B applies that last linear layer and both heads on POINTS (6.3x fewer rows).
+#include <math.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace npcd {
+
+constexpr int kHidden = 256;
+constexpr int kNFreqs = 10;
+constexpr int kEncBlock = 64;          // 3 + 60 positional-encoding columns + 1 zero pad
+constexpr int kRows = 128;             // rows per tile
+constexpr int kRowBytes = kHidden * 2; // 512
+constexpr int kFragBytes = 1024;       // one 32(out) x 16(in) fp16 weight fragment
+constexpr float kLeaky = 0.01f;
+
+struct ShadeLayout {
+    int k0;          // padded input width of layer 0
+    int64_t w[10];   // byte offsets of the packed matrices: A0..A3, A4, S0, C0..C3
+    int64_t bias[10];
+    int64_t s1, c4;  // fp32 vectors: s1 = [256 w | 1 b | pad], c4 = [3*256 w | 3 b | pad]
+    int64_t total;
+};
+__host__ __device__ inline ShadeLayout shade_layout(int feat_dim) {
+    ShadeLayout L;
+    L.k0 = feat_dim + kEncBlock;
+    int64_t off = 0;
+    for (int i = 0; i < 10; ++i) {
+        L.w[i] = off;
+        const int ksteps = (i == 0 ? L.k0 : kHidden) / 16;
+        off += (int64_t)8 * ksteps * kFragBytes;
+    }
+    for (int i = 0; i < 10; ++i) { L.bias[i] = off; off += kHidden * 4; }
+    L.s1 = off; off += 264 * 4;
+    L.c4 = off; off += 776 * 4;
+    L.total = off;
+    return L;
+}
+
+// LDS address of 16-byte chunk `chunk` (0..31) of activation row `row`
+__device__ __forceinline__ int act_off(int row, int chunk) { return row * kRowBytes + ((chunk ^ (row & 15)) << 4); }
+
+// One layer:  acc[oi][cb] (+)= W[(2*wave+oi)*32.., :] . H^T[:, cb*32..]   for oi in {0,1}, cb in 0..3
+template <int KSTEPS>
+__device__ __forceinline__ void layer_mfma(const unsigned char* H, const unsigned char* wfrag, const float* bias, int wave, int lane,
+                                           f32x16 (&acc)[2][4]) {
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int oi = 0; oi < 2; ++oi) {
+        const float* bp = bias + (2 * wave + oi) * 32 + 4 * hh;
+        f32x16 init;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + 8 * g);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) init[4 * g + b] = b4[b];
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[oi][cb] = init;
+    }
+    const f16x8* w0 = reinterpret_cast<const f16x8*>(wfrag + (int64_t)(2 * wave) * KSTEPS * kFragBytes) + lane;
+    const f16x8* w1 = reinterpret_cast<const f16x8*>(wfrag + (int64_t)(2 * wave + 1) * KSTEPS * kFragBytes) + lane;
+    f16x8 a0 = w0[0], a1 = w1[0];
+#pragma unroll 4
+    for (int s = 0; s < KSTEPS; ++s) {
+        f16x8 n0 = a0, n1 = a1;
+        if (s + 1 < KSTEPS) {
+            n0 = w0[(s + 1) * 64];
+            n1 = w1[(s + 1) * 64];
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const f16x8 b = *reinterpret_cast<const f16x8*>(H + act_off(cb * 32 + r, 2 * s + hh));
+            acc[0][cb] = F16::mfma32(a0, b, acc[0][cb]);
+            acc[1][cb] = F16::mfma32(a1, b, acc[1][cb]);
+        }
+        a0 = n0;
+        a1 = n1;
+    }
+}
+
+// epilogue: optional LeakyReLU, convert to fp16, write back in place (4 consecutive channels = 8 bytes)
+template <bool ACT>
+__device__ __forceinline__ void layer_store(unsigned char* H, int wave, int lane, const f32x16 (&acc)[2][4]) {
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int oi = 0; oi < 2; ++oi)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f16x4 v;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    float x = acc[oi][cb][4 * g + b];
+                    if (ACT) x = x > 0.f ? x : kLeaky * x;
+                    v[b] = (_Float16)x;
+                }
+                const int row = cb * 32 + r, chunk = (2 * wave + oi) * 4 + g;
+                *reinterpret_cast<f16x4*>(H + act_off(row, chunk) + 8 * hh) = v;
+            }
+}
+
+struct ShadeArgs {
+    const unsigned char* wpack;
+    int feat_dim, k;
+    const int32_t* nb_idx;
+    const float *pts, *kp_pos, *kp_feat;
+    const int32_t* n_points;
+    _Float16* G;  // [max_points][256] aggregated hidden features (workspace)
+    float *sigma, *rgb;
+};
+
+// ---- positional-encoding column q (0..63) of the [x_rel(3) | per coord: sin f0..9, cos f0..9 | 0] block
+__device__ __forceinline__ float enc_value(int q, const float rel[3]) {
+    if (q < 3) return rel[q];
+    if (q >= 63) return 0.f;
+    const int c = (q - 3) / 20, rem = (q - 3) % 20, i = rem % 10;
+    // sin(x * 2^i * pi) = sin(2 pi u), u = x * 2^(i-1) (exact scaling); v_sin/v_cos take revolutions
+    const float u = rel[c] * (0.5f * (float)(1 << i));
+    const float f = __builtin_amdgcn_fractf(u);
+    return rem < 10 ? __builtin_amdgcn_sinf(f) : __builtin_amdgcn_cosf(f);
+}
+
+// ============================================================================================
+// kernel A: (point, neighbour) pairs.  tile = 16 points x 8 neighbour slots = 128 rows
+// ============================================================================================
+template <int FEAT>
+__global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
+    constexpr int K0 = FEAT + kEncBlock;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+    unsigned char* H = dsmem;
+    float* wrow = reinterpret_cast<float*>(dsmem + kRows * kRowBytes);  // [128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const ShadeLayout L = shade_layout(FEAT);
+    const int P = *a.n_points;
+    const int ntiles = (P + 15) / 16;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // ---- prologue: build the layer-0 input rows -------------------------------------------
+        {
+            const int row = tid & 127, half = tid >> 7;  // half is wave-uniform
+            const int p = tile * 16 + (row >> 3), slot = row & 7;
+            int gi = -1;
+            if (p < P && slot < a.k) gi = a.nb_idx[(int64_t)p * a.k + slot];
+            float rel[3] = {0.f, 0.f, 0.f};
+            if (gi >= 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rel[c] = a.pts[(int64_t)p * 3 + c] - a.kp_pos[(int64_t)gi * 3 + c];
+            }
+            if (half == 0)
+                wrow[row] = gi >= 0 ? 1.f / (sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]) + 1e-5f) : 0.f;
+            // features: this half converts FEAT/2 channels
+            constexpr int FH = FEAT / 2;
+            const float* fp = a.kp_feat + (int64_t)(gi >= 0 ? gi : 0) * FEAT + half * FH;
+#pragma unroll
+            for (int c8 = 0; c8 < FH / 8; ++c8) {
+                f16x8 v;
+                if (gi >= 0) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(fp + c8 * 8);
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(fp + c8 * 8 + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = (_Float16)x0[j]; v[4 + j] = (_Float16)x1[j]; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
+                }
+                *reinterpret_cast<f16x8*>(H + act_off(row, half * (FH / 8) + c8)) = v;
+            }
+            // positional encoding: this half fills 32 of the 64 columns
+#pragma unroll
+            for (int c8 = 0; c8 < 4; ++c8) {
+                f16x8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int q = half * 32 + c8 * 8 + j;
+                    // both halves are compiled; the select on `half` below is wave-uniform
+                    v[j] = (_Float16)0.f;
+                    if (gi >= 0) v[j] = (_Float16)(half == 0 ? enc_value(c8 * 8 + j, rel) : enc_value(32 + c8 * 8 + j, rel));
+                    (void)q;
+                }
+                *reinterpret_cast<f16x8*>(H + act_off(row, FEAT / 8 + half * 4 + c8)) = v;
+            }
+        }
+        __syncthreads();
+        // ---- four non-linear layers ---------------------------------------------------------
+        f32x16 acc[2][4];
+        layer_mfma<K0 / 16>(H, a.wpack + L.w[0], reinterpret_cast<const float*>(a.wpack + L.bias[0]), wave, lane, acc);
+        __syncthreads();
+        layer_store<true>(H, wave, lane, acc);
+        __syncthreads();
+#pragma unroll 1
+        for (int l = 1; l < 4; ++l) {
+            layer_mfma<kHidden / 16>(H, a.wpack + L.w[l], reinterpret_cast<const float*>(a.wpack + L.bias[l]), wave, lane, acc);
+            __syncthreads();
+            layer_store<true>(H, wave, lane, acc);
+            __syncthreads();
+        }
+        // ---- inverse-distance aggregation over the 8 neighbour slots ------------------------
+        {
+            const int pl = tid >> 4, cc = tid & 15;  // point, 16-channel chunk
+            const int p = tile * 16 + pl;
+            float w[8], wsum = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) { w[s] = wrow[pl * 8 + s]; wsum += w[s]; }
+            const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
+            float out[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) out[j] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int row = pl * 8 + s;
+                const float ws = w[s] * inv;
+                const f16x8 v0 = *reinterpret_cast<const f16x8*>(H + act_off(row, 2 * cc));
+                const f16x8 v1 = *reinterpret_cast<const f16x8*>(H + act_off(row, 2 * cc + 1));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { out[j] += ws * (float)v0[j]; out[8 + j] += ws * (float)v1[j]; }
+            }
+            if (p < P) {
+                f16x8 o0, o1;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { o0[j] = (_Float16)out[j]; o1[j] = (_Float16)out[8 + j]; }
+                f16x8* gp = reinterpret_cast<f16x8*>(a.G + (int64_t)p * kHidden + cc * 16);
+                gp[0] = o0;
+                gp[1] = o1;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ============================================================================================
+// kernel B: points.  tile = 128 points
+// ============================================================================================
+__device__ __forceinline__ float softplus_m1(float x) {
+    x -= 1.f;
+    return x > 20.f ? x : log1pf(expf(x));  // F.softplus(beta=1, threshold=20)
+}
+
+__global__ __launch_bounds__(256, 2) void shade_points_kernel(ShadeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+    unsigned char* H = dsmem;
+    float* red = reinterpret_cast<float*>(dsmem + kRows * kRowBytes);  // [4 waves][128 rows][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const ShadeLayout L = shade_layout(a.feat_dim);
+    const int P = *a.n_points;
+    const int ntiles = (P + kRows - 1) / kRows;
+    const float* s1 = reinterpret_cast<const float*>(a.wpack + L.s1);
+    const float* c4 = reinterpret_cast<const float*>(a.wpack + L.c4);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // ---- load the aggregated features of 128 points -------------------------------------
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int cidx = it * 256 + tid, row = cidx >> 5, chunk = cidx & 31;
+            const int p = tile * kRows + row;
+            u32x4 v = {0, 0, 0, 0};
+            if (p < P) v = *reinterpret_cast<const u32x4*>(a.G + (int64_t)p * kHidden + chunk * 8);
+            *reinterpret_cast<u32x4*>(H + act_off(row, chunk)) = v;
+        }
+        __syncthreads();
+        f32x16 acc[2][4];
+        // ---- last aggregator layer (linear): feat ------------------------------------------
+        layer_mfma<16>(H, a.wpack + L.w[4], reinterpret_cast<const float*>(a.wpack + L.bias[4]), wave, lane, acc);
+        __syncthreads();
+        layer_store<false>(H, wave, lane, acc);
+        __syncthreads();
+        // ---- density head: Linear(256,256) + LeakyReLU + Linear(256,1), softplus(x - 1) ------
+        layer_mfma<16>(H, a.wpack + L.w[5], reinterpret_cast<const float*>(a.wpack + L.bias[5]), wave, lane, acc);
+        {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                float part = 0.f;
+#pragma unroll
+                for (int oi = 0; oi < 2; ++oi)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float x = acc[oi][cb][i];
+                        x = x > 0.f ? x : kLeaky * x;
+                        part += x * s1[(2 * wave + oi) * 32 + acc_row(i, hh)];
+                    }
+                part += swap_half(part);
+                if (hh == 0) red[(wave * kRows + cb * 32 + r) * 4 + 3] = part;
+            }
+        }
+        // (H still holds feat: the density pass did not write activations)
+        // ---- colour head: 4 x [Linear(256,256) + LeakyReLU] + Linear(256,3), sigmoid ----------
+#pragma unroll 1
+        for (int l = 0; l < 4; ++l) {
+            layer_mfma<16>(H, a.wpack + L.w[6 + l], reinterpret_cast<const float*>(a.wpack + L.bias[6 + l]), wave, lane, acc);
+            if (l < 3) {
+                __syncthreads();
+                layer_store<true>(H, wave, lane, acc);
+                __syncthreads();
+            }
+        }
+        {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                float pr = 0.f, pg = 0.f, pb = 0.f;
+#pragma unroll
+                for (int oi = 0; oi < 2; ++oi)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        float x = acc[oi][cb][i];
+                        x = x > 0.f ? x : kLeaky * x;
+                        const int o = (2 * wave + oi) * 32 + acc_row(i, hh);
+                        pr += x * c4[o];
+                        pg += x * c4[kHidden + o];
+                        pb += x * c4[2 * kHidden + o];
+                    }
+                pr += swap_half(pr);
+                pg += swap_half(pg);
+                pb += swap_half(pb);
+                if (hh == 0) {
+                    float* q = red + (wave * kRows + cb * 32 + r) * 4;
+                    q[0] = pr; q[1] = pg; q[2] = pb;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < kRows) {
+            const int p = tile * kRows + tid;
+            if (p < P) {
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(red + (w * kRows + tid) * 4);
+                    t += v;
+                }
+                a.sigma[p] = softplus_m1(t[3] + s1[kHidden]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) a.rgb[(int64_t)p * 3 + c] = 1.f / (1.f + expf(-(t[c] + c4[3 * kHidden + c])));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace npcd
+
+using namespace npcd;
+
+static int shade_check(int feat_dim, int n_freqs, int hidden) {
+    if (hidden != kHidden || n_freqs != kNFreqs) return NPCD_ERR_UNSUPPORTED;
+    if (feat_dim != 32 && feat_dim != 128) return NPCD_ERR_UNSUPPORTED;
+    return NPCD_OK;
+}
+
+extern "C" int64_t npcd_shade_wpack_bytes(int feat_dim, int n_freqs, int hidden) {
+    if (shade_check(feat_dim, n_freqs, hidden) != NPCD_OK) return -1;
+    return shade_layout(feat_dim).total;
+}
+
+extern "C" int64_t npcd_shade_workspace_bytes(int max_points, int hidden) {
+    if (hidden != kHidden || max_points < 0) return -1;
+    return (int64_t)(max_points + kRows) * kHidden * 2;
+}
+
+// fragment order: [out block ob][k-step s][lane][8]  with  element = W[ob*32 + (lane&31)][16 s + 8 (lane>>5) + j]
+static void pack_matrix(const float* W, int out_dim, int in_dim, int k_padded, unsigned char* dst) {
+    _Float16* d = reinterpret_cast<_Float16*>(dst);
+    const int ksteps = k_padded / 16;
+    for (int ob = 0; ob < out_dim / 32; ++ob)
+        for (int s = 0; s < ksteps; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int o = ob * 32 + (lane & 31), c = 16 * s + 8 * (lane >> 5) + j;
+                    const float v = c < in_dim ? W[(int64_t)o * in_dim + c] : 0.f;
+                    d[(((int64_t)ob * ksteps + s) * 64 + lane) * 8 + j] = (_Float16)v;
+                }
+}
+
+// weights_host / biases_host: 12 pointers in the order
+//   aggregator.local_field.{0,2,4,6,8}, shape_net.{0,2}, channel_net.{0,2,4,6,8}   
+extern "C" int npcd_shade_pack_weights(const float* const* weights_host, const float* const* biases_host, int feat_dim, int n_freqs,
+                                       int hidden, void* wpack_host) {
+    int rc = shade_check(feat_dim, n_freqs, hidden);
+    if (rc != NPCD_OK) return rc;
+    if (!weights_host || !biases_host || !wpack_host) return NPCD_ERR_ARG;
+    for (int i = 0; i < 12; ++i)
+        if (!weights_host[i] || !biases_host[i]) return NPCD_ERR_ARG;
+    const ShadeLayout L = shade_layout(feat_dim);
+    unsigned char* out = static_cast<unsigned char*>(wpack_host);
+    memset(out, 0, L.total);
+    const int in0 = feat_dim + 3 + 6 * kNFreqs;
+    // packed slot -> source index: A0..A3 = 0..3, A4 = 4, S0 = 5, C0..C3 = 7..10
+    const int src[10] = {0, 1, 2, 3, 4, 5, 7, 8, 9, 10};
+    for (int i = 0; i < 10; ++i) {
+        pack_matrix(weights_host[src[i]], kHidden, i == 0 ? in0 : kHidden, i == 0 ? L.k0 : kHidden, out + L.w[i]);
+        memcpy(out + L.bias[i], biases_host[src[i]], kHidden * 4);
+    }
+    float* s1 = reinterpret_cast<float*>(out + L.s1);
+    memcpy(s1, weights_host[6], kHidden * 4);
+    s1[kHidden] = biases_host[6][0];
+    float* c4 = reinterpret_cast<float*>(out + L.c4);
+    memcpy(c4, weights_host[11], 3 * kHidden * 4);
+    memcpy(c4 + 3 * kHidden, biases_host[11], 3 * 4);
+    return NPCD_OK;
+}
+
+extern "C" int npcd_shade_points(const void* wpack, int feat_dim, int n_freqs, int hidden, const int32_t* nb_idx, const float* pts,
+                                 const float* kp_pos, const float* kp_feat, const int32_t* n_points_dev, int max_points, int k,
+                                 float* sigma, float* rgb, void* workspace, void* stream) {
+    int rc = shade_check(feat_dim, n_freqs, hidden);
+    if (rc != NPCD_OK) return rc;
+    if (!wpack || !nb_idx || !pts || !kp_pos || !kp_feat || !n_points_dev || !sigma || !rgb || !workspace) return NPCD_ERR_ARG;
+    if (k <= 0 || k > 8) return NPCD_ERR_UNSUPPORTED;
+    if (max_points <= 0) return NPCD_OK;
+    ShadeArgs a{};
+    a.wpack = static_cast<const unsigned char*>(wpack);
+    a.feat_dim = feat_dim; a.k = k;
+    a.nb_idx = nb_idx; a.pts = pts; a.kp_pos = kp_pos; a.kp_feat = kp_feat;
+    a.n_points = n_points_dev;
+    a.G = static_cast<_Float16*>(workspace);
+    a.sigma = sigma; a.rgb = rgb;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int ldsA = kRows * kRowBytes + kRows * 4;
+    const int ldsB = kRows * kRowBytes + 4 * kRows * 4 * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(shade_pairs_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsA));
+        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(shade_pairs_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsA));
+        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(shade_points_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsB));
+        attr_done = true;
+    }
+    // persistent-style grids: 2 workgroups per CU, tiles strided over the grid; the tile count is
+    // read from device memory so that no host round trip is needed after the neighbour query
+    const int tilesA = (max_points + 15) / 16, tilesB = (max_points + kRows - 1) / kRows;
+    const int gridA = tilesA < 512 ? tilesA : 512, gridB = tilesB < 512 ? tilesB : 512;
+    if (feat_dim == 32) hipLaunchKernelGGL(shade_pairs_kernel<32>, dim3(gridA), dim3(256), ldsA, st, a);
+    else hipLaunchKernelGGL(shade_pairs_kernel<128>, dim3(gridA), dim3(256), ldsA, st, a);
+    hipLaunchKernelGGL(shade_points_kernel, dim3(gridB), dim3(256), ldsB, st, a);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}

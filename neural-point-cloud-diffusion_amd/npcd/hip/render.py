@@ -1,0 +1,167 @@
+"""Render-path operators on the HIP kernels (csrc/geometry.hip, csrc/shade.hip)."""
+import ctypes
+from typing import Optional, Sequence
+
+import torch
+
+from . import GridParams, check, lib, ptr, require_gpu, stream_ptr
+
+_i32, _f32 = torch.int32, torch.float32
+
+
+def make_grid_params(voxel_size, voxel_scale, kernel_size, max_points_per_voxel, max_occ_voxels_per_example, ranges) -> GridParams:
+    g = GridParams()
+    for a in range(3):
+        g.voxel_size[a] = float(voxel_size[a])
+        g.voxel_scale[a] = int(voxel_scale[a])
+        g.kernel_size[a] = int(kernel_size[a])
+        g.range_min[a] = float(ranges[a])
+        g.range_max[a] = float(ranges[3 + a])
+        g.dims[a] = int(round((float(ranges[3 + a]) - float(ranges[a])) / float(voxel_size[a])))   # host, float64
+        g.cdims[a] = (g.dims[a] + g.voxel_scale[a] - 1) // g.voxel_scale[a]
+    g.max_points_per_voxel = int(max_points_per_voxel)
+    g.max_occ_voxels_per_example = int(max_occ_voxels_per_example)
+    return g
+
+
+def ray_gen(extr: torch.Tensor, intr: torch.Tensor, res: int, box: float = 1.0):
+    """extr [V,4,4] world2cam, intr [V,3,3] -> rays_o, rays_d [V,R,3], t0, t1 [V,R] (R = res*res).
+    ray_sampler.py:10-49 + renderer.py:36-47 (rays that miss the cube get the global limits)."""
+    require_gpu(extr, intr)
+    extr = extr.to(_f32).contiguous()
+    intr = intr.to(_f32).contiguous()
+    V, R = extr.shape[0], res * res
+    dev = extr.device
+    o = torch.empty((V, R, 3), dtype=_f32, device=dev)
+    d = torch.empty((V, R, 3), dtype=_f32, device=dev)
+    t0 = torch.empty((V, R), dtype=_f32, device=dev)
+    t1 = torch.empty((V, R), dtype=_f32, device=dev)
+    ws = torch.empty(4, dtype=_f32, device=dev)
+    check(lib().npcd_ray_gen(ptr(extr), ptr(intr), V, res, float(box), ptr(o), ptr(d), ptr(t0), ptr(t1), ptr(ws), stream_ptr()),
+          "npcd_ray_gen")
+    return o, d, t0, t1
+
+
+class HipVoxelGrid:
+    """Device-side state of a torch_knnquery.VoxelGrid: parameters + the workspace written by
+    set_pointset (per point fine-voxel coordinates / kept flag, per example coarse occupancy)."""
+
+    def __init__(self, voxel_size, voxel_scale, kernel_size, max_points_per_voxel, max_occ_voxels_per_example, ranges):
+        self.params = make_grid_params(voxel_size, voxel_scale, kernel_size, max_points_per_voxel,
+                                       max_occ_voxels_per_example, ranges)
+        self.vsize_tup = tuple(float(v) for v in voxel_size)
+        self.points: Optional[torch.Tensor] = None
+        self.workspace: Optional[torch.Tensor] = None
+
+    def set_pointset(self, points: torch.Tensor, counts: Optional[torch.Tensor] = None):
+        require_gpu(points)
+        pts = points.detach().to(_f32).contiguous()
+        B, N, _ = pts.shape
+        nbytes = lib().npcd_grid_workspace_bytes(ctypes.byref(self.params), B, N)
+        if nbytes < 0:
+            raise RuntimeError(f"voxel grid configuration / point count (N={N}) not supported by the HIP kernels")
+        if self.workspace is None or self.workspace.numel() < nbytes or self.workspace.device != pts.device:
+            self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
+        cnt = None if counts is None else counts.to(device=pts.device, dtype=_i32).contiguous()
+        check(lib().npcd_grid_build(ctypes.byref(self.params), ptr(pts), ptr(cnt), B, N, ptr(self.workspace), stream_ptr()),
+              "npcd_grid_build")
+        self.points = pts
+
+    def query_dense(self, k: int, r: float, M: int, *, x: Optional[torch.Tensor] = None, rays=None, S: Optional[int] = None,
+                    mode: int = 0, points: Optional[torch.Tensor] = None):
+        """Dense per-ray result: idx [B,R,M,k] int32, loc [B,R,M,3], slot_sample [B,R,M] int32, nsel [B,R] int32.
+        Either x [B,R,S,3] or rays=(o [B,R,3], d [B,R,3], t0 [B,R], t1 [B,R]) with S depth samples."""
+        pts = self.points if points is None else points.detach().to(_f32).contiguous()
+        if pts is None:
+            raise RuntimeError("VoxelGrid.query before set_pointset")
+        B, N, _ = pts.shape
+        if x is not None:
+            require_gpu(x)
+            x = x.to(_f32).contiguous()
+            assert x.shape[0] == B
+            R, S = x.shape[1], x.shape[2]
+            o = d = t0 = t1 = None
+        else:
+            o, d, t0, t1 = (t.to(_f32).contiguous() for t in rays)
+            R = o.shape[1]
+        dev = pts.device
+        idx = torch.empty((B, R, M, k), dtype=_i32, device=dev)
+        loc = torch.empty((B, R, M, 3), dtype=_f32, device=dev)
+        ss = torch.empty((B, R, M), dtype=_i32, device=dev)
+        nsel = torch.empty((B, R), dtype=_i32, device=dev)
+        check(lib().npcd_grid_query(ctypes.byref(self.params), ptr(self.workspace if mode == 0 else None), ptr(pts),
+                                    B, N, R, int(S), int(M), int(k), float(r), int(mode), ptr(x), ptr(o), ptr(d), ptr(t0), ptr(t1),
+                                    ptr(idx), ptr(loc), ptr(ss), ptr(nsel), stream_ptr()), "npcd_grid_query")
+        return idx, loc, ss, nsel
+
+    def query(self, x: torch.Tensor, k: int, r: float, max_shading_pts: int):
+        """torch_knnquery.VoxelGrid.query contract (aggregator.py:63-73):
+        sample_idx [R_valid, M, k], sample_loc [R_valid, M, 3], ray_mask [B, R]."""
+        idx, loc, _, nsel = self.query_dense(k, r, max_shading_pts, x=x)
+        ray_mask = nsel > 0
+        return idx[ray_mask], loc[ray_mask], ray_mask
+
+
+# ---- fused shading -------------------------------------------------------------------------------
+FIELD_ORDER = tuple([f"aggregator.local_field.{i}" for i in (0, 2, 4, 6, 8)] + ["shape_net.0", "shape_net.2"]
+                    + [f"channel_net.{i}" for i in (0, 2, 4, 6, 8)])
+
+
+def pack_field_weights(state: dict, feat_dim: int, device, n_freqs: int = 10, hidden: int = 256) -> torch.Tensor:
+    """Pack the 12 Linear layers of a Field (state_dict keys relative to the Field module) into the
+    fp16 MFMA-fragment order the shading kernels stream from L2.  Returns a uint8 device tensor."""
+    L = lib()
+    nbytes = L.npcd_shade_wpack_bytes(feat_dim, n_freqs, hidden)
+    if nbytes < 0:
+        raise RuntimeError(f"shading kernels support feat_dim in (32, 128), n_freqs=10, hidden=256; got "
+                           f"({feat_dim}, {n_freqs}, {hidden})")
+    ws = [state[n + ".weight"].detach().to("cpu", _f32).contiguous() for n in FIELD_ORDER]
+    bs = [state[n + ".bias"].detach().to("cpu", _f32).contiguous() for n in FIELD_ORDER]
+    wp = (ctypes.c_void_p * 12)(*[w.data_ptr() for w in ws])
+    bp = (ctypes.c_void_p * 12)(*[b.data_ptr() for b in bs])
+    host = torch.empty(nbytes, dtype=torch.uint8)
+    check(L.npcd_shade_pack_weights(wp, bp, feat_dim, n_freqs, hidden, ctypes.c_void_p(host.data_ptr())), "npcd_shade_pack_weights")
+    return host.to(device)
+
+
+def shade_points(wpack: torch.Tensor, feat_dim: int, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch.Tensor,
+                 kp_feat: torch.Tensor, n_points: Optional[torch.Tensor] = None, n_freqs: int = 10, hidden: int = 256):
+    """nb_idx [P,k] int32 (global indices, -1 pad), pts [P,3], kp_pos [B*N,3], kp_feat [B*N,F] -> sigma [P], rgb [P,3]."""
+    require_gpu(wpack, nb_idx, pts, kp_pos, kp_feat)
+    P, k = nb_idx.shape
+    dev = pts.device
+    nb_idx = nb_idx.to(_i32).contiguous()
+    pts, kp_pos, kp_feat = pts.to(_f32).contiguous(), kp_pos.to(_f32).contiguous(), kp_feat.to(_f32).contiguous()
+    sigma = torch.empty(P, dtype=_f32, device=dev)
+    rgb = torch.empty((P, 3), dtype=_f32, device=dev)
+    if P == 0:
+        return sigma, rgb
+    if n_points is None:
+        n_points = torch.tensor([P], dtype=_i32, device=dev)
+    L = lib()
+    wsb = L.npcd_shade_workspace_bytes(P, hidden)
+    work = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    check(L.npcd_shade_points(ptr(wpack), feat_dim, n_freqs, hidden, ptr(nb_idx), ptr(pts), ptr(kp_pos), ptr(kp_feat),
+                              ptr(n_points), P, k, ptr(sigma), ptr(rgb), ptr(work), stream_ptr()), "npcd_shade_points")
+    return sigma, rgb
+
+
+def ray_march(sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1, white_back=True):
+    """sigma [P], rgb [P,3] compact (row-major over valid [ray, slot]); slot_valid [Nr,M] bool/uint8,
+    slot_loc [Nr,M,3], point_base [Nr] int32 -> mask [Nr], depth [Nr], channels [Nr,3]."""
+    require_gpu(sigma, slot_valid, slot_loc)
+    Nr, M = slot_valid.shape
+    dev = slot_loc.device
+    sv = slot_valid.to(torch.uint8).contiguous()
+    mask = torch.empty(Nr, dtype=_f32, device=dev)
+    depth = torch.empty(Nr, dtype=_f32, device=dev)
+    chan = torch.empty((Nr, 3), dtype=_f32, device=dev)
+    ws = torch.empty(4, dtype=_f32, device=dev)
+    if sigma.numel() == 0:                      # keep the pointers valid
+        sigma = torch.zeros(1, dtype=_f32, device=dev)
+        rgb = torch.zeros((1, 3), dtype=_f32, device=dev)
+    check(lib().npcd_ray_march(ptr(sigma.contiguous()), ptr(rgb.contiguous()), ptr(sv), ptr(slot_loc.contiguous()),
+                               ptr(point_base.to(_i32).contiguous()), ptr(rays_o.contiguous()), ptr(rays_d.contiguous()),
+                               ptr(t1.contiguous()), Nr, M, int(bool(white_back)), ptr(mask), ptr(depth), ptr(chan), ptr(ws),
+                               stream_ptr()), "npcd_ray_march")
+    return mask, depth, chan

@@ -1,0 +1,102 @@
+"""PointNeRF field: neighbour aggregator + density / colour heads, evaluated by the fused HIP
+shading kernels.  Parameter names follow the reference:
+
+    field.aggregator.local_field.{0,2,4,6,8}   Linear(F+63,256), 3x Linear(256,256), Linear(256,256)
+    field.shape_net.{0,2}                      Linear(256,256), Linear(256,1)
+    field.channel_net.{0,2,4,6,8}              4x Linear(256,256), Linear(256,3)
+
+(reference: fields/field.py, fields/mlp.py, fields/aggregators/{aggregator,mlp}.py, utils/model.py:22-36)."""
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from ...hip import render as hr
+
+
+def define_mlp(dims, d_in, d_out=None, act="LeakyReLU"):
+    """Linear layers at even indices, activations at odd ones (utils/model.py:22-36, layer_norm=False)."""
+    mods, cur = [], d_in
+    for dim in dims:
+        mods += [nn.Linear(cur, dim), getattr(nn, act)(inplace=True)]
+        cur = dim
+    if d_out is not None:
+        mods.append(nn.Linear(cur, d_out))
+    return nn.Sequential(*mods)
+
+
+class Aggregator(nn.Module):
+    """Holds the per-pair MLP and the neighbour-query settings (aggregator.py:12-23, aggregators/mlp.py:13-34)."""
+
+    def __init__(self, in_dim, voxel_grid, k, r, max_shading_pts, ray_subsamples, out_dim, n_freqs, layers,
+                 activation="LeakyReLU", layer_norm=False, freq_mult=1, **unused):
+        super().__init__()
+        assert k > 0, "k for kNN has to be greater than zero"
+        if layer_norm or freq_mult != 1:
+            raise NotImplementedError("the HIP shading kernels implement the reference configuration "
+                                      "(layer_norm=False, freq_mult=1; pointnerf.py:174-179)")
+        self.in_dim, self.voxel_grid = in_dim, voxel_grid
+        self.k, self.r, self.max_shading_pts = k, r, max_shading_pts
+        self.scaled_r = r if voxel_grid is None else r * max(voxel_grid.vsize_tup)
+        self.ray_subsamples, self.out_dim, self.n_freqs = ray_subsamples, out_dim, n_freqs
+        self.local_field = define_mlp(layers, in_dim + 3 * (1 + 2 * n_freqs), out_dim, activation)
+
+    # ---- reference helper surface (used by neural_point_cloud_tv_loss.py:44,62,64) ----------------
+    def query_keypoints(self, x: torch.Tensor, kp_pos: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """x [B,T,R,S,3], kp_pos [B,N,3] -> neighbor_idx [P,k] int64 (-1 pad), shading_pts [P,3],
+        mask [B,T,R,M,1] bool (aggregator.py:25-76).  Requires a preceding voxel_grid.set_pointset."""
+        B, T, R, S = x.shape[:4]
+        M = self.max_shading_pts
+        if self.voxel_grid is None:
+            grid = hr.HipVoxelGrid((0.04,) * 3, (2,) * 3, (3,) * 3, 4, 5000, (-1, -1, -1, 1, 1, 1))
+            idx, loc, _, nsel = grid.query_dense(self.k, self.r, M, x=x.flatten(1, 2), mode=1, points=kp_pos)
+        else:
+            idx, loc, _, nsel = self.voxel_grid.query_dense(self.k, self.r, M, x=x.flatten(1, 2), mode=0)
+        valid = idx[..., 0] >= 0                                  # lists are sorted: slot valid iff first entry valid
+        return idx[valid].long(), loc[valid], valid.view(B, T, R, M, 1)
+
+    @staticmethod
+    def get_keypoint_data(neighbor_idx, mask, kp_pos=None, kp_feat=None) -> Dict[str, torch.Tensor]:
+        data = torch.cat([t for t in (kp_pos, kp_feat) if t is not None], dim=-1)
+        rows = data.reshape(-1, data.shape[-1])[neighbor_idx.clamp_min(0)][mask]
+        out = {}
+        if kp_pos is not None:
+            out["pos"], rows = rows[:, :3], rows[:, 3:]
+        if kp_feat is not None:
+            out["feat"] = rows
+        return out
+
+    @staticmethod
+    def mask_to_batch_ray_idx(valid_neighbor_mask):
+        n = valid_neighbor_mask.shape[0]
+        return torch.arange(n, device=valid_neighbor_mask.device)[:, None].expand_as(valid_neighbor_mask)[valid_neighbor_mask]
+
+
+class Field(nn.Module):
+    def __init__(self, in_dim: int, voxel_grid, aggregator: dict, feat_freqs=0, dir_freqs=8, channel_layers=(256,) * 4,
+                 shape_layers=(256,), activation="LeakyReLU", layer_norm=False, nerf=True, use_dir=False, **unused):
+        super().__init__()
+        if use_dir or feat_freqs or layer_norm or not nerf:
+            raise NotImplementedError("HIP shading implements the published configuration: use_view_dir=False "
+                                      "(configs/npcd_srncars.yaml:8), feat_freqs=0, layer_norm=False, nerf=True")
+        self.aggregator = Aggregator(in_dim, voxel_grid, **aggregator["kwargs"])
+        self.hid_dim = self.aggregator.out_dim
+        self.nerf, self.use_dir = nerf, use_dir
+        self.channel_net = define_mlp(list(channel_layers), self.hid_dim, 3, activation)
+        self.shape_net = define_mlp(list(shape_layers), self.hid_dim, 1, activation)
+        self._pack: Optional[torch.Tensor] = None
+        self._pack_key = None
+
+    def packed_weights(self, device) -> torch.Tensor:
+        """fp16 fragment-ordered copy of all 12 Linear layers; rebuilt when a parameter changed."""
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._pack is None or key != self._pack_key:
+            self._pack = hr.pack_field_weights(self.state_dict(), self.aggregator.in_dim, device, self.aggregator.n_freqs, self.hid_dim)
+            self._pack_key = key
+        return self._pack
+
+    def shade(self, nb_idx, pts, kp_pos, kp_feat):
+        """compact shading points -> sigma [P] (softplus(x-1) applied), rgb [P,3] (sigmoid applied)."""
+        return hr.shade_points(self.packed_weights(pts.device), self.aggregator.in_dim, nb_idx, pts,
+                               kp_pos.reshape(-1, 3), kp_feat.reshape(-1, kp_feat.shape[-1]),
+                               n_freqs=self.aggregator.n_freqs, hidden=self.hid_dim)

@@ -1,0 +1,52 @@
+"""Volume renderer (reference renderers/{renderer,volume_renderer,ray_sampler,math_utils}.py) as one
+device-side pipeline: ray generation -> neighbour query -> fused shading -> ray march."""
+import torch
+import torch.nn as nn
+
+from ...hip import render as hr
+from ...utils import AttrDict
+
+
+class VolumeRenderer(nn.Module):
+    def __init__(self, field, cube_scale: float, depth_resolution: int, ray_limits=None, ray_subsamples: int = 0,
+                 disparity_space_sampling: bool = False, white_back: bool = False):
+        super().__init__()
+        if ray_limits is not None or disparity_space_sampling:
+            raise NotImplementedError("HIP renderer implements the published configuration (pointnerf.py:181-190)")
+        self.field = field                     # registered twice like the reference (renderer.py:26) -> duplicated keys
+        self.cube_scale, self.depth_resolution = cube_scale, depth_resolution
+        self.ray_subsamples, self.white_back = ray_subsamples, white_back
+        self.randomize_depth_samples = False
+
+    def forward(self, kp_pos, kp_feat, extr, intr, resolution: int, sample: bool, return_channels: bool = True,
+                return_kp_weights: bool = False, knn_mode: int = 0):
+        """kp_pos [B,N,3], kp_feat [B,N,F], extr [B,T,4,4] world2cam, intr [B,T,3,3] ->
+        AttrDict(mask [B,T,R,1], depth [B,T,R,1], channels [B,T,R,3])   (renderer.py:202-268)."""
+        if sample or self.randomize_depth_samples:
+            raise NotImplementedError("training-mode rendering (ray subsampling, jittered depths; renderer.py:74-76,"
+                                      "232-238) is not part of the inference hot path yet")
+        if return_kp_weights:
+            raise NotImplementedError("return_kp_weights")
+        B, T = extr.shape[:2]
+        agg = self.field.aggregator
+        grid = agg.voxel_grid
+        o, d, t0, t1 = hr.ray_gen(extr.flatten(0, 1), intr.flatten(0, 1), resolution, self.cube_scale)
+        R = o.shape[1]
+        rays = (o.view(B, T * R, 3), d.view(B, T * R, 3), t0.view(B, T * R), t1.view(B, T * R))
+        idx, loc, _, _ = grid.query_dense(agg.k, agg.r if knn_mode == 0 else agg.scaled_r, agg.max_shading_pts, rays=rays,
+                                          S=self.depth_resolution, mode=knn_mode, points=kp_pos)
+        M = agg.max_shading_pts
+        valid = (idx[..., 0] >= 0).view(B * T * R, M)
+        per_ray = valid.sum(dim=1, dtype=torch.int32)
+        base = torch.cumsum(per_ray, dim=0, dtype=torch.int32) - per_ray
+        nb = idx.view(B * T * R, M, agg.k)[valid]                     # compact, row-major over [ray, slot]
+        pts = loc.view(B * T * R, M, 3)[valid]
+        sigma, rgb = self.field.shade(nb, pts, kp_pos, kp_feat)
+        mask, depth, chan = hr.ray_march(sigma, rgb, valid, loc.view(B * T * R, M, 3), base, o.view(-1, 3), d.view(-1, 3),
+                                         t1.reshape(-1), self.white_back)
+        out = AttrDict(mask=mask.view(B, T, R, 1), depth=depth.view(B, T, R, 1))
+        if return_channels:
+            out["channels"] = chan.view(B, T, R, 3)
+        out["num_shading_points"] = int(nb.shape[0])
+        out["num_pairs"] = int((nb >= 0).sum())
+        return out
