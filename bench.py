@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Benchmark of the NPCD hot path on MI355X (contract: see the repo-level task description).
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one denoiser training step of BASELINE.json configs[1]: zero_grad + forward (bf16
+autocast) + backward + AdamW + EMA on 512 points x 128-d latents, width 1024 / 24 layers / 16 heads,
+GLOBAL batch 64 (strong scaling: 64/N samples per GPU, gradients averaged with an RCCL all-reduce).
+Rank 0 prints ONE JSON line.  `value` = denoiser train steps/s of the whole job; the renderer half of
+the BASELINE metric (rays/s for 128x128 views, k=8, 128 depth samples) is measured in its own timed
+region and reported under "render".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "neural-point-cloud-diffusion_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+CFG = dict(coords_dim=3, feats_dim=128, num_points=512, width=1024, layers=24, heads=16, global_batch=64)
+PEAK_BF16_TFLOPS = 2500.0     # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+def denoiser_flops_per_sample():
+    """fwd = L(24 n W^2 + 4 n^2 W) + 2 N 2(3+F) W + 16 W^2, n = N+1; step = 3x."""
+    W, L, N, F_ = CFG["width"], CFG["layers"], CFG["num_points"], CFG["feats_dim"]
+    n = N + 1
+    fwd = L * (24 * n * W * W + 4 * n * n * W) + 2 * N * 2 * (3 + F_) * W + 16 * W * W
+    return 3 * fwd
+
+
+def build_trainer(device, per_rank_batch):
+    from npcd.models.diffusion import DiffusionModel
+    from npcd.train import DiffusionTrainer
+    torch.manual_seed(1234)                       # identical weights on every rank
+    model = DiffusionModel(CFG["coords_dim"], CFG["feats_dim"], CFG["num_points"], CFG["width"], CFG["layers"], CFG["heads"], True)
+    torch.nn.init.normal_(model.denoiser.output_proj.weight, std=0.02)    # non-zero so grads are non-trivial
+    model = model.to(device).train()
+    return DiffusionTrainer(model, lr=7e-5, weight_decay=0.01, ema_decay=0.9999, dtype=torch.bfloat16)
+
+
+def synthetic_batch(global_batch, rank, world, device):
+    g = torch.Generator().manual_seed(42)
+    coords = torch.randn(global_batch, CFG["coords_dim"], CFG["num_points"], generator=g)
+    feats = torch.rand(global_batch, CFG["feats_dim"], CFG["num_points"], generator=g) * 2 - 1
+    per = global_batch // world
+    sl = slice(rank * per, (rank + 1) * per)
+    return coords[sl].to(device), feats[sl].to(device)
+
+
+def bench_render(device, n_iters=10, burn_in=3):
+    """pointnerf_evaluation.py:217-224 protocol: sync, t0, render, sync, t1; 3 burn-in renders discarded."""
+    from oracle import renderer as orr     # synthetic scene helpers only (inputs), not the measured path
+    from npcd.models.pointnerf import PointNeRF
+    coords, feats = orr.synthetic_cloud(512, 32, 1, seed=0)
+    fp = orr.init_field_params(32, seed=0)
+    net = PointNeRF(1, 32, 512, False)
+    net.field.load_state_dict(fp)
+    net = net.to(device).eval()
+    extr = orr.look_at_pose(30, 20)[None, None].to(device)
+    intr = orr.srn_intrinsics()[None, None].to(device)
+    c, f = coords.to(device), feats.to(device)
+    with torch.no_grad():
+        for _ in range(burn_in):
+            out = net.render(c, f, extr, intr, 128)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_iters):
+            out = net.render(c, f, extr, intr, 128)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_iters
+    P, Q = out["num_shading_points"], out["num_pairs"]
+    flops = Q * 2 * (95 * 256 + 3 * 256 * 256) + P * 2 * (256 * 256 * 6 + 256 + 3 * 256)   # as executed (last agg layer on points)
+    return {"rays_per_s": 128 * 128 / dt, "ms_per_view": dt * 1e3, "resolution": 128, "depth_samples": 128, "k": 8,
+            "shading_points": P, "pairs": Q, "mlp_tflops": flops / dt / 1e12,
+            "mlp_frac_of_f16_mfma_peak": flops / dt / 1e12 / PEAK_BF16_TFLOPS}
+
+
+def cpu_baseline():
+    """The CPU oracle (a restatement of the reference, `kind: port`) timed on this box's host cores:
+    one fp32 denoiser train step (fwd + bwd + AdamW) at B=2 of the same architecture, scaled to the
+    B=64 step; plus one 64x64 render (grid semantics) for the rays/s half."""
+    from oracle import denoiser as od, diffusion as odf, renderer as orr
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    B = 2
+    params = od.init_params(CFG["coords_dim"], CFG["feats_dim"], CFG["width"], CFG["layers"], CFG["heads"], seed=0)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    opt = torch.optim.AdamW(list(leaves.values()), lr=7e-5, weight_decay=0.01)
+    g = torch.Generator().manual_seed(42)
+    c0 = torch.randn(B, 3, CFG["num_points"], generator=g)
+    f0 = torch.rand(B, CFG["feats_dim"], CFG["num_points"], generator=g) * 2 - 1
+    tab = odf.schedule_tables()
+    t = torch.randint(0, 1000, (B,), generator=g)
+    cn, fn = torch.randn_like(c0), torch.randn_like(f0)
+
+    def step():
+        opt.zero_grad()
+        loss, _, _ = odf.p_losses(tab, lambda c, f, tt: od.denoiser_forward(leaves, c, f, tt, CFG["heads"]), c0, f0, t, cn, fn)
+        loss.backward()
+        opt.step()
+
+    t0 = time.perf_counter(); step(); dt = time.perf_counter() - t0
+    steps_per_s = (B / dt) / CFG["global_batch"]
+    fp = orr.init_field_params(32, seed=0)
+    coords, feats = orr.synthetic_cloud(512, 32, 1, seed=0)
+    res = 64
+    K = orr.srn_intrinsics().clone(); K[0, 0] = K[1, 1] = 131.25 * res / 128; K[0, 2] = K[1, 2] = res / 2
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        orr.render(fp, coords, feats, orr.look_at_pose(30, 20)[None, None], K[None, None], res=res)
+    dtr = time.perf_counter() - t0
+    return {"value": steps_per_s, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (fp32 PyTorch CPU restatement of the reference): 1 denoiser train step at B={B} of {CFG['global_batch']} "
+                      f"({dt:.1f} s, scaled to the B=64 step) ; render: one {res}x{res} view = {dtr:.1f} s",
+            "render_rays_per_s": res * res / dtr}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-render", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)     # "nccl" is RCCL on ROCm
+    if CFG["global_batch"] % world:
+        raise SystemExit("global batch 64 must be divisible by the number of GPUs")
+    per = CFG["global_batch"] // world
+
+    from npcd.hip import attention as hattn
+    trainer = build_trainer(device, per)
+    coords, feats = synthetic_batch(CFG["global_batch"], rank, world, device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(coords, feats)
+    barrier()
+    hattn.KERNEL_EVENTS = {"fwd": [], "dq": [], "dkdv": []}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = trainer.step(coords, feats)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    events, hattn.KERNEL_EVENTS = hattn.KERNEL_EVENTS, None
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    assert torch.isfinite(loss), "training diverged"
+
+    kern_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / max(1, len(v))) for k, v in events.items()}
+    n = CFG["num_points"] + 1
+    unit_flops = 2 * per * CFG["heads"] * n * n * 64          # one B x H x n x n x d product
+    alg = {"fwd": 2 * unit_flops, "dq": 3 * unit_flops, "dkdv": 4 * unit_flops}
+    dominant = max(kern_ms, key=lambda k: kern_ms[k])
+    achieved = alg[dominant] / (kern_ms[dominant] * 1e-3) / 1e12
+
+    result = {
+        "metric": "denoiser train steps/sec (+ rendered rays/sec under 'render'), SRN-Cars 512pt x 128d",
+        "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: denoiser fwd/bwd + AdamW + EMA, 512 points x 128-d latents, "
+                               "width 1024 / 24 layers / 16 heads (seq 513), bf16 autocast",
+                   "global_batch": CFG["global_batch"], "per_gpu_batch": per, "parallelism": f"dp{world}"},
+        "step_tflops": denoiser_flops_per_sample() * CFG["global_batch"] / (elapsed / args.steps) / 1e12,
+        "step_frac_of_bf16_mfma_peak": denoiser_flops_per_sample() * CFG["global_batch"] / (elapsed / args.steps) / 1e12
+                                       / (PEAK_BF16_TFLOPS * world),
+        "roofline": {"kernel": {"fwd": "attn_fwd_kernel", "dq": "attn_bwd_dq_kernel", "dkdv": "attn_bwd_dkdv_kernel"}[dominant],
+                     "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                     "avg_ms": kern_ms[dominant], "launches": len(events[dominant]),
+                     "all_attention_kernels_ms": kern_ms,
+                     "all_attention_kernels_tflops": {k: alg[k] / (kern_ms[k] * 1e-3) / 1e12 for k in kern_ms}},
+        "loss": float(loss),
+    }
+    if not args.no_render:
+        r = bench_render(device)
+        if world > 1:       # every rank renders its own views: aggregate rays/s
+            tt = torch.tensor([r["rays_per_s"]], device=device, dtype=torch.float64)
+            dist.all_reduce(tt)
+            r["rays_per_s_all_gpus"] = float(tt)
+        result["render"] = r
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline()
+            result["gpu_over_cpu"] = {"denoiser_steps": result["value"] / result["cpu_baseline"]["value"]}
+            if "render" in result:
+                result["gpu_over_cpu"]["render_rays"] = result["render"]["rays_per_s"] / result["cpu_baseline"]["render_rays_per_s"]
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -66,6 +66,17 @@ int npcd_attn_bwd(const void* q, const void* k, const void* v, const void* out, 
                   int64_t g_sb, int64_t g_sn, int64_t g_sh,
                   float scale, int dtype, void* stream);
 
+/* One pass of the backward on its own: pass 1 = dq (also writes delta), pass 2 = dk/dv (reads delta,
+ * so pass 1 must have run).  Same arguments as npcd_attn_bwd.  Lets a caller time / schedule the two
+ * kernels separately. */
+int npcd_attn_bwd_pass(int pass, const void* q, const void* k, const void* v, const void* out, const void* dout,
+                       const float* lse, void* dq, void* dk, void* dv, float* delta,
+                       int B, int n, int H, int d,
+                       int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh,
+                       int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                       int64_t g_sb, int64_t g_sn, int64_t g_sh,
+                       float scale, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Voxel grid (torch_knnquery.VoxelGrid).  The grid description is passed by value.
  * ------------------------------------------------------------------------------------------ */

@@ -486,13 +486,15 @@ extern "C" int npcd_attn_fwd(const void* q, const void* k, const void* v, void* 
     return NPCD_OK;
 }
 
-extern "C" int npcd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
-                             void* dq, void* dk, void* dv, float* delta, int B, int n, int H, int d,
-                             int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
-                             int64_t g_sb, int64_t g_sn, int64_t g_sh, float scale, int dtype, void* stream) {
+static int attn_bwd_launch(int passes, const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                           void* dq, void* dk, void* dv, float* delta, int B, int n, int H, int d,
+                           int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                           int64_t g_sb, int64_t g_sn, int64_t g_sh, float scale, int dtype, void* stream) {
     int rc = check_common(B, n, H, d, dtype);
     if (rc != NPCD_OK) return rc;
-    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !delta) return NPCD_ERR_ARG;
+    if (!q || !k || !v || !out || !dout || !lse || !delta) return NPCD_ERR_ARG;
+    if ((passes & 1) && !dq) return NPCD_ERR_ARG;
+    if ((passes & 2) && (!dk || !dv)) return NPCD_ERR_ARG;
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(dq) ||
         !aligned16(dk) || !aligned16(dv))
         return NPCD_ERR_ARG;
@@ -508,25 +510,38 @@ extern "C" int npcd_attn_bwd(const void* q, const void* k, const void* v, const 
     const int grid = B * H * ceil_div(n, 128);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int dyn = 2 * kDkdvBuf;
+    static bool attr_set = false;
+    if (!attr_set) {
+        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<BF16>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<F16>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+        attr_set = true;
+    }
     if (dtype == NPCD_BF16) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<BF16>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<BF16>, dim3(grid), dim3(256), 0, st, p);
-        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<BF16>, dim3(grid), dim3(256), dyn, st, p);
+        if (passes & 1) hipLaunchKernelGGL(attn_bwd_dq_kernel<BF16>, dim3(grid), dim3(256), 0, st, p);
+        if (passes & 2) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<BF16>, dim3(grid), dim3(256), dyn, st, p);
     } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<F16>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<F16>, dim3(grid), dim3(256), 0, st, p);
-        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<F16>, dim3(grid), dim3(256), dyn, st, p);
+        if (passes & 1) hipLaunchKernelGGL(attn_bwd_dq_kernel<F16>, dim3(grid), dim3(256), 0, st, p);
+        if (passes & 2) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<F16>, dim3(grid), dim3(256), dyn, st, p);
     }
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
+}
+
+extern "C" int npcd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                             void* dq, void* dk, void* dv, float* delta, int B, int n, int H, int d,
+                             int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                             int64_t g_sb, int64_t g_sn, int64_t g_sh, float scale, int dtype, void* stream) {
+    return attn_bwd_launch(3, q, k, v, out, dout, lse, dq, dk, dv, delta, B, n, H, d, qkv_sb, qkv_sn, qkv_sh, out_sb, out_sn, out_sh,
+                           g_sb, g_sn, g_sh, scale, dtype, stream);
+}
+
+extern "C" int npcd_attn_bwd_pass(int pass, const void* q, const void* k, const void* v, const void* out, const void* dout,
+                                  const float* lse, void* dq, void* dk, void* dv, float* delta, int B, int n, int H, int d,
+                                  int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                                  int64_t g_sb, int64_t g_sn, int64_t g_sh, float scale, int dtype, void* stream) {
+    if (pass != 1 && pass != 2) return NPCD_ERR_ARG;
+    return attn_bwd_launch(pass, q, k, v, out, dout, lse, dq, dk, dv, delta, B, n, H, d, qkv_sb, qkv_sn, qkv_sh, out_sb, out_sn, out_sh,
+                           g_sb, g_sn, g_sh, scale, dtype, stream);
 }

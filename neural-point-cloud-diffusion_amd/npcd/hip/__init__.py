@@ -32,6 +32,7 @@ SIGNATURES = {
     "npcd_last_hip_error": (c_char_p, []),
     "npcd_attn_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int] + [c_int64] * 6 + [c_float, c_int, _P]),
     "npcd_attn_bwd": (c_int, [_P] * 10 + [c_int] * 4 + [c_int64] * 9 + [c_float, c_int, _P]),
+    "npcd_attn_bwd_pass": (c_int, [c_int] + [_P] * 10 + [c_int] * 4 + [c_int64] * 9 + [c_float, c_int, _P]),
     "npcd_grid_workspace_bytes": (c_int64, [POINTER(GridParams), c_int, c_int]),
     "npcd_grid_build": (c_int, [POINTER(GridParams), _P, _P, c_int, c_int, _P, _P]),
     "npcd_grid_query": (c_int, [POINTER(GridParams), _P, _P] + [c_int] * 6 + [c_float, c_int] + [_P] * 9 + [_P]),

@@ -16,20 +16,41 @@ def _fwd(q, k, v, scale):
     out = torch.empty((B, n, H, d), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, n), dtype=torch.float32, device=q.device)
     assert q.stride() == k.stride() == v.stride() and q.stride(3) == 1
-    check(lib().npcd_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), B, n, H, d,
-                              q.stride(0), q.stride(1), q.stride(2), out.stride(0), out.stride(1), out.stride(2),
-                              scale, dtype_code(q), stream_ptr()), "npcd_attn_fwd")
+    check(_timed("fwd", lambda: lib().npcd_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), B, n, H, d,
+                                                    q.stride(0), q.stride(1), q.stride(2), out.stride(0), out.stride(1),
+                                                    out.stride(2), scale, dtype_code(q), stream_ptr())), "npcd_attn_fwd")
     return out, lse
+
+
+# When set to a dict {"fwd": [], "dq": [], "dkdv": []}, every launch is bracketed by HIP events recorded
+# on the launch stream (bench.py measures the kernels in situ with it).
+KERNEL_EVENTS = None
+
+
+def _timed(tag, fn):
+    if KERNEL_EVENTS is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn()
+    e1.record()
+    KERNEL_EVENTS[tag].append((e0, e1))
+    return rc
 
 
 def _bwd(q, k, v, out, dout, lse, dq, dk, dv, scale):
     B, n, H, d = q.shape
     delta = torch.empty((B, H, n), dtype=torch.float32, device=q.device)
     assert dq.stride() == dk.stride() == dv.stride() and dout.stride() == out.stride()
-    check(lib().npcd_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(dq), ptr(dk), ptr(dv),
-                              ptr(delta), B, n, H, d, q.stride(0), q.stride(1), q.stride(2),
-                              out.stride(0), out.stride(1), out.stride(2), dq.stride(0), dq.stride(1), dq.stride(2),
-                              scale, dtype_code(q), stream_ptr()), "npcd_attn_bwd")
+    args = (ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(dq), ptr(dk), ptr(dv),
+            ptr(delta), B, n, H, d, q.stride(0), q.stride(1), q.stride(2),
+            out.stride(0), out.stride(1), out.stride(2), dq.stride(0), dq.stride(1), dq.stride(2),
+            scale, dtype_code(q), stream_ptr())
+    if KERNEL_EVENTS is None:
+        check(lib().npcd_attn_bwd(*args), "npcd_attn_bwd")
+    else:
+        check(_timed("dq", lambda: lib().npcd_attn_bwd_pass(1, *args)), "npcd_attn_bwd_pass(dq)")
+        check(_timed("dkdv", lambda: lib().npcd_attn_bwd_pass(2, *args)), "npcd_attn_bwd_pass(dkdv)")
 
 
 def _check_input(x):

@@ -1,0 +1,164 @@
+"""Denoiser training step for MI355X: flat parameter / gradient / optimizer-state buffers, bucketed
+gradient all-reduce over RCCL overlapped with backward, AdamW + EMA over the flat buffers.
+
+Reproduces one iteration of the reference loop (npcd/train/diffusion_training.py:143-174):
+zero_grad -> autocast(compute_loss) -> backward -> AdamW step (lr 7e-5, wd 0.01 on every parameter,
+:116) -> EMA update (decay 0.9999 on parameters, buffers copied; utils/ema.py:114-138).  The reference
+is single-GPU; data parallelism over diffusion samples (one process per GPU, gradients averaged with
+an all-reduce) is what this build adds.
+
+Memory layout: all trainable parameters of `model` live in ONE contiguous fp32 buffer (each
+nn.Parameter is a view), likewise gradients, Adam moments and the EMA copy.  The optimizer and the
+EMA are then single elementwise passes over 310 M contiguous floats and the gradient all-reduce
+works on slices of one buffer -- no per-tensor launches, no flatten/unflatten copies.
+"""
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+class FlatBuffers:
+    """Re-home the trainable parameters of `module` into one flat buffer (+ flat grads)."""
+
+    def __init__(self, module: nn.Module):
+        self.params: List[nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        dev, dt = self.params[0].device, self.params[0].dtype
+        assert all(p.dtype == dt and p.device == dev for p in self.params)
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4                 # keep every view 16-byte aligned
+        self.numel = n
+        self.flat = torch.zeros(n, dtype=dt, device=dev)
+        self.grad = torch.zeros(n, dtype=dt, device=dev)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                view = self.flat[off:off + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.grad[off:off + p.numel()].view_as(p)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, off in zip(self.params, self.offsets):     # re-attach in case something replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + off * self.grad.element_size():
+                p.grad = self.grad[off:off + p.numel()].view_as(p)
+
+
+class GradReducer:
+    """Bucketed all-reduce(mean) of the flat gradient buffer, overlapped with backward.
+
+    Buckets are contiguous slices of the flat gradient in REVERSE parameter order (the order backward
+    produces them); a bucket's collective is launched from the post-accumulate-grad hook of its last
+    parameter to become ready.  `finish()` waits for all of them."""
+
+    def __init__(self, flat: FlatBuffers, group=None, bucket_bytes: int = 64 << 20):
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.handles = []
+        self.buckets = []           # (start, end) element ranges
+        self.param_bucket = {}      # id(param) -> bucket index
+        self.pending: List[int] = []
+        per = max(1, bucket_bytes // flat.grad.element_size())
+        end = flat.numel
+        members, start_of = [], end
+        for p, off in reversed(list(zip(flat.params, flat.offsets))):
+            members.append(p)
+            start_of = off
+            if end - start_of >= per:
+                self._close(members, start_of, end)
+                members, end = [], start_of
+        if members:
+            self._close(members, start_of, end)
+        self._avg = None
+        if self.world > 1:
+            for p in flat.params:
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    def _close(self, members, start, end):
+        b = len(self.buckets)
+        self.buckets.append((start, end))
+        for p in members:
+            self.param_bucket[id(p)] = b
+        self.pending.append(len(members))
+
+    def start_step(self):
+        self.handles = []
+        self._left = list(self.pending)
+
+    def _launch(self, b):
+        s, e = self.buckets[b]
+        buf = self.flat.grad[s:e]
+        if self._avg is None:       # RCCL has a native average; gloo (CPU tests) does not
+            self._avg = dist.get_backend(self.group) == "nccl"
+        if self._avg:
+            self.handles.append((dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
+        else:
+            self.handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf))
+
+    def _hook(self, p):
+        b = self.param_bucket[id(p)]
+        self._left[b] -= 1
+        if self._left[b] == 0:
+            self._launch(b)
+
+    def finish(self):
+        if self.world == 1:
+            return
+        for b, left in enumerate(self._left):     # parameters that received no gradient this step
+            if left > 0:
+                self._launch(b)
+                self._left[b] = 0
+        for h, buf in self.handles:
+            h.wait()
+            if buf is not None:
+                buf.div_(self.world)
+        self.handles = []
+
+
+class DiffusionTrainer:
+    """One-process-per-GPU trainer of `model.diffusion` (a DiffusionModel)."""
+
+    def __init__(self, diffusion: nn.Module, lr: float = 7e-5, weight_decay: float = 0.01, ema_decay: Optional[float] = 0.9999,
+                 dtype: Optional[torch.dtype] = torch.bfloat16, group=None, bucket_bytes: int = 64 << 20, max_grad_norm=None):
+        self.model = diffusion
+        self.dtype = dtype
+        self.flat = FlatBuffers(diffusion)
+        self.reducer = GradReducer(self.flat, group, bucket_bytes)
+        # one "parameter" for the optimizer: the flat buffer itself
+        self.master = nn.Parameter(self.flat.flat, requires_grad=True)
+        self.master.grad = self.flat.grad
+        fused = self.flat.flat.is_cuda
+        self.optimizer = torch.optim.AdamW([self.master], lr=lr, weight_decay=weight_decay, fused=fused)
+        self.ema_decay = ema_decay
+        self.ema = self.flat.flat.clone() if ema_decay is not None else None
+        self.max_grad_norm = max_grad_norm
+        self.iteration = 0
+
+    def ema_state_dict(self):
+        """state_dict of the EMA model: same keys as the running model (utils/ema.py:80), buffers copied."""
+        sd = {k: v.clone() for k, v in self.model.state_dict().items()}
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        for p, off in zip(self.flat.params, self.flat.offsets):
+            sd[names[id(p)]] = self.ema[off:off + p.numel()].view_as(p).clone()
+        return sd
+
+    def step(self, coords, feats, t=None, coords_noise=None, feats_noise=None):
+        self.flat.zero_grad()
+        self.reducer.start_step()
+        dev_type = "cuda" if coords.is_cuda else "cpu"
+        with torch.autocast(dev_type, dtype=self.dtype, enabled=self.dtype is not None):
+            loss, sub, _ = self.model.compute_loss(coords, feats, t=t, coords_noise=coords_noise, feats_noise=feats_noise)
+        loss.backward()
+        self.reducer.finish()
+        if self.max_grad_norm is not None:
+            torch.nn.utils.clip_grad_norm_([self.master], self.max_grad_norm)
+        self.master.grad = self.flat.grad
+        self.optimizer.step()
+        if self.ema is not None:
+            self.ema.lerp_(self.flat.flat, 1.0 - self.ema_decay)
+        self.iteration += 1
+        return loss.detach(), sub

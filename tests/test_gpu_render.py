@@ -1,0 +1,259 @@
+"""GPU parity of the render path (through the C ABI) against the CPU oracle and the golden vectors.
+
+Bars:
+  * neighbour indices, slot sample ids, counts, slot positions: BIT-EXACT vs oracle/voxel_grid.py
+  * rays / limits: <= 2e-6 abs (fp32, different summation order in the 3x3 transform)
+  * shading (fp16 MFMA inputs, fp32 accumulation): sigma <= 2e-3 * max(1, sigma), rgb <= 2e-3 abs
+  * rendered pixels: max-abs <= 5e-3 and PSNR(hip, oracle) >= 50 dB  (north-star: PSNR within 0.1 dB)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import renderer as orr
+from oracle import voxel_grid as ovg
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _scene(res, n_views=2, N=512, F_=32, seed=0, B=1):
+    coords, feats = orr.synthetic_cloud(N, F_, B, seed=seed)
+    poses = [orr.look_at_pose(30 + 97 * i, 20 - 13 * i) for i in range(n_views)]
+    extr = torch.stack(poses)[None].expand(B, -1, -1, -1).contiguous()
+    K = orr.srn_intrinsics().clone()
+    K[0, 0] = K[1, 1] = 131.25 * res / 128
+    K[0, 2] = K[1, 2] = res / 2
+    intr = K[None, None].expand(B, n_views, 3, 3).contiguous()
+    return coords, feats, extr, intr
+
+
+def _model(F_, N, params):
+    from npcd.models.pointnerf import PointNeRF
+    m = PointNeRF(1, F_, N, False)
+    m.field.load_state_dict(params)
+    return m.cuda().eval()
+
+
+def test_ray_gen_matches_golden_and_oracle(golden):
+    from npcd.hip import render as hr
+    g = golden("rays")
+    for intr_key, okey, dkey in (("intr", "o8", "d8"), ("intr_skew", "o8_skew", "d8_skew")):
+        o, d, t0, t1 = hr.ray_gen(T(g["extr"]).cuda(), T(g[intr_key]).cuda(), 8)
+        np.testing.assert_allclose(o.cpu().numpy(), g[okey], atol=2e-6)
+        np.testing.assert_allclose(d.cpu().numpy(), g[dkey], atol=2e-6)
+    o, d, t0, t1 = hr.ray_gen(T(g["extr"]).cuda(), T(g["intr"]).cuda(), 8)
+    np.testing.assert_allclose(t0.cpu().numpy(), g["lim_start"][0, ..., 0], atol=2e-6)
+    np.testing.assert_allclose(t1.cpu().numpy(), g["lim_end"][0, ..., 0], atol=2e-6)
+    # partial miss: rays that miss the cube receive the global min start / max end (renderer.py:40-43)
+    o, d, t0, t1 = hr.ray_gen(T(g["extr"]).cuda(), T(g["intr_wide"]).cuda(), 8)
+    np.testing.assert_allclose(t0.cpu().numpy(), g["limw_start"][0, ..., 0], atol=2e-6)
+    np.testing.assert_allclose(t1.cpu().numpy(), g["limw_end"][0, ..., 0], atol=2e-6)
+    st = int(g["stride128"])
+    o, d, _, _ = hr.ray_gen(T(g["extr"]).cuda(), T(g["intr"]).cuda(), 128)
+    np.testing.assert_allclose(d.cpu().numpy()[:, ::st], g["d128"], atol=2e-6)
+
+
+def test_ray_gen_all_miss_keeps_sentinels():
+    from npcd.hip import render as hr
+    extr = orr.look_at_pose(10, 5)[None].clone()
+    extr[0, :3, 3] += torch.tensor([0.0, 60.0, 0.0])            # camera far off-axis: every ray misses
+    K = orr.srn_intrinsics()[None]
+    o, d, t0, t1 = hr.ray_gen(extr.cuda(), K.cuda(), 8)
+    ro, rd = orr.camera_rays(extr, K, 8)
+    s, e = orr.ray_box_limits(ro, rd)
+    assert float(s.max()) == -1.0 and float(e.max()) == -2.0
+    assert (t0.cpu() == -1).all() and (t1.cpu() == -2).all()
+
+
+@pytest.mark.parametrize("N,seed", [(512, 0), (64, 3), (2048, 5)])
+def test_grid_query_bit_exact(N, seed):
+    from npcd.hip import render as hr
+    res, S, M, k = 24, 128, 50, 8
+    coords, _, extr, intr = _scene(res, 2, N, 32, seed)
+    o, d = orr.camera_rays(extr[0], intr[0], res)
+    s, e = orr.ray_box_limits(o, d)
+    V, R = o.shape[:2]
+    ro, rd, rs, re = o.reshape(1, V * R, 3), d.reshape(1, V * R, 3), s.reshape(1, V * R), e.reshape(1, V * R)
+    x = (ro[:, :, None] + orr.depth_samples(rs[..., None], re[..., None], S)[..., None] * rd[:, :, None]).numpy()
+    g = ovg.VoxelGridOracle()
+    g.set_pointset(coords.numpy(), np.array([N], dtype=np.int32))
+    ridx, rloc, rnsel, rss = g.query_dense(x, k, 2.0, M)
+    hg = hr.HipVoxelGrid(**orr.DEFAULT_GRID)
+    hg.set_pointset(coords.cuda(), torch.full((1,), N, dtype=torch.int32, device="cuda"))
+    for kw in (dict(rays=(ro.cuda(), rd.cuda(), rs.cuda(), re.cuda()), S=S), dict(x=T(x).cuda())):
+        idx, loc, ss, nsel = hg.query_dense(k, 2.0, M, **kw)
+        np.testing.assert_array_equal(nsel.cpu().numpy(), rnsel)
+        np.testing.assert_array_equal(ss.cpu().numpy(), rss)
+        np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+        np.testing.assert_array_equal(loc.cpu().numpy(), rloc)
+    assert (ridx[..., 0] >= 0).sum() > 1000
+    # the torch_knnquery.VoxelGrid.query contract (compaction over rays)
+    from torch_knnquery import VoxelGrid
+    vg = VoxelGrid(**orr.DEFAULT_GRID)
+    assert vg.vsize_tup == (0.04, 0.04, 0.04)
+    vg.set_pointset(coords.cuda(), torch.full((1,), N, dtype=torch.int32, device="cuda"))
+    sidx, sloc, ray_mask = vg.query(T(x).cuda(), k, 2.0, M)
+    oidx, oloc, omask = g.query(x, k, 2.0, M)
+    np.testing.assert_array_equal(ray_mask.cpu().numpy(), omask)
+    np.testing.assert_array_equal(sidx.cpu().numpy(), oidx)
+    np.testing.assert_array_equal(sloc.cpu().numpy(), oloc)
+    # brute-force branch
+    bidx, bloc, bn = ovg.brute_force_query(x, coords.numpy(), k, 0.08, M)
+    idx, loc, ss, nsel = hg.query_dense(k, 0.08, M, x=T(x).cuda(), mode=1)
+    np.testing.assert_array_equal(idx.cpu().numpy(), bidx)
+    np.testing.assert_array_equal(nsel.cpu().numpy(), bn)
+    np.testing.assert_array_equal(loc.cpu().numpy(), bloc)
+
+
+def test_grid_capacity_limits_and_batches():
+    """> max_points_per_voxel points in one voxel, occupied-voxel cap, ragged counts, out-of-range points."""
+    from npcd.hip import render as hr
+    rng = np.random.default_rng(4)
+    B, N = 3, 96
+    pts = rng.normal(0, 0.25, size=(B, N, 3)).astype(np.float32)
+    pts[0, :12] = np.array([0.01, 0.01, 0.01], np.float32) + rng.uniform(0, 0.02, size=(12, 3)).astype(np.float32)
+    pts[1, 5] = [1.5, 0, 0]
+    pts[1, 6] = [np.nan, 0, 0]
+    pts[2, 7] = [1.0, 1.0, 1.0]                     # exactly on the upper bound -> outside
+    counts = np.array([N, N - 10, N], dtype=np.int32)
+    x = (pts[:, rng.integers(0, N, size=40)][:, :, None, :] + rng.normal(0, 0.03, size=(B, 40, 24, 3))).astype(np.float32)
+    for cap in (5000, 20):
+        cfg = dict(orr.DEFAULT_GRID, max_occ_voxels_per_example=cap)
+        g = ovg.VoxelGridOracle(**cfg)
+        g.set_pointset(pts, counts)
+        ridx, rloc, rnsel, rss = g.query_dense(x, 8, 2.0, 10)
+        hg = hr.HipVoxelGrid(**cfg)
+        hg.set_pointset(T(pts).cuda(), T(counts).cuda())
+        idx, loc, ss, nsel = hg.query_dense(8, 2.0, 10, x=T(x).cuda())
+        np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+        np.testing.assert_array_equal(nsel.cpu().numpy(), rnsel)
+        np.testing.assert_array_equal(ss.cpu().numpy(), rss)
+    # k < 8 and M < 8 paths
+    g = ovg.VoxelGridOracle(); g.set_pointset(pts, counts)
+    hg = hr.HipVoxelGrid(**orr.DEFAULT_GRID); hg.set_pointset(T(pts).cuda(), T(counts).cuda())
+    ridx, _, rnsel, _ = g.query_dense(x, 3, 2.0, 5)
+    idx, _, _, nsel = hg.query_dense(3, 2.0, 5, x=T(x).cuda())
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_array_equal(nsel.cpu().numpy(), rnsel)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        hg.query_dense(9, 2.0, 5, x=T(x).cuda())
+
+
+def test_shading_matches_reference_golden(golden):
+    """The reference's own neighbour lists (brute-force branch) and its own sigma / rgb."""
+    g = golden("render_brute")
+    p = orr.init_field_params(32, seed=int(g["field_seed"]))
+    m = _model(32, 64, p)
+    sig, rgb = m.field.shade(T(g["nb_idx"]).int().cuda(), T(g["shading_pts"]).cuda(), T(g["coords"]).cuda(), T(g["feats"]).cuda())
+    np.testing.assert_allclose(sig.cpu().numpy(), g["sigma"][:, 0], atol=2e-3)
+    np.testing.assert_allclose(rgb.cpu().numpy(), g["rgb"], atol=2e-3)
+
+
+@pytest.mark.parametrize("F_", [32, 128])
+def test_shading_large_weights(F_):
+    """Scaled-up weights (activations ~ O(10)) so that fp16 rounding is actually exercised."""
+    p = orr.init_field_params(F_, seed=5)
+    for kname in p:
+        if kname.endswith("weight"):
+            p[kname] = p[kname] * 1.7
+    coords, feats = orr.synthetic_cloud(256, F_, 1, seed=2)
+    gen = torch.Generator().manual_seed(0)
+    P = 1000
+    base = coords[0][torch.randint(0, 256, (P,), generator=gen)]
+    pts = base + torch.randn(P, 3, generator=gen) * 0.02
+    d = torch.cdist(pts, coords[0])
+    dist, nb = torch.topk(d, 8, largest=False)
+    nb[dist >= 0.08] = -1
+    nb[::7, 3:] = -1                                 # ragged neighbour counts
+    keep = (nb >= 0).any(dim=1)
+    nb, pts = nb[keep], pts[keep]
+    sig_ref, rgb_ref, _ = orr.shade_points(p, nb, pts, coords, feats)
+    m = _model(F_, 256, p)
+    sig, rgb = m.field.shade(nb.int().cuda(), pts.cuda(), coords.cuda(), feats.cuda())
+    es = ((sig.cpu() - sig_ref[:, 0]).abs() / sig_ref[:, 0].clamp_min(1.0)).max()
+    er = (rgb.cpu() - rgb_ref).abs().max()
+    assert float(es) < 5e-3 and float(er) < 5e-3, (float(es), float(er))
+
+
+def test_ray_march_golden(golden):
+    from npcd.hip import render as hr
+    g = golden("raymarch")
+    Nr, M = g["mask"].shape[2:4]
+    mask = T(g["mask"]).reshape(Nr, M)
+    per_ray = mask.sum(1).int()
+    base = (torch.cumsum(per_ray, 0) - per_ray).int()
+    sig_c = T(g["sigma"]).reshape(Nr, M)[mask]
+    tot, dep, ch = hr.ray_march(sig_c.cuda(), T(g["rgb_compact"]).cuda(), mask.cuda(), T(g["pts"]).reshape(Nr, M, 3).cuda(),
+                                base.cuda(), T(g["o"]).reshape(Nr, 3).cuda(), T(g["d"]).reshape(Nr, 3).cuda(),
+                                T(g["ray_end"]).reshape(Nr).cuda(), True)
+    np.testing.assert_allclose(tot.cpu().numpy(), g["out_mask"].reshape(Nr), atol=2e-6)
+    np.testing.assert_allclose(dep.cpu().numpy(), g["out_depth"].reshape(Nr), atol=2e-5)
+    np.testing.assert_allclose(ch.cpu().numpy(), g["out_channels"].reshape(Nr, 3), atol=2e-6)
+
+
+def test_render_matches_reference_golden_brute(golden):
+    """End to end against the reference's own rendering (its voxel_grid=None branch)."""
+    g = golden("render_brute")
+    p = orr.init_field_params(32, seed=int(g["field_seed"]))
+    m = _model(32, 64, p)
+    agg = m.field.aggregator
+    agg.max_shading_pts, agg.k = int(g["M"]), int(g["k"])
+    m.renderer.depth_resolution = int(g["S"])
+    with torch.no_grad():
+        out = m.renderer(T(g["coords"]).cuda(), T(g["feats"]).cuda(), T(g["extr"]).cuda(), T(g["intr"]).cuda(),
+                         int(g["res"]), False, knn_mode=1)
+    np.testing.assert_allclose(out["mask"].cpu().numpy(), g["out_mask"], atol=2e-3)
+    np.testing.assert_allclose(out["channels"].cpu().numpy(), g["out_channels"], atol=2e-3)
+    np.testing.assert_allclose(out["depth"].cpu().numpy(), g["out_depth"], atol=2e-3)
+
+
+@pytest.mark.parametrize("res,B,views", [(32, 2, 2), (128, 1, 1)])
+def test_render_vs_oracle_grid(res, B, views):
+    """Full pipeline (incl. BASELINE cfg 3: 128x128, k=8) vs the oracle with voxel-grid semantics."""
+    coords, feats, extr, intr = _scene(res, views, 512, 32, seed=1, B=B)
+    if B > 1:
+        coords[1] = coords[1].flip(-1) * 1.3              # a different cloud per batch element
+    p = orr.init_field_params(32, seed=0)
+    for kname in p:
+        if "shape_net.2" in kname:
+            p[kname] = p[kname] * 8 + 1.0                 # raise densities so the object is opaque-ish
+    m = _model(32, 512, p)
+    with torch.no_grad():
+        out = m.render(coords.cuda(), feats.cuda(), extr.cuda(), intr.cuda(), res)
+    ref = orr.render(p, coords, feats, extr, intr, res=res, mode="grid", return_aux=True)
+    assert out["num_shading_points"] == ref["aux"]["P"] and out["num_pairs"] == ref["aux"]["Q"]
+    assert float(ref["mask"].max()) > 0.5
+    for key in ("mask", "depth", "channels"):
+        err = float((out[key].cpu() - ref[key]).abs().max())
+        assert err < 5e-3, (key, err)
+    img_h = orr.unflatten_image(out["channels"].cpu())
+    img_r = orr.unflatten_image(ref["channels"])
+    assert orr.psnr(img_h, img_r) > 50.0
+
+
+def test_pointnerf_forward_surface():
+    """PointNeRF.forward(obj_idx, intrinsics, extrinsics, sample_rays) -> (pred, aux) like pointnerf.py:56-105."""
+    from npcd.models import NPCD
+    coords, feats, extr, intr = _scene(16, 1, 512, 32, seed=3, B=2)
+    net = NPCD(n_obj=5, coords_dim=3, feats_dim=32, num_points=512, use_view_dir=False, width=64, layers=1, heads=1,
+               pointnerf_only=True).cuda().eval()
+    net.pointnerf.opt.sizes.default_resolution = 16               # 128 in the reference (pointnerf.py:192)
+    net.pointnerf.set_all_coords(torch.cat([coords, coords, coords[:1]]).cuda())
+    with torch.no_grad():
+        table = net.pointnerf.feats.get_emb().weight.view(5, 512, 64)
+        table[:2, :, :32] = feats.cuda()
+        pred, aux = net.pointnerf(torch.tensor([0, 1]).cuda(), intr.cuda(), extr.cuda(), sample_rays=False)
+    assert pred.mask.shape == (2, 1, 256, 1) and pred.channels.shape == (2, 1, 256, 3) and pred.depth.shape == (2, 1, 256, 1)
+    assert set(aux) == {"coords", "feats", "feats_mean", "feats_log_var", "feats_std"}
+    fp = {k: v.cpu() for k, v in net.pointnerf.field.state_dict().items()}
+    ref = orr.render(fp, coords, feats, extr, intr, res=16)
+    assert float((pred.channels.cpu() - ref["channels"]).abs().max()) < 5e-3
+    with torch.no_grad():
+        r2 = net.pointnerf.render(coords.cuda(), feats.cuda(), extr.cuda(), intr.cuda(), resolution=16, max_shading_points=20)
+    ref2 = orr.render(fp, coords, feats, extr, intr, res=16, M=20)
+    assert float((r2.channels.cpu() - ref2["channels"]).abs().max()) < 5e-3
+    assert net.pointnerf.field.aggregator.max_shading_pts == 50
+    assert net.pointnerf.get_all_coords().shape == (5, 512, 3) and net.pointnerf.get_all_feats().shape == (5, 512, 32)
+    with pytest.raises(NotImplementedError):
+        net.pointnerf(torch.tensor([0]).cuda(), intr[:1].cuda(), extr[:1].cuda(), sample_rays=True)
