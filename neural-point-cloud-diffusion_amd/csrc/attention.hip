@@ -37,35 +37,27 @@ struct AttnParams {
 };
 
 // ---- tile staging (256 threads, 64 rows x 64 sixteen-bit elements) --------------------------
-// row-major image: thread t -> row t>>2, 16-byte chunks 2(t&3), 2(t&3)+1
+// thread t loads rows 2(t>>3), 2(t>>3)+1, 16-byte element chunk t&7 (8 lanes cover one 128-byte row);
+// the same registers feed the row-major image and/or the transposed image.
+// Rows past the end are CLAMPED to the last valid row instead of being predicated: the loads stay
+// branch-free (so the compiler can use counted s_waitcnt vmcnt(N) and keep a later tile in flight) and
+// the duplicated rows are neutralised downstream (masked scores / P = 0 / outputs never stored).
 template <class E>
-__device__ __forceinline__ void rm_load(u32x4 (&reg)[2], const E* base, int64_t row_stride, int row0, int nrows, int tid) {
-    const int grow = row0 + (tid >> 2);
-    if (grow < nrows) {
-        const u32x4* p = reinterpret_cast<const u32x4*>(base + grow * row_stride + (tid & 3) * 16);
-        reg[0] = p[0];
-        reg[1] = p[1];
-    } else {
-        reg[0] = u32x4{0, 0, 0, 0};
-        reg[1] = u32x4{0, 0, 0, 0};
-    }
-}
-__device__ __forceinline__ void rm_store(unsigned char* lds, const u32x4 (&reg)[2], int tid) {
-    const int row = tid >> 2, c0 = (tid & 3) * 2;
-    *reinterpret_cast<u32x4*>(lds + tile_off(row, c0)) = reg[0];
-    *reinterpret_cast<u32x4*>(lds + tile_off(row, c0 + 1)) = reg[1];
-}
-// transposed image T[d][pos(row)]: thread t -> rows 2(t>>3), 2(t>>3)+1, element chunk t&7.
-// Within each group of 16 rows, row 8a+4h+b is stored at position 8h+4a+b, so that the 8 rows a
-// lane-half h needs for one MFMA k-step (the accumulator-row order, acc_row()) are 16 contiguous
-// bytes.
-template <class E>
-__device__ __forceinline__ void tr_load(u32x4 (&reg)[2], const E* base, int64_t row_stride, int row0, int nrows, int tid) {
+__device__ __forceinline__ void pair_load(u32x4 (&reg)[2], const E* base, int64_t row_stride, int row0, int nrows, int tid) {
     const int grow = row0 + 2 * (tid >> 3);
-    const E* p = base + grow * row_stride + (tid & 7) * 8;
-    reg[0] = (grow < nrows) ? *reinterpret_cast<const u32x4*>(p) : u32x4{0, 0, 0, 0};
-    reg[1] = (grow + 1 < nrows) ? *reinterpret_cast<const u32x4*>(p + row_stride) : u32x4{0, 0, 0, 0};
+    const int r0 = min(grow, nrows - 1), r1 = min(grow + 1, nrows - 1);
+    reg[0] = *reinterpret_cast<const u32x4*>(base + r0 * row_stride + (tid & 7) * 8);
+    reg[1] = *reinterpret_cast<const u32x4*>(base + r1 * row_stride + (tid & 7) * 8);
 }
+// row-major image [row][64]
+__device__ __forceinline__ void rm_store(unsigned char* lds, const u32x4 (&reg)[2], int tid) {
+    const int row = 2 * (tid >> 3), dc = tid & 7;
+    *reinterpret_cast<u32x4*>(lds + tile_off(row, dc)) = reg[0];
+    *reinterpret_cast<u32x4*>(lds + tile_off(row + 1, dc)) = reg[1];
+}
+// transposed image T[d][pos(row)]: within each group of 16 rows, row 8a+4h+b is stored at position
+// 8h+4a+b, so that the 8 rows a lane-half h needs for one MFMA k-step (the accumulator-row order,
+// acc_row()) are 16 contiguous bytes.
 __device__ __forceinline__ void tr_store(unsigned char* lds, const u32x4 (&reg)[2], int tid) {
     const int row = 2 * (tid >> 3), dc = tid & 7;
     const int g = row >> 4, kl = row & 15;
@@ -105,8 +97,80 @@ __device__ __forceinline__ void store_rows(typename TR::elem* row_ptr, const f32
 // ============================================================================================
 // forward
 // ============================================================================================
+// exchange between lanes l and l^32 on the VALU (v_permlane32_swap), no LDS crossbar
+__device__ __forceinline__ float half_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// The running maximum is only advanced when a row's tile maximum exceeds it by more than kDeferLog2
+// (in log2 units): P is then bounded by 2^kDeferLog2 instead of 1, which costs nothing in bf16/f16
+// relative precision and removes the O-wide rescale from (almost) every tile after the first.
+// (Tried and rejected in round 1: subtracting m through an extra MFMA k-step and taking the row sum
+// from an all-ones MFMA block -- fewer vector instructions on paper, but hipcc's register allocation
+// for the retry loop spilled 51 VGPRs and the kernel ran 2x slower.)
+constexpr float kDeferLog2 = 8.f;
+
+template <class TR, bool MASK>
+__device__ __forceinline__ void fwd_tile(const unsigned char* Kc, const unsigned char* Vc, const typename TR::vec8 (&qf)[4], f32x16& o0,
+                                         f32x16& o1, float& m, float& l, float c, int key0, int n, int r, int hh) {
+    using E = typename TR::elem;
+    using V8 = typename TR::vec8;
+    f32x16 s0 = {0}, s1 = {0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        s0 = TR::mfma32(lds_frag<TR>(Kc, r, 2 * s + hh), qf[s], s0);
+        s1 = TR::mfma32(lds_frag<TR>(Kc, 32 + r, 2 * s + hh), qf[s], s1);
+    }
+    if (MASK) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k0 = key0 + acc_row(i, hh);
+            if (k0 >= n) s0[i] = -INFINITY;
+            if (k0 + 32 >= n) s1[i] = -INFINITY;
+        }
+    }
+    float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, s0[i]), s1[i]);
+    mx = half_max(mx) * c;   // c = scale * log2(e) > 0: m lives in the exp2 domain
+    if (__any(mx > m + kDeferLog2)) {
+        const float mn = (mx > m + kDeferLog2) ? mx : m;
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            o0[i] *= alpha;
+            o1[i] *= alpha;
+        }
+    }
+    float rs = 0.f;
+    V8 pf[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float a = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[j], c, -m)), b2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[8 + j], c, -m));
+        const float c2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[j], c, -m)), d2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[8 + j], c, -m));
+        rs += (a + b2) + (c2 + d2);
+        pf[0][j] = (E)a;
+        pf[1][j] = (E)b2;
+        pf[2][j] = (E)c2;
+        pf[3][j] = (E)d2;
+    }
+    l += rs;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        o0 = TR::mfma32(lds_frag<TR>(Vc, r, 2 * g + hh), pf[g], o0);
+        o1 = TR::mfma32(lds_frag<TR>(Vc, 32 + r, 2 * g + hh), pf[g], o1);
+    }
+}
+
 template <class TR>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384];
@@ -120,93 +184,51 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     const int q0 = qt * 128 + wave * 32;
     const bool wave_active = q0 < p.n;
     const int qrow = q0 + r;
+    const float c = p.scale_log2;
 
+    // Q fragments stay unscaled (scores are scaled in fp32 after the MFMA, identically in fwd and bwd, so
+    // that P recomputed in the backward matches the forward's LSE even for very large logits)
     V8 qf[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        u32x4 raw = (qrow < p.n) ? *reinterpret_cast<const u32x4*>(qb + qrow * p.sn + 16 * s + 8 * hh) : u32x4{0, 0, 0, 0};
-        qf[s] = __builtin_bit_cast(V8, raw);
-    }
+    for (int s = 0; s < 4; ++s)
+        qf[s] = *reinterpret_cast<const V8*>(qb + (int64_t)min(qrow, p.n - 1) * p.sn + 16 * s + 8 * hh);
     f32x16 o0 = {0}, o1 = {0};
     float m = -INFINITY, l = 0.f;
     const int nt = (p.n + 63) >> 6;
-    const float c = p.scale_log2;
 
-    u32x4 kreg[2], vreg[2];
-    rm_load(kreg, kb, p.sn, 0, p.n, tid);
-    tr_load(vreg, vb, p.sn, 0, p.n, tid);
-    rm_store(smem, kreg, tid);
-    tr_store(smem + 8192, vreg, tid);
+    // Register staging two tiles ahead: tile t+1 sits in one register set while tile t+2 is in flight in
+    // the other, so a global load has two compute phases to land before it is written to LDS.
+    u32x4 kA[2], vA[2], kB[2], vB[2];
+    pair_load(kA, kb, p.sn, 0, p.n, tid);
+    pair_load(vA, vb, p.sn, 0, p.n, tid);
+    rm_store(smem, kA, tid);
+    tr_store(smem + 8192, vA, tid);
+    // (prefetches past the last tile re-read clamped rows; they are never stored to LDS)
+    pair_load(kA, kb, p.sn, 64, p.n, tid); pair_load(vA, vb, p.sn, 64, p.n, tid);
+    pair_load(kB, kb, p.sn, 128, p.n, tid); pair_load(vB, vb, p.sn, 128, p.n, tid);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
         const unsigned char* Kc = smem + (t & 1) * 16384;
-        const unsigned char* Vc = Kc + 8192;
-        const bool more = t + 1 < nt;
-        if (more) {
-            rm_load(kreg, kb, p.sn, (t + 1) * 64, p.n, tid);
-            tr_load(vreg, vb, p.sn, (t + 1) * 64, p.n, tid);
-        }
         if (wave_active) {
-            f32x16 s0 = {0}, s1 = {0};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                s0 = TR::mfma32(lds_frag<TR>(Kc, r, 2 * s + hh), qf[s], s0);
-                s1 = TR::mfma32(lds_frag<TR>(Kc, 32 + r, 2 * s + hh), qf[s], s1);
-            }
-            const bool partial = t * 64 + 64 > p.n;
-            float mx = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float x0 = s0[i] * c, x1 = s1[i] * c;
-                if (partial) {
-                    const int k0 = t * 64 + acc_row(i, hh);
-                    if (k0 >= p.n) x0 = -INFINITY;
-                    if (k0 + 32 >= p.n) x1 = -INFINITY;
-                }
-                s0[i] = x0;
-                s1[i] = x1;
-                mx = fmaxf(mx, fmaxf(x0, x1));
-            }
-            mx = fmaxf(mx, swap_half(mx));
-            const float mn = fmaxf(m, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m - mn);
-            m = mn;
-            float rs = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                s0[i] = __builtin_amdgcn_exp2f(s0[i] - mn);
-                s1[i] = __builtin_amdgcn_exp2f(s1[i] - mn);
-                rs += s0[i] + s1[i];
-            }
-            l = l * alpha + rs;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                o0[i] *= alpha;
-                o1[i] *= alpha;
-            }
-            V8 pf[4];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                pf[0][j] = (E)s0[j];
-                pf[1][j] = (E)s0[8 + j];
-                pf[2][j] = (E)s1[j];
-                pf[3][j] = (E)s1[8 + j];
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                o0 = TR::mfma32(lds_frag<TR>(Vc, r, 2 * g + hh), pf[g], o0);
-                o1 = TR::mfma32(lds_frag<TR>(Vc, 32 + r, 2 * g + hh), pf[g], o1);
-            }
+            if (t * 64 + 64 > p.n) fwd_tile<TR, true>(Kc, Kc + 8192, qf, o0, o1, m, l, c, t * 64, p.n, r, hh);
+            else fwd_tile<TR, false>(Kc, Kc + 8192, qf, o0, o1, m, l, c, t * 64, p.n, r, hh);
         }
-        if (more) {
+        if (t + 1 < nt) {                       // tile t+1 is in set A when t is even, in set B when t is odd
             unsigned char* Kn = smem + ((t + 1) & 1) * 16384;
-            rm_store(Kn, kreg, tid);
-            tr_store(Kn + 8192, vreg, tid);
+            if (t & 1) {
+                rm_store(Kn, kB, tid);
+                tr_store(Kn + 8192, vB, tid);
+                pair_load(kB, kb, p.sn, (t + 3) * 64, p.n, tid); pair_load(vB, vb, p.sn, (t + 3) * 64, p.n, tid);
+            } else {
+                rm_store(Kn, kA, tid);
+                tr_store(Kn + 8192, vA, tid);
+                pair_load(kA, kb, p.sn, (t + 3) * 64, p.n, tid); pair_load(vA, vb, p.sn, (t + 3) * 64, p.n, tid);
+            }
         }
         __syncthreads();
     }
-    l += swap_half(l);
+    l = half_sum(l);
     if (qrow < p.n) {
         E* orow = static_cast<E*>(p.o_w) + b * p.osb + qrow * p.osn + h * p.osh;
         store_rows<TR>(orow, o0, o1, 1.f / l, hh);
@@ -217,8 +239,52 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 // ============================================================================================
 // backward, pass 1: dQ (+ delta)
 // ============================================================================================
+template <class TR, bool MASK>
+__device__ __forceinline__ void dq_tile(const unsigned char* Kc, const unsigned char* Vc, const unsigned char* KTc,
+                                        const typename TR::vec8 (&qf)[4], const typename TR::vec8 (&dof)[4], f32x16& dq0, f32x16& dq1,
+                                        float c, float lse2, float delta, int key0, int n, int r, int hh) {
+    using E = typename TR::elem;
+    using V8 = typename TR::vec8;
+    f32x16 s0 = {0}, s1 = {0}, d0 = {0}, d1 = {0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        s0 = TR::mfma32(lds_frag<TR>(Kc, r, 2 * s + hh), qf[s], s0);
+        s1 = TR::mfma32(lds_frag<TR>(Kc, 32 + r, 2 * s + hh), qf[s], s1);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        d0 = TR::mfma32(lds_frag<TR>(Vc, r, 2 * s + hh), dof[s], d0);
+        d1 = TR::mfma32(lds_frag<TR>(Vc, 32 + r, 2 * s + hh), dof[s], d1);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], c, -lse2));
+        float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], c, -lse2));
+        if (MASK) {
+            const int k0 = key0 + acc_row(i, hh);
+            if (k0 >= n) p0 = 0.f;
+            if (k0 + 32 >= n) p1 = 0.f;
+        }
+        s0[i] = p0 * (d0[i] - delta);
+        s1[i] = p1 * (d1[i] - delta);
+    }
+    V8 df[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        df[0][j] = (E)s0[j];
+        df[1][j] = (E)s0[8 + j];
+        df[2][j] = (E)s1[j];
+        df[3][j] = (E)s1[8 + j];
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        dq0 = TR::mfma32(lds_frag<TR>(KTc, r, 2 * g + hh), df[g], dq0);
+        dq1 = TR::mfma32(lds_frag<TR>(KTc, 32 + r, 2 * g + hh), df[g], dq1);
+    }
+}
+
 template <class TR>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 24576];
@@ -247,7 +313,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) delta += (float)dof[s][j] * (float)of[j];
     }
-    delta += swap_half(delta);
+    delta = half_sum(delta);
     const int64_t stat = (int64_t)(b * p.H + h) * p.n + qrow;
     if (row_ok && hh == 0) p.delta[stat] = delta;
     const float lse2 = row_ok ? p.lse[stat] * kLog2e : INFINITY;
@@ -256,69 +322,35 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     const int nt = (p.n + 63) >> 6;
     const float c = p.scale_log2;
 
-    u32x4 kreg[2], vreg[2], ktreg[2];
-    rm_load(kreg, kb, p.sn, 0, p.n, tid);
-    rm_load(vreg, vb, p.sn, 0, p.n, tid);
-    tr_load(ktreg, kb, p.sn, 0, p.n, tid);
-    rm_store(smem, kreg, tid);
-    rm_store(smem + 8192, vreg, tid);
-    tr_store(smem + 16384, ktreg, tid);
+    u32x4 kA[2], vA[2], kB[2], vB[2];
+    auto stage_store = [&](unsigned char* buf, const u32x4 (&kr)[2], const u32x4 (&vr)[2]) {
+        rm_store(buf, kr, tid);
+        rm_store(buf + 8192, vr, tid);
+        tr_store(buf + 16384, kr, tid);
+    };
+    pair_load(kA, kb, p.sn, 0, p.n, tid);
+    pair_load(vA, vb, p.sn, 0, p.n, tid);
+    stage_store(smem, kA, vA);
+    // (prefetches past the last tile re-read clamped rows; they are never stored to LDS)
+    pair_load(kA, kb, p.sn, 64, p.n, tid); pair_load(vA, vb, p.sn, 64, p.n, tid);
+    pair_load(kB, kb, p.sn, 128, p.n, tid); pair_load(vB, vb, p.sn, 128, p.n, tid);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
         const unsigned char* Kc = smem + (t & 1) * 24576;
-        const unsigned char* Vc = Kc + 8192;
-        const unsigned char* KTc = Kc + 16384;
-        const bool more = t + 1 < nt;
-        if (more) {
-            rm_load(kreg, kb, p.sn, (t + 1) * 64, p.n, tid);
-            rm_load(vreg, vb, p.sn, (t + 1) * 64, p.n, tid);
-            tr_load(ktreg, kb, p.sn, (t + 1) * 64, p.n, tid);
-        }
         if (wave_active) {
-            f32x16 s0 = {0}, s1 = {0}, d0 = {0}, d1 = {0};
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                s0 = TR::mfma32(lds_frag<TR>(Kc, r, 2 * s + hh), qf[s], s0);
-                s1 = TR::mfma32(lds_frag<TR>(Kc, 32 + r, 2 * s + hh), qf[s], s1);
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                d0 = TR::mfma32(lds_frag<TR>(Vc, r, 2 * s + hh), dof[s], d0);
-                d1 = TR::mfma32(lds_frag<TR>(Vc, 32 + r, 2 * s + hh), dof[s], d1);
-            }
-            const bool partial = t * 64 + 64 > p.n;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float p0 = __builtin_amdgcn_exp2f(s0[i] * c - lse2);
-                float p1 = __builtin_amdgcn_exp2f(s1[i] * c - lse2);
-                if (partial) {
-                    const int k0 = t * 64 + acc_row(i, hh);
-                    if (k0 >= p.n) p0 = 0.f;
-                    if (k0 + 32 >= p.n) p1 = 0.f;
-                }
-                s0[i] = p0 * (d0[i] - delta);
-                s1[i] = p1 * (d1[i] - delta);
-            }
-            V8 df[4];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                df[0][j] = (E)s0[j];
-                df[1][j] = (E)s0[8 + j];
-                df[2][j] = (E)s1[j];
-                df[3][j] = (E)s1[8 + j];
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                dq0 = TR::mfma32(lds_frag<TR>(KTc, r, 2 * g + hh), df[g], dq0);
-                dq1 = TR::mfma32(lds_frag<TR>(KTc, 32 + r, 2 * g + hh), df[g], dq1);
-            }
+            if (t * 64 + 64 > p.n) dq_tile<TR, true>(Kc, Kc + 8192, Kc + 16384, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
+            else dq_tile<TR, false>(Kc, Kc + 8192, Kc + 16384, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
         }
-        if (more) {
+        if (t + 1 < nt) {
             unsigned char* Kn = smem + ((t + 1) & 1) * 24576;
-            rm_store(Kn, kreg, tid);
-            rm_store(Kn + 8192, vreg, tid);
-            tr_store(Kn + 16384, ktreg, tid);
+            if (t & 1) {
+                stage_store(Kn, kB, vB);
+                pair_load(kB, kb, p.sn, (t + 3) * 64, p.n, tid); pair_load(vB, vb, p.sn, (t + 3) * 64, p.n, tid);
+            } else {
+                stage_store(Kn, kA, vA);
+                pair_load(kA, kb, p.sn, (t + 3) * 64, p.n, tid); pair_load(vA, vb, p.sn, (t + 3) * 64, p.n, tid);
+            }
         }
         __syncthreads();
     }
@@ -334,7 +366,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 constexpr int kDkdvBuf = 4 * 8192 + 512;  // Q, dO row-major; Q^T, dO^T; lse2[64], delta[64]
 
 template <class TR>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
@@ -364,79 +396,84 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnParams p) {
     const int nt = (p.n + 63) >> 6;
     const float c = p.scale_log2;
 
-    u32x4 qreg[2], doreg[2], qtreg[2], dotreg[2];
-    float stat = 0.f;  // threads 0..63 stage lse2, 64..127 stage delta
-    auto load_stats = [&](int row0) {
-        if (tid < 128) {
-            const int row = row0 + (tid & 63);
-            if (tid < 64) stat = (row < p.n) ? lse[row] * kLog2e : INFINITY;
-            else stat = (row < p.n) ? dlt[row] : 0.f;
-        }
+    u32x4 qA[2], doA[2], qB[2], doB[2];
+    float statA = 0.f, statB = 0.f;  // threads 0..63 stage lse2, 64..127 stage delta
+    auto stage_load = [&](int row0, u32x4 (&qr)[2], u32x4 (&dr)[2], float& stat) {
+        pair_load(qr, qb, p.sn, row0, p.n, tid);
+        pair_load(dr, dob, p.osn, row0, p.n, tid);
+        // waves 0/2 stage lse2, waves 1/3 stage delta (branch-free; only threads < 128 store it)
+        const int row = row0 + (tid & 63);
+        const bool is_delta = (tid >> 6) & 1;
+        const float v = (is_delta ? dlt : lse)[min(row, p.n - 1)];
+        stat = is_delta ? (row < p.n ? v : 0.f) : (row < p.n ? v * kLog2e : INFINITY);  // +inf -> P = 0 for pad rows
     };
-    auto stage_load = [&](int row0) {
-        rm_load(qreg, qb, p.sn, row0, p.n, tid);
-        rm_load(doreg, dob, p.osn, row0, p.n, tid);
-        tr_load(qtreg, qb, p.sn, row0, p.n, tid);
-        tr_load(dotreg, dob, p.osn, row0, p.n, tid);
-        load_stats(row0);
-    };
-    auto stage_store = [&](unsigned char* buf) {
-        rm_store(buf, qreg, tid);
-        rm_store(buf + 8192, doreg, tid);
-        tr_store(buf + 16384, qtreg, tid);
-        tr_store(buf + 24576, dotreg, tid);
+    auto stage_store = [&](unsigned char* buf, const u32x4 (&qr)[2], const u32x4 (&dr)[2], float stat) {
+        rm_store(buf, qr, tid);
+        rm_store(buf + 8192, dr, tid);
+        tr_store(buf + 16384, qr, tid);
+        tr_store(buf + 24576, dr, tid);
         if (tid < 128) reinterpret_cast<float*>(buf + 32768)[tid] = stat;
     };
-    stage_load(0);
-    stage_store(dsmem);
+    stage_load(0, qA, doA, statA);
+    stage_store(dsmem, qA, doA, statA);
+    stage_load(64, qA, doA, statA);
+    stage_load(128, qB, doB, statB);
     __syncthreads();
 
-    for (int t = 0; t < nt; ++t) {
-        const unsigned char* Qc = dsmem + (t & 1) * kDkdvBuf;
+    auto compute = [&](const unsigned char* Qc) {
+        if (!wave_active) return;
         const unsigned char* DOc = Qc + 8192;
         const unsigned char* QTc = Qc + 16384;
         const unsigned char* DOTc = Qc + 24576;
         const float* st = reinterpret_cast<const float*>(Qc + 32768);
-        const bool more = t + 1 < nt;
-        if (more) stage_load((t + 1) * 64);
-        if (wave_active) {
-            V8 pf[4], df[4];
+        V8 pf[4], df[4];
 #pragma unroll
-            for (int qb2 = 0; qb2 < 2; ++qb2) {
-                f32x16 s = {0}, d = {0};
+        for (int qb2 = 0; qb2 < 2; ++qb2) {
+            f32x16 s = {0}, d = {0};
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) s = TR::mfma32(lds_frag<TR>(Qc, qb2 * 32 + r, 2 * ks + hh), kf[ks], s);
+            for (int ks = 0; ks < 4; ++ks) s = TR::mfma32(lds_frag<TR>(Qc, qb2 * 32 + r, 2 * ks + hh), kf[ks], s);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) d = TR::mfma32(lds_frag<TR>(DOc, qb2 * 32 + r, 2 * ks + hh), vf[ks], d);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(st + qb2 * 32 + 8 * g + 4 * hh);
-                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(st + 64 + qb2 * 32 + 8 * g + 4 * hh);
-#pragma unroll
-                    for (int bq = 0; bq < 4; ++bq) {
-                        const int i = 4 * g + bq;
-                        const float pr = __builtin_amdgcn_exp2f(s[i] * c - l4[bq]);
-                        s[i] = pr;
-                        d[i] = pr * (d[i] - d4[bq]);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    pf[2 * qb2][j] = (E)s[j];
-                    pf[2 * qb2 + 1][j] = (E)s[8 + j];
-                    df[2 * qb2][j] = (E)d[j];
-                    df[2 * qb2 + 1][j] = (E)d[8 + j];
-                }
-            }
+            for (int ks = 0; ks < 4; ++ks) d = TR::mfma32(lds_frag<TR>(DOc, qb2 * 32 + r, 2 * ks + hh), vf[ks], d);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                dv0 = TR::mfma32(lds_frag<TR>(DOTc, r, 2 * g + hh), pf[g], dv0);
-                dv1 = TR::mfma32(lds_frag<TR>(DOTc, 32 + r, 2 * g + hh), pf[g], dv1);
-                dk0 = TR::mfma32(lds_frag<TR>(QTc, r, 2 * g + hh), df[g], dk0);
-                dk1 = TR::mfma32(lds_frag<TR>(QTc, 32 + r, 2 * g + hh), df[g], dk1);
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(st + qb2 * 32 + 8 * g + 4 * hh);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(st + 64 + qb2 * 32 + 8 * g + 4 * hh);
+#pragma unroll
+                for (int bq = 0; bq < 4; ++bq) {
+                    const int i = 4 * g + bq;
+                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, -l4[bq]));
+                    s[i] = pr;
+                    d[i] = pr * (d[i] - d4[bq]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                pf[2 * qb2][j] = (E)s[j];
+                pf[2 * qb2 + 1][j] = (E)s[8 + j];
+                df[2 * qb2][j] = (E)d[j];
+                df[2 * qb2 + 1][j] = (E)d[8 + j];
             }
         }
-        if (more) stage_store(dsmem + ((t + 1) & 1) * kDkdvBuf);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            dv0 = TR::mfma32(lds_frag<TR>(DOTc, r, 2 * g + hh), pf[g], dv0);
+            dv1 = TR::mfma32(lds_frag<TR>(DOTc, 32 + r, 2 * g + hh), pf[g], dv1);
+            dk0 = TR::mfma32(lds_frag<TR>(QTc, r, 2 * g + hh), df[g], dk0);
+            dk1 = TR::mfma32(lds_frag<TR>(QTc, 32 + r, 2 * g + hh), df[g], dk1);
+        }
+    };
+    for (int t = 0; t < nt; ++t) {
+        compute(dsmem + (t & 1) * kDkdvBuf);
+        if (t + 1 < nt) {
+            unsigned char* nb = dsmem + ((t + 1) & 1) * kDkdvBuf;
+            if (t & 1) {
+                stage_store(nb, qB, doB, statB);
+                stage_load((t + 3) * 64, qB, doB, statB);
+            } else {
+                stage_store(nb, qA, doA, statA);
+                stage_load((t + 3) * 64, qA, doA, statA);
+            }
+        }
         __syncthreads();
     }
     if (key_ok) {

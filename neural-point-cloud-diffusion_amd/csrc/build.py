@@ -23,9 +23,11 @@ ARCH = "gfx950"
 # bit-exactly, so they are compiled without FMA contraction.
 SOURCES = {
     "api.hip": [],
-    "attention.hip": [],
+    # VGPR-form MFMA: accumulators stay in VGPRs (gfx950 has a unified register file), no v_accvgpr moves
+    # -fno-honor-nans: no NaN can arise in the softmax math; drops the canonicalising v_max before every fmaxf
+    "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "geometry.hip": ["-ffp-contract=off"],
-    "shade.hip": [],
+    "shade.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
     "elementwise.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",

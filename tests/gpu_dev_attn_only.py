@@ -1,0 +1,11 @@
+import sys, os
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
+import torch
+from npcd.hip.attention import attention_qkvpacked
+B, n, H = 64, 513, 16
+qkv = torch.randn(B, n, 3 * H * 64, device="cuda").bfloat16().requires_grad_(True)
+gout = torch.randn(B, n, H * 64, device="cuda").bfloat16()
+for _ in range(int(os.environ.get("REPS", 3))):
+    out = attention_qkvpacked(qkv, H); out.backward(gout)
+torch.cuda.synchronize()
