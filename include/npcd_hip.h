@@ -152,6 +152,35 @@ int npcd_ray_march(const float* sigma, const float* rgb, const uint8_t* slot_val
                    int Nr, int M, int white_back, float* mask, float* depth, float* channels,
                    float* depth_ws, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Elementwise / normalisation / optimizer kernels of the denoiser training step (HBM-bound).
+ * They fuse the eager op chains of transformer.py:169-172,136-137 (under autocast) and of
+ * diffusion_training.py:169-174 + utils/ema.py:114-138.  bf16 tensors are passed as void*.
+ * ------------------------------------------------------------------------------------------ */
+/* x_out = x_in (+ delta); y = LayerNorm(x_out)*gamma+beta as bf16; mean/rstd [T] saved.
+ * delta (bf16 [T,W]) and x_out may be NULL.  W % 4 == 0, W <= 2048. */
+int npcd_add_ln_fwd(const float* x_in, const void* delta, const float* gamma, const float* beta,
+                    float* x_out, void* y, float* mean, float* rstd, int T, int W, float eps, void* stream);
+/* LayerNorm backward: dx = LNbwd(dy) (+ dres), optionally also as bf16 (dxb); column partials
+ * [npcd_ln_bwd_blocks(T)][W] of dgamma, dbeta and of dx (any may be NULL). */
+int npcd_ln_bwd_blocks(int T);
+int npcd_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                const float* dres, float* dx, void* dxb, float* part_gamma, float* part_beta,
+                float* part_col, int T, int W, void* stream);
+/* out[c] (+)= sum_b part[b][c], fixed summation order */
+int npcd_colsum_finalize(const float* part, int nblk, int N, float* out, int accumulate, void* stream);
+/* GELU (exact erf form) on bf16; backward also emits column partials [npcd_colsum_blocks(T)][N] of dh */
+int npcd_gelu_fwd(const void* h, void* g, int64_t numel, void* stream);
+int npcd_colsum_blocks(int T);
+int npcd_gelu_bwd(const void* dg, const void* h, void* dh, float* part, int T, int N, void* stream);
+int npcd_colsum_bf16(const void* a, float* part, int T, int N, void* stream);
+/* AdamW (torch semantics) + EMA lerp + bf16 shadow copy + optional gradient zeroing, one pass.
+ * ema and shadow_bf16 may be NULL; step is the 1-based step count (bias correction). */
+int npcd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* shadow_bf16, int64_t numel,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                   float ema_decay, int zero_grad, void* stream);
+int npcd_cast_f32_bf16(const float* src, void* dst, int64_t numel, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

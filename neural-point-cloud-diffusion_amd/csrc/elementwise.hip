@@ -1,0 +1,390 @@
+// HBM-bound elementwise / normalisation / optimizer kernels of the denoiser training step (gfx950).
+//
+// They replace chains of eager PyTorch kernels of the reference step
+// (npcd/models/diffusion/denoisers/transformer.py:169-172,136-137 under autocast, and
+//  npcd/train/diffusion_training.py:169-174 + npcd/utils/ema.py:114-138):
+//   residual add + LayerNorm + cast            -> add_ln_fwd      (1 pass instead of 3)
+//   LayerNorm backward (dx, dgamma, dbeta) + residual-gradient add + cast + bias-gradient column sum
+//                                              -> ln_bwd          (1 pass + a tiny finalize)
+//   GELU(erf) forward / backward (+ bias-gradient column sum)     -> gelu_fwd / gelu_bwd
+//   column sum of a bf16 matrix (bias gradient of c_qkv)          -> colsum
+//   AdamW + EMA + bf16 weight shadow + gradient zeroing           -> adamw_ema (1 pass over 310 M params)
+// All are pure streaming kernels: 16-byte accesses per lane, fp32 math, no LDS except the cross-wave
+// reduction of column partials.  Roofline: HBM.
+#include <math.h>
+
+#include "common.h"
+
+namespace npcd {
+
+constexpr int kMaxChunks = 8;  // a wave covers 256 columns per chunk -> width <= 2048
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+__device__ __forceinline__ f32x4 bf16x4_to_f32(bf16x4 v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+__device__ __forceinline__ bf16x4 f32_to_bf16x4(f32x4 v) { return bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; }
+
+// ============================================================================================
+// x_out = x_in (+ delta);  y = LayerNorm(x_out) * gamma + beta  (bf16);  mean / rstd saved
+// one wave per row
+// ============================================================================================
+template <int NCH>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ x_in, const __bf16* __restrict__ delta,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ x_out, __bf16* __restrict__ y, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, int T, int W, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= T) return;
+    const int64_t base = (int64_t)row * W;
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = ch * 256 + lane * 4;
+        v[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < W) {
+            v[ch] = *reinterpret_cast<const f32x4*>(x_in + base + c);
+            if (delta) v[ch] += bf16x4_to_f32(*reinterpret_cast<const bf16x4*>(delta + base + c));
+            if (x_out) *reinterpret_cast<f32x4*>(x_out + base + c) = v[ch];
+            s += (v[ch][0] + v[ch][1]) + (v[ch][2] + v[ch][3]);
+        }
+    }
+    const float mu = wave_sum(s) / (float)W;
+    float q = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = ch * 256 + lane * 4;
+        if (c < W) {
+            const f32x4 d = v[ch] - mu;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)W + eps);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = ch * 256 + lane * 4;
+        if (c < W) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+            *reinterpret_cast<bf16x4*>(y + base + c) = f32_to_bf16x4((v[ch] - mu) * rs * g + b);
+        }
+    }
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+}
+
+// ============================================================================================
+// LayerNorm backward.  Per row:  xhat = (x - mean) rstd,  g = dy * gamma,
+//   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) (+ dres);  also dx as bf16 for the GEMMs.
+// Column partials per workgroup: dgamma += dy * xhat, dbeta += dy, dcol += dx (the bias gradient of the
+// Linear whose output was added to the residual stream right before this LayerNorm).
+// Workgroup = 4 waves x kRowsPerWave rows; partials [gridDim.x][W] are summed by colsum_finalize.
+// ============================================================================================
+constexpr int kRowsPerWave = 8;
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dres, float* __restrict__ dx, __bf16* __restrict__ dxb,
+                                                     float* __restrict__ part_gamma, float* __restrict__ part_beta,
+                                                     float* __restrict__ part_col, int T, int W) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+    float* red = reinterpret_cast<float*>(dsmem);  // [3][4 waves][W]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 ag[NCH], ab[NCH], ac[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) ag[ch] = ab[ch] = ac[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int row0 = (blockIdx.x * 4 + wave) * kRowsPerWave;
+    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+        const int row = row0 + rr;
+        if (row >= T) break;
+        const int64_t base = (int64_t)row * W;
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 gy[NCH], xh[NCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = ch * 256 + lane * 4;
+            gy[ch] = xh[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < W) {
+                const f32x4 d = bf16x4_to_f32(*reinterpret_cast<const bf16x4*>(dy + base + c));
+                xh[ch] = (*reinterpret_cast<const f32x4*>(x + base + c) - mu) * rs;
+                ag[ch] += d * xh[ch];
+                ab[ch] += d;
+                gy[ch] = d * *reinterpret_cast<const f32x4*>(gamma + c);
+                const f32x4 t = gy[ch] * xh[ch];
+                s1 += (gy[ch][0] + gy[ch][1]) + (gy[ch][2] + gy[ch][3]);
+                s2 += (t[0] + t[1]) + (t[2] + t[3]);
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)W, c2 = wave_sum(s2) / (float)W;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = ch * 256 + lane * 4;
+            if (c < W) {
+                f32x4 o = (gy[ch] - c1 - xh[ch] * c2) * rs;
+                if (dres) o += *reinterpret_cast<const f32x4*>(dres + base + c);
+                *reinterpret_cast<f32x4*>(dx + base + c) = o;
+                if (dxb) *reinterpret_cast<bf16x4*>(dxb + base + c) = f32_to_bf16x4(o);
+                ac[ch] += o;
+            }
+        }
+    }
+    // cross-wave reduction of the column partials
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int c = ch * 256 + lane * 4;
+        if (c < W) {
+            *reinterpret_cast<f32x4*>(red + (0 * 4 + wave) * W + c) = ag[ch];
+            *reinterpret_cast<f32x4*>(red + (1 * 4 + wave) * W + c) = ab[ch];
+            *reinterpret_cast<f32x4*>(red + (2 * 4 + wave) * W + c) = ac[ch];
+        }
+    }
+    __syncthreads();
+    float* outs[3] = {part_gamma, part_beta, part_col};
+    for (int q = 0; q < 3; ++q) {
+        if (!outs[q]) continue;
+        for (int c = threadIdx.x; c < W; c += 256) {
+            const float* p = red + q * 4 * W + c;
+            outs[q][(int64_t)blockIdx.x * W + c] = (p[0] + p[W]) + (p[2 * W] + p[3 * W]);
+        }
+    }
+}
+
+// out[c] (+)= sum_b part[b][c]   (fixed order -> bitwise reproducible)
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int N, float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < nblk; b += 4) {
+        s0 += part[(int64_t)b * N + c];
+        s1 += part[(int64_t)(b + 1) * N + c];
+        s2 += part[(int64_t)(b + 2) * N + c];
+        s3 += part[(int64_t)(b + 3) * N + c];
+    }
+    for (; b < nblk; ++b) s0 += part[(int64_t)b * N + c];
+    const float s = (s0 + s1) + (s2 + s3);
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// ============================================================================================
+// GELU (exact erf form, nn.GELU() default)
+// ============================================================================================
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16x8* __restrict__ h, bf16x8* __restrict__ g, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const bf16x8 v = h[i];
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)gelu_f((float)v[j]);
+        g[i] = o;
+    }
+}
+
+// column-partial reductions: a thread owns 8 consecutive columns and walks kColRows rows
+constexpr int kColRows = 64;
+
+template <bool GELU>
+__global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ hpre, __bf16* __restrict__ out,
+                                                     float* __restrict__ part, int T, int N) {
+    const int col = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (col >= N) return;
+    const int row0 = blockIdx.y * kColRows;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int rr = 0; rr < kColRows; ++rr) {
+        const int row = row0 + rr;
+        if (row >= T) break;
+        const int64_t off = (int64_t)row * N + col;
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(a + off);
+        if (GELU) {
+            const bf16x8 hp = *reinterpret_cast<const bf16x8*>(hpre + off);
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o[j] = (__bf16)((float)v[j] * gelu_grad_f((float)hp[j]));
+                acc[j] += (float)o[j];      // the bias gradient sums the SAME rounded values the GEMMs see
+            }
+            *reinterpret_cast<bf16x8*>(out + off) = o;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+        }
+    }
+    float* p = part + (int64_t)blockIdx.y * N + col;
+    *reinterpret_cast<f32x4*>(p) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+}
+
+// ============================================================================================
+// AdamW (torch.optim.AdamW semantics, amsgrad=False, maximize=False) + EMA + bf16 shadow + grad zeroing
+//   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+//   p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps);  ema = ema + (1-decay) (p - ema)   [lerp]
+// ============================================================================================
+struct AdamArgs {
+    float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, ema_w;
+};
+
+__global__ __launch_bounds__(256) void adamw_ema_kernel(f32x4* __restrict__ p, f32x4* __restrict__ g, f32x4* __restrict__ m, f32x4* __restrict__ v,
+                                                        f32x4* __restrict__ ema, bf16x4* __restrict__ shadow, int64_t n4, AdamArgs a, int zero_grad) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 pp = p[i];
+        const f32x4 gg = g[i];
+        f32x4 mm = m[i], vv = v[i];
+        pp *= (1.f - a.lr * a.wd);
+        mm = mm * a.beta1 + gg * (1.f - a.beta1);
+        vv = vv * a.beta2 + gg * gg * (1.f - a.beta2);
+        const float step = a.lr / a.bc1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pp[j] -= step * (mm[j] / (sqrtf(vv[j]) / a.bc2_sqrt + a.eps));
+        p[i] = pp;
+        m[i] = mm;
+        v[i] = vv;
+        if (ema) {
+            const f32x4 e = ema[i];
+            ema[i] = e + (pp - e) * a.ema_w;
+        }
+        if (shadow) shadow[i] = f32_to_bf16x4(pp);
+        if (zero_grad) g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const f32x4* __restrict__ src, bf16x4* __restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) dst[i] = f32_to_bf16x4(src[i]);
+}
+
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace npcd
+
+using namespace npcd;
+
+extern "C" int npcd_add_ln_fwd(const float* x_in, const void* delta, const float* gamma, const float* beta, float* x_out, void* y,
+                               float* mean, float* rstd, int T, int W, float eps, void* stream) {
+    if (!x_in || !gamma || !beta || !y || !mean || !rstd || T <= 0 || W <= 0) return NPCD_ERR_ARG;
+    if (W % 4 != 0 || W > 256 * kMaxChunks) return NPCD_ERR_UNSUPPORTED;
+    if (!al16(x_in) || !al16(gamma) || !al16(beta) || (x_out && !al16(x_out)) || (reinterpret_cast<uintptr_t>(y) & 7) ||
+        (delta && (reinterpret_cast<uintptr_t>(delta) & 7)))
+        return NPCD_ERR_ARG;
+#define NPCD_LAUNCH_LN_FWD(NCH)                                                                                               \
+    hipLaunchKernelGGL(add_ln_fwd_kernel<NCH>, dim3((T + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x_in,        \
+                       static_cast<const __bf16*>(delta), gamma, beta, x_out, static_cast<__bf16*>(y), mean, rstd, T, W, eps)
+    if (W <= 256) NPCD_LAUNCH_LN_FWD(1);
+    else if (W <= 512) NPCD_LAUNCH_LN_FWD(2);
+    else if (W <= 1024) NPCD_LAUNCH_LN_FWD(4);
+    else NPCD_LAUNCH_LN_FWD(8);
+#undef NPCD_LAUNCH_LN_FWD
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int npcd_ln_bwd_blocks(int T) { return (T + 4 * kRowsPerWave - 1) / (4 * kRowsPerWave); }
+
+extern "C" int npcd_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
+                           float* dx, void* dxb, float* part_gamma, float* part_beta, float* part_col, int T, int W, void* stream) {
+    if (!dy || !x || !mean || !rstd || !gamma || !dx || T <= 0 || W <= 0) return NPCD_ERR_ARG;
+    if (W % 4 != 0 || W > 256 * kMaxChunks) return NPCD_ERR_UNSUPPORTED;
+    if (!al16(x) || !al16(gamma) || !al16(dx) || (dres && !al16(dres))) return NPCD_ERR_ARG;
+    const int nblk = npcd_ln_bwd_blocks(T);
+    const size_t lds = (size_t)3 * 4 * W * sizeof(float);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static bool attr_set = false;
+    if (!attr_set) {   // W = 2048 needs 96 KiB of dynamic LDS
+        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4 * 2048 * 4));
+        attr_set = true;
+    }
+#define NPCD_LAUNCH_LN_BWD(NCH)                                                                                                \
+    hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3(nblk), dim3(256), lds, st, static_cast<const __bf16*>(dy), x, mean, rstd, gamma, \
+                       dres, dx, static_cast<__bf16*>(dxb), part_gamma, part_beta, part_col, T, W)
+    if (W <= 256) NPCD_LAUNCH_LN_BWD(1);
+    else if (W <= 512) NPCD_LAUNCH_LN_BWD(2);
+    else if (W <= 1024) NPCD_LAUNCH_LN_BWD(4);
+    else NPCD_LAUNCH_LN_BWD(8);
+#undef NPCD_LAUNCH_LN_BWD
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int npcd_colsum_finalize(const float* part, int nblk, int N, float* out, int accumulate, void* stream) {
+    if (!part || !out || nblk <= 0 || N <= 0) return NPCD_ERR_ARG;
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), part, nblk, N, out, accumulate);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int npcd_gelu_fwd(const void* h, void* g, int64_t numel, void* stream) {
+    if (!h || !g || numel <= 0) return NPCD_ERR_ARG;
+    if (numel % 8 != 0 || !al16(h) || !al16(g)) return NPCD_ERR_UNSUPPORTED;
+    const int64_t n8 = numel / 8;
+    const int grid = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16x8*>(h),
+                       static_cast<bf16x8*>(g), n8);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int npcd_colsum_blocks(int T) { return (T + kColRows - 1) / kColRows; }
+
+// dh = dg * gelu'(h) (bf16) and column partials of dh: part [npcd_colsum_blocks(T)][N]
+extern "C" int npcd_gelu_bwd(const void* dg, const void* h, void* dh, float* part, int T, int N, void* stream) {
+    if (!dg || !h || !dh || !part || T <= 0 || N <= 0) return NPCD_ERR_ARG;
+    if (N % 8 != 0 || !al16(dg) || !al16(h) || !al16(dh) || !al16(part)) return NPCD_ERR_UNSUPPORTED;
+    dim3 grid((N / 8 + 255) / 256, npcd_colsum_blocks(T));
+    hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const __bf16*>(dg),
+                       static_cast<const __bf16*>(h), static_cast<__bf16*>(dh), part, T, N);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int npcd_colsum_bf16(const void* a, float* part, int T, int N, void* stream) {
+    if (!a || !part || T <= 0 || N <= 0) return NPCD_ERR_ARG;
+    if (N % 8 != 0 || !al16(a) || !al16(part)) return NPCD_ERR_UNSUPPORTED;
+    dim3 grid((N / 8 + 255) / 256, npcd_colsum_blocks(T));
+    hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const __bf16*>(a),
+                       static_cast<const __bf16*>(nullptr), static_cast<__bf16*>(nullptr), part, T, N);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int npcd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* shadow_bf16, int64_t numel, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, float ema_decay, int zero_grad, void* stream) {
+    if (!p || !g || !m || !v || numel <= 0 || step <= 0) return NPCD_ERR_ARG;
+    if (numel % 4 != 0 || !al16(p) || !al16(g) || !al16(m) || !al16(v) || (ema && !al16(ema)) ||
+        (shadow_bf16 && (reinterpret_cast<uintptr_t>(shadow_bf16) & 7)))
+        return NPCD_ERR_UNSUPPORTED;
+    AdamArgs a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+    a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    a.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    a.ema_w = 1.f - ema_decay;
+    const int64_t n4 = numel / 4;
+    const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<f32x4*>(p),
+                       reinterpret_cast<f32x4*>(g), reinterpret_cast<f32x4*>(m), reinterpret_cast<f32x4*>(v), reinterpret_cast<f32x4*>(ema),
+                       static_cast<bf16x4*>(shadow_bf16), n4, a, zero_grad);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int npcd_cast_f32_bf16(const float* src, void* dst, int64_t numel, void* stream) {
+    if (!src || !dst || numel <= 0) return NPCD_ERR_ARG;
+    if (numel % 4 != 0 || !al16(src) || (reinterpret_cast<uintptr_t>(dst) & 7)) return NPCD_ERR_UNSUPPORTED;
+    const int64_t n4 = numel / 4;
+    const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const f32x4*>(src),
+                       static_cast<bf16x4*>(dst), n4);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}

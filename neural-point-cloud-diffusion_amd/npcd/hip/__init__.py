@@ -42,6 +42,16 @@ SIGNATURES = {
     "npcd_shade_pack_weights": (c_int, [POINTER(_P), POINTER(_P), c_int, c_int, c_int, _P]),
     "npcd_shade_points": (c_int, [_P, c_int, c_int, c_int] + [_P] * 5 + [c_int, c_int] + [_P] * 3 + [_P]),
     "npcd_ray_march": (c_int, [_P] * 8 + [c_int, c_int, c_int] + [_P] * 4 + [_P]),
+    "npcd_add_ln_fwd": (c_int, [_P] * 8 + [c_int, c_int, c_float, _P]),
+    "npcd_ln_bwd_blocks": (c_int, [c_int]),
+    "npcd_ln_bwd": (c_int, [_P] * 11 + [c_int, c_int, _P]),
+    "npcd_colsum_finalize": (c_int, [_P, c_int, c_int, _P, c_int, _P]),
+    "npcd_gelu_fwd": (c_int, [_P, _P, c_int64, _P]),
+    "npcd_colsum_blocks": (c_int, [c_int]),
+    "npcd_gelu_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "npcd_colsum_bf16": (c_int, [_P, _P, c_int, c_int, _P]),
+    "npcd_adamw_ema": (c_int, [_P] * 6 + [c_int64] + [c_float] * 5 + [c_int, c_float, c_int, _P]),
+    "npcd_cast_f32_bf16": (c_int, [_P, _P, c_int64, _P]),
 }
 
 _lib = None

@@ -1,0 +1,130 @@
+"""Explicit forward/backward of the transformer backbone for the MI355X training step.
+
+One autograd node for all L residual blocks (reference ResidualAttentionBlock, transformer.py:140-172)
+instead of ~40 autograd nodes per block:
+  * activations are saved explicitly, the backward is written out by hand;
+  * GEMMs are hipBLASLt calls on a bf16 shadow copy of the flat fp32 parameter buffer (no per-step
+    weight casts); weight gradients are produced in fp32 straight into the flat gradient buffer;
+  * residual add + LayerNorm + cast, LayerNorm backward (+ bias-gradient column sums), GELU fwd/bwd are
+    single HIP kernels (csrc/elementwise.hip); attention is csrc/attention.hip;
+  * gradients never pass through AccumulateGrad; the gradient reducer is told explicitly when a
+    block's gradients are final so the RCCL all-reduce overlaps with the rest of backward.
+Numerics follow the reference's bf16-autocast step: bf16 GEMM inputs with fp32 accumulation, fp32
+residual stream, fp32 LayerNorm statistics, exact-erf GELU.
+"""
+import math
+
+import torch
+
+from ...hip import attention as hattn
+from ...hip import elementwise as ew
+
+_bf16, _f32 = torch.bfloat16, torch.float32
+_BLOCK_PARAMS = ("ln_1.weight", "ln_1.bias", "attn.c_qkv.weight", "attn.c_qkv.bias", "attn.c_proj.weight", "attn.c_proj.bias",
+                 "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias")
+
+
+def _wgrad(dy, x, out):
+    """out (fp32 view of the flat gradient) = dy^T @ x, fp32 accumulate AND fp32 output."""
+    out.copy_(torch.mm(dy.t(), x, out_dtype=_f32))
+
+
+class FusedBackboneEngine:
+    """Views into the flat fp32 parameter / gradient buffers and the bf16 shadow for every block."""
+
+    def __init__(self, backbone, flat, shadow, reducer=None):
+        self.heads = backbone.resblocks[0].attn.heads
+        self.width = backbone.width
+        self.reducer = reducer
+        offset = {id(p): off for p, off in zip(flat.params, flat.offsets)}
+        self.blocks = []
+        for blk in backbone.resblocks:
+            named = dict(blk.named_parameters())
+            entry = {"params": [named[n] for n in _BLOCK_PARAMS]}
+            for n in _BLOCK_PARAMS:
+                p = named[n]
+                off = offset[id(p)]
+                key = n.replace(".", "_")
+                entry[key] = p.data                                              # fp32 master (LN affine is used in fp32)
+                entry[key + "_16"] = shadow[off:off + p.numel()].view_as(p)     # bf16 shadow (GEMM operands)
+                entry[key + "_g"] = flat.grad[off:off + p.numel()].view_as(p)   # fp32 gradient
+            self.blocks.append(entry)
+
+    def __call__(self, x):
+        return _BackboneFn.apply(x, self)
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eng):
+        B, n, W = x.shape
+        T, H = B * n, eng.heads
+        d = W // H
+        scale = 1.0 / math.sqrt(d)
+        saved = []
+        with torch.autocast("cuda", enabled=False):
+            xs = x.reshape(T, W).contiguous()
+            delta = None
+            for e in eng.blocks:
+                x1, y1, mean1, rstd1 = ew.add_ln_fwd(xs, delta, e["ln_1_weight"], e["ln_1_bias"])
+                x_cur = xs if x1 is None else x1
+                qkv = torch.addmm(e["attn_c_qkv_bias_16"], y1, e["attn_c_qkv_weight_16"].t())
+                q4 = qkv.view(B, n, H, 3 * d)
+                a, lse = hattn._fwd(q4[..., :d], q4[..., d:2 * d], q4[..., 2 * d:], scale)
+                a = a.view(T, W)
+                o = torch.addmm(e["attn_c_proj_bias_16"], a, e["attn_c_proj_weight_16"].t())
+                x2, y2, mean2, rstd2 = ew.add_ln_fwd(x_cur, o, e["ln_2_weight"], e["ln_2_bias"])
+                h = torch.addmm(e["mlp_c_fc_bias_16"], y2, e["mlp_c_fc_weight_16"].t())
+                g = ew.gelu_fwd(h)
+                delta = torch.addmm(e["mlp_c_proj_bias_16"], g, e["mlp_c_proj_weight_16"].t())
+                saved.append((x_cur, mean1, rstd1, y1, qkv, a, lse, x2, mean2, rstd2, y2, h, g))
+                xs = x2
+            out = xs + delta                       # fp32 + bf16 -> fp32
+        ctx.eng, ctx.saved, ctx.dims, ctx.scale = eng, saved, (B, n, W, H, d), scale
+        return out.view(B, n, W)
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng, (B, n, W, H, d), scale = ctx.eng, ctx.dims, ctx.scale
+        T = B * n
+        with torch.autocast("cuda", enabled=False):
+            dx = dout.reshape(T, W).contiguous().float()
+            dxb = dx.to(_bf16)
+            last = eng.blocks[-1]
+            last["mlp_c_proj_bias_g"].copy_(dx.sum(dim=0))
+            for bi in range(len(eng.blocks) - 1, -1, -1):
+                e = eng.blocks[bi]
+                x_cur, mean1, rstd1, y1, qkv, a, lse, x2, mean2, rstd2, y2, h, g = ctx.saved[bi]
+                ctx.saved[bi] = None
+                # ---- MLP branch: x3 = x2 + c_proj(gelu(c_fc(ln_2(x2)))) ------------------------------
+                dg = torch.mm(dxb, e["mlp_c_proj_weight_16"])
+                _wgrad(dxb, g, e["mlp_c_proj_weight_g"])
+                dh = ew.gelu_bwd(dg, h, e["mlp_c_fc_bias_g"])
+                del dg, g, h
+                dy2 = torch.mm(dh, e["mlp_c_fc_weight_16"])
+                _wgrad(dh, y2, e["mlp_c_fc_weight_g"])
+                del dh, y2
+                dx2, dx2b = ew.ln_bwd(dy2, x2, mean2, rstd2, e["ln_2_weight"], dx, e["ln_2_weight_g"], e["ln_2_bias_g"],
+                                      e["attn_c_proj_bias_g"])
+                del dy2, x2, dx, dxb
+                # ---- attention branch: x2 = x + c_proj(attn(c_qkv(ln_1(x)))) ---------------------------
+                da = torch.mm(dx2b, e["attn_c_proj_weight_16"])
+                _wgrad(dx2b, a, e["attn_c_proj_weight_g"])
+                dqkv = torch.empty_like(qkv)
+                q4, g4 = qkv.view(B, n, H, 3 * d), dqkv.view(B, n, H, 3 * d)
+                hattn._bwd(q4[..., :d], q4[..., d:2 * d], q4[..., 2 * d:], a.view(B, n, H, d), da.view(B, n, H, d), lse,
+                           g4[..., :d], g4[..., d:2 * d], g4[..., 2 * d:], scale)
+                del da, a, qkv, dx2b
+                ew.colsum_bf16(dqkv, e["attn_c_qkv_bias_g"])
+                dy1 = torch.mm(dqkv, e["attn_c_qkv_weight_16"])
+                _wgrad(dqkv, y1, e["attn_c_qkv_weight_g"])
+                del dqkv, y1
+                prev_bias_g = eng.blocks[bi - 1]["mlp_c_proj_bias_g"] if bi > 0 else None
+                dx, dxb = ew.ln_bwd(dy1, x_cur, mean1, rstd1, e["ln_1_weight"], dx2, e["ln_1_weight_g"], e["ln_1_bias_g"],
+                                    prev_bias_g, want_bf16=bi > 0)
+                del dy1, dx2
+                if eng.reducer is not None:
+                    # this block's gradients are final (mlp.c_proj.bias was finished by the block above / the tail)
+                    for p in e["params"]:
+                        eng.reducer.mark_ready(p)
+        return dx.view(B, n, W), None

@@ -97,8 +97,13 @@ class Transformer(nn.Module):
         self.resblocks = nn.ModuleList(
             ResidualAttentionBlock(width=width, heads=heads, init_scale=std, use_flash_attn=use_flash_attn)
             for _ in range(layers))
+        self.fused_engine = None        # set by npcd.train.DiffusionTrainer (explicit fwd/bwd over flat buffers)
 
     def forward(self, x):
+        eng = self.fused_engine
+        if (eng is not None and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
+                and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+            return eng(x)
         for blk in self.resblocks:
             x = blk(x)
         return x

@@ -99,6 +99,11 @@ class GradReducer:
         else:
             self.handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf))
 
+    def mark_ready(self, p):
+        """For gradients written outside autograd (the fused backbone backward)."""
+        if self.world > 1:
+            self._hook(p)
+
     def _hook(self, p):
         b = self.param_bucket[id(p)]
         self._left[b] -= 1
@@ -123,20 +128,36 @@ class DiffusionTrainer:
     """One-process-per-GPU trainer of `model.diffusion` (a DiffusionModel)."""
 
     def __init__(self, diffusion: nn.Module, lr: float = 7e-5, weight_decay: float = 0.01, ema_decay: Optional[float] = 0.9999,
-                 dtype: Optional[torch.dtype] = torch.bfloat16, group=None, bucket_bytes: int = 64 << 20, max_grad_norm=None):
+                 dtype: Optional[torch.dtype] = torch.bfloat16, group=None, bucket_bytes: int = 64 << 20, max_grad_norm=None,
+                 fused: bool = True):
         self.model = diffusion
         self.dtype = dtype
         self.flat = FlatBuffers(diffusion)
         self.reducer = GradReducer(self.flat, group, bucket_bytes)
-        # one "parameter" for the optimizer: the flat buffer itself
-        self.master = nn.Parameter(self.flat.flat, requires_grad=True)
-        self.master.grad = self.flat.grad
-        fused = self.flat.flat.is_cuda
-        self.optimizer = torch.optim.AdamW([self.master], lr=lr, weight_decay=weight_decay, fused=fused)
+        self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, (0.9, 0.999), 1e-8
         self.ema_decay = ema_decay
         self.ema = self.flat.flat.clone() if ema_decay is not None else None
         self.max_grad_norm = max_grad_norm
         self.iteration = 0
+        self.native = self.flat.flat.is_cuda and fused
+        if self.native:
+            # HIP path: one fused AdamW+EMA kernel over the flat buffers, a bf16 shadow of the parameters for
+            # the GEMMs and the explicit backbone forward/backward (npcd.models.diffusion.fused)
+            from ..hip import elementwise as ew
+            from ..models.diffusion.fused import FusedBackboneEngine
+            self._ew = ew
+            self.exp_avg = torch.zeros_like(self.flat.flat)
+            self.exp_avg_sq = torch.zeros_like(self.flat.flat)
+            self.shadow = torch.empty(self.flat.numel, dtype=torch.bfloat16, device=self.flat.flat.device)
+            ew.cast_f32_bf16(self.flat.flat, self.shadow)
+            denoiser = getattr(diffusion, "denoiser", None)
+            if denoiser is not None and dtype == torch.bfloat16 and denoiser.backbone.width // denoiser.backbone.resblocks[0].attn.heads == 64:
+                denoiser.backbone.fused_engine = FusedBackboneEngine(denoiser.backbone, self.flat, self.shadow, self.reducer)
+        else:
+            # reference path (CPU tests / ablation): torch AdamW over ONE flat "parameter"
+            self.master = nn.Parameter(self.flat.flat, requires_grad=True)
+            self.master.grad = self.flat.grad
+            self.optimizer = torch.optim.AdamW([self.master], lr=lr, weight_decay=weight_decay, fused=self.flat.flat.is_cuda)
 
     def ema_state_dict(self):
         """state_dict of the EMA model: same keys as the running model (utils/ema.py:80), buffers copied."""
@@ -147,7 +168,8 @@ class DiffusionTrainer:
         return sd
 
     def step(self, coords, feats, t=None, coords_noise=None, feats_noise=None):
-        self.flat.zero_grad()
+        if not self.native or self.iteration == 0:
+            self.flat.zero_grad()                 # afterwards the fused optimizer kernel leaves the gradients zeroed
         self.reducer.start_step()
         dev_type = "cuda" if coords.is_cuda else "cpu"
         with torch.autocast(dev_type, dtype=self.dtype, enabled=self.dtype is not None):
@@ -155,10 +177,19 @@ class DiffusionTrainer:
         loss.backward()
         self.reducer.finish()
         if self.max_grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_([self.master], self.max_grad_norm)
-        self.master.grad = self.flat.grad
-        self.optimizer.step()
-        if self.ema is not None:
-            self.ema.lerp_(self.flat.flat, 1.0 - self.ema_decay)
+            torch.nn.utils.clip_grad_norm_([self.flat.flat if self.native else self.master], self.max_grad_norm) \
+                if not self.native else self._clip_native()
         self.iteration += 1
+        if self.native:
+            self._ew.adamw_ema(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.ema, self.shadow, self.lr,
+                               self.betas[0], self.betas[1], self.eps, self.weight_decay, self.iteration, self.ema_decay, zero_grad=True)
+        else:
+            self.master.grad = self.flat.grad
+            self.optimizer.step()
+            if self.ema is not None:
+                self.ema.lerp_(self.flat.flat, 1.0 - self.ema_decay)
         return loss.detach(), sub
+
+    def _clip_native(self):
+        norm = torch.linalg.vector_norm(self.flat.grad)
+        self.flat.grad.mul_(torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0))
