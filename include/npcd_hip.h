@@ -167,7 +167,9 @@ int npcd_ln_bwd_blocks(int T);
 int npcd_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                 const float* dres, float* dx, void* dxb, float* part_gamma, float* part_beta,
                 float* part_col, int T, int W, void* stream);
-/* out[c] (+)= sum_b part[b][c], fixed summation order */
+/* out[c] (+)= sum_b part[b][c], fixed summation order.  `part` [nblk][N] must be followed by
+ * npcd_colsum_scratch_rows() more rows of N floats (used as the stage buffer of the 2-stage sum). */
+int npcd_colsum_scratch_rows(void);
 int npcd_colsum_finalize(const float* part, int nblk, int N, float* out, int accumulate, void* stream);
 /* GELU (exact erf form) on bf16; backward also emits column partials [npcd_colsum_blocks(T)][N] of dh */
 int npcd_gelu_fwd(const void* h, void* g, int64_t numel, void* stream);

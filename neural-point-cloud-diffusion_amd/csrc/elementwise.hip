@@ -157,20 +157,38 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
     }
 }
 
-// out[c] (+)= sum_b part[b][c]   (fixed order -> bitwise reproducible)
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int N, float* __restrict__ out, int accumulate) {
+// out[c] (+)= sum_b part[b][c]   (fixed order -> bitwise reproducible).
+// Two stages so that the 4 MB of partials are read by many waves: stage 1 = 64 columns x kFinSlices row
+// slices per workgroup (coalesced 256-byte rows, 4 row lanes per workgroup reduced through LDS) ->
+// stage[kFinSlices][N]; stage 2 sums the slices.
+constexpr int kFinSlices = 16;
+
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ part, int nblk, int N, float* __restrict__ stage) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    const int per = (nblk + kFinSlices - 1) / kFinSlices;
+    const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+    float s0 = 0.f, s1 = 0.f;
+    if (c < N) {
+        int b = b0 + ty;
+        for (; b + 4 < b1; b += 8) {
+            s0 += part[(int64_t)b * N + c];
+            s1 += part[(int64_t)(b + 4) * N + c];
+        }
+        if (b < b1) s0 += part[(int64_t)b * N + c];
+    }
+    red[ty][tx] = s0 + s1;
+    __syncthreads();
+    if (ty == 0 && c < N) stage[(int64_t)blockIdx.y * N + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ stage, int N, float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= N) return;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 3 < nblk; b += 4) {
-        s0 += part[(int64_t)b * N + c];
-        s1 += part[(int64_t)(b + 1) * N + c];
-        s2 += part[(int64_t)(b + 2) * N + c];
-        s3 += part[(int64_t)(b + 3) * N + c];
-    }
-    for (; b < nblk; ++b) s0 += part[(int64_t)b * N + c];
-    const float s = (s0 + s1) + (s2 + s3);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kFinSlices; ++k) s += stage[(int64_t)k * N + c];
     out[c] = accumulate ? out[c] + s : s;
 }
 
@@ -317,9 +335,16 @@ extern "C" int npcd_ln_bwd(const void* dy, const float* x, const float* mean, co
     return NPCD_OK;
 }
 
+// `part` must have room for kFinSlices extra rows after its nblk rows (npcd_colsum_scratch_rows()):
+// they are used as the stage buffer.
+extern "C" int npcd_colsum_scratch_rows(void) { return kFinSlices; }
+
 extern "C" int npcd_colsum_finalize(const float* part, int nblk, int N, float* out, int accumulate, void* stream) {
     if (!part || !out || nblk <= 0 || N <= 0) return NPCD_ERR_ARG;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), part, nblk, N, out, accumulate);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* stage = const_cast<float*>(part) + (int64_t)nblk * N;
+    hipLaunchKernelGGL(colsum_stage1_kernel, dim3((N + 63) / 64, kFinSlices), dim3(256), 0, st, part, nblk, N, stage);
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, st, stage, N, out, accumulate);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }

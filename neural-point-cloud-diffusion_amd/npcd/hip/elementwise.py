@@ -29,7 +29,7 @@ def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma_out, dbeta_out, dcol_out=None,
     nblk = L.npcd_ln_bwd_blocks(T)
     dx = torch.empty((T, W), dtype=_f32, device=dev)
     dxb = torch.empty((T, W), dtype=_bf16, device=dev) if want_bf16 else None
-    parts = torch.empty((3, nblk, W), dtype=_f32, device=dev)
+    parts = torch.empty((3, nblk + L.npcd_colsum_scratch_rows(), W), dtype=_f32, device=dev)
     check(L.npcd_ln_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(dxb), ptr(parts[0]), ptr(parts[1]),
                         ptr(parts[2]) if dcol_out is not None else ptr(None), T, W, stream_ptr()), "npcd_ln_bwd")
     s = stream_ptr()
@@ -52,7 +52,7 @@ def gelu_bwd(dg, h, dbias_out):
     L = lib()
     nblk = L.npcd_colsum_blocks(T)
     dh = torch.empty_like(h)
-    part = torch.empty((nblk, N), dtype=_f32, device=h.device)
+    part = torch.empty((nblk + L.npcd_colsum_scratch_rows(), N), dtype=_f32, device=h.device)
     check(L.npcd_gelu_bwd(ptr(dg), ptr(h), ptr(dh), ptr(part), T, N, stream_ptr()), "npcd_gelu_bwd")
     check(L.npcd_colsum_finalize(ptr(part), nblk, N, ptr(dbias_out), 0, stream_ptr()), "npcd_colsum_finalize")
     return dh
@@ -63,7 +63,7 @@ def colsum_bf16(a, out):
     T, N = a.shape
     L = lib()
     nblk = L.npcd_colsum_blocks(T)
-    part = torch.empty((nblk, N), dtype=_f32, device=a.device)
+    part = torch.empty((nblk + L.npcd_colsum_scratch_rows(), N), dtype=_f32, device=a.device)
     check(L.npcd_colsum_bf16(ptr(a), ptr(part), T, N, stream_ptr()), "npcd_colsum_bf16")
     check(L.npcd_colsum_finalize(ptr(part), nblk, N, ptr(out), 0, stream_ptr()), "npcd_colsum_finalize")
     return out
