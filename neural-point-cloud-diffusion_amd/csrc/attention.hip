@@ -22,6 +22,10 @@
 
 #include "common.h"
 
+#ifndef NPCD_ABL
+#define NPCD_ABL 0   // developer ablation switch (never set in the shipped build)
+#endif
+
 namespace npcd {
 
 struct AttnParams {
@@ -55,20 +59,93 @@ __device__ __forceinline__ void rm_store(unsigned char* lds, const u32x4 (&reg)[
     *reinterpret_cast<u32x4*>(lds + tile_off(row, dc)) = reg[0];
     *reinterpret_cast<u32x4*>(lds + tile_off(row + 1, dc)) = reg[1];
 }
-// transposed image T[d][pos(row)]: within each group of 16 rows, row 8a+4h+b is stored at position
-// 8h+4a+b, so that the 8 rows a lane-half h needs for one MFMA k-step (the accumulator-row order,
-// acc_row()) are 16 contiguous bytes.
-__device__ __forceinline__ void tr_store(unsigned char* lds, const u32x4 (&reg)[2], int tid) {
-    const int row = 2 * (tid >> 3), dc = tid & 7;
-    const int g = row >> 4, kl = row & 15;
-    const int a = kl >> 3, h = (kl >> 2) & 1, b = kl & 3;
-    const int chunk = 2 * g + h, e = 4 * a + b;  // e is even
+// ---- LDS-DMA staging ----------------------------------------------------------------------------
+// Two 64x64 tiles (A at buf, B at buf+8192) are filled by 16 global_load_lds_dwordx4 pieces of 1 KiB
+// (8 rows x 128 B); wave w issues 4 of them (waves 0,1: tile A, waves 2,3: tile B).  The LDS destination of
+// a piece is linear (wave-uniform base + lane*16), so the XOR swizzle is applied on the SOURCE side: the
+// lane that fills (row, chunk') fetches logical chunk chunk' ^ tile_swz(row).  No VGPRs, no ds_write, and
+// the loads stay in flight across barriers (counted s_waitcnt vmcnt + raw s_barrier, never __syncthreads).
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+template <class E>
+__device__ __forceinline__ void dma_tile_pair(unsigned char* buf, const E* a_base, int64_t a_stride, const E* b_base, int64_t b_stride,
+                                              int row0, int nrows, int wave, int lane) {
+    const bool second = wave >= 2;          // wave-uniform
+    const E* base = second ? b_base : a_base;
+    const int64_t stride = second ? b_stride : a_stride;
+    unsigned char* tile = buf + (second ? 8192 : 0);
+    const int w2 = wave & 1;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const uint32_t lo = (reg[0][i >> 1] >> (16 * (i & 1))) & 0xffffu;
-        const uint32_t hi = (reg[1][i >> 1] >> (16 * (i & 1))) & 0xffffu;
-        *reinterpret_cast<uint32_t*>(lds + tile_off(8 * dc + i, chunk) + e * 2) = lo | (hi << 16);
+    for (int i = 0; i < 4; ++i) {
+        const int prow = (w2 * 4 + i) * 8 + (lane >> 3);              // row inside the tile
+        const int grow = min(row0 + prow, nrows - 1);                  // clamp: duplicated rows are neutralised downstream
+        const E* src = base + grow * stride + (((lane & 7) ^ tile_swz(prow)) << 3);
+        unsigned char* dst = tile + __builtin_amdgcn_readfirstlane((w2 * 4 + i) * 1024);
+        __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)dst, 16, 0, 0);
     }
+}
+// barrier that does NOT drain the vector-memory counter (keeps later tiles' DMA in flight)
+#define NPCD_DMA_WAIT_BARRIER(N)                                   \
+    do {                                                           \
+        asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");      \
+        __builtin_amdgcn_s_barrier();                              \
+        asm volatile("" ::: "memory");                             \
+    } while (0)
+
+// Transposed fragment straight from a ROW-MAJOR tile (no second, transposed LDS image): the A operand
+// T^T[d = db*32 + (lane&31)][k] of a 32x32x16 MFMA whose 16 k-indices are rows 16*g16 .. 16*g16+15 of
+// the tile, in the accumulator-row order (element j of lane-half h <-> row 16 g16 + 8 (j>>2) + 4 h + (j&3)),
+// i.e. exactly the order in which a preceding 32x32 accumulator is handed over as the B operand.
+// Two ds_read_b64_tr_b16 per fragment: each returns 4 consecutive rows at one column per lane.
+// The reads are issued as inline asm: hipcc (ROCm 7.2) treats the ds_read_tr builtin as possibly aliasing
+// an in-flight LDS-DMA and drains it with s_waitcnt vmcnt(0).  The caller must execute tr_wait() before the
+// first use of any tr_issue() result (cdna_hip_programming.md §5.4 rule 18, §5.7).
+__device__ __forceinline__ uint32_t lds_addr(const unsigned char* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+__device__ __forceinline__ u32x2 tr_issue_one(uint32_t addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+struct TrPair {
+    u32x2 lo, hi;
+};
+__device__ __forceinline__ TrPair tr_issue(const unsigned char* tile, int g16, int db, int lane) {
+    const int grp = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h = grp >> 1;
+    const int col = db * 32 + 16 * (grp & 1) + 4 * pp;
+    const int r0 = 16 * g16 + 4 * h + q;
+    TrPair t;
+    t.lo = tr_issue_one(lds_addr(tile + tile_off(r0, col >> 3) + (col & 7) * 2));
+    t.hi = tr_issue_one(lds_addr(tile + tile_off(r0 + 8, col >> 3) + (col & 7) * 2));
+    return t;
+}
+__device__ __forceinline__ void tr_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// compiler-scheduled variant (ds_read_tr builtin) for kernels without LDS-DMA in flight
+template <class TR>
+__device__ __forceinline__ typename TR::vec8 tr_frag(const unsigned char* tile, int g16, int db, int lane) {
+    const int grp = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h = grp >> 1;
+    const int col = db * 32 + 16 * (grp & 1) + 4 * pp;
+    const int r0 = 16 * g16 + 4 * h + q;
+    const typename TR::vec4 lo = TR::tr_read(tile + tile_off(r0, col >> 3) + (col & 7) * 2);
+    const typename TR::vec4 hi = TR::tr_read(tile + tile_off(r0 + 8, col >> 3) + (col & 7) * 2);
+    typename TR::vec8 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = lo[j];
+        v[4 + j] = hi[j];
+    }
+    return v;
+}
+
+template <class TR>
+__device__ __forceinline__ typename TR::vec8 tr_vec(const TrPair& t) {
+    const u32x4 x = {t.lo[0], t.lo[1], t.hi[0], t.hi[1]};
+    return __builtin_bit_cast(typename TR::vec8, x);
 }
 
 template <class TR>
@@ -134,6 +211,27 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* Kc, const unsigned
             if (k0 + 32 >= n) s1[i] = -INFINITY;
         }
     }
+    TrPair vt[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        vt[g][0] = tr_issue(Vc, g, 0, (hh << 5) | r);
+        vt[g][1] = tr_issue(Vc, g, 1, (hh << 5) | r);
+    }
+#if NPCD_ABL == 1 || NPCD_ABL == 2
+    {
+        V8 pf[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pf[0][j] = (E)s0[j]; pf[1][j] = (E)s0[8 + j]; pf[2][j] = (E)s1[j]; pf[3][j] = (E)s1[8 + j]; }
+        tr_wait();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            o0 = TR::mfma32(tr_vec<TR>(vt[g][0]), pf[g], o0);
+            o1 = TR::mfma32(tr_vec<TR>(vt[g][1]), pf[g], o1);
+        }
+        l = 1.f; m = 0.f;
+        return;
+    }
+#endif
     float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
     for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, s0[i]), s1[i]);
@@ -162,10 +260,11 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* Kc, const unsigned
         pf[3][j] = (E)d2;
     }
     l += rs;
+    tr_wait();
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        o0 = TR::mfma32(lds_frag<TR>(Vc, r, 2 * g + hh), pf[g], o0);
-        o1 = TR::mfma32(lds_frag<TR>(Vc, 32 + r, 2 * g + hh), pf[g], o1);
+        o0 = TR::mfma32(tr_vec<TR>(vt[g][0]), pf[g], o0);
+        o1 = TR::mfma32(tr_vec<TR>(vt[g][1]), pf[g], o1);
     }
 }
 
@@ -173,7 +272,7 @@ template <class TR>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 16384];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int nqt = (p.n + 127) >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -196,37 +295,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     float m = -INFINITY, l = 0.f;
     const int nt = (p.n + 63) >> 6;
 
-    // Register staging two tiles ahead: tile t+1 sits in one register set while tile t+2 is in flight in
-    // the other, so a global load has two compute phases to land before it is written to LDS.
-    u32x4 kA[2], vA[2], kB[2], vB[2];
-    pair_load(kA, kb, p.sn, 0, p.n, tid);
-    pair_load(vA, vb, p.sn, 0, p.n, tid);
-    rm_store(smem, kA, tid);
-    tr_store(smem + 8192, vA, tid);
-    // (prefetches past the last tile re-read clamped rows; they are never stored to LDS)
-    pair_load(kA, kb, p.sn, 64, p.n, tid); pair_load(vA, vb, p.sn, 64, p.n, tid);
-    pair_load(kB, kb, p.sn, 128, p.n, tid); pair_load(vB, vb, p.sn, 128, p.n, tid);
-    __syncthreads();
-
+    // 3-deep LDS ring filled by LDS-DMA, two tiles ahead of the compute.
+    dma_tile_pair(smem, kb, p.sn, vb, p.sn, 0, p.n, wave, lane);
+    dma_tile_pair(smem + 16384, kb, p.sn, vb, p.sn, 64, p.n, wave, lane);
+    NPCD_DMA_WAIT_BARRIER(4);                                   // tile 0 has landed (tile 1 may still be in flight)
     for (int t = 0; t < nt; ++t) {
-        const unsigned char* Kc = smem + (t & 1) * 16384;
+        const int slot = t % 3, nslot = (t + 2) % 3;
+        // slot (t+2)%3 == (t-1)%3 was last read in iteration t-1, before the barrier every wave has passed
+        dma_tile_pair(smem + nslot * 16384, kb, p.sn, vb, p.sn, (t + 2) * 64, p.n, wave, lane);
+        const unsigned char* Kc = smem + slot * 16384;
         if (wave_active) {
             if (t * 64 + 64 > p.n) fwd_tile<TR, true>(Kc, Kc + 8192, qf, o0, o1, m, l, c, t * 64, p.n, r, hh);
             else fwd_tile<TR, false>(Kc, Kc + 8192, qf, o0, o1, m, l, c, t * 64, p.n, r, hh);
         }
-        if (t + 1 < nt) {                       // tile t+1 is in set A when t is even, in set B when t is odd
-            unsigned char* Kn = smem + ((t + 1) & 1) * 16384;
-            if (t & 1) {
-                rm_store(Kn, kB, tid);
-                tr_store(Kn + 8192, vB, tid);
-                pair_load(kB, kb, p.sn, (t + 3) * 64, p.n, tid); pair_load(vB, vb, p.sn, (t + 3) * 64, p.n, tid);
-            } else {
-                rm_store(Kn, kA, tid);
-                tr_store(Kn + 8192, vA, tid);
-                pair_load(kA, kb, p.sn, (t + 3) * 64, p.n, tid); pair_load(vA, vb, p.sn, (t + 3) * 64, p.n, tid);
-            }
-        }
-        __syncthreads();
+        NPCD_DMA_WAIT_BARRIER(4);                               // tile t+1 landed for every wave; tile t fully consumed
     }
     l = half_sum(l);
     if (qrow < p.n) {
@@ -240,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 // backward, pass 1: dQ (+ delta)
 // ============================================================================================
 template <class TR, bool MASK>
-__device__ __forceinline__ void dq_tile(const unsigned char* Kc, const unsigned char* Vc, const unsigned char* KTc,
+__device__ __forceinline__ void dq_tile(const unsigned char* Kc, const unsigned char* Vc,
                                         const typename TR::vec8 (&qf)[4], const typename TR::vec8 (&dof)[4], f32x16& dq0, f32x16& dq1,
                                         float c, float lse2, float delta, int key0, int n, int r, int hh) {
     using E = typename TR::elem;
@@ -278,8 +360,8 @@ __device__ __forceinline__ void dq_tile(const unsigned char* Kc, const unsigned 
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        dq0 = TR::mfma32(lds_frag<TR>(KTc, r, 2 * g + hh), df[g], dq0);
-        dq1 = TR::mfma32(lds_frag<TR>(KTc, 32 + r, 2 * g + hh), df[g], dq1);
+        dq0 = TR::mfma32(tr_frag<TR>(Kc, g, 0, (hh << 5) | r), df[g], dq0);
+        dq1 = TR::mfma32(tr_frag<TR>(Kc, g, 1, (hh << 5) | r), df[g], dq1);
     }
 }
 
@@ -287,7 +369,7 @@ template <class TR>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 24576];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int nqt = (p.n + 127) >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -326,7 +408,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     auto stage_store = [&](unsigned char* buf, const u32x4 (&kr)[2], const u32x4 (&vr)[2]) {
         rm_store(buf, kr, tid);
         rm_store(buf + 8192, vr, tid);
-        tr_store(buf + 16384, kr, tid);
     };
     pair_load(kA, kb, p.sn, 0, p.n, tid);
     pair_load(vA, vb, p.sn, 0, p.n, tid);
@@ -337,13 +418,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
-        const unsigned char* Kc = smem + (t & 1) * 24576;
+        const unsigned char* Kc = smem + (t & 1) * 16384;
         if (wave_active) {
-            if (t * 64 + 64 > p.n) dq_tile<TR, true>(Kc, Kc + 8192, Kc + 16384, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
-            else dq_tile<TR, false>(Kc, Kc + 8192, Kc + 16384, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
+            if (t * 64 + 64 > p.n) dq_tile<TR, true>(Kc, Kc + 8192, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
+            else dq_tile<TR, false>(Kc, Kc + 8192, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
         }
         if (t + 1 < nt) {
-            unsigned char* Kn = smem + ((t + 1) & 1) * 24576;
+            unsigned char* Kn = smem + ((t + 1) & 1) * 16384;
             if (t & 1) {
                 stage_store(Kn, kB, vB);
                 pair_load(kB, kb, p.sn, (t + 3) * 64, p.n, tid); pair_load(vB, vb, p.sn, (t + 3) * 64, p.n, tid);
@@ -363,7 +444,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
 // ============================================================================================
 // backward, pass 2: dK, dV
 // ============================================================================================
-constexpr int kDkdvBuf = 4 * 8192 + 512;  // Q, dO row-major; Q^T, dO^T; lse2[64], delta[64]
+constexpr int kDkdvBuf = 2 * 8192 + 512;  // Q, dO row-major (also read transposed); lse2[64], delta[64]
 
 template <class TR>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
@@ -410,9 +491,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
     auto stage_store = [&](unsigned char* buf, const u32x4 (&qr)[2], const u32x4 (&dr)[2], float stat) {
         rm_store(buf, qr, tid);
         rm_store(buf + 8192, dr, tid);
-        tr_store(buf + 16384, qr, tid);
-        tr_store(buf + 24576, dr, tid);
-        if (tid < 128) reinterpret_cast<float*>(buf + 32768)[tid] = stat;
+        if (tid < 128) reinterpret_cast<float*>(buf + 16384)[tid] = stat;
     };
     stage_load(0, qA, doA, statA);
     stage_store(dsmem, qA, doA, statA);
@@ -423,9 +502,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
     auto compute = [&](const unsigned char* Qc) {
         if (!wave_active) return;
         const unsigned char* DOc = Qc + 8192;
-        const unsigned char* QTc = Qc + 16384;
-        const unsigned char* DOTc = Qc + 24576;
-        const float* st = reinterpret_cast<const float*>(Qc + 32768);
+        const float* st = reinterpret_cast<const float*>(Qc + 16384);
         V8 pf[4], df[4];
 #pragma unroll
         for (int qb2 = 0; qb2 < 2; ++qb2) {
@@ -456,10 +533,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
         }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            dv0 = TR::mfma32(lds_frag<TR>(DOTc, r, 2 * g + hh), pf[g], dv0);
-            dv1 = TR::mfma32(lds_frag<TR>(DOTc, 32 + r, 2 * g + hh), pf[g], dv1);
-            dk0 = TR::mfma32(lds_frag<TR>(QTc, r, 2 * g + hh), df[g], dk0);
-            dk1 = TR::mfma32(lds_frag<TR>(QTc, 32 + r, 2 * g + hh), df[g], dk1);
+            dv0 = TR::mfma32(tr_frag<TR>(DOc, g, 0, lane), pf[g], dv0);
+            dv1 = TR::mfma32(tr_frag<TR>(DOc, g, 1, lane), pf[g], dv1);
+            dk0 = TR::mfma32(tr_frag<TR>(Qc, g, 0, lane), df[g], dk0);
+            dk1 = TR::mfma32(tr_frag<TR>(Qc, g, 1, lane), df[g], dk1);
         }
     };
     for (int t = 0; t < nt; ++t) {

@@ -21,10 +21,18 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
 // ---- element traits: the 16-bit MFMA input types -------------------------------------------
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 fp16x4_raw;
+typedef __attribute__((address_space(3))) fp16x4_raw lds_f16x4;
+
 struct BF16 {
     using elem = __bf16;
     using vec8 = bf16x8;
     using vec4 = bf16x4;
+    // ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-column block, delivered column-major
+    static __device__ __forceinline__ vec4 tr_read(const unsigned char* p) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+    }
     static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
@@ -33,6 +41,9 @@ struct F16 {
     using elem = _Float16;
     using vec8 = f16x8;
     using vec4 = f16x4;
+    static __device__ __forceinline__ vec4 tr_read(const unsigned char* p) {
+        return __builtin_bit_cast(vec4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_f16x4*)p));
+    }
     static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
@@ -53,12 +64,14 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 // lanes l and l^32 exchange a value
 __device__ __forceinline__ float swap_half(float x) { return __shfl_xor(x, 32, 64); }
 
-// 64-wide tiles of 16-bit elements live in LDS as 128-byte rows; the 16-byte chunk index is
-// XOR-swizzled with (row>>1)&7 so that the 32 lanes (rows r..r+31, same logical chunk) of a
-// ds_read_b128 fragment read hit 16 distinct 16-byte slots per 16-lane group (conflict-free).
-__device__ __forceinline__ int tile_off(int row, int chunk) {
-    return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4);
-}
+// 64-wide tiles of 16-bit elements live in LDS as 128-byte rows; the 16-byte chunk index is XOR-swizzled
+// with f(row) = bit-permutation of (row>>1)&7 chosen so that BOTH access patterns are conflict-free:
+//   * row reads (ds_read_b128, lanes = 32 consecutive rows, same logical chunk): every 16-lane group of
+//     the instruction touches 16 distinct 16-byte slots of the 256-byte bank row;
+//   * transposed reads (ds_read_b64_tr_b16, a half-wave = 4 consecutive rows x 4 consecutive chunks): rows
+//     q and q+2 (same bank-row half) get XOR values that differ in bit 2, i.e. disjoint chunk sets.
+__device__ __forceinline__ int tile_swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ int tile_off(int row, int chunk) { return row * 128 + (((chunk ^ tile_swz(row)) & 7) << 4); }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
