@@ -115,6 +115,17 @@ int npcd_grid_query(const npcd_grid_params* g, const void* workspace, const floa
                     int32_t* sample_idx, float* sample_loc, int32_t* slot_sample, int32_t* nsel,
                     void* stream);
 
+/* query, fused-render form (voxel-grid semantics only): COMPACT shading-point lists instead of the
+ * dense [ray, slot] arrays, no host round trip.  Per ray: ray_base (row of its first valid slot in the
+ * compact lists), ray_nsel, ray_bits (bit j = slot j has >= 1 neighbour).  Compact rows (slot order
+ * within a ray, ray order unspecified): nb_idx [capacity,k] int32, pts [capacity,3] fp32.
+ * counter[0] = number of compact rows P, counter[1] != 0 if capacity was too small. */
+int npcd_grid_query_compact(const npcd_grid_params* g, const void* workspace, const float* points,
+                            int B, int N, int R, int S, int M, int k, float r,
+                            const float* rays_o, const float* rays_d, const float* t0, const float* t1,
+                            int32_t* counter, int32_t capacity, int32_t* ray_base, int32_t* ray_nsel,
+                            uint64_t* ray_bits, int32_t* nb_idx, float* pts, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Ray generation + box limits (ray_sampler.py:10-49, math_utils.py:46-97, renderer.py:36-47).
  * extr [V,4,4] world2cam fp32, intr [V,3,3] fp32 -> rays_o/rays_d [V,res*res,3], t0/t1 [V,res*res].
@@ -182,6 +193,12 @@ int npcd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* sha
                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    float ema_decay, int zero_grad, void* stream);
 int npcd_cast_f32_bf16(const float* src, void* dst, int64_t numel, void* stream);
+
+/* ray march on the compact layout of npcd_grid_query_compact (same math as npcd_ray_march) */
+int npcd_ray_march_compact(const float* sigma, const float* rgb, const uint64_t* ray_bits, const float* pts,
+                           const int32_t* ray_base, const float* rays_o, const float* rays_d, const float* t1,
+                           int Nr, int M, int white_back, float* mask, float* depth, float* channels,
+                           float* depth_ws, void* stream);
 
 #ifdef __cplusplus
 }

@@ -377,6 +377,150 @@ __global__ __launch_bounds__(256) void grid_query_kernel(QueryArgs a, int blocks
     if (lane == 0) a.nsel[ray] = nsel;
 }
 
+// ---- wave-cooperative neighbour search (grid semantics) -------------------------------------------
+// One wave per ray.  Pass A as above (occupancy -> first M selected samples).  Pass B walks the selected
+// samples one at a time and lets the 64 LANES test 64 points in parallel (conflict-free 16-byte LDS reads
+// instead of 512 serial broadcast reads per lane); the few candidates inside the radius (ballot mask) are
+// inserted one by one into a sorted top-k list that lives across lanes 0..7 (lane t = t-th best), keyed by
+// (dist^2 bits << 32 | point index): dist^2 >= 0, so the unsigned order of the key is exactly the
+// (dist^2, index) order of the spec.  ~5x fewer instructions than one lane per sample.
+struct CompactOut {
+    int32_t* counter;     // [2]: number of compact points, overflow flag
+    int32_t capacity;     // rows available in nb / pts
+    int32_t* ray_base;    // [B*R]
+    int32_t* ray_nsel;    // [B*R]
+    unsigned long long* ray_bits;  // [B*R] valid-slot mask
+    int32_t* nb;          // [capacity][k]
+    float* pts;           // [capacity][3]
+};
+
+template <bool COMPACT>
+__global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, CompactOut co, int blocks_per_example) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+    float4* pts = reinterpret_cast<float4*>(dsmem);
+    uint32_t* bitmap = reinterpret_cast<uint32_t*>(pts + a.N);
+    int* sel = reinterpret_cast<int*>(bitmap + a.nwords);          // [4][64]
+    int* stage_idx = sel + 4 * 64;                                 // [4][64][8]   (COMPACT)
+    float* stage_pos = reinterpret_cast<float*>(stage_idx + 4 * 64 * 8);  // [4][64][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / blocks_per_example;
+    const int rb = blockIdx.x % blocks_per_example;
+    for (int j = tid; j < a.N; j += blockDim.x) {
+        const float* P = a.points + ((int64_t)b * a.N + j) * 3;
+        pts[j] = make_float4(P[0], P[1], P[2], __int_as_float(a.pcoord[(int64_t)b * a.N + j]));
+    }
+    for (int w = tid; w < a.nwords; w += blockDim.x) bitmap[w] = a.occ[(int64_t)b * a.nwords + w];
+    __syncthreads();
+    const int r = rb * 4 + wave;
+    if (r >= a.R) return;
+    const int64_t ray = (int64_t)b * a.R + r;
+    float o[3] = {0, 0, 0}, d[3] = {0, 0, 0}, t0 = 0, t1 = 0;
+    if (!a.x) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { o[c] = a.rays_o[ray * 3 + c]; d[c] = a.rays_d[ray * 3 + c]; }
+        t0 = a.t0[ray];
+        t1 = a.t1[ray];
+    }
+    int* mysel = sel + wave * 64;
+    int nsel = 0;
+    for (int s0 = 0; s0 < a.S && nsel < a.M; s0 += 64) {
+        const int s = s0 + lane;
+        bool occ = false;
+        if (s < a.S) {
+            float p[3];
+            sample_pos(a, ray, s, o, d, t0, t1, p);
+            const FineCoord fc = fine_coord(a.g, p[0], p[1], p[2]);
+            if (fc.ok) {
+                const int bit = ((fc.c[0] / a.g.voxel_scale[0]) * a.g.cdims[1] + fc.c[1] / a.g.voxel_scale[1]) * a.g.cdims[2] + fc.c[2] / a.g.voxel_scale[2];
+                occ = (bitmap[bit >> 5] >> (bit & 31)) & 1u;
+            }
+        }
+        const unsigned long long m = __ballot(occ);
+        const int slot = nsel + __popcll(m & ((1ull << lane) - 1ull));
+        if (occ && slot < a.M) mysel[slot] = s;
+        nsel = min(a.M, nsel + __popcll(m));
+    }
+    const int hx = (a.g.kernel_size[0] - 1) / 2, hy = (a.g.kernel_size[1] - 1) / 2, hz = (a.g.kernel_size[2] - 1) / 2;
+    const int gbase = b * a.N;
+    int32_t* out_idx = COMPACT ? nullptr : a.sample_idx + ray * a.M * a.k;
+    float* out_loc = COMPACT ? nullptr : a.sample_loc + ray * a.M * 3;
+    int32_t* out_ss = COMPACT ? nullptr : a.slot_sample + ray * a.M;
+    unsigned long long valid_bits = 0ull;
+    for (int slot = 0; slot < nsel; ++slot) {
+        const int s = mysel[slot];                     // same-wave LDS write -> read is ordered
+        float p[3];
+        sample_pos(a, ray, s, o, d, t0, t1, p);       // wave-uniform values
+        const FineCoord fc = fine_coord(a.g, p[0], p[1], p[2]);
+        uint32_t key_hi = 0xffffffffu, key_lo = 0xffffffffu;   // lanes 0..7 hold the sorted list
+        for (int j0 = 0; j0 < a.N; j0 += 64) {
+            const int j = j0 + lane;
+            bool cand = false;
+            float d2 = 0.f;
+            if (j < a.N) {
+                const float4 q = pts[j];
+                const float dx = p[0] - q.x, dy = p[1] - q.y, dz = p[2] - q.z;
+                d2 = (dx * dx + dy * dy) + dz * dz;
+                const int pc = __float_as_int(q.w);
+                const int ix = pc & 1023, iy = (pc >> 10) & 1023, iz = (pc >> 20) & 1023;
+                cand = (d2 < a.r2) && ((pc >> 30) & 1) && (abs(ix - fc.c[0]) <= hx) && (abs(iy - fc.c[1]) <= hy) && (abs(iz - fc.c[2]) <= hz);
+            }
+            unsigned long long cm = __ballot(cand);
+            while (cm) {                                // wave-uniform loop over the (few) candidates, ascending index
+                const int bl = __ffsll((long long)cm) - 1;
+                cm &= cm - 1;
+                const uint32_t ch = __builtin_amdgcn_readlane(__float_as_uint(d2), bl);
+                const uint32_t cl = (uint32_t)(j0 + bl);
+                const bool le = (key_hi < ch) || (key_hi == ch && key_lo < cl);   // existing entry sorts before the candidate
+                const int pos = __popcll(__ballot(le) & 0xffull);
+                if (pos < 8) {
+                    const uint32_t up_hi = __shfl_up(key_hi, 1, 64), up_lo = __shfl_up(key_lo, 1, 64);
+                    if (lane == pos) { key_hi = ch; key_lo = cl; }
+                    else if (lane > pos) { key_hi = up_hi; key_lo = up_lo; }
+                }
+            }
+        }
+        const bool has = key_lo != 0xffffffffu;
+        const int first = __builtin_amdgcn_readfirstlane(has ? 1 : 0);   // lane 0 = best entry
+        if (COMPACT) {
+            if (lane < 8) stage_idx[(wave * 64 + slot) * 8 + lane] = has ? gbase + (int)key_lo : -1;
+            if (lane < 3) stage_pos[(wave * 64 + slot) * 4 + lane] = lane == 0 ? p[0] : (lane == 1 ? p[1] : p[2]);
+            if (first) valid_bits |= (1ull << slot);
+        } else {
+            if (lane < a.k) out_idx[slot * a.k + lane] = has ? gbase + (int)key_lo : -1;
+            if (lane < 3) out_loc[slot * 3 + lane] = lane == 0 ? p[0] : (lane == 1 ? p[1] : p[2]);
+            if (lane == 0) out_ss[slot] = s;
+        }
+    }
+    if (COMPACT) {
+        const int cnt = __popcll(valid_bits);
+        int base = 0;
+        if (cnt > 0) {
+            if (lane == 0) base = atomicAdd(co.counter, cnt);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base + cnt > co.capacity) {
+                if (lane == 0) atomicOr(co.counter + 1, 1);
+            } else if (lane < nsel && ((valid_bits >> lane) & 1ull)) {
+                const int row = base + __popcll(valid_bits & ((1ull << lane) - 1ull));
+                for (int t = 0; t < a.k; ++t) co.nb[(int64_t)row * a.k + t] = stage_idx[(wave * 64 + lane) * 8 + t];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) co.pts[(int64_t)row * 3 + c] = stage_pos[(wave * 64 + lane) * 4 + c];
+            }
+        }
+        if (lane == 0) {
+            co.ray_base[ray] = base;
+            co.ray_nsel[ray] = nsel;
+            co.ray_bits[ray] = valid_bits;
+        }
+    } else {
+        for (int slot = nsel + lane; slot < a.M; slot += 64) {
+            for (int t = 0; t < a.k; ++t) out_idx[slot * a.k + t] = -1;
+            out_loc[slot * 3 + 0] = 0.f; out_loc[slot * 3 + 1] = 0.f; out_loc[slot * 3 + 2] = 0.f;
+            out_ss[slot] = -1;
+        }
+        if (lane == 0) a.nsel[ray] = nsel;
+    }
+}
+
 // ============================================================================================
 // ray march
 // ============================================================================================
@@ -385,6 +529,8 @@ __global__ void march_init_kernel(uint32_t* ws) {
     ws[1] = 0u;           // max depth key
 }
 
+// COMPACT: slot validity comes from a per-ray 64-bit mask and slot positions from the compact point list
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void ray_march_kernel(const float* __restrict__ sigma, const float* __restrict__ rgb, const uint8_t* __restrict__ slot_valid,
                                                         const float* __restrict__ slot_loc, const int32_t* __restrict__ point_base,
                                                         const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ t1,
@@ -396,15 +542,16 @@ __global__ __launch_bounds__(256) void ray_march_kernel(const float* __restrict_
         const float o[3] = {rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2]};
         const float d[3] = {rays_d[ray * 3], rays_d[ray * 3 + 1], rays_d[ray * 3 + 2]};
         const float ray_end = t1[ray];
-        const uint8_t* sv = slot_valid + (int64_t)ray * M;
-        const float* sl = slot_loc + (int64_t)ray * M * 3;
+        const uint8_t* sv = COMPACT ? nullptr : slot_valid + (int64_t)ray * M;
+        const float* sl = COMPACT ? nullptr : slot_loc + (int64_t)ray * M * 3;
+        const unsigned long long bits = COMPACT ? reinterpret_cast<const unsigned long long*>(slot_valid)[ray] : 0ull;
         int cp = point_base[ray];
         float run_max = -INFINITY;
         float T = 1.f, total = 0.f, wd = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
         float pd = 0.f, ps = 0.f, pr = 0.f, pg = 0.f, pb = 0.f;  // previous slot
         bool pv = false;
         for (int j = 0; j < M; ++j) {
-            const bool valid = sv[j] != 0;
+            const bool valid = COMPACT ? ((bits >> j) & 1ull) != 0 : sv[j] != 0;
             float sg = 0.f, r_ = 0.f, g_ = 0.f, b_ = 0.f;
             if (valid) {
                 // depth = nanmean_xyz((p - o) / d)   (renderer.py:103)
@@ -412,7 +559,8 @@ __global__ __launch_bounds__(256) void ray_march_kernel(const float* __restrict_
                 int cnt = 0;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const float q = (sl[j * 3 + c] - o[c]) / d[c];
+                    const float pc = COMPACT ? slot_loc[(int64_t)cp * 3 + c] : sl[j * 3 + c];
+                    const float q = (pc - o[c]) / d[c];
                     if (q == q) { acc += q; ++cnt; }
                 }
                 const float dep = acc / (float)cnt;  // cnt == 0 -> NaN, like torch.nanmean
@@ -556,7 +704,15 @@ extern "C" int npcd_grid_query(const npcd_grid_params* g, const void* workspace,
         NPCD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set[mode] = lds;
     }
-    if (mode == 0) hipLaunchKernelGGL(grid_query_kernel<true>, dim3(B * bpe), dim3(256), lds, st, a, bpe);
+    if (mode == 0) {
+        const size_t lds2 = lds + 4 * 64 * 8 * 4 + 4 * 64 * 4 * 4;
+        static size_t lds2_set = 0;
+        if (lds2 > 65536 && lds2 > lds2_set) {
+            NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_query_wave_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            lds2_set = lds2;
+        }
+        hipLaunchKernelGGL(grid_query_wave_kernel<false>, dim3(B * bpe), dim3(256), lds2, st, a, CompactOut{}, bpe);
+    }
     else hipLaunchKernelGGL(grid_query_kernel<false>, dim3(B * bpe), dim3(256), lds, st, a, bpe);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
@@ -572,8 +728,69 @@ extern "C" int npcd_ray_march(const float* sigma, const float* rgb, const uint8_
     uint32_t* ws = reinterpret_cast<uint32_t*>(depth_ws);
     const int grid = (Nr + 255) / 256;
     hipLaunchKernelGGL(march_init_kernel, dim3(1), dim3(1), 0, st, ws);
-    hipLaunchKernelGGL(ray_march_kernel, dim3(grid), dim3(256), 0, st, sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1,
+    hipLaunchKernelGGL(ray_march_kernel<false>, dim3(grid), dim3(256), 0, st, sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1,
                        Nr, M, white_back, mask, depth, channels, ws);
+    hipLaunchKernelGGL(depth_clamp_kernel, dim3(grid), dim3(256), 0, st, Nr, depth, ws);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+// Fused-render form of the neighbour query: compact shading-point lists instead of the dense [ray, slot]
+// arrays.  counter[0] receives the number of compact points, counter[1] an overflow flag (capacity too small;
+// nothing is written for the overflowing rays).  Rows of one ray are contiguous and in slot order.
+extern "C" int npcd_grid_query_compact(const npcd_grid_params* g, const void* workspace, const float* points, int B, int N, int R, int S,
+                                       int M, int k, float r, const float* rays_o, const float* rays_d, const float* t0, const float* t1,
+                                       int32_t* counter, int32_t capacity, int32_t* ray_base, int32_t* ray_nsel, uint64_t* ray_bits,
+                                       int32_t* nb_idx, float* pts, void* stream) {
+    int rc = grid_check(g, B, N);
+    if (rc != NPCD_OK) return rc;
+    if (!workspace || !points || !rays_o || !rays_d || !t0 || !t1 || !counter || !ray_base || !ray_nsel || !ray_bits || !nb_idx || !pts)
+        return NPCD_ERR_ARG;
+    if (R <= 0 || S <= 1 || M <= 0 || k <= 0 || capacity <= 0 || !(r > 0.f)) return NPCD_ERR_ARG;
+    if (M > 64 || k > 8) return NPCD_ERR_UNSUPPORTED;
+    QueryArgs a{};
+    a.g = *g;
+    a.pcoord = static_cast<const int32_t*>(workspace);
+    a.nwords = occ_words(*g);
+    a.occ = reinterpret_cast<const uint32_t*>(a.pcoord + (int64_t)B * N);
+    a.points = points;
+    a.B = B; a.N = N; a.R = R; a.S = S; a.M = M; a.k = k;
+    float vmax = g->voxel_size[0];
+    if (g->voxel_size[1] > vmax) vmax = g->voxel_size[1];
+    if (g->voxel_size[2] > vmax) vmax = g->voxel_size[2];
+    const float radius = (float)((double)r * (double)vmax);
+    a.r2 = radius * radius;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.t0 = t0; a.t1 = t1;
+    CompactOut co{};
+    co.counter = counter; co.capacity = capacity; co.ray_base = ray_base; co.ray_nsel = ray_nsel;
+    co.ray_bits = reinterpret_cast<unsigned long long*>(ray_bits); co.nb = nb_idx; co.pts = pts;
+    const int bpe = (R + 3) / 4;
+    const size_t lds = (size_t)N * 16 + (size_t)a.nwords * 4 + 4 * 64 * 4 + 4 * 64 * 8 * 4 + 4 * 64 * 4 * 4;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static size_t lds_set = 0;
+    if (lds > 65536 && lds > lds_set) {
+        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_query_wave_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
+    }
+    NPCD_HIP_CHECK(hipMemsetAsync(counter, 0, 2 * sizeof(int32_t), st));
+    hipLaunchKernelGGL(grid_query_wave_kernel<true>, dim3(B * bpe), dim3(256), lds, st, a, co, bpe);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+// Ray march on the compact layout produced by npcd_grid_query_compact.
+extern "C" int npcd_ray_march_compact(const float* sigma, const float* rgb, const uint64_t* ray_bits, const float* pts, const int32_t* ray_base,
+                                      const float* rays_o, const float* rays_d, const float* t1, int Nr, int M, int white_back, float* mask,
+                                      float* depth, float* channels, float* depth_ws, void* stream) {
+    if (!sigma || !rgb || !ray_bits || !pts || !ray_base || !rays_o || !rays_d || !t1 || !mask || !depth || !channels || !depth_ws)
+        return NPCD_ERR_ARG;
+    if (Nr <= 0 || M <= 0 || M > 64) return NPCD_ERR_ARG;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint32_t* ws = reinterpret_cast<uint32_t*>(depth_ws);
+    const int grid = (Nr + 255) / 256;
+    hipLaunchKernelGGL(march_init_kernel, dim3(1), dim3(1), 0, st, ws);
+    hipLaunchKernelGGL(ray_march_kernel<true>, dim3(grid), dim3(256), 0, st, sigma, rgb, reinterpret_cast<const uint8_t*>(ray_bits), pts, ray_base,
+                       rays_o, rays_d, t1, Nr, M, white_back, mask, depth, channels, ws);
     hipLaunchKernelGGL(depth_clamp_kernel, dim3(grid), dim3(256), 0, st, Nr, depth, ws);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;

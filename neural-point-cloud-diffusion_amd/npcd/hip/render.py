@@ -94,6 +94,26 @@ class HipVoxelGrid:
                                     ptr(idx), ptr(loc), ptr(ss), ptr(nsel), stream_ptr()), "npcd_grid_query")
         return idx, loc, ss, nsel
 
+    def query_compact(self, k: int, r: float, M: int, rays, S: int, capacity: int, points: Optional[torch.Tensor] = None):
+        """Fused-render form (npcd_grid_query_compact): returns counter [2] int32 (P, overflow flag),
+        ray_base [B*R] int32, ray_nsel [B*R] int32, ray_bits [B*R] int64 (valid-slot masks),
+        nb [capacity,k] int32, pts [capacity,3] fp32 -- all on the device, no host round trip."""
+        pts_t = self.points if points is None else points.detach().to(_f32).contiguous()
+        B, N, _ = pts_t.shape
+        o, d, t0, t1 = (t.to(_f32).contiguous() for t in rays)
+        R = o.shape[1]
+        dev = pts_t.device
+        counter = torch.empty(2, dtype=_i32, device=dev)
+        ray_base = torch.empty(B * R, dtype=_i32, device=dev)
+        ray_nsel = torch.empty(B * R, dtype=_i32, device=dev)
+        ray_bits = torch.empty(B * R, dtype=torch.int64, device=dev)
+        nb = torch.empty((capacity, k), dtype=_i32, device=dev)
+        cpts = torch.empty((capacity, 3), dtype=_f32, device=dev)
+        check(lib().npcd_grid_query_compact(ctypes.byref(self.params), ptr(self.workspace), ptr(pts_t), B, N, R, int(S), int(M), int(k),
+                                            float(r), ptr(o), ptr(d), ptr(t0), ptr(t1), ptr(counter), int(capacity), ptr(ray_base),
+                                            ptr(ray_nsel), ptr(ray_bits), ptr(nb), ptr(cpts), stream_ptr()), "npcd_grid_query_compact")
+        return counter, ray_base, ray_nsel, ray_bits, nb, cpts
+
     def query(self, x: torch.Tensor, k: int, r: float, max_shading_pts: int):
         """torch_knnquery.VoxelGrid.query contract (aggregator.py:63-73):
         sample_idx [R_valid, M, k], sample_loc [R_valid, M, 3], ray_mask [B, R]."""
@@ -137,13 +157,27 @@ def shade_points(wpack: torch.Tensor, feat_dim: int, nb_idx: torch.Tensor, pts: 
     if P == 0:
         return sigma, rgb
     if n_points is None:
-        n_points = torch.tensor([P], dtype=_i32, device=dev)
+        n_points = torch.full((1,), P, dtype=_i32, device=dev)
     L = lib()
     wsb = L.npcd_shade_workspace_bytes(P, hidden)
     work = torch.empty(wsb, dtype=torch.uint8, device=dev)
     check(L.npcd_shade_points(ptr(wpack), feat_dim, n_freqs, hidden, ptr(nb_idx), ptr(pts), ptr(kp_pos), ptr(kp_feat),
                               ptr(n_points), P, k, ptr(sigma), ptr(rgb), ptr(work), stream_ptr()), "npcd_shade_points")
     return sigma, rgb
+
+
+def ray_march_compact(sigma, rgb, ray_bits, pts, ray_base, rays_o, rays_d, t1, M, white_back=True):
+    """Ray march on the compact layout of HipVoxelGrid.query_compact."""
+    Nr = ray_base.shape[0]
+    dev = ray_base.device
+    mask = torch.empty(Nr, dtype=_f32, device=dev)
+    depth = torch.empty(Nr, dtype=_f32, device=dev)
+    chan = torch.empty((Nr, 3), dtype=_f32, device=dev)
+    ws = torch.empty(4, dtype=_f32, device=dev)
+    check(lib().npcd_ray_march_compact(ptr(sigma), ptr(rgb), ptr(ray_bits), ptr(pts), ptr(ray_base), ptr(rays_o.contiguous()),
+                                       ptr(rays_d.contiguous()), ptr(t1.contiguous()), Nr, int(M), int(bool(white_back)), ptr(mask),
+                                       ptr(depth), ptr(chan), ptr(ws), stream_ptr()), "npcd_ray_march_compact")
+    return mask, depth, chan
 
 
 def ray_march(sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1, white_back=True):

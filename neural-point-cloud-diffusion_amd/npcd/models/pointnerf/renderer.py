@@ -17,6 +17,8 @@ class VolumeRenderer(nn.Module):
         self.cube_scale, self.depth_resolution = cube_scale, depth_resolution
         self.ray_subsamples, self.white_back = ray_subsamples, white_back
         self.randomize_depth_samples = False
+        self.capacity_fraction = 0.25      # compact shading-point buffers: fraction of rays*slots reserved up front
+        self.count_pairs = True            # report the number of (point, neighbour) pairs (one extra reduction)
 
     def forward(self, kp_pos, kp_feat, extr, intr, resolution: int, sample: bool, return_channels: bool = True,
                 return_kp_weights: bool = False, knn_mode: int = 0):
@@ -33,20 +35,38 @@ class VolumeRenderer(nn.Module):
         o, d, t0, t1 = hr.ray_gen(extr.flatten(0, 1), intr.flatten(0, 1), resolution, self.cube_scale)
         R = o.shape[1]
         rays = (o.view(B, T * R, 3), d.view(B, T * R, 3), t0.view(B, T * R), t1.view(B, T * R))
-        idx, loc, _, _ = grid.query_dense(agg.k, agg.r if knn_mode == 0 else agg.scaled_r, agg.max_shading_pts, rays=rays,
-                                          S=self.depth_resolution, mode=knn_mode, points=kp_pos)
         M = agg.max_shading_pts
-        valid = (idx[..., 0] >= 0).view(B * T * R, M)
-        per_ray = valid.sum(dim=1, dtype=torch.int32)
-        base = torch.cumsum(per_ray, dim=0, dtype=torch.int32) - per_ray
-        nb = idx.view(B * T * R, M, agg.k)[valid]                     # compact, row-major over [ray, slot]
-        pts = loc.view(B * T * R, M, 3)[valid]
-        sigma, rgb = self.field.shade(nb, pts, kp_pos, kp_feat)
-        mask, depth, chan = hr.ray_march(sigma, rgb, valid, loc.view(B * T * R, M, 3), base, o.view(-1, 3), d.view(-1, 3),
-                                         t1.reshape(-1), self.white_back)
+        if knn_mode == 0:
+            # fused path: compact shading-point lists are produced on the device; the shading kernels read the
+            # point count from device memory, so nothing round-trips through the host until the result is used
+            capacity = max(4096, int(B * T * R * M * self.capacity_fraction))
+            while True:
+                counter, ray_base, _, ray_bits, nb, pts = grid.query_compact(agg.k, agg.r, M, rays, self.depth_resolution, capacity,
+                                                                           points=kp_pos)
+                sigma, rgb = hr.shade_points(self.field.packed_weights(kp_pos.device), agg.in_dim, nb, pts, kp_pos.reshape(-1, 3),
+                                             kp_feat.reshape(-1, kp_feat.shape[-1]), n_points=counter[:1], n_freqs=agg.n_freqs,
+                                             hidden=self.field.hid_dim)
+                mask, depth, chan = hr.ray_march_compact(sigma, rgb, ray_bits, pts, ray_base, o.view(-1, 3), d.view(-1, 3), t1.reshape(-1),
+                                                         M, self.white_back)
+                P, overflow = counter.tolist()
+                if not overflow:
+                    break
+                capacity = B * T * R * M                       # worst case: every slot of every ray is valid
+            n_pairs = int((nb[:P] >= 0).sum()) if self.count_pairs else -1
+        else:
+            idx, loc, _, _ = grid.query_dense(agg.k, agg.scaled_r, M, rays=rays, S=self.depth_resolution, mode=knn_mode, points=kp_pos)
+            valid = (idx[..., 0] >= 0).view(B * T * R, M)
+            per_ray = valid.sum(dim=1, dtype=torch.int32)
+            base = torch.cumsum(per_ray, dim=0, dtype=torch.int32) - per_ray
+            nb = idx.view(B * T * R, M, agg.k)[valid]                     # compact, row-major over [ray, slot]
+            pts = loc.view(B * T * R, M, 3)[valid]
+            sigma, rgb = self.field.shade(nb, pts, kp_pos, kp_feat)
+            mask, depth, chan = hr.ray_march(sigma, rgb, valid, loc.view(B * T * R, M, 3), base, o.view(-1, 3), d.view(-1, 3),
+                                             t1.reshape(-1), self.white_back)
+            P, n_pairs = int(nb.shape[0]), int((nb >= 0).sum())
         out = AttrDict(mask=mask.view(B, T, R, 1), depth=depth.view(B, T, R, 1))
         if return_channels:
             out["channels"] = chan.view(B, T, R, 3)
-        out["num_shading_points"] = int(nb.shape[0])
-        out["num_pairs"] = int((nb >= 0).sum())
+        out["num_shading_points"] = P
+        out["num_pairs"] = n_pairs
         return out

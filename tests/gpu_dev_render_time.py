@@ -1,0 +1,16 @@
+import sys, os, time
+R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R_); sys.path.insert(0, os.path.join(R_, "neural-point-cloud-diffusion_amd"))
+import torch
+from oracle import renderer as orr
+from npcd.models.pointnerf import PointNeRF
+coords, feats = orr.synthetic_cloud(512, 32, 1, seed=0)
+model = PointNeRF(1, 32, 512, False); model.field.load_state_dict(orr.init_field_params(32, seed=0)); model = model.cuda().eval()
+extr = orr.look_at_pose(30, 20)[None, None].cuda(); intr = orr.srn_intrinsics()[None, None].cuda()
+c, f = coords.cuda(), feats.cuda()
+with torch.no_grad():
+    for _ in range(3): out = model.render(c, f, extr, intr, 128)
+    torch.cuda.synchronize(); t = time.time()
+    for _ in range(10): out = model.render(c, f, extr, intr, 128)
+    torch.cuda.synchronize(); dt = (time.time() - t) / 10
+print("128^2 view: %.3f ms  %.2f Mrays/s  P=%d Q=%d" % (dt*1e3, 16384/dt/1e6, out["num_shading_points"], out["num_pairs"]))
