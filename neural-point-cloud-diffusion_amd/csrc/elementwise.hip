@@ -86,22 +86,23 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
 // Linear whose output was added to the residual stream right before this LayerNorm).
 // Workgroup = 4 waves x kRowsPerWave rows; partials [gridDim.x][W] are summed by colsum_finalize.
 // ============================================================================================
-constexpr int kRowsPerWave = 8;
+// rows per wave are chosen per launch so that the grid keeps >= ~1000 workgroups also at small token counts
+static inline int ln_rows_per_wave(int T) { int r = T / (4 * 1024); return r < 1 ? 1 : (r > 8 ? 8 : r); }
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      const float* __restrict__ dres, float* __restrict__ dx, __bf16* __restrict__ dxb,
                                                      float* __restrict__ part_gamma, float* __restrict__ part_beta,
-                                                     float* __restrict__ part_col, int T, int W) {
+                                                     float* __restrict__ part_col, int T, int W, int rows_per_wave) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
     float* red = reinterpret_cast<float*>(dsmem);  // [3][4 waves][W]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 ag[NCH], ab[NCH], ac[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) ag[ch] = ab[ch] = ac[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int row0 = (blockIdx.x * 4 + wave) * kRowsPerWave;
-    for (int rr = 0; rr < kRowsPerWave; ++rr) {
+    const int row0 = (blockIdx.x * 4 + wave) * rows_per_wave;
+    for (int rr = 0; rr < rows_per_wave; ++rr) {
         const int row = row0 + rr;
         if (row >= T) break;
         const int64_t base = (int64_t)row * W;
@@ -183,12 +184,11 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restr
     if (ty == 0 && c < N) stage[(int64_t)blockIdx.y * N + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
-__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ stage, int N, float* __restrict__ out, int accumulate) {
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ stage, int nrows, int N, float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= N) return;
     float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < kFinSlices; ++k) s += stage[(int64_t)k * N + c];
+    for (int k = 0; k < nrows; ++k) s += stage[(int64_t)k * N + c];
     out[c] = accumulate ? out[c] + s : s;
 }
 
@@ -211,18 +211,18 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16x8* __restrict_
 }
 
 // column-partial reductions: a thread owns 8 consecutive columns and walks kColRows rows
-constexpr int kColRows = 64;
+static inline int col_rows(int T) { int r = T / 512; return r < 8 ? 8 : (r > 64 ? 64 : r); }
 
 template <bool GELU>
 __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ hpre, __bf16* __restrict__ out,
-                                                     float* __restrict__ part, int T, int N) {
+                                                     float* __restrict__ part, int T, int N, int rows) {
     const int col = (blockIdx.x * 256 + threadIdx.x) * 8;
     if (col >= N) return;
-    const int row0 = blockIdx.y * kColRows;
+    const int row0 = blockIdx.y * rows;
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int rr = 0; rr < kColRows; ++rr) {
+    for (int rr = 0; rr < rows; ++rr) {
         const int row = row0 + rr;
         if (row >= T) break;
         const int64_t off = (int64_t)row * N + col;
@@ -308,7 +308,7 @@ extern "C" int npcd_add_ln_fwd(const float* x_in, const void* delta, const float
     return NPCD_OK;
 }
 
-extern "C" int npcd_ln_bwd_blocks(int T) { return (T + 4 * kRowsPerWave - 1) / (4 * kRowsPerWave); }
+extern "C" int npcd_ln_bwd_blocks(int T) { const int r = ln_rows_per_wave(T); return (T + 4 * r - 1) / (4 * r); }
 
 extern "C" int npcd_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
                            float* dx, void* dxb, float* part_gamma, float* part_beta, float* part_col, int T, int W, void* stream) {
@@ -325,7 +325,7 @@ extern "C" int npcd_ln_bwd(const void* dy, const float* x, const float* mean, co
     }
 #define NPCD_LAUNCH_LN_BWD(NCH)                                                                                                \
     hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3(nblk), dim3(256), lds, st, static_cast<const __bf16*>(dy), x, mean, rstd, gamma, \
-                       dres, dx, static_cast<__bf16*>(dxb), part_gamma, part_beta, part_col, T, W)
+                       dres, dx, static_cast<__bf16*>(dxb), part_gamma, part_beta, part_col, T, W, ln_rows_per_wave(T))
     if (W <= 256) NPCD_LAUNCH_LN_BWD(1);
     else if (W <= 512) NPCD_LAUNCH_LN_BWD(2);
     else if (W <= 1024) NPCD_LAUNCH_LN_BWD(4);
@@ -342,9 +342,13 @@ extern "C" int npcd_colsum_scratch_rows(void) { return kFinSlices; }
 extern "C" int npcd_colsum_finalize(const float* part, int nblk, int N, float* out, int accumulate, void* stream) {
     if (!part || !out || nblk <= 0 || N <= 0) return NPCD_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    float* stage = const_cast<float*>(part) + (int64_t)nblk * N;
-    hipLaunchKernelGGL(colsum_stage1_kernel, dim3((N + 63) / 64, kFinSlices), dim3(256), 0, st, part, nblk, N, stage);
-    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, st, stage, N, out, accumulate);
+    if (nblk <= 2 * kFinSlices) {   // few partial rows: one pass
+        hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, nblk, N, out, accumulate);
+    } else {
+        float* stage = const_cast<float*>(part) + (int64_t)nblk * N;
+        hipLaunchKernelGGL(colsum_stage1_kernel, dim3((N + 63) / 64, kFinSlices), dim3(256), 0, st, part, nblk, N, stage);
+        hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, st, stage, kFinSlices, N, out, accumulate);
+    }
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }
@@ -360,7 +364,7 @@ extern "C" int npcd_gelu_fwd(const void* h, void* g, int64_t numel, void* stream
     return NPCD_OK;
 }
 
-extern "C" int npcd_colsum_blocks(int T) { return (T + kColRows - 1) / kColRows; }
+extern "C" int npcd_colsum_blocks(int T) { const int r = col_rows(T); return (T + r - 1) / r; }
 
 // dh = dg * gelu'(h) (bf16) and column partials of dh: part [npcd_colsum_blocks(T)][N]
 extern "C" int npcd_gelu_bwd(const void* dg, const void* h, void* dh, float* part, int T, int N, void* stream) {
@@ -368,7 +372,7 @@ extern "C" int npcd_gelu_bwd(const void* dg, const void* h, void* dh, float* par
     if (N % 8 != 0 || !al16(dg) || !al16(h) || !al16(dh) || !al16(part)) return NPCD_ERR_UNSUPPORTED;
     dim3 grid((N / 8 + 255) / 256, npcd_colsum_blocks(T));
     hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const __bf16*>(dg),
-                       static_cast<const __bf16*>(h), static_cast<__bf16*>(dh), part, T, N);
+                       static_cast<const __bf16*>(h), static_cast<__bf16*>(dh), part, T, N, col_rows(T));
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }
@@ -378,7 +382,7 @@ extern "C" int npcd_colsum_bf16(const void* a, float* part, int T, int N, void* 
     if (N % 8 != 0 || !al16(a) || !al16(part)) return NPCD_ERR_UNSUPPORTED;
     dim3 grid((N / 8 + 255) / 256, npcd_colsum_blocks(T));
     hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const __bf16*>(a),
-                       static_cast<const __bf16*>(nullptr), static_cast<__bf16*>(nullptr), part, T, N);
+                       static_cast<const __bf16*>(nullptr), static_cast<__bf16*>(nullptr), part, T, N, col_rows(T));
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }

@@ -34,6 +34,7 @@ def _wgrad(dy, x, out):
     mlp.c_proj 308 -> 255 us."""
     T = dy.shape[0]
     S = 8 if out.numel() <= (1 << 20) else 4
+    S = min(S, max(1, T // 4096))          # keep >= 4096 rows per slice: short reductions need no split
     while S > 1 and T % S:
         S //= 2
     if S == 1:

@@ -5,8 +5,9 @@ sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-di
 import torch
 import bench
 dev = torch.device("cuda", 0)
-tr = bench.build_trainer(dev, 64)
-coords, feats = bench.synthetic_batch(64, 0, 1, dev)
+B_ = int(os.environ.get("B", 64))
+tr = bench.build_trainer(dev, B_)
+coords, feats = bench.synthetic_batch(64, 0, 64 // B_, dev)
 for _ in range(3): tr.step(coords, feats)
 torch.cuda.synchronize(); t0 = time.time()
 for _ in range(5): tr.step(coords, feats)
