@@ -183,6 +183,14 @@ def main():
     dominant = max(kern_ms, key=lambda k: kern_ms[k])
     achieved = alg[dominant] / (kern_ms[dominant] * 1e-3) / 1e12
 
+    # HBM traffic of the dominant kernel: measured with rocprofv3 PMC counters (FETCH_SIZE/WRITE_SIZE, separate passes,
+    # gfx950 x2 read correction) on this exact kernel and shape -- bench.py itself cannot collect PMC counters
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r1_attention_hbm_traffic_pmc.json")
+    kname = {"fwd": "attn_fwd_kernel", "dq": "attn_bwd_dq_kernel", "dkdv": "attn_bwd_dkdv_kernel"}[dominant]
+    if per == 64 and os.path.exists(tfile):
+        traffic = json.load(open(tfile)).get(kname, {}).get("hbm_bytes")
+
     result = {
         "metric": "denoiser train steps/sec (+ rendered rays/sec under 'render'), SRN-Cars 512pt x 128d",
         "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -194,9 +202,11 @@ def main():
         "step_tflops": denoiser_flops_per_sample() * CFG["global_batch"] / (elapsed / args.steps) / 1e12,
         "step_frac_of_bf16_mfma_peak": denoiser_flops_per_sample() * CFG["global_batch"] / (elapsed / args.steps) / 1e12
                                        / (PEAK_BF16_TFLOPS * world),
-        "roofline": {"kernel": {"fwd": "attn_fwd_kernel", "dq": "attn_bwd_dq_kernel", "dkdv": "attn_bwd_dkdv_kernel"}[dominant],
+        "roofline": {"kernel": kname,
                      "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": None,
+                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
+                     "traffic_source": "profiles/r1_attention_hbm_traffic_pmc.json (rocprofv3 --pmc, bytes per launch)" if traffic else None,
+                     "algorithmic_flops_per_launch": alg[dominant],
                      "avg_ms": kern_ms[dominant], "launches": len(events[dominant]),
                      "all_attention_kernels_ms": kern_ms,
                      "all_attention_kernels_tflops": {k: alg[k] / (kern_ms[k] * 1e-3) / 1e12 for k in kern_ms}},
