@@ -192,49 +192,31 @@ __device__ __forceinline__ float half_sum(float x) {
 // for the retry loop spilled 51 VGPRs and the kernel ran 2x slower.)
 constexpr float kDeferLog2 = 8.f;
 
+// One 32-key half tile: S^T (4 MFMAs) -> online softmax on 16 scores per lane -> O^T += V^T P^T (4 MFMAs).
+// Working in 32-key halves keeps the live register set small enough for 3-4 waves per SIMD, which is what
+// hides the MFMA->VALU and LDS latencies of this vector-ALU-bound kernel.
 template <class TR, bool MASK>
-__device__ __forceinline__ void fwd_tile(const unsigned char* Kc, const unsigned char* Vc, const typename TR::vec8 (&qf)[4], f32x16& o0,
-                                         f32x16& o1, float& m, float& l, float c, int key0, int n, int r, int hh) {
+__device__ __forceinline__ void fwd_half(const unsigned char* Kc, const unsigned char* Vc, int kb, const typename TR::vec8 (&qf)[4],
+                                         f32x16& o0, f32x16& o1, float& m, float& l, float c, int key0, int n, int r, int hh) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
-    f32x16 s0 = {0}, s1 = {0};
+    f32x16 s0 = {0};
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        s0 = TR::mfma32(lds_frag<TR>(Kc, r, 2 * s + hh), qf[s], s0);
-        s1 = TR::mfma32(lds_frag<TR>(Kc, 32 + r, 2 * s + hh), qf[s], s1);
+    for (int s = 0; s < 4; ++s) s0 = TR::mfma32(lds_frag<TR>(Kc, kb * 32 + r, 2 * s + hh), qf[s], s0);
+    TrPair vt[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        vt[g][0] = tr_issue(Vc, kb * 2 + g, 0, (hh << 5) | r);
+        vt[g][1] = tr_issue(Vc, kb * 2 + g, 1, (hh << 5) | r);
     }
     if (MASK) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int k0 = key0 + acc_row(i, hh);
-            if (k0 >= n) s0[i] = -INFINITY;
-            if (k0 + 32 >= n) s1[i] = -INFINITY;
-        }
+        for (int i = 0; i < 16; ++i)
+            if (key0 + kb * 32 + acc_row(i, hh) >= n) s0[i] = -INFINITY;
     }
-    TrPair vt[4][2];
+    float mx = fmaxf(s0[0], s0[1]);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        vt[g][0] = tr_issue(Vc, g, 0, (hh << 5) | r);
-        vt[g][1] = tr_issue(Vc, g, 1, (hh << 5) | r);
-    }
-#if NPCD_ABL == 1 || NPCD_ABL == 2
-    {
-        V8 pf[4];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { pf[0][j] = (E)s0[j]; pf[1][j] = (E)s0[8 + j]; pf[2][j] = (E)s1[j]; pf[3][j] = (E)s1[8 + j]; }
-        tr_wait();
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            o0 = TR::mfma32(tr_vec<TR>(vt[g][0]), pf[g], o0);
-            o1 = TR::mfma32(tr_vec<TR>(vt[g][1]), pf[g], o1);
-        }
-        l = 1.f; m = 0.f;
-        return;
-    }
-#endif
-    float mx = fmaxf(s0[0], s1[0]);
-#pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(fmaxf(mx, s0[i]), s1[i]);
+    for (int i = 2; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s0[i]), s0[i + 1]);
     mx = half_max(mx) * c;   // c = scale * log2(e) > 0: m lives in the exp2 domain
     if (__any(mx > m + kDeferLog2)) {
         const float mn = (mx > m + kDeferLog2) ? mx : m;
@@ -248,28 +230,32 @@ __device__ __forceinline__ void fwd_tile(const unsigned char* Kc, const unsigned
         }
     }
     float rs = 0.f;
-    V8 pf[4];
+    V8 pf[2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const float a = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[j], c, -m)), b2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[8 + j], c, -m));
-        const float c2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[j], c, -m)), d2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[8 + j], c, -m));
-        rs += (a + b2) + (c2 + d2);
+        rs += a + b2;
         pf[0][j] = (E)a;
         pf[1][j] = (E)b2;
-        pf[2][j] = (E)c2;
-        pf[3][j] = (E)d2;
     }
     l += rs;
     tr_wait();
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < 2; ++g) {
         o0 = TR::mfma32(tr_vec<TR>(vt[g][0]), pf[g], o0);
         o1 = TR::mfma32(tr_vec<TR>(vt[g][1]), pf[g], o1);
     }
 }
 
+template <class TR, bool MASK>
+__device__ __forceinline__ void fwd_tile(const unsigned char* Kc, const unsigned char* Vc, const typename TR::vec8 (&qf)[4], f32x16& o0,
+                                         f32x16& o1, float& m, float& l, float c, int key0, int n, int r, int hh) {
+    fwd_half<TR, MASK>(Kc, Vc, 0, qf, o0, o1, m, l, c, key0, n, r, hh);
+    fwd_half<TR, MASK>(Kc, Vc, 1, qf, o0, o1, m, l, c, key0, n, r, hh);
+}
+
 template <class TR>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams p) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 16384];
@@ -321,55 +307,51 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 // ============================================================================================
 // backward, pass 1: dQ (+ delta)
 // ============================================================================================
+// one 32-key half tile of the dQ pass
 template <class TR, bool MASK>
-__device__ __forceinline__ void dq_tile(const unsigned char* Kc, const unsigned char* Vc,
-                                        const typename TR::vec8 (&qf)[4], const typename TR::vec8 (&dof)[4], f32x16& dq0, f32x16& dq1,
-                                        float c, float lse2, float delta, int key0, int n, int r, int hh) {
+__device__ __forceinline__ void dq_half(const unsigned char* Kc, const unsigned char* Vc, int kb, const typename TR::vec8 (&qf)[4],
+                                        const typename TR::vec8 (&dof)[4], f32x16& dq0, f32x16& dq1, float c, float lse2, float delta,
+                                        int key0, int n, int r, int hh) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
-    f32x16 s0 = {0}, s1 = {0}, d0 = {0}, d1 = {0};
+    f32x16 s0 = {0}, d0 = {0};
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        s0 = TR::mfma32(lds_frag<TR>(Kc, r, 2 * s + hh), qf[s], s0);
-        s1 = TR::mfma32(lds_frag<TR>(Kc, 32 + r, 2 * s + hh), qf[s], s1);
-    }
+    for (int s = 0; s < 4; ++s) s0 = TR::mfma32(lds_frag<TR>(Kc, kb * 32 + r, 2 * s + hh), qf[s], s0);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        d0 = TR::mfma32(lds_frag<TR>(Vc, r, 2 * s + hh), dof[s], d0);
-        d1 = TR::mfma32(lds_frag<TR>(Vc, 32 + r, 2 * s + hh), dof[s], d1);
+    for (int s = 0; s < 4; ++s) d0 = TR::mfma32(lds_frag<TR>(Vc, kb * 32 + r, 2 * s + hh), dof[s], d0);
+    TrPair kt[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        kt[g][0] = tr_issue(Kc, kb * 2 + g, 0, (hh << 5) | r);
+        kt[g][1] = tr_issue(Kc, kb * 2 + g, 1, (hh << 5) | r);
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], c, -lse2));
-        float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[i], c, -lse2));
         if (MASK) {
-            const int k0 = key0 + acc_row(i, hh);
-            if (k0 >= n) p0 = 0.f;
-            if (k0 + 32 >= n) p1 = 0.f;
+            if (key0 + kb * 32 + acc_row(i, hh) >= n) p0 = 0.f;
         }
         s0[i] = p0 * (d0[i] - delta);
-        s1[i] = p1 * (d1[i] - delta);
     }
-    V8 df[4];
+    V8 df[2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         df[0][j] = (E)s0[j];
         df[1][j] = (E)s0[8 + j];
-        df[2][j] = (E)s1[j];
-        df[3][j] = (E)s1[8 + j];
     }
+    tr_wait();
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        dq0 = TR::mfma32(tr_frag<TR>(Kc, g, 0, (hh << 5) | r), df[g], dq0);
-        dq1 = TR::mfma32(tr_frag<TR>(Kc, g, 1, (hh << 5) | r), df[g], dq1);
+    for (int g = 0; g < 2; ++g) {
+        dq0 = TR::mfma32(tr_vec<TR>(kt[g][0]), df[g], dq0);
+        dq1 = TR::mfma32(tr_vec<TR>(kt[g][1]), df[g], dq1);
     }
 }
 
 template <class TR>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 16384];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 16384];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const int nqt = (p.n + 127) >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -383,57 +365,43 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnParams p) {
     const bool wave_active = q0 < p.n;
     const int qrow = q0 + r;
     const bool row_ok = qrow < p.n;
+    const int nt = (p.n + 63) >> 6;
+    const float c = p.scale_log2;
+
+    // start the K/V stream first, then fetch the per-row operands while it is in flight
+    dma_tile_pair(smem, kb, p.sn, vb, p.sn, 0, p.n, wave, lane);
+    dma_tile_pair(smem + 16384, kb, p.sn, vb, p.sn, 64, p.n, wave, lane);
 
     V8 qf[4], dof[4];
     float delta = 0.f;
+    const int qclamp = min(qrow, p.n - 1);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const u32x4 z = {0, 0, 0, 0};
-        qf[s] = __builtin_bit_cast(V8, row_ok ? *reinterpret_cast<const u32x4*>(qb + qrow * p.sn + 16 * s + 8 * hh) : z);
-        dof[s] = __builtin_bit_cast(V8, row_ok ? *reinterpret_cast<const u32x4*>(dob + qrow * p.osn + 16 * s + 8 * hh) : z);
-        V8 of = __builtin_bit_cast(V8, row_ok ? *reinterpret_cast<const u32x4*>(ob + qrow * p.osn + 16 * s + 8 * hh) : z);
+        qf[s] = *reinterpret_cast<const V8*>(qb + (int64_t)qclamp * p.sn + 16 * s + 8 * hh);
+        dof[s] = *reinterpret_cast<const V8*>(dob + (int64_t)qclamp * p.osn + 16 * s + 8 * hh);
+        const V8 of = *reinterpret_cast<const V8*>(ob + (int64_t)qclamp * p.osn + 16 * s + 8 * hh);
 #pragma unroll
         for (int j = 0; j < 8; ++j) delta += (float)dof[s][j] * (float)of[j];
     }
     delta = half_sum(delta);
-    const int64_t stat = (int64_t)(b * p.H + h) * p.n + qrow;
+    const int64_t stat = (int64_t)(b * p.H + h) * p.n + qclamp;
     if (row_ok && hh == 0) p.delta[stat] = delta;
-    const float lse2 = row_ok ? p.lse[stat] * kLog2e : INFINITY;
-
+    const float lse2 = p.lse[stat] * kLog2e;      // rows past the end duplicate the last row; they are never stored
     f32x16 dq0 = {0}, dq1 = {0};
-    const int nt = (p.n + 63) >> 6;
-    const float c = p.scale_log2;
-
-    u32x4 kA[2], vA[2], kB[2], vB[2];
-    auto stage_store = [&](unsigned char* buf, const u32x4 (&kr)[2], const u32x4 (&vr)[2]) {
-        rm_store(buf, kr, tid);
-        rm_store(buf + 8192, vr, tid);
-    };
-    pair_load(kA, kb, p.sn, 0, p.n, tid);
-    pair_load(vA, vb, p.sn, 0, p.n, tid);
-    stage_store(smem, kA, vA);
-    // (prefetches past the last tile re-read clamped rows; they are never stored to LDS)
-    pair_load(kA, kb, p.sn, 64, p.n, tid); pair_load(vA, vb, p.sn, 64, p.n, tid);
-    pair_load(kB, kb, p.sn, 128, p.n, tid); pair_load(vB, vb, p.sn, 128, p.n, tid);
-    __syncthreads();
-
+    NPCD_DMA_WAIT_BARRIER(4);
     for (int t = 0; t < nt; ++t) {
-        const unsigned char* Kc = smem + (t & 1) * 16384;
+        dma_tile_pair(smem + ((t + 2) % 3) * 16384, kb, p.sn, vb, p.sn, (t + 2) * 64, p.n, wave, lane);
+        const unsigned char* Kc = smem + (t % 3) * 16384;
         if (wave_active) {
-            if (t * 64 + 64 > p.n) dq_tile<TR, true>(Kc, Kc + 8192, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
-            else dq_tile<TR, false>(Kc, Kc + 8192, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
-        }
-        if (t + 1 < nt) {
-            unsigned char* Kn = smem + ((t + 1) & 1) * 16384;
-            if (t & 1) {
-                stage_store(Kn, kB, vB);
-                pair_load(kB, kb, p.sn, (t + 3) * 64, p.n, tid); pair_load(vB, vb, p.sn, (t + 3) * 64, p.n, tid);
+            if (t * 64 + 64 > p.n) {
+                dq_half<TR, true>(Kc, Kc + 8192, 0, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
+                dq_half<TR, true>(Kc, Kc + 8192, 1, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
             } else {
-                stage_store(Kn, kA, vA);
-                pair_load(kA, kb, p.sn, (t + 3) * 64, p.n, tid); pair_load(vA, vb, p.sn, (t + 3) * 64, p.n, tid);
+                dq_half<TR, false>(Kc, Kc + 8192, 0, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
+                dq_half<TR, false>(Kc, Kc + 8192, 1, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
             }
         }
-        __syncthreads();
+        NPCD_DMA_WAIT_BARRIER(4);
     }
     if (row_ok) {
         E* grow = static_cast<E*>(p.dq) + b * p.gsb + qrow * p.gsn + h * p.gsh;
