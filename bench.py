@@ -212,20 +212,27 @@ def main():
                      "all_attention_kernels_tflops": {k: alg[k] / (kern_ms[k] * 1e-3) / 1e12 for k in kern_ms}},
         "loss": float(loss),
     }
+    # the secondary measurements must never take the headline line down with them
     if not args.no_render:
-        r = bench_render(device)
-        if world > 1:       # every rank renders its own views: aggregate rays/s
+        try:
+            r = bench_render(device)
+        except Exception as e:                      # noqa: BLE001
+            r = {"error": f"{type(e).__name__}: {e}", "rays_per_s": 0.0}
+        if world > 1:       # every rank renders its own views: aggregate rays/s (replicas, no collective on the path)
             tt = torch.tensor([r["rays_per_s"]], device=device, dtype=torch.float64)
             dist.all_reduce(tt)
             r["rays_per_s_all_gpus"] = float(tt)
         result["render"] = r
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline()
-            result["gpu_over_cpu"] = {"denoiser_steps": result["value"] / result["cpu_baseline"]["value"]}
-            if "render" in result:
-                result["gpu_over_cpu"]["render_rays"] = result["render"]["rays_per_s"] / result["cpu_baseline"]["render_rays_per_s"]
-        print(json.dumps(result))
+            try:
+                result["cpu_baseline"] = cpu_baseline()
+                result["gpu_over_cpu"] = {"denoiser_steps": result["value"] / result["cpu_baseline"]["value"]}
+                if result.get("render", {}).get("rays_per_s"):
+                    result["gpu_over_cpu"]["render_rays"] = result["render"]["rays_per_s"] / result["cpu_baseline"]["render_rays_per_s"]
+            except Exception as e:                  # noqa: BLE001
+                result["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -49,6 +49,8 @@ const char* npcd_last_hip_error(void);
  * autograd backward.  q/k/v are [B, n, H, d] views (typically of one interleaved [B,n,H,3d]
  * buffer, transformer.py:71-72) sharing the stride triple (sb, sn, sh); d must be 64.
  * lse [B, H, n] fp32 receives log(sum_j exp(scale * <q_i, k_j>)).
+ * dtype NPCD_F32 selects the exact-fp32 inference kernel (the reference's fp32 sampling path,
+ * diffusion_model.py:108-133): forward only, lse is not written (may be NULL), no backward.
  * ------------------------------------------------------------------------------------------ */
 int npcd_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
                   int B, int n, int H, int d,

@@ -530,6 +530,87 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
 }
 
 // ============================================================================================
+// fp32 forward (sampling / fp32 inference path: the reference runs DiffusionModel.generate in fp32 with
+// the einsum attention, diffusion_model.py:108-133, npcd.py:8 use_flash_attn=False).  Exact fp32 math on
+// the vector ALU: no 16-bit rounding anywhere.  One wave = 4 query rows, workgroup = 16 rows; 64-key K/V
+// tiles in LDS (rows padded to 65 floats: the per-lane row reads are conflict-free); pass 1 has the key on
+// the lane (scores), pass 2 the feature dimension on the lane (P.V with P broadcast from LDS).
+// ============================================================================================
+constexpr int kF32Pad = 65;
+
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                           float* __restrict__ out, int B, int n, int H, int64_t sb, int64_t sn, int64_t sh,
+                                                           int64_t osb, int64_t osn, int64_t osh, float scale) {
+    __shared__ float Ks[64 * kF32Pad];
+    __shared__ float Vs[64 * 64];
+    __shared__ float Qs[16 * 64];
+    __shared__ float Ps[16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nqt = (n + 15) / 16;
+    const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt, h = bh % H, b = bh / H;
+    const float* qb = q + b * sb + h * sh;
+    const float* kb = k + b * sb + h * sh;
+    const float* vb = v + b * sb + h * sh;
+    for (int i = tid; i < 16 * 64; i += 256) {
+        const int row = min(qt * 16 + (i >> 6), n - 1);
+        Qs[i] = qb[row * sn + (i & 63)] * scale;
+    }
+    float m[4], l[4], acc[4];
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) { m[rq] = -INFINITY; l[rq] = 0.f; acc[rq] = 0.f; }
+    const int nt = (n + 63) / 64;
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();
+        for (int i = tid; i < 64 * 64; i += 256) {
+            const int row = min(t * 64 + (i >> 6), n - 1);
+            Ks[(i >> 6) * kF32Pad + (i & 63)] = kb[row * sn + (i & 63)];
+            Vs[i] = vb[row * sn + (i & 63)];
+        }
+        __syncthreads();
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* krow = Ks + lane * kF32Pad;
+        const float* qrow = Qs + wave * 4 * 64;
+#pragma unroll 8
+        for (int d = 0; d < 64; ++d) {
+            const float kv = krow[d];
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) s[rq] = fmaf(qrow[rq * 64 + d], kv, s[rq]);
+        }
+        const bool key_ok = t * 64 + lane < n;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const float sc = key_ok ? s[rq] : -INFINITY;
+            float mx = sc;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+            const float mn = fmaxf(m[rq], mx);
+            const float alpha = expf(m[rq] - mn);
+            const float pe = expf(sc - mn);
+            float ps = pe;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
+            l[rq] = l[rq] * alpha + ps;
+            acc[rq] *= alpha;
+            m[rq] = mn;
+            Ps[(wave * 4 + rq) * 64 + lane] = pe;
+        }
+        // same-wave LDS write -> read: ordered within the wave
+        const float* prow = Ps + wave * 4 * 64;
+#pragma unroll 8
+        for (int kk = 0; kk < 64; ++kk) {
+            const float vv = Vs[kk * 64 + lane];
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) acc[rq] = fmaf(prow[rq * 64 + kk], vv, acc[rq]);
+        }
+    }
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+        const int row = qt * 16 + wave * 4 + rq;
+        if (row < n) out[b * osb + row * osn + h * osh + lane] = acc[rq] / l[rq];
+    }
+}
+
+// ============================================================================================
 // host entry points
 // ============================================================================================
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -549,6 +630,16 @@ using namespace npcd;
 extern "C" int npcd_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int n, int H, int d,
                              int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
                              float scale, int dtype, void* stream) {
+    if (dtype == NPCD_F32) {   // inference-only exact fp32 path (no LSE, no backward)
+        if (B <= 0 || n <= 0 || H <= 0 || !q || !k || !v || !out) return NPCD_ERR_ARG;
+        if (d != 64) return NPCD_ERR_UNSUPPORTED;
+        const int grid32 = B * H * ceil_div(n, 16);
+        hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(grid32), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float*>(q),
+                           static_cast<const float*>(k), static_cast<const float*>(v), static_cast<float*>(out), B, n, H, qkv_sb, qkv_sn,
+                           qkv_sh, out_sb, out_sn, out_sh, scale);
+        NPCD_HIP_CHECK(hipGetLastError());
+        return NPCD_OK;
+    }
     int rc = check_common(B, n, H, d, dtype);
     if (rc != NPCD_OK) return rc;
     if (!q || !k || !v || !out || !lse) return NPCD_ERR_ARG;

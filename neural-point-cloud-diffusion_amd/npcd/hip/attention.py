@@ -55,9 +55,20 @@ def _bwd(q, k, v, out, dout, lse, dq, dk, dv, scale):
 
 def _check_input(x):
     require_gpu(x)
-    if x.dtype not in (torch.bfloat16, torch.float16):
-        raise RuntimeError(f"HIP attention computes in bf16/f16 (MFMA); got {x.dtype}. Run the denoiser under "
-                           "autocast(bfloat16) as train_diffusion.py does for --dtype bfloat16.")
+    if x.dtype == torch.float32:
+        if x.requires_grad and torch.is_grad_enabled():
+            raise RuntimeError("fp32 HIP attention is inference-only (exact fp32 forward for sampling); training runs the "
+                               "bf16/f16 MFMA kernels: use autocast(bfloat16) as train_diffusion.py does for --dtype bfloat16.")
+    elif x.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError(f"HIP attention supports bf16/f16 (MFMA, fwd+bwd) and fp32 (forward only); got {x.dtype}")
+
+
+def _fwd_f32(q, k, v, scale):
+    B, n, H, d = q.shape
+    out = torch.empty((B, n, H, d), dtype=torch.float32, device=q.device)
+    check(lib().npcd_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(None), B, n, H, d, q.stride(0), q.stride(1), q.stride(2),
+                              out.stride(0), out.stride(1), out.stride(2), scale, dtype_code(q), stream_ptr()), "npcd_attn_fwd(f32)")
+    return out
 
 
 class _AttnPacked(torch.autograd.Function):
@@ -92,6 +103,11 @@ class _AttnPacked(torch.autograd.Function):
 def attention_qkvpacked(qkv: torch.Tensor, heads: int) -> torch.Tensor:
     """qkv [B, n, 3W] with head h at columns [3d*h, 3d*(h+1)) = q|k|v  ->  [B, n, W]."""
     _check_input(qkv)
+    if qkv.dtype == torch.float32:
+        B, n, w3 = qkv.shape
+        d = w3 // heads // 3
+        x = qkv.detach().contiguous().view(B, n, heads, 3 * d)
+        return _fwd_f32(x[..., :d], x[..., d:2 * d], x[..., 2 * d:], 1.0 / math.sqrt(d)).view(B, n, heads * d)
     return _AttnPacked.apply(qkv, heads)
 
 
@@ -127,4 +143,8 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, **
     for t in (q, k, v):
         _check_input(t)
     scale = 1.0 / math.sqrt(q.shape[-1]) if softmax_scale is None else float(softmax_scale)
+    if q.dtype == torch.float32:
+        if not (q.stride() == k.stride() == v.stride() and q.stride(3) == 1):
+            q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        return _fwd_f32(q.detach(), k.detach(), v.detach(), scale)
     return _AttnQKV.apply(q, k, v, scale)

@@ -141,8 +141,8 @@ def test_unsupported_shapes_fail_loudly():
     from npcd.hip.attention import attention_qkvpacked
     with pytest.raises(RuntimeError, match="unsupported"):
         attention_qkvpacked(torch.zeros(1, 8, 3 * 2 * 32, device="cuda", dtype=torch.bfloat16), 2)   # d = 32
-    with pytest.raises(RuntimeError, match="bf16"):
-        attention_qkvpacked(torch.zeros(1, 8, 192, device="cuda"), 1)                               # fp32
+    with pytest.raises(RuntimeError, match="inference-only"):
+        attention_qkvpacked(torch.zeros(1, 8, 192, device="cuda", requires_grad=True), 1)           # fp32 training
 
 
 @pytest.mark.parametrize("tag", ["f32_w64", "f128_w64"])
@@ -165,3 +165,59 @@ def test_denoiser_matches_reference_golden(golden, tag):
             p = dict(net.named_parameters())[k[2:]]
             worst = max(worst, rel_l2(p.grad, T(v)))
     assert worst < 5e-2, f"worst param-grad rel-L2 {worst:.3e}"
+
+
+@pytest.mark.parametrize("n,H", [(1, 1), (17, 2), (64, 1), (130, 3), (513, 2)])
+def test_attention_fp32_inference_exact(n, H):
+    """fp32 sampling path (the reference runs generate() with the fp32 einsum attention): exact fp32 math."""
+    from flash_attn import flash_attn_func
+    from npcd.hip.attention import attention_qkvpacked
+    gen = torch.Generator().manual_seed(n)
+    qkv = torch.randn(2, n, 3 * H * 64, generator=gen) * 1.5
+    ref = od.attention_qkvpacked(qkv, H)
+    with torch.no_grad():
+        out = attention_qkvpacked(qkv.cuda(), H)
+        q, k, v = torch.split(qkv.cuda().view(2, n, H, -1), 64, dim=-1)
+        out2 = flash_attn_func(q, k, v)
+    assert out.dtype == torch.float32
+    assert float((out.cpu() - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert torch.equal(out2.reshape(2, n, -1), out)
+
+
+def test_generate_reverse_step_and_sampler(golden):
+    """DiffusionModel.generate (diffusion_model.py:108-133): fp32, einsum-equivalent attention, x0 clipping.
+    One reverse step is checked against the oracle with the SAME noise; the full loop for shape / finiteness."""
+    from oracle import diffusion as odf
+    from npcd.models.diffusion import DiffusionModel
+    torch.manual_seed(0)
+    F_, N, W, L, H = 32, 48, 128, 2, 2
+    params = od.init_params(3, F_, W, L, H, seed=4)
+    model = DiffusionModel(3, F_, N, W, L, H, False)
+    model.denoiser.load_state_dict(params)
+    model = model.cuda().eval()
+    gd = model.diffusion_process
+    g = torch.Generator().manual_seed(1)
+    c_t, f_t = torch.randn(2, 3, N, generator=g), torch.randn(2, F_, N, generator=g)
+    t = torch.tensor([999, 3])
+    clip_c, clip_f = (torch.tensor([-2.0]), torch.tensor([2.5])), (torch.tensor([-1.0]), torch.tensor([1.0]))
+    torch.manual_seed(77)
+    nc, nf = torch.randn(2, 3, N, device="cuda"), torch.randn(2, F_, N, device="cuda")     # what p_sample will draw
+    torch.manual_seed(77)
+    with torch.no_grad():
+        c1, c0, f1, f0 = gd.p_sample(model.denoiser, c_t.cuda(), f_t.cuda(), t.cuda(), tuple(x.cuda() for x in clip_c),
+                                     tuple(x.cuda() for x in clip_f))
+    ec, ef = od.denoiser_forward(params, c_t, f_t, t, H)
+    tab = odf.schedule_tables()
+    rc1, rc0 = odf.p_sample_step(tab, c_t, ec, t, nc.cpu(), clip_c)
+    rf1, rf0 = odf.p_sample_step(tab, f_t, ef, t, nf.cpu(), clip_f)
+    for a, b in ((c1, rc1), (c0, rc0), (f1, rf1), (f0, rf0)):
+        assert float((a.cpu() - b).abs().max()) < 2e-4
+    # full sampling loop on a shortened chain
+    gd.num_timesteps = 12
+    model.coords_normalization.min.fill_(-3); model.coords_normalization.max.fill_(3)
+    model.feats_normalization.min.fill_(-1); model.feats_normalization.max.fill_(1)
+    coords, feats = model.generate(3, batch_size=2, progress=False)
+    assert len(coords) == 3 and coords[0].shape == (3, N) and feats[0].shape == (F_, N)
+    assert all(torch.isfinite(x).all() for x in coords + feats)
+    with pytest.raises(AssertionError):
+        model.train().generate(1)
