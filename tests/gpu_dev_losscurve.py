@@ -1,0 +1,31 @@
+"""Developer probe: fused explicit runtime vs nn.Module/autograd path at full scale (cfg-D), same data/noise."""
+import sys, os, time, copy
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
+import torch, bench
+from npcd.models.diffusion import DiffusionModel
+from npcd.train import DiffusionTrainer
+dev = torch.device("cuda", 0)
+def make(fused):
+    torch.manual_seed(1234)
+    m = DiffusionModel(3, 128, 512, 1024, 24, 16, True)
+    torch.nn.init.normal_(m.denoiser.output_proj.weight, std=0.02)
+    return DiffusionTrainer(m.to(dev).train(), lr=7e-5, weight_decay=0.01, fused=fused)
+B = 16
+coords, feats = bench.synthetic_batch(64, 0, 4, dev)
+g = torch.Generator(device=dev).manual_seed(0)
+ts = [torch.randint(0, 1000, (B,), device=dev, generator=g) for _ in range(12)]
+ns = [(torch.randn(B, 3, 512, device=dev, generator=g), torch.randn(B, 128, 512, device=dev, generator=g)) for _ in range(12)]
+res = {}
+for fused in (True, False):
+    tr = make(fused)
+    losses = []
+    for t, (cn, fn) in zip(ts, ns):
+        l, _ = tr.step(coords, feats, t=t, coords_noise=cn, feats_noise=fn)
+        losses.append(float(l))
+    res[fused] = (losses, tr.flat.flat.clone())
+    del tr; torch.cuda.empty_cache()
+print("fused  :", " ".join(f"{x:.4f}" for x in res[True][0]))
+print("modules:", " ".join(f"{x:.4f}" for x in res[False][0]))
+a, b = res[True][1], res[False][1]
+print("param rel diff after 12 steps:", float((a - b).norm() / b.norm()))
