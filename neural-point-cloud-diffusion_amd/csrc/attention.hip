@@ -22,10 +22,6 @@
 
 #include "common.h"
 
-#ifndef NPCD_ABL
-#define NPCD_ABL 0   // developer ablation switch (never set in the shipped build)
-#endif
-
 namespace npcd {
 
 struct AttnParams {

@@ -698,11 +698,10 @@ extern "C" int npcd_grid_query(const npcd_grid_params* g, const void* workspace,
     const int bpe = (R + 3) / 4;
     const size_t lds = (size_t)N * 16 + (size_t)a.nwords * 4 + 4 * 64 * 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static size_t lds_set[2] = {0, 0};
-    if (lds > 65536 && lds > lds_set[mode]) {
-        const void* fn = mode == 0 ? reinterpret_cast<const void*>(grid_query_kernel<true>) : reinterpret_cast<const void*>(grid_query_kernel<false>);
-        NPCD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set[mode] = lds;
+    static size_t lds_set = 0;
+    if (mode == 1 && lds > 65536 && lds > lds_set) {
+        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_query_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        lds_set = lds;
     }
     if (mode == 0) {
         const size_t lds2 = lds + 4 * 64 * 8 * 4 + 4 * 64 * 4 * 4;
