@@ -87,9 +87,11 @@ class GradReducer:
 
     def start_step(self):
         self.handles = []
+        self.launched = []          # bucket index of every handle, in launch order
         self._left = list(self.pending)
 
     def _launch(self, b):
+        self.launched.append(b)
         s, e = self.buckets[b]
         buf = self.flat.grad[s:e]
         if self._avg is None:       # RCCL has a native average; gloo (CPU tests) does not
@@ -110,18 +112,24 @@ class GradReducer:
         if self._left[b] == 0:
             self._launch(b)
 
-    def finish(self):
+    def finish(self, on_bucket_ready=None):
+        """Wait for every bucket's collective.  `on_bucket_ready(start, end)` is called right after the wait of
+        each bucket (in launch order): work it enqueues on the current stream only depends on THAT bucket's
+        all-reduce, so it overlaps with the collectives still in flight (used to pipeline the optimizer)."""
         if self.world == 1:
-            return
+            return False
         for b, left in enumerate(self._left):     # parameters that received no gradient this step
             if left > 0:
                 self._launch(b)
                 self._left[b] = 0
-        for h, buf in self.handles:
+        for (h, buf), b in zip(self.handles, self.launched):
             h.wait()
             if buf is not None:
                 buf.div_(self.world)
+            if on_bucket_ready is not None:
+                on_bucket_ready(*self.buckets[b])
         self.handles = []
+        return on_bucket_ready is not None
 
 
 class DiffusionTrainer:
@@ -175,20 +183,34 @@ class DiffusionTrainer:
         with torch.autocast(dev_type, dtype=self.dtype, enabled=self.dtype is not None):
             loss, sub, _ = self.model.compute_loss(coords, feats, t=t, coords_noise=coords_noise, feats_noise=feats_noise)
         loss.backward()
-        self.reducer.finish()
-        if self.max_grad_norm is not None:
-            torch.nn.utils.clip_grad_norm_([self.flat.flat if self.native else self.master], self.max_grad_norm) \
-                if not self.native else self._clip_native()
         self.iteration += 1
+        pipelined = False
+        if self.native and self.max_grad_norm is None:
+            # multi-GPU: update each bucket's slice as soon as ITS all-reduce is done, under the remaining collectives
+            pipelined = self.reducer.finish(self._adamw_range)
+        else:
+            self.reducer.finish()
+        if pipelined:
+            return loss.detach(), sub
+        if self.max_grad_norm is not None:
+            if self.native:
+                self._clip_native()
+            else:
+                torch.nn.utils.clip_grad_norm_([self.master], self.max_grad_norm)
         if self.native:
-            self._ew.adamw_ema(self.flat.flat, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.ema, self.shadow, self.lr,
-                               self.betas[0], self.betas[1], self.eps, self.weight_decay, self.iteration, self.ema_decay, zero_grad=True)
+            self._adamw_range(0, self.flat.numel)
         else:
             self.master.grad = self.flat.grad
             self.optimizer.step()
             if self.ema is not None:
                 self.ema.lerp_(self.flat.flat, 1.0 - self.ema_decay)
         return loss.detach(), sub
+
+    def _adamw_range(self, s0, e0):
+        ema = None if self.ema is None else self.ema[s0:e0]
+        self._ew.adamw_ema(self.flat.flat[s0:e0], self.flat.grad[s0:e0], self.exp_avg[s0:e0], self.exp_avg_sq[s0:e0], ema,
+                           self.shadow[s0:e0], self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.iteration,
+                           self.ema_decay, zero_grad=True)
 
     def _clip_native(self):
         norm = torch.linalg.vector_norm(self.flat.grad)
