@@ -137,9 +137,18 @@ __device__ __forceinline__ FineCoord fine_coord(const npcd_grid_params& g, float
 
 static inline int occ_words(const npcd_grid_params& g) { return (g.cdims[0] * g.cdims[1] * g.cdims[2] + 31) / 32; }
 
+// Dense fine-voxel -> point table (4 x int16 per voxel, -1 = empty): the kept points of a voxel, in index
+// order.  With it a query only tests the <= 4*27 points of the 3^3 neighbourhood instead of scanning the cloud.
+// Available when <= 4 points per voxel are kept, the kernel window fits one wave and the table is <= 32 MB.
+static inline int64_t table_voxels(const npcd_grid_params& g) { return (int64_t)g.dims[0] * g.dims[1] * g.dims[2]; }
+static inline bool table_ok(const npcd_grid_params& g) {
+    return g.max_points_per_voxel <= 4 && g.kernel_size[0] * g.kernel_size[1] * g.kernel_size[2] <= 64 && table_voxels(g) * 8 <= (32ll << 20);
+}
+
 // one workgroup per example.  LDS: lin[N] int32, flag[N] uint8-as-int, bitmap[occ_words]
 __global__ __launch_bounds__(256) void grid_build_kernel(npcd_grid_params g, const float* __restrict__ points, const int32_t* __restrict__ counts,
-                                                         int N, int nwords, int32_t* __restrict__ pcoord, uint32_t* __restrict__ occ) {
+                                                         int N, int nwords, int32_t* __restrict__ pcoord, uint32_t* __restrict__ occ,
+                                                         int16_t* __restrict__ table) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
     int* lin = reinterpret_cast<int*>(dsmem);
     int* first = lin + N;
@@ -182,6 +191,7 @@ __global__ __launch_bounds__(256) void grid_build_kernel(npcd_grid_params g, con
             cx = l / (g.dims[2] * g.dims[1]);
         }
         pcoord[(int64_t)b * N + i] = pack_coord(cx, cy, cz, kept);
+        if (kept && table) table[((int64_t)b * g.dims[0] * g.dims[1] * g.dims[2] + l) * 4 + rank] = (int16_t)i;
         if (kept) {
             const int ccx = cx / g.voxel_scale[0], ccy = cy / g.voxel_scale[1], ccz = cz / g.voxel_scale[2];
             const int hx = (g.kernel_size[0] - 1) / 2, hy = (g.kernel_size[1] - 1) / 2, hz = (g.kernel_size[2] - 1) / 2;
@@ -225,6 +235,7 @@ struct QueryArgs {
     npcd_grid_params g;
     const int32_t* pcoord;
     const uint32_t* occ;
+    const int16_t* table;   // dense voxel -> points table or nullptr
     const float* points;
     int B, N, R, S, M, k, nwords;
     float r2;
@@ -446,37 +457,72 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
     float* out_loc = COMPACT ? nullptr : a.sample_loc + ray * a.M * 3;
     int32_t* out_ss = COMPACT ? nullptr : a.slot_sample + ray * a.M;
     unsigned long long valid_bits = 0ull;
-    for (int slot = 0; slot < nsel; ++slot) {
+    auto process = [&](int slot, u32x2 raw_in) {
         const int s = mysel[slot];                     // same-wave LDS write -> read is ordered
         float p[3];
         sample_pos(a, ray, s, o, d, t0, t1, p);       // wave-uniform values
         const FineCoord fc = fine_coord(a.g, p[0], p[1], p[2]);
         uint32_t key_hi = 0xffffffffu, key_lo = 0xffffffffu;   // lanes 0..7 hold the sorted list
-        for (int j0 = 0; j0 < a.N; j0 += 64) {
-            const int j = j0 + lane;
-            bool cand = false;
-            float d2 = 0.f;
-            if (j < a.N) {
-                const float4 q = pts[j];
-                const float dx = p[0] - q.x, dy = p[1] - q.y, dz = p[2] - q.z;
-                d2 = (dx * dx + dy * dy) + dz * dz;
-                const int pc = __float_as_int(q.w);
-                const int ix = pc & 1023, iy = (pc >> 10) & 1023, iz = (pc >> 20) & 1023;
-                cand = (d2 < a.r2) && ((pc >> 30) & 1) && (abs(ix - fc.c[0]) <= hx) && (abs(iy - fc.c[1]) <= hy) && (abs(iz - fc.c[2]) <= hz);
-            }
-            unsigned long long cm = __ballot(cand);
-            while (cm) {                                // wave-uniform loop over the (few) candidates, ascending index
+        // insert the lanes flagged in `cm` (dist^2 in d2, point index in jj) into the cross-lane sorted list
+        auto insert_all = [&](unsigned long long cm, float d2, int jj) {
+            while (cm) {                                // wave-uniform loop over the (few) candidates
                 const int bl = __ffsll((long long)cm) - 1;
                 cm &= cm - 1;
                 const uint32_t ch = __builtin_amdgcn_readlane(__float_as_uint(d2), bl);
-                const uint32_t cl = (uint32_t)(j0 + bl);
+                const uint32_t cl = (uint32_t)__builtin_amdgcn_readlane(jj, bl);
                 const bool le = (key_hi < ch) || (key_hi == ch && key_lo < cl);   // existing entry sorts before the candidate
                 const int pos = __popcll(__ballot(le) & 0xffull);
                 if (pos < 8) {
-                    const uint32_t up_hi = __shfl_up(key_hi, 1, 64), up_lo = __shfl_up(key_lo, 1, 64);
+                    // shift lanes pos..6 up by one with a DPP row shift (lanes 0..7 share a 16-lane row): one VALU op
+                    // per word instead of an LDS-crossbar shuffle
+                    const uint32_t up_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key_hi, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+                    const uint32_t up_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key_lo, 0x111, 0xf, 0xf, false);
                     if (lane == pos) { key_hi = ch; key_lo = cl; }
                     else if (lane > pos) { key_hi = up_hi; key_lo = up_lo; }
                 }
+            }
+        };
+        if (a.table) {
+            // lanes 0..26: one fine voxel of the 3^3 window each -> its <= 4 kept points
+            const int ky = a.g.kernel_size[1], kz = a.g.kernel_size[2], nk = a.g.kernel_size[0] * ky * kz;
+            (void)raw_in;
+            int cand_idx[4] = {-1, -1, -1, -1};
+            if (lane < nk) {
+                const int vx = fc.c[0] + lane / (ky * kz) - hx, vy = fc.c[1] + (lane / kz) % ky - hy, vz = fc.c[2] + lane % kz - hz;
+                if (vx >= 0 && vy >= 0 && vz >= 0 && vx < a.g.dims[0] && vy < a.g.dims[1] && vz < a.g.dims[2]) {
+                    const int64_t vox = (int64_t)b * a.g.dims[0] * a.g.dims[1] * a.g.dims[2] + ((int64_t)vx * a.g.dims[1] + vy) * a.g.dims[2] + vz;
+                    const u32x2 raw = *reinterpret_cast<const u32x2*>(a.table + vox * 4);
+                    cand_idx[0] = (int)(int16_t)(raw[0] & 0xffffu); cand_idx[1] = (int)(int16_t)(raw[0] >> 16);
+                    cand_idx[2] = (int)(int16_t)(raw[1] & 0xffffu); cand_idx[3] = (int)(int16_t)(raw[1] >> 16);
+                }
+            }
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                const int j = cand_idx[qi];
+                bool cand = false;
+                float d2 = 0.f;
+                if (j >= 0) {
+                    const float4 q = pts[j];
+                    const float dx = p[0] - q.x, dy = p[1] - q.y, dz = p[2] - q.z;
+                    d2 = (dx * dx + dy * dy) + dz * dz;
+                    cand = d2 < a.r2;                   // "kept" and voxel adjacency are implied by the table lookup
+                }
+                insert_all(__ballot(cand), d2, j);
+            }
+        } else {
+            for (int j0 = 0; j0 < a.N; j0 += 64) {
+                const int j = j0 + lane;
+                bool cand = false;
+                float d2 = 0.f;
+                if (j < a.N) {
+                    const float4 q = pts[j];
+                    const float dx = p[0] - q.x, dy = p[1] - q.y, dz = p[2] - q.z;
+                    d2 = (dx * dx + dy * dy) + dz * dz;
+                    const int pc = __float_as_int(q.w);
+                    const int ix = pc & 1023, iy = (pc >> 10) & 1023, iz = (pc >> 20) & 1023;
+                    cand = (d2 < a.r2) && ((pc >> 30) & 1) && (abs(ix - fc.c[0]) <= hx) && (abs(iy - fc.c[1]) <= hy) && (abs(iz - fc.c[2]) <= hz);
+                }
+                insert_all(__ballot(cand), d2, j);
             }
         }
         const bool has = key_lo != 0xffffffffu;
@@ -490,7 +536,8 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
             if (lane < 3) out_loc[slot * 3 + lane] = lane == 0 ? p[0] : (lane == 1 ? p[1] : p[2]);
             if (lane == 0) out_ss[slot] = s;
         }
-    }
+    };
+    for (int slot = 0; slot < nsel; ++slot) process(slot, u32x2{0u, 0u});
     if (COMPACT) {
         const int cnt = __popcll(valid_bits);
         int base = 0;
@@ -641,9 +688,13 @@ static int grid_check(const npcd_grid_params* g, int B, int N) {
     return NPCD_OK;
 }
 
+static inline int64_t table_offset(const npcd_grid_params& g, int B, int N) {   // 16-byte aligned
+    return (((int64_t)B * N * 4 + (int64_t)B * occ_words(g) * 4) + 15) / 16 * 16;
+}
+
 extern "C" int64_t npcd_grid_workspace_bytes(const npcd_grid_params* g, int B, int N) {
     if (grid_check(g, B, N) != NPCD_OK) return -1;
-    return (int64_t)B * N * 4 + (int64_t)B * occ_words(*g) * 4;
+    return table_offset(*g, B, N) + (table_ok(*g) ? (int64_t)B * table_voxels(*g) * 8 : 0);
 }
 
 extern "C" int npcd_grid_build(const npcd_grid_params* g, const float* points, const int32_t* counts, int B, int N,
@@ -661,7 +712,12 @@ extern "C" int npcd_grid_build(const npcd_grid_params* g, const float* points, c
         NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         lds_set = lds;
     }
-    hipLaunchKernelGGL(grid_build_kernel, dim3(B), dim3(256), lds, st, *g, points, counts, N, nwords, pcoord, occ);
+    int16_t* table = nullptr;
+    if (table_ok(*g)) {
+        table = reinterpret_cast<int16_t*>(static_cast<unsigned char*>(workspace) + table_offset(*g, B, N));
+        NPCD_HIP_CHECK(hipMemsetAsync(table, 0xff, (size_t)B * table_voxels(*g) * 8, st));
+    }
+    hipLaunchKernelGGL(grid_build_kernel, dim3(B), dim3(256), lds, st, *g, points, counts, N, nwords, pcoord, occ, table);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }
@@ -683,6 +739,8 @@ extern "C" int npcd_grid_query(const npcd_grid_params* g, const void* workspace,
     a.pcoord = static_cast<const int32_t*>(workspace);
     a.nwords = occ_words(*g);
     a.occ = reinterpret_cast<const uint32_t*>(a.pcoord + (int64_t)B * N);
+    a.table = (mode == 0 && workspace && table_ok(*g))
+                  ? reinterpret_cast<const int16_t*>(static_cast<const unsigned char*>(workspace) + table_offset(*g, B, N)) : nullptr;
     a.points = points;
     a.B = B; a.N = N; a.R = R; a.S = S; a.M = M; a.k = k;
     float radius = r;
@@ -752,6 +810,7 @@ extern "C" int npcd_grid_query_compact(const npcd_grid_params* g, const void* wo
     a.pcoord = static_cast<const int32_t*>(workspace);
     a.nwords = occ_words(*g);
     a.occ = reinterpret_cast<const uint32_t*>(a.pcoord + (int64_t)B * N);
+    a.table = table_ok(*g) ? reinterpret_cast<const int16_t*>(static_cast<const unsigned char*>(workspace) + table_offset(*g, B, N)) : nullptr;
     a.points = points;
     a.B = B; a.N = N; a.R = R; a.S = S; a.M = M; a.k = k;
     float vmax = g->voxel_size[0];
