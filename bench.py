@@ -161,6 +161,18 @@ def main():
         raise SystemExit("global batch 64 must be divisible by the number of GPUs")
     per = CFG["global_batch"] // world
 
+    # hipBLASLt / rocBLAS solution choices recorded once with PyTorch TunableOp (tools/tune_gemms.py) for the GEMM shapes
+    # of this step; loaded with tuning DISABLED (shapes not in the file use the library default).  NPCD_NO_TUNED_GEMM=1 skips it.
+    tuned = os.path.join(ROOT, "profiles", "tunableop_gfx950.csv")
+    use_tuned = os.path.exists(tuned) and not os.environ.get("NPCD_NO_TUNED_GEMM")
+    if use_tuned:
+        import torch.cuda.tunable as tun
+        tun.enable(True)
+        tun.tuning_enable(False)
+        tun.record_untuned_enable(False) if hasattr(tun, "record_untuned_enable") else None
+        tun.set_filename(os.path.join("/tmp", f"npcd_tunableop_unused_{rank}.csv"))    # never overwrite the committed file
+        use_tuned = bool(tun.read_file(tuned))
+
     from npcd.hip import attention as hattn
     trainer = build_trainer(device, per)
     coords, feats = synthetic_batch(CFG["global_batch"], rank, world, device)
@@ -221,6 +233,7 @@ def main():
                      "all_attention_kernels_ms": kern_ms,
                      "all_attention_kernels_tflops": {k: alg[k] / (kern_ms[k] * 1e-3) / 1e12 for k in kern_ms}},
         "loss": float(loss),
+        "tuned_gemm_file": "profiles/tunableop_gfx950.csv" if use_tuned else None,
     }
     # the secondary measurements must never take the headline line down with them
     if not args.no_render:

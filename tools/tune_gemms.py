@@ -1,0 +1,23 @@
+"""Record hipBLASLt/rocBLAS solution choices for the GEMM shapes of the denoiser step with PyTorch TunableOp
+(run on an MI355X; writes profiles/tunableop_gfx950.csv, which bench.py loads with tuning DISABLED)."""
+import os, sys
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
+import torch
+import torch.cuda.tunable as tun
+import bench
+out = os.path.join(R, "gpurun_out", "tunableop_gfx950.csv")
+tun.enable(True); tun.tuning_enable(True); tun.set_max_tuning_duration(40); tun.set_max_tuning_iterations(30)
+tun.set_filename(out)
+dev = torch.device("cuda", 0)
+for B in (64, 32, 16, 8):                       # per-GPU batches of the 1/2/4/8-GPU strong-scaling runs
+    tr = bench.build_trainer(dev, B)
+    coords, feats = bench.synthetic_batch(64, 0, 64 // B, dev)
+    for _ in range(2):
+        tr.step(coords, feats)
+    torch.cuda.synchronize()
+    del tr
+    torch.cuda.empty_cache()
+    print("tuned per-GPU batch", B, flush=True)
+tun.write_file(out) if hasattr(tun, "write_file") else None
+print("results ->", out)
