@@ -184,6 +184,16 @@ int npcd_ln_bwd(const void* dy, const float* x, const float* mean, const float* 
  * npcd_colsum_scratch_rows() more rows of N floats (used as the stage buffer of the 2-stage sum). */
 int npcd_colsum_scratch_rows(void);
 int npcd_colsum_finalize(const float* part, int nblk, int N, float* out, int accumulate, void* stream);
+/* Up to NPCD_COLSUM_MAX_JOBS independent column sums in one pair of launches (bit-identical to the single
+ * call per job).  One residual block's backward emits eight: LN dgamma/dbeta x2, four Linear bias gradients
+ * (the reference gets them from autograd's SumBackward nodes, transformer.py:162-172). */
+#define NPCD_COLSUM_MAX_JOBS 8
+typedef struct NpcdColsumJob {
+    const float* part; /* [nblk + npcd_colsum_scratch_rows()][N] */
+    float* out;        /* [N] */
+    int nblk, N, accumulate, reserved;
+} NpcdColsumJob;
+int npcd_colsum_finalize_batch(const NpcdColsumJob* jobs, int njobs, void* stream);
 /* GELU (exact erf form) on bf16; backward also emits column partials [npcd_colsum_blocks(T)][N] of dh */
 int npcd_gelu_fwd(const void* h, void* g, int64_t numel, void* stream);
 int npcd_colsum_blocks(int T);

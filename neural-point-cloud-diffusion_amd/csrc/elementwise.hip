@@ -164,10 +164,30 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
 // stage[kFinSlices][N]; stage 2 sums the slices.
 constexpr int kFinSlices = 16;
 
-__global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ part, int nblk, int N, float* __restrict__ stage) {
+// A batch of up to NPCD_COLSUM_MAX_JOBS independent column sums shares the two launches (one residual block's
+// backward produces eight of them; launched one by one they were 16 launches of ~5 us each per block).
+struct FinBatch {
+    NpcdColsumJob job[NPCD_COLSUM_MAX_JOBS];
+    int first1[NPCD_COLSUM_MAX_JOBS + 1];   // stage-1 blockIdx.x range of each job (64 columns per block)
+    int first2[NPCD_COLSUM_MAX_JOBS + 1];   // stage-2 range (256 columns per block)
+    int njobs;
+};
+__device__ __forceinline__ int fin_job(const int* first, int njobs, int bx) {
+    int j = 0;
+    while (j + 1 < njobs && bx >= first[j + 1]) ++j;
+    return j;
+}
+__device__ __forceinline__ bool fin_two_stage(int nblk) { return nblk > 2 * kFinSlices; }
+
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(FinBatch fb) {
     __shared__ float red[4][64];
+    const int j = fin_job(fb.first1, fb.njobs, blockIdx.x);
+    const float* __restrict__ part = fb.job[j].part;
+    const int nblk = fb.job[j].nblk, N = fb.job[j].N;
+    if (!fin_two_stage(nblk)) return;                // few partial rows: stage 2 reads them directly
+    float* __restrict__ stage = const_cast<float*>(part) + (int64_t)nblk * N;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+    const int c = (blockIdx.x - fb.first1[j]) * 64 + tx;
     const int per = (nblk + kFinSlices - 1) / kFinSlices;
     const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
     float s0 = 0.f, s1 = 0.f;
@@ -184,12 +204,18 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restr
     if (ty == 0 && c < N) stage[(int64_t)blockIdx.y * N + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
-__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ stage, int nrows, int N, float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(FinBatch fb) {
+    const int j = fin_job(fb.first2, fb.njobs, blockIdx.x);
+    const int nblk = fb.job[j].nblk, N = fb.job[j].N;
+    const int c = (blockIdx.x - fb.first2[j]) * 256 + threadIdx.x;
     if (c >= N) return;
+    const bool two = fin_two_stage(nblk);
+    const float* __restrict__ src = two ? fb.job[j].part + (int64_t)nblk * N : fb.job[j].part;
+    const int nrows = two ? kFinSlices : nblk;
     float s = 0.f;
-    for (int k = 0; k < nrows; ++k) s += stage[(int64_t)k * N + c];
-    out[c] = accumulate ? out[c] + s : s;
+    for (int k = 0; k < nrows; ++k) s += src[(int64_t)k * N + c];
+    float* __restrict__ out = fb.job[j].out;
+    out[c] = fb.job[j].accumulate ? out[c] + s : s;
 }
 
 // ============================================================================================
@@ -339,18 +365,33 @@ extern "C" int npcd_ln_bwd(const void* dy, const float* x, const float* mean, co
 // they are used as the stage buffer.
 extern "C" int npcd_colsum_scratch_rows(void) { return kFinSlices; }
 
-extern "C" int npcd_colsum_finalize(const float* part, int nblk, int N, float* out, int accumulate, void* stream) {
-    if (!part || !out || nblk <= 0 || N <= 0) return NPCD_ERR_ARG;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    if (nblk <= 2 * kFinSlices) {   // few partial rows: one pass
-        hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, nblk, N, out, accumulate);
-    } else {
-        float* stage = const_cast<float*>(part) + (int64_t)nblk * N;
-        hipLaunchKernelGGL(colsum_stage1_kernel, dim3((N + 63) / 64, kFinSlices), dim3(256), 0, st, part, nblk, N, stage);
-        hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N + 255) / 256), dim3(256), 0, st, stage, kFinSlices, N, out, accumulate);
+extern "C" int npcd_colsum_finalize_batch(const NpcdColsumJob* jobs, int njobs, void* stream) {
+    if (!jobs || njobs <= 0 || njobs > NPCD_COLSUM_MAX_JOBS) return NPCD_ERR_ARG;
+    FinBatch fb;
+    fb.njobs = njobs;
+    bool any_two_stage = false;
+    int n1 = 0, n2 = 0;
+    for (int j = 0; j < njobs; ++j) {
+        if (!jobs[j].part || !jobs[j].out || jobs[j].nblk <= 0 || jobs[j].N <= 0) return NPCD_ERR_ARG;
+        fb.job[j] = jobs[j];
+        fb.first1[j] = n1;
+        fb.first2[j] = n2;
+        n1 += (jobs[j].N + 63) / 64;
+        n2 += (jobs[j].N + 255) / 256;
+        any_two_stage |= jobs[j].nblk > 2 * kFinSlices;
     }
+    for (int j = njobs; j <= NPCD_COLSUM_MAX_JOBS; ++j) { fb.first1[j] = n1; fb.first2[j] = n2; }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (any_two_stage) hipLaunchKernelGGL(colsum_stage1_kernel, dim3(n1, kFinSlices), dim3(256), 0, st, fb);
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3(n2), dim3(256), 0, st, fb);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
+}
+
+extern "C" int npcd_colsum_finalize(const float* part, int nblk, int N, float* out, int accumulate, void* stream) {
+    NpcdColsumJob job;
+    job.part = part; job.out = out; job.nblk = nblk; job.N = N; job.accumulate = accumulate; job.reserved = 0;
+    return npcd_colsum_finalize_batch(&job, 1, stream);
 }
 
 extern "C" int npcd_gelu_fwd(const void* h, void* g, int64_t numel, void* stream) {

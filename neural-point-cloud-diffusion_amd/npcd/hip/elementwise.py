@@ -1,9 +1,46 @@
 """Wrappers of the HBM-bound elementwise kernels (csrc/elementwise.hip)."""
+import ctypes
+
 import torch
 
 from . import check, lib, ptr, require_gpu, stream_ptr
 
 _f32, _bf16 = torch.float32, torch.bfloat16
+MAX_JOBS = 8          # NPCD_COLSUM_MAX_JOBS
+
+
+class ColsumJob(ctypes.Structure):
+    """NpcdColsumJob (include/npcd_hip.h)."""
+    _fields_ = [("part", ctypes.c_void_p), ("out", ctypes.c_void_p), ("nblk", ctypes.c_int), ("N", ctypes.c_int),
+                ("accumulate", ctypes.c_int), ("reserved", ctypes.c_int)]
+
+
+class ColsumBatch:
+    """Collects the column sums a block's backward produces and finalises them with one pair of launches per
+    MAX_JOBS.  Holds the partial buffers alive until `flush`."""
+
+    def __init__(self):
+        self.jobs = []
+
+    def add(self, part, nblk, N, out):
+        self.jobs.append((part, nblk, N, out))
+
+    def flush(self):
+        L, s = lib(), stream_ptr()
+        for i in range(0, len(self.jobs), MAX_JOBS):
+            chunk = self.jobs[i:i + MAX_JOBS]
+            arr = (ColsumJob * len(chunk))()
+            for a, (part, nblk, N, out) in zip(arr, chunk):
+                a.part, a.out, a.nblk, a.N, a.accumulate, a.reserved = part.data_ptr(), out.data_ptr(), nblk, N, 0, 0
+            check(L.npcd_colsum_finalize_batch(ctypes.cast(arr, ctypes.c_void_p), len(chunk), s), "npcd_colsum_finalize_batch")
+        self.jobs = []
+
+
+def _finish(batch, part, nblk, N, out):
+    if batch is not None:
+        batch.add(part, nblk, N, out)
+    else:
+        check(lib().npcd_colsum_finalize(ptr(part), nblk, N, ptr(out), 0, stream_ptr()), "npcd_colsum_finalize")
 
 
 def add_ln_fwd(x_in, delta, gamma, beta, eps=1e-5, want_sum=True):
@@ -20,9 +57,9 @@ def add_ln_fwd(x_in, delta, gamma, beta, eps=1e-5, want_sum=True):
     return x_out, y, mean, rstd
 
 
-def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma_out, dbeta_out, dcol_out=None, want_bf16=True):
+def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma_out, dbeta_out, dcol_out=None, want_bf16=True, batch=None):
     """dx = LNbwd(dy) + dres (fp32) [+ bf16 copy]; writes dgamma/dbeta (and the column sum of dx) into the
-    given fp32 [W] tensors (overwrite)."""
+    given fp32 [W] tensors (overwrite) -- immediately, or at `batch.flush()` when a ColsumBatch is given."""
     T, W = x.shape
     dev = x.device
     L = lib()
@@ -32,11 +69,10 @@ def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma_out, dbeta_out, dcol_out=None,
     parts = torch.empty((3, nblk + L.npcd_colsum_scratch_rows(), W), dtype=_f32, device=dev)
     check(L.npcd_ln_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(dxb), ptr(parts[0]), ptr(parts[1]),
                         ptr(parts[2]) if dcol_out is not None else ptr(None), T, W, stream_ptr()), "npcd_ln_bwd")
-    s = stream_ptr()
-    check(L.npcd_colsum_finalize(ptr(parts[0]), nblk, W, ptr(dgamma_out), 0, s), "npcd_colsum_finalize")
-    check(L.npcd_colsum_finalize(ptr(parts[1]), nblk, W, ptr(dbeta_out), 0, s), "npcd_colsum_finalize")
+    _finish(batch, parts[0], nblk, W, dgamma_out)
+    _finish(batch, parts[1], nblk, W, dbeta_out)
     if dcol_out is not None:
-        check(L.npcd_colsum_finalize(ptr(parts[2]), nblk, W, ptr(dcol_out), 0, s), "npcd_colsum_finalize")
+        _finish(batch, parts[2], nblk, W, dcol_out)
     return dx, dxb
 
 
@@ -46,7 +82,7 @@ def gelu_fwd(h):
     return g
 
 
-def gelu_bwd(dg, h, dbias_out):
+def gelu_bwd(dg, h, dbias_out, batch=None):
     """dh = dg * gelu'(h) (bf16); dbias_out[N] (fp32) = column sum of dh."""
     T, N = h.shape
     L = lib()
@@ -54,18 +90,18 @@ def gelu_bwd(dg, h, dbias_out):
     dh = torch.empty_like(h)
     part = torch.empty((nblk + L.npcd_colsum_scratch_rows(), N), dtype=_f32, device=h.device)
     check(L.npcd_gelu_bwd(ptr(dg), ptr(h), ptr(dh), ptr(part), T, N, stream_ptr()), "npcd_gelu_bwd")
-    check(L.npcd_colsum_finalize(ptr(part), nblk, N, ptr(dbias_out), 0, stream_ptr()), "npcd_colsum_finalize")
+    _finish(batch, part, nblk, N, dbias_out)
     return dh
 
 
-def colsum_bf16(a, out):
+def colsum_bf16(a, out, batch=None):
     """out[N] (fp32) = column sum of the bf16 matrix a [T,N]."""
     T, N = a.shape
     L = lib()
     nblk = L.npcd_colsum_blocks(T)
     part = torch.empty((nblk + L.npcd_colsum_scratch_rows(), N), dtype=_f32, device=a.device)
     check(L.npcd_colsum_bf16(ptr(a), ptr(part), T, N, stream_ptr()), "npcd_colsum_bf16")
-    check(L.npcd_colsum_finalize(ptr(part), nblk, N, ptr(out), 0, stream_ptr()), "npcd_colsum_finalize")
+    _finish(batch, part, nblk, N, out)
     return out
 
 

@@ -38,7 +38,7 @@ def _wgrad(dy, x, out):
     while S > 1 and T % S:
         S //= 2
     if S == 1:
-        out.copy_(torch.mm(dy.t(), x, out_dtype=_f32))
+        torch.mm(dy.t(), x, out_dtype=_f32, out=out)
         return
     part = torch.bmm(dy.view(S, T // S, -1).transpose(1, 2), x.view(S, T // S, -1), out_dtype=_f32)
     torch.sum(part, dim=0, out=out)
@@ -111,16 +111,17 @@ class _BackboneFn(torch.autograd.Function):
                 e = eng.blocks[bi]
                 x_cur, mean1, rstd1, y1, qkv, a, lse, x2, mean2, rstd2, y2, h, g = ctx.saved[bi]
                 ctx.saved[bi] = None
+                sums = ew.ColsumBatch()            # this block's 8 bias / LN-affine column sums: one finalize
                 # ---- MLP branch: x3 = x2 + c_proj(gelu(c_fc(ln_2(x2)))) ------------------------------
                 dg = torch.mm(dxb, e["mlp_c_proj_weight_16"])
                 _wgrad(dxb, g, e["mlp_c_proj_weight_g"])
-                dh = ew.gelu_bwd(dg, h, e["mlp_c_fc_bias_g"])
+                dh = ew.gelu_bwd(dg, h, e["mlp_c_fc_bias_g"], batch=sums)
                 del dg, g, h
                 dy2 = torch.mm(dh, e["mlp_c_fc_weight_16"])
                 _wgrad(dh, y2, e["mlp_c_fc_weight_g"])
                 del dh, y2
                 dx2, dx2b = ew.ln_bwd(dy2, x2, mean2, rstd2, e["ln_2_weight"], dx, e["ln_2_weight_g"], e["ln_2_bias_g"],
-                                      e["attn_c_proj_bias_g"])
+                                      e["attn_c_proj_bias_g"], batch=sums)
                 del dy2, x2, dx, dxb
                 # ---- attention branch: x2 = x + c_proj(attn(c_qkv(ln_1(x)))) ---------------------------
                 da = torch.mm(dx2b, e["attn_c_proj_weight_16"])
@@ -130,14 +131,15 @@ class _BackboneFn(torch.autograd.Function):
                 hattn._bwd(q4[..., :d], q4[..., d:2 * d], q4[..., 2 * d:], a.view(B, n, H, d), da.view(B, n, H, d), lse,
                            g4[..., :d], g4[..., d:2 * d], g4[..., 2 * d:], scale)
                 del da, a, qkv, dx2b
-                ew.colsum_bf16(dqkv, e["attn_c_qkv_bias_g"])
+                ew.colsum_bf16(dqkv, e["attn_c_qkv_bias_g"], batch=sums)
                 dy1 = torch.mm(dqkv, e["attn_c_qkv_weight_16"])
                 _wgrad(dqkv, y1, e["attn_c_qkv_weight_g"])
                 del dqkv, y1
                 prev_bias_g = eng.blocks[bi - 1]["mlp_c_proj_bias_g"] if bi > 0 else None
                 dx, dxb = ew.ln_bwd(dy1, x_cur, mean1, rstd1, e["ln_1_weight"], dx2, e["ln_1_weight_g"], e["ln_1_bias_g"],
-                                    prev_bias_g, want_bf16=bi > 0)
+                                    prev_bias_g, want_bf16=bi > 0, batch=sums)
                 del dy1, dx2
+                sums.flush()
                 if eng.reducer is not None:
                     # this block's gradients are final (mlp.c_proj.bias was finished by the block above / the tail)
                     for p in e["params"]:
