@@ -89,6 +89,71 @@ __device__ __forceinline__ void dma_tile_pair(unsigned char* buf, const E* a_bas
         asm volatile("" ::: "memory");                             \
     } while (0)
 
+// Fast form for tiles that lie completely inside the sequence: one wave-uniform base per tile (scalar
+// registers) + a loop-invariant 32-bit lane offset, i.e. the saddr + voffset form of global_load_lds.  The
+// XOR swizzle of a piece only depends on the piece's parity (tile_swz uses row bits 1..3), so two lane offsets
+// serve all pieces.  q, k and v are views of one c_qkv output and share their strides.
+struct DmaLane {
+    uint32_t off[2];
+};
+template <class E>
+__device__ __forceinline__ DmaLane dma_lane(int64_t stride, int lane) {
+    DmaLane d;
+    const int rowin = lane >> 3;
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+        d.off[par] = (uint32_t)((rowin * stride + (((lane & 7) ^ tile_swz(8 * par + rowin)) << 3)) * (int64_t)sizeof(E));
+    return d;
+}
+template <class E, int SLOT>
+__device__ __forceinline__ void dma_tile_pair_fast(unsigned char* smem, const E* a_base, const E* b_base, int64_t stride, int row0,
+                                                   int wave /* wave-uniform (scalar) */, const DmaLane& dl) {
+    const bool second = wave >= 2;
+    const int w2 = wave & 1;
+    const char* sbase = reinterpret_cast<const char*>((second ? b_base : a_base) + (int64_t)(row0 + w2 * 32) * stride);
+    unsigned char* dst0 = smem + SLOT * 16384 + (second ? 8192 : 0) + w2 * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const char* src = sbase + (int64_t)i * 8 * stride * (int64_t)sizeof(E) + (uint64_t)dl.off[i & 1];
+        __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst0 + i * 1024), 16, 0, 0);
+    }
+}
+
+// Per-lane LDS byte addresses of the MFMA fragments of a 64x64 tile at offset 0 of the ring, computed once per
+// kernel.  Everything else (ring slot, K or V image, 32-key half, 16-row group) is a compile-time constant
+// that goes into the instructions' 16-bit offset field: the swizzle only uses row bits 1..3.
+struct FragAddr {
+    uint32_t row[4];    // ds_read_b128: row (lane&31), logical chunk 2s + (lane>>5)
+    uint32_t tr[2][2];  // ds_read_b64_tr_b16: [db][second read, 8 rows further]
+};
+__device__ __forceinline__ uint32_t lds_addr(const unsigned char* p);
+__device__ __forceinline__ FragAddr frag_addr(const unsigned char* smem, int lane) {
+    FragAddr f;
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) f.row[s2] = lds_addr(smem) + tile_off(r, 2 * s2 + hh);
+    const int grp = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h = grp >> 1;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const int col = db * 32 + 16 * (grp & 1) + 4 * pp;
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) f.tr[db][hi] = lds_addr(smem) + tile_off(4 * h + q + 8 * hi, col >> 3) + (col & 7) * 2;
+    }
+    return f;
+}
+// hand-issued form (the caller waits with tr_wait() before the first use): keeps the issue order of a batch of reads
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_b128_issue(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <class TR, int OFF>
+__device__ __forceinline__ typename TR::vec8 lds_frag_at(uint32_t addr) {
+    typedef __attribute__((address_space(3))) const typename TR::vec8 lds_v8;
+    return *reinterpret_cast<lds_v8*>((uintptr_t)(addr + OFF));
+}
+
 // Transposed fragment straight from a ROW-MAJOR tile (no second, transposed LDS image): the A operand
 // T^T[d = db*32 + (lane&31)][k] of a 32x32x16 MFMA whose 16 k-indices are rows 16*g16 .. 16*g16+15 of
 // the tile, in the accumulator-row order (element j of lane-half h <-> row 16 g16 + 8 (j>>2) + 4 h + (j&3)),
@@ -108,6 +173,20 @@ __device__ __forceinline__ u32x2 tr_issue_one(uint32_t addr) {
 struct TrPair {
     u32x2 lo, hi;
 };
+template <int OFF>
+__device__ __forceinline__ u32x2 tr_issue_imm(uint32_t addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+// fragment (g16, db) of the tile at byte offset TILE of the ring
+template <int TILE, int G16>
+__device__ __forceinline__ TrPair tr_issue_at(const FragAddr& fa, int db) {
+    TrPair t;
+    t.lo = tr_issue_imm<TILE + G16 * 2048>(fa.tr[db][0]);
+    t.hi = tr_issue_imm<TILE + G16 * 2048>(fa.tr[db][1]);
+    return t;
+}
 __device__ __forceinline__ TrPair tr_issue(const unsigned char* tile, int g16, int db, int lane) {
     const int grp = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h = grp >> 1;
     const int col = db * 32 + 16 * (grp & 1) + 4 * pp;
@@ -189,26 +268,29 @@ __device__ __forceinline__ float half_sum(float x) {
 constexpr float kDeferLog2 = 8.f;
 
 // One 32-key half tile: S^T (4 MFMAs) -> online softmax on 16 scores per lane -> O^T += V^T P^T (4 MFMAs).
-// Working in 32-key halves keeps the live register set small enough for 3-4 waves per SIMD, which is what
-// hides the MFMA->VALU and LDS latencies of this vector-ALU-bound kernel.
-template <class TR, bool MASK>
-__device__ __forceinline__ void fwd_half(const unsigned char* Kc, const unsigned char* Vc, int kb, const typename TR::vec8 (&qf)[4],
-                                         f32x16& o0, f32x16& o1, float& m, float& l, float c, int key0, int n, int r, int hh) {
+// Working in 32-key halves keeps the live register set small enough for 3 waves per SIMD.  The kernel is bound
+// by vector-instruction ISSUE (MI355X_MICROARCH.md, per-instruction cycle constants): every address in here
+// is a loop-invariant register + an immediate.
+template <class TR, bool MASK, int SLOT, int KB>
+__device__ __forceinline__ void fwd_half(const FragAddr& fa, const typename TR::vec8 (&qf)[4], f32x16& o0, f32x16& o1, float& m, float& l,
+                                         float c, int key0, int n, int hh) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
+    constexpr int KT = SLOT * 16384 + KB * 4096, VT = SLOT * 16384 + 8192;
     f32x16 s0 = {0};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) s0 = TR::mfma32(lds_frag<TR>(Kc, kb * 32 + r, 2 * s + hh), qf[s], s0);
+    s0 = TR::mfma32(lds_frag_at<TR, KT>(fa.row[0]), qf[0], s0);
+    s0 = TR::mfma32(lds_frag_at<TR, KT>(fa.row[1]), qf[1], s0);
+    s0 = TR::mfma32(lds_frag_at<TR, KT>(fa.row[2]), qf[2], s0);
+    s0 = TR::mfma32(lds_frag_at<TR, KT>(fa.row[3]), qf[3], s0);
     TrPair vt[2][2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        vt[g][0] = tr_issue(Vc, kb * 2 + g, 0, (hh << 5) | r);
-        vt[g][1] = tr_issue(Vc, kb * 2 + g, 1, (hh << 5) | r);
-    }
+    vt[0][0] = tr_issue_at<VT, KB * 2>(fa, 0);
+    vt[0][1] = tr_issue_at<VT, KB * 2>(fa, 1);
+    vt[1][0] = tr_issue_at<VT, KB * 2 + 1>(fa, 0);
+    vt[1][1] = tr_issue_at<VT, KB * 2 + 1>(fa, 1);
     if (MASK) {
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-            if (key0 + kb * 32 + acc_row(i, hh) >= n) s0[i] = -INFINITY;
+            if (key0 + KB * 32 + acc_row(i, hh) >= n) s0[i] = -INFINITY;
     }
     float mx = fmaxf(s0[0], s0[1]);
 #pragma unroll
@@ -243,19 +325,61 @@ __device__ __forceinline__ void fwd_half(const unsigned char* Kc, const unsigned
     }
 }
 
-template <class TR, bool MASK>
-__device__ __forceinline__ void fwd_tile(const unsigned char* Kc, const unsigned char* Vc, const typename TR::vec8 (&qf)[4], f32x16& o0,
-                                         f32x16& o1, float& m, float& l, float c, int key0, int n, int r, int hh) {
-    fwd_half<TR, MASK>(Kc, Vc, 0, qf, o0, o1, m, l, c, key0, n, r, hh);
-    fwd_half<TR, MASK>(Kc, Vc, 1, qf, o0, o1, m, l, c, key0, n, r, hh);
+// Stream control shared by the forward and the dQ kernel: before computing on tile t (ring slot SLOT), start
+// the LDS-DMA of tile t+2 into slot SLOT+2 (last read in iteration t-1, which every wave has left).
+template <class E, int SLOT>
+__device__ __forceinline__ void kv_prefetch(unsigned char* smem, const E* kb, const E* vb, int64_t sn, int t, int nt, int n, int wave,
+                                            int lane, const DmaLane& dl) {
+    if (t + 2 < nt) {
+        if ((t + 3) * 64 <= n) dma_tile_pair_fast<E, (SLOT + 2) % 3>(smem, kb, vb, sn, (t + 2) * 64, wave, dl);
+        else dma_tile_pair(smem + ((SLOT + 2) % 3) * 16384, kb, sn, vb, sn, (t + 2) * 64, n, wave, lane);
+    }
+}
+// tile t+1 has landed for every wave and tile t is fully consumed (tile t+2, if any, stays in flight)
+#define NPCD_KV_ADVANCE(t, nt)                     \
+    do {                                           \
+        if ((t) + 2 < (nt)) NPCD_DMA_WAIT_BARRIER(4); \
+        else NPCD_DMA_WAIT_BARRIER(0);             \
+    } while (0)
+
+template <class TR, int SLOT>
+__device__ __forceinline__ void fwd_step(unsigned char* smem, const FragAddr& fa, const DmaLane& dl, const typename TR::elem* kb,
+                                         const typename TR::elem* vb, int64_t sn, int t, int nt, int n, int wave, int lane,
+                                         const typename TR::vec8 (&qf)[4], f32x16& o0, f32x16& o1, float& m, float& l, float c) {
+    kv_prefetch<typename TR::elem, SLOT>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
+    if (t * 64 + 64 <= n) {
+        fwd_half<TR, false, SLOT, 0>(fa, qf, o0, o1, m, l, c, t * 64, n, lane >> 5);
+        fwd_half<TR, false, SLOT, 1>(fa, qf, o0, o1, m, l, c, t * 64, n, lane >> 5);
+    } else {
+        fwd_half<TR, true, SLOT, 0>(fa, qf, o0, o1, m, l, c, t * 64, n, lane >> 5);
+        if (t * 64 + 32 < n) fwd_half<TR, true, SLOT, 1>(fa, qf, o0, o1, m, l, c, t * 64, n, lane >> 5);
+    }
+    NPCD_KV_ADVANCE(t, nt);
+}
+// a wave without query rows (last query tile of a ragged sequence) only keeps the K/V stream and the barriers going
+template <class E>
+__device__ __forceinline__ void kv_idle_loop(unsigned char* smem, const E* kb, const E* vb, int64_t sn, int nt, int n, int wave, int lane,
+                                             const DmaLane& dl) {
+    int slot = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (slot == 0) kv_prefetch<E, 0>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
+        else if (slot == 1) kv_prefetch<E, 1>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
+        else kv_prefetch<E, 2>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
+        NPCD_KV_ADVANCE(t, nt);
+        slot = slot == 2 ? 0 : slot + 1;
+    }
 }
 
+#ifndef NPCD_FWD_WAVES
+#define NPCD_FWD_WAVES 2
+#endif
 template <class TR>
-__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, NPCD_FWD_WAVES) void attn_fwd_kernel(AttnParams p) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 16384];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nqt = (p.n + 127) >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = bid % nqt, bh = bid / nqt, h = bh % p.H, b = bh / p.H;
@@ -266,37 +390,39 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams p) {
     const bool wave_active = q0 < p.n;
     const int qrow = q0 + r;
     const float c = p.scale_log2;
+    const int n = p.n, nt = (n + 63) >> 6;
+    const DmaLane dl = dma_lane<E>(p.sn, lane);
+    const FragAddr fa = frag_addr(smem, lane);
+
+    // 3-deep LDS ring filled by LDS-DMA, two tiles ahead of the compute.
+    dma_tile_pair(smem, kb, p.sn, vb, p.sn, 0, n, wave, lane);
+    if (nt > 1) dma_tile_pair(smem + 16384, kb, p.sn, vb, p.sn, 64, n, wave, lane);
 
     // Q fragments stay unscaled (scores are scaled in fp32 after the MFMA, identically in fwd and bwd, so
     // that P recomputed in the backward matches the forward's LSE even for very large logits)
     V8 qf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-        qf[s] = *reinterpret_cast<const V8*>(qb + (int64_t)min(qrow, p.n - 1) * p.sn + 16 * s + 8 * hh);
+        qf[s] = *reinterpret_cast<const V8*>(qb + (int64_t)min(qrow, n - 1) * p.sn + 16 * s + 8 * hh);
     f32x16 o0 = {0}, o1 = {0};
     float m = -INFINITY, l = 0.f;
-    const int nt = (p.n + 63) >> 6;
-
-    // 3-deep LDS ring filled by LDS-DMA, two tiles ahead of the compute.
-    dma_tile_pair(smem, kb, p.sn, vb, p.sn, 0, p.n, wave, lane);
-    dma_tile_pair(smem + 16384, kb, p.sn, vb, p.sn, 64, p.n, wave, lane);
-    NPCD_DMA_WAIT_BARRIER(4);                                   // tile 0 has landed (tile 1 may still be in flight)
-    for (int t = 0; t < nt; ++t) {
-        const int slot = t % 3, nslot = (t + 2) % 3;
-        // slot (t+2)%3 == (t-1)%3 was last read in iteration t-1, before the barrier every wave has passed
-        dma_tile_pair(smem + nslot * 16384, kb, p.sn, vb, p.sn, (t + 2) * 64, p.n, wave, lane);
-        const unsigned char* Kc = smem + slot * 16384;
-        if (wave_active) {
-            if (t * 64 + 64 > p.n) fwd_tile<TR, true>(Kc, Kc + 8192, qf, o0, o1, m, l, c, t * 64, p.n, r, hh);
-            else fwd_tile<TR, false>(Kc, Kc + 8192, qf, o0, o1, m, l, c, t * 64, p.n, r, hh);
-        }
-        NPCD_DMA_WAIT_BARRIER(4);                               // tile t+1 landed for every wave; tile t fully consumed
+    if (nt > 1) NPCD_DMA_WAIT_BARRIER(4);                        // tile 0 has landed (tile 1 may still be in flight)
+    else NPCD_DMA_WAIT_BARRIER(0);
+    if (!wave_active) {                                          // wave-uniform
+        kv_idle_loop<E>(smem, kb, vb, p.sn, nt, n, wave, lane, dl);
+        return;
+    }
+    // the ring position is a compile-time constant inside each step: three steps per trip
+    for (int t = 0; t < nt; t += 3) {
+        fwd_step<TR, 0>(smem, fa, dl, kb, vb, p.sn, t, nt, n, wave, lane, qf, o0, o1, m, l, c);
+        if (t + 1 < nt) fwd_step<TR, 1>(smem, fa, dl, kb, vb, p.sn, t + 1, nt, n, wave, lane, qf, o0, o1, m, l, c);
+        if (t + 2 < nt) fwd_step<TR, 2>(smem, fa, dl, kb, vb, p.sn, t + 2, nt, n, wave, lane, qf, o0, o1, m, l, c);
     }
     l = half_sum(l);
-    if (qrow < p.n) {
+    if (qrow < n) {
         E* orow = static_cast<E*>(p.o_w) + b * p.osb + qrow * p.osn + h * p.osh;
         store_rows<TR>(orow, o0, o1, 1.f / l, hh);
-        if (hh == 0) p.lse[(int64_t)(b * p.H + h) * p.n + qrow] = m * kLn2 + logf(l);
+        if (hh == 0) p.lse[(int64_t)(b * p.H + h) * n + qrow] = m * kLn2 + logf(l);
     }
 }
 
@@ -381,8 +507,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
     }
     delta = half_sum(delta);
     const int64_t stat = (int64_t)(b * p.H + h) * p.n + qclamp;
-    if (row_ok && hh == 0) p.delta[stat] = delta;
-    const float lse2 = p.lse[stat] * kLog2e;      // rows past the end duplicate the last row; they are never stored
+    const float lse_row = p.lse[stat];            // rows past the end duplicate the last row; they are never stored
+    if (row_ok && hh == 0) {                      // row constants of the dK/dV pass (initial accumulators there)
+        p.delta[stat] = -lse_row / p.scale;
+        p.delta[(int64_t)p.B * p.H * p.n + stat] = -delta;
+    }
+    const float lse2 = lse_row * kLog2e;
     f32x16 dq0 = {0}, dq1 = {0};
     NPCD_DMA_WAIT_BARRIER(4);
     for (int t = 0; t < nt; ++t) {
@@ -408,27 +538,214 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
 // ============================================================================================
 // backward, pass 2: dK, dV
 // ============================================================================================
-constexpr int kDkdvBuf = 2 * 8192 + 512;  // Q, dO row-major (also read transposed); lse2[64], delta[64]
+// Ring slot of the dK/dV pass: Q tile, dO tile (row-major, also read transposed), then the two per-row
+// constants of the 64 query rows written by the dQ pass: -lse/scale [64] and -delta [64] (fp32).
+constexpr int kDkdvSlot = 2 * 8192 + 512;
+
+__device__ __forceinline__ f32x4 lds_f32x4_at(uint32_t addr) {
+    typedef __attribute__((address_space(3))) const f32x4 lds_f4;
+    return *reinterpret_cast<lds_f4*>((uintptr_t)addr);
+}
+
+// per-wave LDS-DMA context of the dK/dV pass: waves 0,1 stream the Q tile, waves 2,3 the dO tile (32 rows each);
+// waves with an even / odd index also fetch the 64 -lse/scale / -delta values of the tile (4 bytes per lane).
+template <class E>
+struct QdoStream {
+    const E* base;        // q or dout of this (batch, head), advanced to the wave's first row
+    const E* q;           // for the clamped (ragged last tile) form
+    const E* dout;
+    const float* stat;    // row-constant plane of this wave
+    int64_t stride, qstride, dostride;
+    DmaLane dl;
+    int dst;              // byte offset of the wave's first piece inside a slot
+    int stat_dst;
+};
+
+template <class E>
+__device__ __forceinline__ void qdo_prefetch(unsigned char* slot, const QdoStream<E>& qs, int t, int n, int wave, int lane) {
+    const int row0 = t * 64;
+    if (row0 + 64 <= n) {
+        const char* sbase = reinterpret_cast<const char*>(qs.base + (int64_t)row0 * qs.stride);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const char* src = sbase + (int64_t)i * 8 * qs.stride * (int64_t)sizeof(E) + (uint64_t)qs.dl.off[i & 1];
+            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(slot + qs.dst + i * 1024), 16, 0, 0);
+        }
+    } else {
+        dma_tile_pair(slot, qs.q, qs.qstride, qs.dout, qs.dostride, row0, n, wave, lane);
+    }
+    const float* ssrc = qs.stat + min(row0 + lane, n - 1);      // pad rows duplicate the last row; their P is masked
+    __builtin_amdgcn_global_load_lds((gptr_t*)ssrc, (lptr_t*)(slot + qs.stat_dst), 4, 0, 0);
+}
+
+// S'^T = K Q^T - lse/scale and dP'^T = V dO^T - delta for the 32 query rows SUB of the tile in ring slot SLOT
+// (keys on the lanes): the row constants enter as the initial accumulators, so that P = exp2(c S') and
+// dS = P dP' need no subtraction (cdna_hip_programming.md, 'Row constants as the initial accumulator').
+template <class TR, int SLOT, int SUB>
+__device__ __forceinline__ void dkdv_scores(const FragAddr& fa, uint32_t st_addr, const typename TR::vec8 (&kf)[4],
+                                            const typename TR::vec8 (&vf)[4], f32x16& s, f32x16& d) {
+    using V8 = typename TR::vec8;
+    constexpr int QT = SLOT * kDkdvSlot + SUB * 4096, DT = QT + 8192, ST = SLOT * kDkdvSlot + 16384 + SUB * 128;
+    // one batch of 16 LDS reads (row constants straight into the accumulators, then the 8 row fragments), one wait
+    u32x4 si[4], di[4], qr[4], dr[4];
+    si[0] = lds_b128_issue<ST>(st_addr);       si[1] = lds_b128_issue<ST + 32>(st_addr);
+    si[2] = lds_b128_issue<ST + 64>(st_addr);  si[3] = lds_b128_issue<ST + 96>(st_addr);
+    qr[0] = lds_b128_issue<QT>(fa.row[0]);     qr[1] = lds_b128_issue<QT>(fa.row[1]);
+    qr[2] = lds_b128_issue<QT>(fa.row[2]);     qr[3] = lds_b128_issue<QT>(fa.row[3]);
+    di[0] = lds_b128_issue<ST + 256>(st_addr); di[1] = lds_b128_issue<ST + 288>(st_addr);
+    di[2] = lds_b128_issue<ST + 320>(st_addr); di[3] = lds_b128_issue<ST + 352>(st_addr);
+    dr[0] = lds_b128_issue<DT>(fa.row[0]);     dr[1] = lds_b128_issue<DT>(fa.row[1]);
+    dr[2] = lds_b128_issue<DT>(fa.row[2]);     dr[3] = lds_b128_issue<DT>(fa.row[3]);
+    tr_wait();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) {
+            s[4 * g + bq] = __uint_as_float(si[g][bq]);
+            d[4 * g + bq] = __uint_as_float(di[g][bq]);
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) s = TR::mfma32(__builtin_bit_cast(V8, qr[ks]), kf[ks], s);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) d = TR::mfma32(__builtin_bit_cast(V8, dr[ks]), vf[ks], d);
+}
+
+// two fp32 -> one packed 16-bit pair (v_cvt_pk_*)
+template <class TR>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    typedef typename TR::elem E2 __attribute__((ext_vector_type(2)));
+    const E2 t = {(typename TR::elem)a, (typename TR::elem)b};
+    return __builtin_bit_cast(uint32_t, t);
+}
+
+// P and dS of one 32-row sub-block as the 16-bit B operands of the dV^T / dK^T products
+template <class TR, bool MASK>
+__device__ __forceinline__ void dkdv_softmax(const f32x16& s, const f32x16& d, float c, int row0, int n, int hh,
+                                             typename TR::vec8 (&pf)[2], typename TR::vec8 (&df)[2]) {
+    using V8 = typename TR::vec8;
+    u32x4 pw[2], dw[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float p0 = __builtin_amdgcn_exp2f(s[2 * j] * c), p1 = __builtin_amdgcn_exp2f(s[2 * j + 1] * c);
+        if (MASK) {
+            if (row0 + acc_row(2 * j, hh) >= n) p0 = 0.f;
+            if (row0 + acc_row(2 * j + 1, hh) >= n) p1 = 0.f;
+        }
+        pw[j >> 2][j & 3] = pack2<TR>(p0, p1);
+        dw[j >> 2][j & 3] = pack2<TR>(p0 * d[2 * j], p1 * d[2 * j + 1]);
+    }
+    pf[0] = __builtin_bit_cast(V8, pw[0]);
+    pf[1] = __builtin_bit_cast(V8, pw[1]);
+    df[0] = __builtin_bit_cast(V8, dw[0]);
+    df[1] = __builtin_bit_cast(V8, dw[1]);
+}
+
+// dV^T += dO^T P and dK^T += Q^T dS for sub-block SUB of the tile in slot SLOT
+template <class TR, int SLOT, int SUB>
+__device__ __forceinline__ void dkdv_accum(const FragAddr& fa, const typename TR::vec8 (&pf)[2], const typename TR::vec8 (&df)[2],
+                                           f32x16& dk0, f32x16& dk1, f32x16& dv0, f32x16& dv1) {
+    constexpr int QT = SLOT * kDkdvSlot, DT = QT + 8192;
+    TrPair t[2][2];
+    t[0][0] = tr_issue_at<DT, 2 * SUB>(fa, 0);
+    t[0][1] = tr_issue_at<DT, 2 * SUB>(fa, 1);
+    t[1][0] = tr_issue_at<DT, 2 * SUB + 1>(fa, 0);
+    t[1][1] = tr_issue_at<DT, 2 * SUB + 1>(fa, 1);
+    tr_wait();
+    dv0 = TR::mfma32(tr_vec<TR>(t[0][0]), pf[0], dv0);
+    dv1 = TR::mfma32(tr_vec<TR>(t[0][1]), pf[0], dv1);
+    dv0 = TR::mfma32(tr_vec<TR>(t[1][0]), pf[1], dv0);
+    dv1 = TR::mfma32(tr_vec<TR>(t[1][1]), pf[1], dv1);
+    t[0][0] = tr_issue_at<QT, 2 * SUB>(fa, 0);
+    t[0][1] = tr_issue_at<QT, 2 * SUB>(fa, 1);
+    t[1][0] = tr_issue_at<QT, 2 * SUB + 1>(fa, 0);
+    t[1][1] = tr_issue_at<QT, 2 * SUB + 1>(fa, 1);
+    tr_wait();
+    dk0 = TR::mfma32(tr_vec<TR>(t[0][0]), df[0], dk0);
+    dk1 = TR::mfma32(tr_vec<TR>(t[0][1]), df[0], dk1);
+    dk0 = TR::mfma32(tr_vec<TR>(t[1][0]), df[1], dk0);
+    dk1 = TR::mfma32(tr_vec<TR>(t[1][1]), df[1], dk1);
+}
+
+// One 64-row query tile.  The two matrix products that consume a sub-block's P / dS are issued one stage later,
+// behind the NEXT sub-block's score products: the matrix pipe then works on them while the vector ALU turns the
+// new scores into P / dS.  Ring protocol: tile t+1 is awaited (and tile t+2 requested, into the slot of tile t-1)
+// in the MIDDLE of tile t, after the last reads of tile t-1.
+struct DkdvState {
+    f32x16 dk0, dk1, dv0, dv1;
+    bool pend;          // sub-block 1 of the previous tile still has to be accumulated (wave-uniform)
+};
+template <class TR, int SLOT>
+__device__ __forceinline__ void dkdv_step(unsigned char* smem, const FragAddr& fa, uint32_t st_addr, const QdoStream<typename TR::elem>& qs,
+                                          int t, int nt, int n, int wave, int lane, const typename TR::vec8 (&kf)[4],
+                                          const typename TR::vec8 (&vf)[4], float c, DkdvState& a, typename TR::vec8 (&pf)[2],
+                                          typename TR::vec8 (&df)[2]) {
+    constexpr int PREV = (SLOT + 2) % 3;
+    const int hh = lane >> 5;
+    const bool masked = t * 64 + 64 > n;
+    f32x16 s, d;
+    dkdv_scores<TR, SLOT, 0>(fa, st_addr, kf, vf, s, d);
+    if (a.pend) dkdv_accum<TR, PREV, 1>(fa, pf, df, a.dk0, a.dk1, a.dv0, a.dv1);
+    if (masked) dkdv_softmax<TR, true>(s, d, c, t * 64, n, hh, pf, df);
+    else dkdv_softmax<TR, false>(s, d, c, t * 64, n, hh, pf, df);
+    NPCD_DMA_WAIT_BARRIER(0);                                    // tile t+1 landed; every wave is done with tile t-1
+    if (t + 2 < nt) qdo_prefetch(smem + PREV * kDkdvSlot, qs, t + 2, n, wave, lane);
+    if (!masked || t * 64 + 32 < n) {
+        dkdv_scores<TR, SLOT, 1>(fa, st_addr, kf, vf, s, d);
+        dkdv_accum<TR, SLOT, 0>(fa, pf, df, a.dk0, a.dk1, a.dv0, a.dv1);
+        if (masked) dkdv_softmax<TR, true>(s, d, c, t * 64 + 32, n, hh, pf, df);
+        else dkdv_softmax<TR, false>(s, d, c, t * 64 + 32, n, hh, pf, df);
+        a.pend = true;
+    } else {
+        dkdv_accum<TR, SLOT, 0>(fa, pf, df, a.dk0, a.dk1, a.dv0, a.dv1);
+        a.pend = false;
+    }
+}
 
 template <class TR>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    const int nkt = (p.n + 127) >> 7;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = p.n, nt = (n + 63) >> 6;
+    const int nkt = (n + 127) >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int kt = bid % nkt, bh = bid / nkt, h = bh % p.H, b = bh / p.H;
     const E* qb = static_cast<const E*>(p.q) + b * p.sb + h * p.sh;
     const E* kb = static_cast<const E*>(p.k) + b * p.sb + h * p.sh;
     const E* vb = static_cast<const E*>(p.v) + b * p.sb + h * p.sh;
     const E* dob = static_cast<const E*>(p.dout) + b * p.osb + h * p.osh;
-    const float* lse = p.lse + (int64_t)(b * p.H + h) * p.n;
-    const float* dlt = p.delta + (int64_t)(b * p.H + h) * p.n;
     const int key0 = kt * 128 + wave * 32;
-    const bool wave_active = key0 < p.n;
+    const bool wave_active = key0 < n;
     const int key = key0 + r;
-    const bool key_ok = key < p.n;
+    const bool key_ok = key < n;
+
+    QdoStream<E> qs;
+    {
+        const bool second = wave >= 2;
+        const int w2 = wave & 1;
+        qs.q = qb; qs.dout = dob; qs.qstride = p.sn; qs.dostride = p.osn;
+        qs.stride = second ? p.osn : p.sn;
+        qs.base = (second ? dob : qb) + (int64_t)(w2 * 32) * qs.stride;
+        qs.dl = dma_lane<E>(qs.stride, lane);
+        qs.dst = (second ? 8192 : 0) + w2 * 4096;
+        qs.stat = p.delta + (int64_t)w2 * p.B * p.H * n + (int64_t)(b * p.H + h) * n;
+        qs.stat_dst = 16384 + w2 * 256;
+    }
+    qdo_prefetch(dsmem, qs, 0, n, wave, lane);
+    if (nt > 1) qdo_prefetch(dsmem + kDkdvSlot, qs, 1, n, wave, lane);
+
+    if (!wave_active) {      // wave-uniform: no keys in this wave (ragged last key block): keep the stream and the barriers going
+        if (nt > 1) NPCD_DMA_WAIT_BARRIER(5);
+        else NPCD_DMA_WAIT_BARRIER(0);
+        for (int t = 0; t < nt; ++t) {
+            NPCD_DMA_WAIT_BARRIER(0);
+            if (t + 2 < nt) qdo_prefetch(dsmem + ((t + 2) % 3) * kDkdvSlot, qs, t + 2, n, wave, lane);
+        }
+        return;
+    }
 
     V8 kf[4], vf[4];
 #pragma unroll
@@ -437,91 +754,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
         kf[s] = __builtin_bit_cast(V8, key_ok ? *reinterpret_cast<const u32x4*>(kb + key * p.sn + 16 * s + 8 * hh) : z);
         vf[s] = __builtin_bit_cast(V8, key_ok ? *reinterpret_cast<const u32x4*>(vb + key * p.sn + 16 * s + 8 * hh) : z);
     }
-    f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
-    const int nt = (p.n + 63) >> 6;
+    DkdvState a;
+    a.dk0 = f32x16{0}; a.dk1 = f32x16{0}; a.dv0 = f32x16{0}; a.dv1 = f32x16{0};
+    a.pend = false;
+    V8 pf[2], df[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        pf[g] = V8{0};
+        df[g] = V8{0};
+    }
     const float c = p.scale_log2;
-
-    u32x4 qA[2], doA[2], qB[2], doB[2];
-    float statA = 0.f, statB = 0.f;  // threads 0..63 stage lse2, 64..127 stage delta
-    auto stage_load = [&](int row0, u32x4 (&qr)[2], u32x4 (&dr)[2], float& stat) {
-        pair_load(qr, qb, p.sn, row0, p.n, tid);
-        pair_load(dr, dob, p.osn, row0, p.n, tid);
-        // waves 0/2 stage lse2, waves 1/3 stage delta (branch-free; only threads < 128 store it)
-        const int row = row0 + (tid & 63);
-        const bool is_delta = (tid >> 6) & 1;
-        const float v = (is_delta ? dlt : lse)[min(row, p.n - 1)];
-        stat = is_delta ? (row < p.n ? v : 0.f) : (row < p.n ? v * kLog2e : INFINITY);  // +inf -> P = 0 for pad rows
-    };
-    auto stage_store = [&](unsigned char* buf, const u32x4 (&qr)[2], const u32x4 (&dr)[2], float stat) {
-        rm_store(buf, qr, tid);
-        rm_store(buf + 8192, dr, tid);
-        if (tid < 128) reinterpret_cast<float*>(buf + 16384)[tid] = stat;
-    };
-    stage_load(0, qA, doA, statA);
-    stage_store(dsmem, qA, doA, statA);
-    stage_load(64, qA, doA, statA);
-    stage_load(128, qB, doB, statB);
-    __syncthreads();
-
-    auto compute = [&](const unsigned char* Qc) {
-        if (!wave_active) return;
-        const unsigned char* DOc = Qc + 8192;
-        const float* st = reinterpret_cast<const float*>(Qc + 16384);
-        V8 pf[4], df[4];
-#pragma unroll
-        for (int qb2 = 0; qb2 < 2; ++qb2) {
-            f32x16 s = {0}, d = {0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = TR::mfma32(lds_frag<TR>(Qc, qb2 * 32 + r, 2 * ks + hh), kf[ks], s);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) d = TR::mfma32(lds_frag<TR>(DOc, qb2 * 32 + r, 2 * ks + hh), vf[ks], d);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 l4 = *reinterpret_cast<const f32x4*>(st + qb2 * 32 + 8 * g + 4 * hh);
-                const f32x4 d4 = *reinterpret_cast<const f32x4*>(st + 64 + qb2 * 32 + 8 * g + 4 * hh);
-#pragma unroll
-                for (int bq = 0; bq < 4; ++bq) {
-                    const int i = 4 * g + bq;
-                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[i], c, -l4[bq]));
-                    s[i] = pr;
-                    d[i] = pr * (d[i] - d4[bq]);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                pf[2 * qb2][j] = (E)s[j];
-                pf[2 * qb2 + 1][j] = (E)s[8 + j];
-                df[2 * qb2][j] = (E)d[j];
-                df[2 * qb2 + 1][j] = (E)d[8 + j];
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            dv0 = TR::mfma32(tr_frag<TR>(DOc, g, 0, lane), pf[g], dv0);
-            dv1 = TR::mfma32(tr_frag<TR>(DOc, g, 1, lane), pf[g], dv1);
-            dk0 = TR::mfma32(tr_frag<TR>(Qc, g, 0, lane), df[g], dk0);
-            dk1 = TR::mfma32(tr_frag<TR>(Qc, g, 1, lane), df[g], dk1);
-        }
-    };
-    for (int t = 0; t < nt; ++t) {
-        compute(dsmem + (t & 1) * kDkdvBuf);
-        if (t + 1 < nt) {
-            unsigned char* nb = dsmem + ((t + 1) & 1) * kDkdvBuf;
-            if (t & 1) {
-                stage_store(nb, qB, doB, statB);
-                stage_load((t + 3) * 64, qB, doB, statB);
-            } else {
-                stage_store(nb, qA, doA, statA);
-                stage_load((t + 3) * 64, qA, doA, statA);
-            }
-        }
-        __syncthreads();
+    const FragAddr fa = frag_addr(dsmem, lane);
+    const uint32_t st_addr = lds_addr(dsmem) + hh * 16;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // K/V fragments (and tile 0/1) have arrived
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int t = 0; t < nt; t += 3) {
+        dkdv_step<TR, 0>(dsmem, fa, st_addr, qs, t, nt, n, wave, lane, kf, vf, c, a, pf, df);
+        if (t + 1 < nt) dkdv_step<TR, 1>(dsmem, fa, st_addr, qs, t + 1, nt, n, wave, lane, kf, vf, c, a, pf, df);
+        if (t + 2 < nt) dkdv_step<TR, 2>(dsmem, fa, st_addr, qs, t + 2, nt, n, wave, lane, kf, vf, c, a, pf, df);
+    }
+    if (a.pend) {
+        const int last = (nt - 1) % 3;
+        if (last == 0) dkdv_accum<TR, 0, 1>(fa, pf, df, a.dk0, a.dk1, a.dv0, a.dv1);
+        else if (last == 1) dkdv_accum<TR, 1, 1>(fa, pf, df, a.dk0, a.dk1, a.dv0, a.dv1);
+        else dkdv_accum<TR, 2, 1>(fa, pf, df, a.dk0, a.dk1, a.dv0, a.dv1);
     }
     if (key_ok) {
         E* gk = static_cast<E*>(p.dk) + b * p.gsb + key * p.gsn + h * p.gsh;
         E* gv = static_cast<E*>(p.dv) + b * p.gsb + key * p.gsn + h * p.gsh;
-        store_rows<TR>(gk, dk0, dk1, p.scale, hh);
-        store_rows<TR>(gv, dv0, dv1, 1.f, hh);
+        store_rows<TR>(gk, a.dk0, a.dk1, p.scale, hh);
+        store_rows<TR>(gv, a.dv0, a.dv1, 1.f, hh);
     }
 }
 
@@ -678,7 +941,7 @@ static int attn_bwd_launch(int passes, const void* q, const void* k, const void*
     p.scale = scale; p.scale_log2 = scale * kLog2e;
     const int grid = B * H * ceil_div(n, 128);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int dyn = 2 * kDkdvBuf;
+    const int dyn = 3 * kDkdvSlot;
     static bool attr_set = false;
     if (!attr_set) {
         NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<BF16>),

@@ -40,7 +40,7 @@ def _timed(tag, fn):
 
 def _bwd(q, k, v, out, dout, lse, dq, dk, dv, scale):
     B, n, H, d = q.shape
-    delta = torch.empty((B, H, n), dtype=torch.float32, device=q.device)
+    delta = torch.empty((2, B, H, n), dtype=torch.float32, device=q.device)   # row constants handed from pass 1 to pass 2
     assert dq.stride() == dk.stride() == dv.stride() and dout.stride() == out.stride()
     args = (ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(dq), ptr(dk), ptr(dv),
             ptr(delta), B, n, H, d, q.stride(0), q.stride(1), q.stride(2),
