@@ -59,8 +59,9 @@ int npcd_attn_fwd(const void* q, const void* k, const void* v, void* out, float*
                   float scale, int dtype, void* stream);
 
 /* Backward of the above.  dq/dk/dv share (g_sb, g_sn, g_sh); out/dout share the out strides.
- * delta [2, B, H, n] fp32 is scratch, written by the call: the per-row constants the dK/dV pass starts its
- * accumulators from, plane 0 = -lse / scale, plane 1 = -rowsum(dout * out). */
+ * delta [2, B, H, npad] fp32 (npad = n rounded up to a multiple of 64) is scratch, written by the call: the per-row
+ * constants the dK/dV pass starts its accumulators from, plane 0 = -lse / scale, plane 1 = -rowsum(dout * out);
+ * the pad rows hold -inf / 0. */
 int npcd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                   const float* lse, void* dq, void* dk, void* dv, float* delta,
                   int B, int n, int H, int d,

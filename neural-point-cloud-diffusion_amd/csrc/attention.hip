@@ -24,6 +24,17 @@
 
 namespace npcd {
 
+#ifdef NPCD_TIMELINE
+// diagnostic build only: s_memtime stamps of one wave (block NPCD_TIMELINE, wave 0), read back with npcd_debug_read
+__device__ long long g_timeline[64];
+#define NPCD_TS(i)                                                                       \
+    do {                                                                                 \
+        if (tl_on) tl[(i)] = __builtin_amdgcn_s_memtime();                               \
+    } while (0)
+#else
+#define NPCD_TS(i) do { } while (0)
+#endif
+
 struct AttnParams {
     const void *q, *k, *v, *out, *dout;
     void *o_w, *dq, *dk, *dv;
@@ -64,21 +75,38 @@ __device__ __forceinline__ void rm_store(unsigned char* lds, const u32x4 (&reg)[
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
+// One LDS-DMA wave-instruction in the saddr + voffset form: wave-uniform 64-bit base in scalar registers, one 32-bit
+// byte offset per lane, LDS destination (wave-uniform byte address; lane l lands at +16 l / +4 l) through M0.
+// Hand-issued so that a tile costs two address VGPRs in total instead of a 64-bit pointer per piece.
+__device__ __forceinline__ uint32_t lds_addr(const unsigned char* p);
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {     // pin a wave-uniform pointer into scalar registers
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<const void*>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ void dma16_issue(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    sbase = uniform_ptr(sbase);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma4_issue(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    sbase = uniform_ptr(sbase);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 template <class E>
 __device__ __forceinline__ void dma_tile_pair(unsigned char* buf, const E* a_base, int64_t a_stride, const E* b_base, int64_t b_stride,
                                               int row0, int nrows, int wave, int lane) {
     const bool second = wave >= 2;          // wave-uniform
     const E* base = second ? b_base : a_base;
     const int64_t stride = second ? b_stride : a_stride;
-    unsigned char* tile = buf + (second ? 8192 : 0);
+    const uint32_t tile = lds_addr(buf) + (second ? 8192 : 0);
     const int w2 = wave & 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int prow = (w2 * 4 + i) * 8 + (lane >> 3);              // row inside the tile
         const int grow = min(row0 + prow, nrows - 1);                  // clamp: duplicated rows are neutralised downstream
-        const E* src = base + grow * stride + (((lane & 7) ^ tile_swz(prow)) << 3);
-        unsigned char* dst = tile + __builtin_amdgcn_readfirstlane((w2 * 4 + i) * 1024);
-        __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)dst, 16, 0, 0);
+        const uint32_t voff = (uint32_t)((grow * stride + (((lane & 7) ^ tile_swz(prow)) << 3)) * (int64_t)sizeof(E));
+        dma16_issue(base, voff, __builtin_amdgcn_readfirstlane(tile + (w2 * 4 + i) * 1024));
     }
 }
 // barrier that does NOT drain the vector-memory counter (keeps later tiles' DMA in flight)
@@ -111,12 +139,10 @@ __device__ __forceinline__ void dma_tile_pair_fast(unsigned char* smem, const E*
     const bool second = wave >= 2;
     const int w2 = wave & 1;
     const char* sbase = reinterpret_cast<const char*>((second ? b_base : a_base) + (int64_t)(row0 + w2 * 32) * stride);
-    unsigned char* dst0 = smem + SLOT * 16384 + (second ? 8192 : 0) + w2 * 4096;
+    const uint32_t dst0 = lds_addr(smem) + SLOT * 16384 + (second ? 8192 : 0) + w2 * 4096;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const char* src = sbase + (int64_t)i * 8 * stride * (int64_t)sizeof(E) + (uint64_t)dl.off[i & 1];
-        __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(dst0 + i * 1024), 16, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i)
+        dma16_issue(sbase + (int64_t)i * 8 * stride * (int64_t)sizeof(E), dl.off[i & 1], __builtin_amdgcn_readfirstlane(dst0 + i * 1024));
 }
 
 // Per-lane LDS byte addresses of the MFMA fragments of a 64x64 tile at offset 0 of the ring, computed once per
@@ -506,11 +532,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
         for (int j = 0; j < 8; ++j) delta += (float)dof[s][j] * (float)of[j];
     }
     delta = half_sum(delta);
-    const int64_t stat = (int64_t)(b * p.H + h) * p.n + qclamp;
-    const float lse_row = p.lse[stat];            // rows past the end duplicate the last row; they are never stored
-    if (row_ok && hh == 0) {                      // row constants of the dK/dV pass (initial accumulators there)
-        p.delta[stat] = -lse_row / p.scale;
-        p.delta[(int64_t)p.B * p.H * p.n + stat] = -delta;
+    const float lse_row = p.lse[(int64_t)(b * p.H + h) * p.n + qclamp];   // rows past the end duplicate the last row; never stored
+    {   // row constants of the dK/dV pass (its initial accumulators), planes [2][B][H][npad]; the pad rows of the last
+        // 64-row tile get -inf / 0 so that their P and dS vanish there without masking
+        const int npad = ((p.n + 63) >> 6) << 6;
+        if (hh == 0 && qrow < npad) {
+            const int64_t at = (int64_t)(b * p.H + h) * npad + qrow;
+            p.delta[at] = row_ok ? -lse_row / p.scale : -INFINITY;
+            p.delta[(int64_t)p.B * p.H * npad + at] = row_ok ? -delta : 0.f;
+        }
     }
     const float lse2 = lse_row * kLog2e;
     f32x16 dq0 = {0}, dq1 = {0};
@@ -564,29 +594,63 @@ struct QdoStream {
 template <class E>
 __device__ __forceinline__ void qdo_prefetch(unsigned char* slot, const QdoStream<E>& qs, int t, int n, int wave, int lane) {
     const int row0 = t * 64;
+    const uint32_t sl = lds_addr(slot);
     if (row0 + 64 <= n) {
         const char* sbase = reinterpret_cast<const char*>(qs.base + (int64_t)row0 * qs.stride);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const char* src = sbase + (int64_t)i * 8 * qs.stride * (int64_t)sizeof(E) + (uint64_t)qs.dl.off[i & 1];
-            __builtin_amdgcn_global_load_lds((gptr_t*)src, (lptr_t*)(slot + qs.dst + i * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i)
+            dma16_issue(sbase + (int64_t)i * 8 * qs.stride * (int64_t)sizeof(E), qs.dl.off[i & 1],
+                        __builtin_amdgcn_readfirstlane(sl + qs.dst + i * 1024));
     } else {
         dma_tile_pair(slot, qs.q, qs.qstride, qs.dout, qs.dostride, row0, n, wave, lane);
     }
-    const float* ssrc = qs.stat + min(row0 + lane, n - 1);      // pad rows duplicate the last row; their P is masked
-    __builtin_amdgcn_global_load_lds((gptr_t*)ssrc, (lptr_t*)(slot + qs.stat_dst), 4, 0, 0);
+    dma4_issue(qs.stat, (uint32_t)(row0 + lane) * 4u, __builtin_amdgcn_readfirstlane(sl + qs.stat_dst));
 }
 
-// S'^T = K Q^T - lse/scale and dP'^T = V dO^T - delta for the 32 query rows SUB of the tile in ring slot SLOT
-// (keys on the lanes): the row constants enter as the initial accumulators, so that P = exp2(c S') and
-// dS = P dP' need no subtraction (cdna_hip_programming.md, 'Row constants as the initial accumulator').
-template <class TR, int SLOT, int SUB>
-__device__ __forceinline__ void dkdv_scores(const FragAddr& fa, uint32_t st_addr, const typename TR::vec8 (&kf)[4],
-                                            const typename TR::vec8 (&vf)[4], f32x16& s, f32x16& d) {
+// two fp32 -> one packed 16-bit pair (v_cvt_pk_*)
+template <class TR>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    typedef typename TR::elem E2 __attribute__((ext_vector_type(2)));
+    typedef float F2 __attribute__((ext_vector_type(2)));
+    const F2 f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, E2));     // one vector conversion -> one v_cvt_pk
+}
+
+struct DkdvState {
+    f32x16 dk0, dk1, dv0, dv1;
+#ifdef NPCD_TIMELINE
+    long long* tl;
+    bool tl_on;
+#endif
+};
+#ifdef NPCD_TIMELINE
+#ifndef NPCD_TL_TILE
+#define NPCD_TL_TILE 3
+#endif
+#define NPCD_TS_STEP(i)                                                                        \
+    do {                                                                                       \
+        if (a.tl_on && t == NPCD_TL_TILE) { __builtin_amdgcn_sched_barrier(0); a.tl[(i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } \
+    } while (0)
+#else
+#define NPCD_TS_STEP(i) do { } while (0)
+#endif
+
+// One stage of the dK/dV pass = one 32-row query sub-block (SLOT, SUB) of the ring, keys on the lanes:
+//   A  one batch of LDS reads: the sub-block's row constants and Q / dO row fragments, plus (ACC) the transposed
+//      dO / Q fragments of the PREVIOUS sub-block (PSLOT, PSUB), one wait;
+//   B  S'^T = K Q^T - lse/scale and dP'^T = V dO^T - delta: the row constants enter as the initial accumulators,
+//      so that P = exp2(c S') and dS = P dP' need no subtraction (cdna_hip_programming.md, 'Row constants as
+//      the initial accumulator');
+//   C  dV^T += dO^T P, dK^T += Q^T dS of the previous sub-block (its P / dS sit in pf / df) -- issued behind B on
+//      the matrix pipe while the vector ALU turns this sub-block's scores into the next pf / df.
+template <class TR, int SLOT, int SUB, int PSLOT, int PSUB, bool ACC>
+__device__ __forceinline__ void dkdv_stage(const FragAddr& fa, uint32_t st_addr, const typename TR::vec8 (&kf)[4],
+                                           const typename TR::vec8 (&vf)[4], float c, DkdvState& a,
+                                           typename TR::vec8 (&pf)[2], typename TR::vec8 (&df)[2]) {
     using V8 = typename TR::vec8;
     constexpr int QT = SLOT * kDkdvSlot + SUB * 4096, DT = QT + 8192, ST = SLOT * kDkdvSlot + 16384 + SUB * 128;
-    // one batch of 16 LDS reads (row constants straight into the accumulators, then the 8 row fragments), one wait
+    constexpr int PQ = PSLOT * kDkdvSlot, PD = PQ + 8192;
+    // ---- A
     u32x4 si[4], di[4], qr[4], dr[4];
     si[0] = lds_b128_issue<ST>(st_addr);       si[1] = lds_b128_issue<ST + 32>(st_addr);
     si[2] = lds_b128_issue<ST + 64>(st_addr);  si[3] = lds_b128_issue<ST + 96>(st_addr);
@@ -597,6 +661,9 @@ __device__ __forceinline__ void dkdv_scores(const FragAddr& fa, uint32_t st_addr
     dr[0] = lds_b128_issue<DT>(fa.row[0]);     dr[1] = lds_b128_issue<DT>(fa.row[1]);
     dr[2] = lds_b128_issue<DT>(fa.row[2]);     dr[3] = lds_b128_issue<DT>(fa.row[3]);
     tr_wait();
+    // ---- B (first half), then the transposed fragments of the previous sub-block are requested so that their LDS
+    // latency passes under the score products
+    f32x16 s, d;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -606,100 +673,105 @@ __device__ __forceinline__ void dkdv_scores(const FragAddr& fa, uint32_t st_addr
         }
     }
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) s = TR::mfma32(__builtin_bit_cast(V8, qr[ks]), kf[ks], s);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) d = TR::mfma32(__builtin_bit_cast(V8, dr[ks]), vf[ks], d);
-}
-
-// two fp32 -> one packed 16-bit pair (v_cvt_pk_*)
-template <class TR>
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
-    typedef typename TR::elem E2 __attribute__((ext_vector_type(2)));
-    const E2 t = {(typename TR::elem)a, (typename TR::elem)b};
-    return __builtin_bit_cast(uint32_t, t);
-}
-
-// P and dS of one 32-row sub-block as the 16-bit B operands of the dV^T / dK^T products
-template <class TR, bool MASK>
-__device__ __forceinline__ void dkdv_softmax(const f32x16& s, const f32x16& d, float c, int row0, int n, int hh,
-                                             typename TR::vec8 (&pf)[2], typename TR::vec8 (&df)[2]) {
-    using V8 = typename TR::vec8;
-    u32x4 pw[2], dw[2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float p0 = __builtin_amdgcn_exp2f(s[2 * j] * c), p1 = __builtin_amdgcn_exp2f(s[2 * j + 1] * c);
-        if (MASK) {
-            if (row0 + acc_row(2 * j, hh) >= n) p0 = 0.f;
-            if (row0 + acc_row(2 * j + 1, hh) >= n) p1 = 0.f;
-        }
-        pw[j >> 2][j & 3] = pack2<TR>(p0, p1);
-        dw[j >> 2][j & 3] = pack2<TR>(p0 * d[2 * j], p1 * d[2 * j + 1]);
+    for (int ks = 0; ks < 2; ++ks) {
+        s = TR::mfma32(__builtin_bit_cast(V8, qr[ks]), kf[ks], s);
+        d = TR::mfma32(__builtin_bit_cast(V8, dr[ks]), vf[ks], d);
     }
+    TrPair to[2][2], tq[2][2];
+    if (ACC) {
+        __builtin_amdgcn_sched_barrier(0);
+        to[0][0] = tr_issue_at<PD, 2 * PSUB>(fa, 0);     to[0][1] = tr_issue_at<PD, 2 * PSUB>(fa, 1);
+        to[1][0] = tr_issue_at<PD, 2 * PSUB + 1>(fa, 0); to[1][1] = tr_issue_at<PD, 2 * PSUB + 1>(fa, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ks = 2; ks < 4; ++ks) {
+        s = TR::mfma32(__builtin_bit_cast(V8, qr[ks]), kf[ks], s);
+        d = TR::mfma32(__builtin_bit_cast(V8, dr[ks]), vf[ks], d);
+    }
+    // ---- C: [dV products] [request Q^T] [first half of the vector work] [dK products] [second half]
+    u32x4 pw[2], dw[2];
+    auto softmax_half = [&](int h2) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * h2 + jj;
+            // rows past the end of the sequence carry -inf / 0 as row constants (written by the dQ pass): P = dS = 0
+            const float p0 = __builtin_amdgcn_exp2f(s[2 * j] * c), p1 = __builtin_amdgcn_exp2f(s[2 * j + 1] * c);
+            pw[h2][jj] = pack2<TR>(p0, p1);
+            dw[h2][jj] = pack2<TR>(p0 * d[2 * j], p1 * d[2 * j + 1]);
+        }
+    };
+    if (ACC) {
+        tr_wait();
+        a.dv0 = TR::mfma32(tr_vec<TR>(to[0][0]), pf[0], a.dv0);
+        a.dv1 = TR::mfma32(tr_vec<TR>(to[0][1]), pf[0], a.dv1);
+        a.dv0 = TR::mfma32(tr_vec<TR>(to[1][0]), pf[1], a.dv0);
+        a.dv1 = TR::mfma32(tr_vec<TR>(to[1][1]), pf[1], a.dv1);
+        __builtin_amdgcn_sched_barrier(0);
+        tq[0][0] = tr_issue_at<PQ, 2 * PSUB>(fa, 0);     tq[0][1] = tr_issue_at<PQ, 2 * PSUB>(fa, 1);
+        tq[1][0] = tr_issue_at<PQ, 2 * PSUB + 1>(fa, 0); tq[1][1] = tr_issue_at<PQ, 2 * PSUB + 1>(fa, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    softmax_half(0);
+    if (ACC) {
+        tr_wait();
+        a.dk0 = TR::mfma32(tr_vec<TR>(tq[0][0]), df[0], a.dk0);
+        a.dk1 = TR::mfma32(tr_vec<TR>(tq[0][1]), df[0], a.dk1);
+        a.dk0 = TR::mfma32(tr_vec<TR>(tq[1][0]), df[1], a.dk0);
+        a.dk1 = TR::mfma32(tr_vec<TR>(tq[1][1]), df[1], a.dk1);
+    }
+    softmax_half(1);
     pf[0] = __builtin_bit_cast(V8, pw[0]);
     pf[1] = __builtin_bit_cast(V8, pw[1]);
     df[0] = __builtin_bit_cast(V8, dw[0]);
     df[1] = __builtin_bit_cast(V8, dw[1]);
 }
 
-// dV^T += dO^T P and dK^T += Q^T dS for sub-block SUB of the tile in slot SLOT
-template <class TR, int SLOT, int SUB>
-__device__ __forceinline__ void dkdv_accum(const FragAddr& fa, const typename TR::vec8 (&pf)[2], const typename TR::vec8 (&df)[2],
-                                           f32x16& dk0, f32x16& dk1, f32x16& dv0, f32x16& dv1) {
-    constexpr int QT = SLOT * kDkdvSlot, DT = QT + 8192;
-    TrPair t[2][2];
-    t[0][0] = tr_issue_at<DT, 2 * SUB>(fa, 0);
-    t[0][1] = tr_issue_at<DT, 2 * SUB>(fa, 1);
-    t[1][0] = tr_issue_at<DT, 2 * SUB + 1>(fa, 0);
-    t[1][1] = tr_issue_at<DT, 2 * SUB + 1>(fa, 1);
+// the accumulation products of the very last sub-block
+template <class TR, int PSLOT, int PSUB>
+__device__ __forceinline__ void dkdv_flush(const FragAddr& fa, DkdvState& a, const typename TR::vec8 (&pf)[2],
+                                           const typename TR::vec8 (&df)[2]) {
+    constexpr int PQ = PSLOT * kDkdvSlot, PD = PQ + 8192;
+    TrPair to[2][2], tq[2][2];
+    to[0][0] = tr_issue_at<PD, 2 * PSUB>(fa, 0);     to[0][1] = tr_issue_at<PD, 2 * PSUB>(fa, 1);
+    to[1][0] = tr_issue_at<PD, 2 * PSUB + 1>(fa, 0); to[1][1] = tr_issue_at<PD, 2 * PSUB + 1>(fa, 1);
+    tq[0][0] = tr_issue_at<PQ, 2 * PSUB>(fa, 0);     tq[0][1] = tr_issue_at<PQ, 2 * PSUB>(fa, 1);
+    tq[1][0] = tr_issue_at<PQ, 2 * PSUB + 1>(fa, 0); tq[1][1] = tr_issue_at<PQ, 2 * PSUB + 1>(fa, 1);
     tr_wait();
-    dv0 = TR::mfma32(tr_vec<TR>(t[0][0]), pf[0], dv0);
-    dv1 = TR::mfma32(tr_vec<TR>(t[0][1]), pf[0], dv1);
-    dv0 = TR::mfma32(tr_vec<TR>(t[1][0]), pf[1], dv0);
-    dv1 = TR::mfma32(tr_vec<TR>(t[1][1]), pf[1], dv1);
-    t[0][0] = tr_issue_at<QT, 2 * SUB>(fa, 0);
-    t[0][1] = tr_issue_at<QT, 2 * SUB>(fa, 1);
-    t[1][0] = tr_issue_at<QT, 2 * SUB + 1>(fa, 0);
-    t[1][1] = tr_issue_at<QT, 2 * SUB + 1>(fa, 1);
-    tr_wait();
-    dk0 = TR::mfma32(tr_vec<TR>(t[0][0]), df[0], dk0);
-    dk1 = TR::mfma32(tr_vec<TR>(t[0][1]), df[0], dk1);
-    dk0 = TR::mfma32(tr_vec<TR>(t[1][0]), df[1], dk0);
-    dk1 = TR::mfma32(tr_vec<TR>(t[1][1]), df[1], dk1);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        a.dv0 = TR::mfma32(tr_vec<TR>(to[g][0]), pf[g], a.dv0);
+        a.dv1 = TR::mfma32(tr_vec<TR>(to[g][1]), pf[g], a.dv1);
+        a.dk0 = TR::mfma32(tr_vec<TR>(tq[g][0]), df[g], a.dk0);
+        a.dk1 = TR::mfma32(tr_vec<TR>(tq[g][1]), df[g], a.dk1);
+    }
 }
 
-// One 64-row query tile.  The two matrix products that consume a sub-block's P / dS are issued one stage later,
-// behind the NEXT sub-block's score products: the matrix pipe then works on them while the vector ALU turns the
-// new scores into P / dS.  Ring protocol: tile t+1 is awaited (and tile t+2 requested, into the slot of tile t-1)
-// in the MIDDLE of tile t, after the last reads of tile t-1.
-struct DkdvState {
-    f32x16 dk0, dk1, dv0, dv1;
-    bool pend;          // sub-block 1 of the previous tile still has to be accumulated (wave-uniform)
-};
+// One 64-row query tile t >= 1 in ring slot SLOT.  Ring protocol: tile t+1 is awaited (and tile t+2 requested, into
+// the slot of tile t-1) in the MIDDLE of tile t, after the last reads of tile t-1 (the transposed fragments read by the
+// first stage of tile t).  Returns false when the tile's second sub-block lies completely past the sequence.
+#ifdef NPCD_EXP_NOBARRIER
+#define NPCD_DKDV_MID() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define NPCD_DKDV_MID() NPCD_DMA_WAIT_BARRIER(0)
+#endif
 template <class TR, int SLOT>
-__device__ __forceinline__ void dkdv_step(unsigned char* smem, const FragAddr& fa, uint32_t st_addr, const QdoStream<typename TR::elem>& qs,
+__device__ __forceinline__ bool dkdv_step(unsigned char* smem, const FragAddr& fa, uint32_t st_addr, const QdoStream<typename TR::elem>& qs,
                                           int t, int nt, int n, int wave, int lane, const typename TR::vec8 (&kf)[4],
                                           const typename TR::vec8 (&vf)[4], float c, DkdvState& a, typename TR::vec8 (&pf)[2],
                                           typename TR::vec8 (&df)[2]) {
     constexpr int PREV = (SLOT + 2) % 3;
-    const int hh = lane >> 5;
-    const bool masked = t * 64 + 64 > n;
-    f32x16 s, d;
-    dkdv_scores<TR, SLOT, 0>(fa, st_addr, kf, vf, s, d);
-    if (a.pend) dkdv_accum<TR, PREV, 1>(fa, pf, df, a.dk0, a.dk1, a.dv0, a.dv1);
-    if (masked) dkdv_softmax<TR, true>(s, d, c, t * 64, n, hh, pf, df);
-    else dkdv_softmax<TR, false>(s, d, c, t * 64, n, hh, pf, df);
-    NPCD_DMA_WAIT_BARRIER(0);                                    // tile t+1 landed; every wave is done with tile t-1
+    NPCD_TS_STEP(22);
+    dkdv_stage<TR, SLOT, 0, PREV, 1, true>(fa, st_addr, kf, vf, c, a, pf, df);
+    NPCD_TS_STEP(25);
+    NPCD_DKDV_MID();                                             // tile t+1 landed; every wave is done with tile t-1
+    NPCD_TS_STEP(26);
     if (t + 2 < nt) qdo_prefetch(smem + PREV * kDkdvSlot, qs, t + 2, n, wave, lane);
-    if (!masked || t * 64 + 32 < n) {
-        dkdv_scores<TR, SLOT, 1>(fa, st_addr, kf, vf, s, d);
-        dkdv_accum<TR, SLOT, 0>(fa, pf, df, a.dk0, a.dk1, a.dv0, a.dv1);
-        if (masked) dkdv_softmax<TR, true>(s, d, c, t * 64 + 32, n, hh, pf, df);
-        else dkdv_softmax<TR, false>(s, d, c, t * 64 + 32, n, hh, pf, df);
-        a.pend = true;
-    } else {
-        dkdv_accum<TR, SLOT, 0>(fa, pf, df, a.dk0, a.dk1, a.dv0, a.dv1);
-        a.pend = false;
-    }
+    NPCD_TS_STEP(27);
+    if (t * 64 + 32 >= n) return false;
+    dkdv_stage<TR, SLOT, 1, SLOT, 0, true>(fa, st_addr, kf, vf, c, a, pf, df);
+    NPCD_TS_STEP(30);
+    return true;
 }
 
 template <class TR>
@@ -722,6 +794,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
     const int key = key0 + r;
     const bool key_ok = key < n;
 
+#ifdef NPCD_TIMELINE
+    const bool tl_on = (blockIdx.x == NPCD_TIMELINE) && wave == 0;
+    long long tl[40];
+    for (int i = 0; i < 40; ++i) tl[i] = 0;
+#endif
+    NPCD_TS(0);
     QdoStream<E> qs;
     {
         const bool second = wave >= 2;
@@ -731,7 +809,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
         qs.base = (second ? dob : qb) + (int64_t)(w2 * 32) * qs.stride;
         qs.dl = dma_lane<E>(qs.stride, lane);
         qs.dst = (second ? 8192 : 0) + w2 * 4096;
-        qs.stat = p.delta + (int64_t)w2 * p.B * p.H * n + (int64_t)(b * p.H + h) * n;
+        const int npad = nt * 64;                    // row constants: planes [2][B][H][npad], pad rows hold -inf / 0
+        qs.stat = p.delta + ((int64_t)w2 * p.B * p.H + (b * p.H + h)) * npad;
         qs.stat_dst = 16384 + w2 * 256;
     }
     qdo_prefetch(dsmem, qs, 0, n, wave, lane);
@@ -756,7 +835,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
     }
     DkdvState a;
     a.dk0 = f32x16{0}; a.dk1 = f32x16{0}; a.dv0 = f32x16{0}; a.dv1 = f32x16{0};
-    a.pend = false;
+#ifdef NPCD_TIMELINE
+    a.tl = tl;
+    a.tl_on = tl_on;
+#endif
     V8 pf[2], df[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -766,19 +848,44 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
     const float c = p.scale_log2;
     const FragAddr fa = frag_addr(dsmem, lane);
     const uint32_t st_addr = lds_addr(dsmem) + hh * 16;
+    NPCD_TS(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // K/V fragments (and tile 0/1) have arrived
+    // make the arrival visible to the compiler's wait-count tracking HERE: otherwise it re-waits with vmcnt(0) at the
+    // fragments' first use inside the loop, which also drains the LDS-DMA prefetch
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(kf[s]), "+v"(vf[s]));
+    NPCD_TS(2);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    for (int t = 0; t < nt; t += 3) {
-        dkdv_step<TR, 0>(dsmem, fa, st_addr, qs, t, nt, n, wave, lane, kf, vf, c, a, pf, df);
-        if (t + 1 < nt) dkdv_step<TR, 1>(dsmem, fa, st_addr, qs, t + 1, nt, n, wave, lane, kf, vf, c, a, pf, df);
-        if (t + 2 < nt) dkdv_step<TR, 2>(dsmem, fa, st_addr, qs, t + 2, nt, n, wave, lane, kf, vf, c, a, pf, df);
+    NPCD_TS(3);
+    // tile 0 (slot 0) is peeled: its first stage has no predecessor to accumulate
+    bool both = true;      // the last tile ended with its second sub-block
+    {
+        const int t = 0;
+        dkdv_stage<TR, 0, 0, 2, 1, false>(fa, st_addr, kf, vf, c, a, pf, df);
+        NPCD_DKDV_MID();
+        if (2 < nt) qdo_prefetch(dsmem + 2 * kDkdvSlot, qs, 2, n, wave, lane);
+        if (32 < n) dkdv_stage<TR, 0, 1, 0, 0, true>(fa, st_addr, kf, vf, c, a, pf, df);
+        else both = false;
+        (void)t;
     }
-    if (a.pend) {
+    for (int t = 1; t < nt; t += 3) {
+        both = dkdv_step<TR, 1>(dsmem, fa, st_addr, qs, t, nt, n, wave, lane, kf, vf, c, a, pf, df);
+        if (t + 1 < nt) both = dkdv_step<TR, 2>(dsmem, fa, st_addr, qs, t + 1, nt, n, wave, lane, kf, vf, c, a, pf, df);
+        if (t + 2 < nt) both = dkdv_step<TR, 0>(dsmem, fa, st_addr, qs, t + 2, nt, n, wave, lane, kf, vf, c, a, pf, df);
+    }
+    NPCD_TS(20);
+    {
         const int last = (nt - 1) % 3;
-        if (last == 0) dkdv_accum<TR, 0, 1>(fa, pf, df, a.dk0, a.dk1, a.dv0, a.dv1);
-        else if (last == 1) dkdv_accum<TR, 1, 1>(fa, pf, df, a.dk0, a.dk1, a.dv0, a.dv1);
-        else dkdv_accum<TR, 2, 1>(fa, pf, df, a.dk0, a.dk1, a.dv0, a.dv1);
+        if (both) {
+            if (last == 0) dkdv_flush<TR, 0, 1>(fa, a, pf, df);
+            else if (last == 1) dkdv_flush<TR, 1, 1>(fa, a, pf, df);
+            else dkdv_flush<TR, 2, 1>(fa, a, pf, df);
+        } else {
+            if (last == 0) dkdv_flush<TR, 0, 0>(fa, a, pf, df);
+            else if (last == 1) dkdv_flush<TR, 1, 0>(fa, a, pf, df);
+            else dkdv_flush<TR, 2, 0>(fa, a, pf, df);
+        }
     }
     if (key_ok) {
         E* gk = static_cast<E*>(p.dk) + b * p.gsb + key * p.gsn + h * p.gsh;
@@ -786,6 +893,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
         store_rows<TR>(gk, a.dk0, a.dk1, p.scale, hh);
         store_rows<TR>(gv, a.dv0, a.dv1, 1.f, hh);
     }
+#ifdef NPCD_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NPCD_TS(21);
+    if (tl_on && lane == 0)
+        for (int i = 0; i < 40; ++i) g_timeline[i] = tl[i];
+#endif
 }
 
 // ============================================================================================
@@ -886,6 +999,12 @@ static bool strides_ok(int64_t sb, int64_t sn, int64_t sh) { return (sb % 8 == 0
 
 using namespace npcd;
 
+#ifdef NPCD_TIMELINE
+extern "C" int npcd_debug_read(long long* out, int count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(npcd::g_timeline), sizeof(long long) * count);
+}
+#endif
+
 extern "C" int npcd_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int n, int H, int d,
                              int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
                              float scale, int dtype, void* stream) {
@@ -941,7 +1060,11 @@ static int attn_bwd_launch(int passes, const void* q, const void* k, const void*
     p.scale = scale; p.scale_log2 = scale * kLog2e;
     const int grid = B * H * ceil_div(n, 128);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    #ifdef NPCD_EXP_LDS
+    const int dyn = NPCD_EXP_LDS;
+#else
     const int dyn = 3 * kDkdvSlot;
+#endif
     static bool attr_set = false;
     if (!attr_set) {
         NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<BF16>),

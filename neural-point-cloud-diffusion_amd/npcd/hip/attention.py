@@ -40,7 +40,7 @@ def _timed(tag, fn):
 
 def _bwd(q, k, v, out, dout, lse, dq, dk, dv, scale):
     B, n, H, d = q.shape
-    delta = torch.empty((2, B, H, n), dtype=torch.float32, device=q.device)   # row constants handed from pass 1 to pass 2
+    delta = torch.empty((2, B, H, (n + 63) // 64 * 64), dtype=torch.float32, device=q.device)   # row constants handed from pass 1 to pass 2
     assert dq.stride() == dk.stride() == dv.stride() and dout.stride() == out.stride()
     args = (ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(dq), ptr(dk), ptr(dv),
             ptr(delta), B, n, H, d, q.stride(0), q.stride(1), q.stride(2),
