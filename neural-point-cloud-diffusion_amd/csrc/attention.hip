@@ -272,6 +272,42 @@ __device__ __forceinline__ void store_rows(typename TR::elem* row_ptr, const f32
     }
 }
 
+// two fp32 -> one packed 16-bit pair (v_cvt_pk_*)
+template <class TR>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    typedef typename TR::elem E2 __attribute__((ext_vector_type(2)));
+    typedef float F2 __attribute__((ext_vector_type(2)));
+    const F2 f = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, E2));     // one vector conversion -> one v_cvt_pk
+}
+
+// Same result as store_rows, but through a wave-private 4 KiB LDS stage so that every global store instruction
+// writes 8 complete 128-byte rows (16 B per lane) instead of 8-byte pieces of 32 different rows: 4 store
+// instructions per matrix instead of 8, and whole cache lines (cdna_hip_programming.md, attention forward: 'O staged
+// through LDS and stored as whole rows').  `stage` must not be in use by any other wave; rows >= rows_valid are
+// not written.  The 16-byte chunk index is XOR-ed with the row so that the 8-byte writes spread over the banks.
+template <class TR>
+__device__ __forceinline__ void store_rows_staged(unsigned char* stage, typename TR::elem* row0_ptr, int64_t row_stride, int rows_valid,
+                                                  const f32x16& a0, const f32x16& a1, float mul, int lane) {
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        u32x2 x, y;
+        x[0] = pack2<TR>(a0[4 * g] * mul, a0[4 * g + 1] * mul);
+        x[1] = pack2<TR>(a0[4 * g + 2] * mul, a0[4 * g + 3] * mul);
+        y[0] = pack2<TR>(a1[4 * g] * mul, a1[4 * g + 1] * mul);
+        y[1] = pack2<TR>(a1[4 * g + 2] * mul, a1[4 * g + 3] * mul);
+        *reinterpret_cast<u32x2*>(stage + r * 128 + (((g) ^ (r & 7)) << 4) + hh * 8) = x;        // elements 8g + 4hh ..
+        *reinterpret_cast<u32x2*>(stage + r * 128 + (((4 + g) ^ (r & 7)) << 4) + hh * 8) = y;    // elements 32 + 8g + 4hh ..
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = i * 8 + (lane >> 3);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
+        if (row < rows_valid) *reinterpret_cast<u32x4*>(row0_ptr + row * row_stride + (lane & 7) * 8) = v;
+    }
+}
+
 // ============================================================================================
 // forward
 // ============================================================================================
@@ -445,63 +481,77 @@ __global__ __launch_bounds__(256, NPCD_FWD_WAVES) void attn_fwd_kernel(AttnParam
         if (t + 2 < nt) fwd_step<TR, 2>(smem, fa, dl, kb, vb, p.sn, t + 2, nt, n, wave, lane, qf, o0, o1, m, l, c);
     }
     l = half_sum(l);
-    if (qrow < n) {
-        E* orow = static_cast<E*>(p.o_w) + b * p.osb + qrow * p.osn + h * p.osh;
-        store_rows<TR>(orow, o0, o1, 1.f / l, hh);
-        if (hh == 0) p.lse[(int64_t)(b * p.H + h) * n + qrow] = m * kLn2 + logf(l);
-    }
+    // every wave has left the ring (last barrier of the loop): 4 KiB of it per wave stage the output rows
+    E* orow0 = static_cast<E*>(p.o_w) + b * p.osb + (int64_t)q0 * p.osn + h * p.osh;
+    store_rows_staged<TR>(smem + wave * 4096, orow0, p.osn, n - q0, o0, o1, 1.f / l, lane);
+    if (qrow < n && hh == 0) p.lse[(int64_t)(b * p.H + h) * n + qrow] = m * kLn2 + logf(l);
 }
 
 // ============================================================================================
 // backward, pass 1: dQ (+ delta)
 // ============================================================================================
-// one 32-key half tile of the dQ pass
-template <class TR, bool MASK>
-__device__ __forceinline__ void dq_half(const unsigned char* Kc, const unsigned char* Vc, int kb, const typename TR::vec8 (&qf)[4],
-                                        const typename TR::vec8 (&dof)[4], f32x16& dq0, f32x16& dq1, float c, float lse2, float delta,
-                                        int key0, int n, int r, int hh) {
-    using E = typename TR::elem;
+// one 32-key half tile (ring slot SLOT, half KB) of the dQ pass
+template <class TR, bool MASK, int SLOT, int KB>
+__device__ __forceinline__ void dq_half(const FragAddr& fa, const typename TR::vec8 (&qf)[4], const typename TR::vec8 (&dof)[4],
+                                        f32x16& dq0, f32x16& dq1, float c, float lse2, float delta, int key0, int n, int hh) {
     using V8 = typename TR::vec8;
+    constexpr int KT = SLOT * 16384 + KB * 4096, VT = KT + 8192, KTR = SLOT * 16384;
     f32x16 s0 = {0}, d0 = {0};
 #pragma unroll
-    for (int s = 0; s < 4; ++s) s0 = TR::mfma32(lds_frag<TR>(Kc, kb * 32 + r, 2 * s + hh), qf[s], s0);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) d0 = TR::mfma32(lds_frag<TR>(Vc, kb * 32 + r, 2 * s + hh), dof[s], d0);
+    for (int s = 0; s < 4; ++s) {
+        s0 = TR::mfma32(lds_frag_at<TR, KT>(fa.row[s]), qf[s], s0);
+        d0 = TR::mfma32(lds_frag_at<TR, VT>(fa.row[s]), dof[s], d0);
+    }
     TrPair kt[2][2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        kt[g][0] = tr_issue(Kc, kb * 2 + g, 0, (hh << 5) | r);
-        kt[g][1] = tr_issue(Kc, kb * 2 + g, 1, (hh << 5) | r);
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[i], c, -lse2));
-        if (MASK) {
-            if (key0 + kb * 32 + acc_row(i, hh) >= n) p0 = 0.f;
-        }
-        s0[i] = p0 * (d0[i] - delta);
-    }
-    V8 df[2];
+    kt[0][0] = tr_issue_at<KTR, KB * 2>(fa, 0);
+    kt[0][1] = tr_issue_at<KTR, KB * 2>(fa, 1);
+    kt[1][0] = tr_issue_at<KTR, KB * 2 + 1>(fa, 0);
+    kt[1][1] = tr_issue_at<KTR, KB * 2 + 1>(fa, 1);
+    u32x4 dw[2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        df[0][j] = (E)s0[j];
-        df[1][j] = (E)s0[8 + j];
+        float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[2 * j], c, -lse2)), p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[2 * j + 1], c, -lse2));
+        if (MASK) {
+            if (key0 + KB * 32 + acc_row(2 * j, hh) >= n) p0 = 0.f;
+            if (key0 + KB * 32 + acc_row(2 * j + 1, hh) >= n) p1 = 0.f;
+        }
+        dw[j >> 2][j & 3] = pack2<TR>(p0 * (d0[2 * j] - delta), p1 * (d0[2 * j + 1] - delta));
     }
     tr_wait();
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        dq0 = TR::mfma32(tr_vec<TR>(kt[g][0]), df[g], dq0);
-        dq1 = TR::mfma32(tr_vec<TR>(kt[g][1]), df[g], dq1);
-    }
+    dq0 = TR::mfma32(tr_vec<TR>(kt[0][0]), __builtin_bit_cast(V8, dw[0]), dq0);
+    dq1 = TR::mfma32(tr_vec<TR>(kt[0][1]), __builtin_bit_cast(V8, dw[0]), dq1);
+    dq0 = TR::mfma32(tr_vec<TR>(kt[1][0]), __builtin_bit_cast(V8, dw[1]), dq0);
+    dq1 = TR::mfma32(tr_vec<TR>(kt[1][1]), __builtin_bit_cast(V8, dw[1]), dq1);
 }
 
+template <class TR, int SLOT>
+__device__ __forceinline__ void dq_step(unsigned char* smem, const FragAddr& fa, const DmaLane& dl, const typename TR::elem* kb,
+                                        const typename TR::elem* vb, int64_t sn, int t, int nt, int n, int wave, int lane,
+                                        const typename TR::vec8 (&qf)[4], const typename TR::vec8 (&dof)[4], f32x16& dq0, f32x16& dq1,
+                                        float c, float lse2, float delta) {
+    kv_prefetch<typename TR::elem, SLOT>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
+    if (t * 64 + 64 <= n) {
+        dq_half<TR, false, SLOT, 0>(fa, qf, dof, dq0, dq1, c, lse2, delta, t * 64, n, lane >> 5);
+        dq_half<TR, false, SLOT, 1>(fa, qf, dof, dq0, dq1, c, lse2, delta, t * 64, n, lane >> 5);
+    } else {
+        dq_half<TR, true, SLOT, 0>(fa, qf, dof, dq0, dq1, c, lse2, delta, t * 64, n, lane >> 5);
+        if (t * 64 + 32 < n) dq_half<TR, true, SLOT, 1>(fa, qf, dof, dq0, dq1, c, lse2, delta, t * 64, n, lane >> 5);
+    }
+    NPCD_KV_ADVANCE(t, nt);
+}
+
+#ifndef NPCD_DQ_WAVES
+#define NPCD_DQ_WAVES 2
+#endif
 template <class TR>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, NPCD_DQ_WAVES) void attn_bwd_dq_kernel(AttnParams p) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 16384];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-    const int nqt = (p.n + 127) >> 7;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = p.n, nt = (n + 63) >> 6;
+    const int nqt = (n + 127) >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = bid % nqt, bh = bid / nqt, h = bh % p.H, b = bh / p.H;
     const E* qb = static_cast<const E*>(p.q) + b * p.sb + h * p.sh;
@@ -510,19 +560,19 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
     const E* ob = static_cast<const E*>(p.out) + b * p.osb + h * p.osh;
     const E* dob = static_cast<const E*>(p.dout) + b * p.osb + h * p.osh;
     const int q0 = qt * 128 + wave * 32;
-    const bool wave_active = q0 < p.n;
+    const bool wave_active = q0 < n;
     const int qrow = q0 + r;
-    const bool row_ok = qrow < p.n;
-    const int nt = (p.n + 63) >> 6;
+    const bool row_ok = qrow < n;
     const float c = p.scale_log2;
+    const DmaLane dl = dma_lane<E>(p.sn, lane);
 
     // start the K/V stream first, then fetch the per-row operands while it is in flight
-    dma_tile_pair(smem, kb, p.sn, vb, p.sn, 0, p.n, wave, lane);
-    dma_tile_pair(smem + 16384, kb, p.sn, vb, p.sn, 64, p.n, wave, lane);
+    dma_tile_pair(smem, kb, p.sn, vb, p.sn, 0, n, wave, lane);
+    if (nt > 1) dma_tile_pair(smem + 16384, kb, p.sn, vb, p.sn, 64, n, wave, lane);
 
     V8 qf[4], dof[4];
     float delta = 0.f;
-    const int qclamp = min(qrow, p.n - 1);
+    const int qclamp = min(qrow, n - 1);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         qf[s] = *reinterpret_cast<const V8*>(qb + (int64_t)qclamp * p.sn + 16 * s + 8 * hh);
@@ -532,10 +582,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
         for (int j = 0; j < 8; ++j) delta += (float)dof[s][j] * (float)of[j];
     }
     delta = half_sum(delta);
-    const float lse_row = p.lse[(int64_t)(b * p.H + h) * p.n + qclamp];   // rows past the end duplicate the last row; never stored
+    const float lse_row = p.lse[(int64_t)(b * p.H + h) * n + qclamp];   // rows past the end duplicate the last row; never stored
     {   // row constants of the dK/dV pass (its initial accumulators), planes [2][B][H][npad]; the pad rows of the last
         // 64-row tile get -inf / 0 so that their P and dS vanish there without masking
-        const int npad = ((p.n + 63) >> 6) << 6;
+        const int npad = nt << 6;
         if (hh == 0 && qrow < npad) {
             const int64_t at = (int64_t)(b * p.H + h) * npad + qrow;
             p.delta[at] = row_ok ? -lse_row / p.scale : -INFINITY;
@@ -544,25 +594,21 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(AttnParams p) {
     }
     const float lse2 = lse_row * kLog2e;
     f32x16 dq0 = {0}, dq1 = {0};
-    NPCD_DMA_WAIT_BARRIER(4);
-    for (int t = 0; t < nt; ++t) {
-        dma_tile_pair(smem + ((t + 2) % 3) * 16384, kb, p.sn, vb, p.sn, (t + 2) * 64, p.n, wave, lane);
-        const unsigned char* Kc = smem + (t % 3) * 16384;
-        if (wave_active) {
-            if (t * 64 + 64 > p.n) {
-                dq_half<TR, true>(Kc, Kc + 8192, 0, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
-                dq_half<TR, true>(Kc, Kc + 8192, 1, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
-            } else {
-                dq_half<TR, false>(Kc, Kc + 8192, 0, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
-                dq_half<TR, false>(Kc, Kc + 8192, 1, qf, dof, dq0, dq1, c, lse2, delta, t * 64, p.n, r, hh);
-            }
-        }
-        NPCD_DMA_WAIT_BARRIER(4);
+    if (nt > 1) NPCD_DMA_WAIT_BARRIER(4);
+    else NPCD_DMA_WAIT_BARRIER(0);
+    if (!wave_active) {                                          // wave-uniform
+        kv_idle_loop<E>(smem, kb, vb, p.sn, nt, n, wave, lane, dl);
+        return;
     }
-    if (row_ok) {
-        E* grow = static_cast<E*>(p.dq) + b * p.gsb + qrow * p.gsn + h * p.gsh;
-        store_rows<TR>(grow, dq0, dq1, p.scale, hh);
+    const FragAddr fa = frag_addr(smem, lane);
+    for (int t = 0; t < nt; t += 3) {
+        dq_step<TR, 0>(smem, fa, dl, kb, vb, p.sn, t, nt, n, wave, lane, qf, dof, dq0, dq1, c, lse2, delta);
+        if (t + 1 < nt) dq_step<TR, 1>(smem, fa, dl, kb, vb, p.sn, t + 1, nt, n, wave, lane, qf, dof, dq0, dq1, c, lse2, delta);
+        if (t + 2 < nt) dq_step<TR, 2>(smem, fa, dl, kb, vb, p.sn, t + 2, nt, n, wave, lane, qf, dof, dq0, dq1, c, lse2, delta);
     }
+    // every wave has left the ring (last barrier of the loop): 4 KiB of it per wave stage the gradient rows
+    E* grow0 = static_cast<E*>(p.dq) + b * p.gsb + (int64_t)q0 * p.gsn + h * p.gsh;
+    store_rows_staged<TR>(smem + wave * 4096, grow0, p.gsn, n - q0, dq0, dq1, p.scale, lane);
 }
 
 // ============================================================================================
@@ -607,14 +653,6 @@ __device__ __forceinline__ void qdo_prefetch(unsigned char* slot, const QdoStrea
     dma4_issue(qs.stat, (uint32_t)(row0 + lane) * 4u, __builtin_amdgcn_readfirstlane(sl + qs.stat_dst));
 }
 
-// two fp32 -> one packed 16-bit pair (v_cvt_pk_*)
-template <class TR>
-__device__ __forceinline__ uint32_t pack2(float a, float b) {
-    typedef typename TR::elem E2 __attribute__((ext_vector_type(2)));
-    typedef float F2 __attribute__((ext_vector_type(2)));
-    const F2 f = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, E2));     // one vector conversion -> one v_cvt_pk
-}
 
 struct DkdvState {
     f32x16 dk0, dk1, dv0, dv1;
@@ -887,11 +925,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
             else dkdv_flush<TR, 2, 0>(fa, a, pf, df);
         }
     }
-    if (key_ok) {
-        E* gk = static_cast<E*>(p.dk) + b * p.gsb + key * p.gsn + h * p.gsh;
-        E* gv = static_cast<E*>(p.dv) + b * p.gsb + key * p.gsn + h * p.gsh;
-        store_rows<TR>(gk, a.dk0, a.dk1, p.scale, hh);
-        store_rows<TR>(gv, a.dv0, a.dv1, 1.f, hh);
+    {   // the slot after the last tile's was released at the last mid-tile barrier: 4 KiB of it per wave stage the rows
+        unsigned char* stage = dsmem + (nt % 3) * kDkdvSlot + wave * 4096;
+        E* gk = static_cast<E*>(p.dk) + b * p.gsb + (int64_t)key0 * p.gsn + h * p.gsh;
+        E* gv = static_cast<E*>(p.dv) + b * p.gsb + (int64_t)key0 * p.gsn + h * p.gsh;
+        store_rows_staged<TR>(stage, gk, p.gsn, n - key0, a.dk0, a.dk1, p.scale, lane);
+        store_rows_staged<TR>(stage, gv, p.gsn, n - key0, a.dv0, a.dv1, 1.f, lane);
     }
 #ifdef NPCD_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
