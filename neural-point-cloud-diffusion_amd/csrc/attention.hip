@@ -490,10 +490,94 @@ __global__ __launch_bounds__(256, NPCD_FWD_WAVES) void attn_fwd_kernel(AttnParam
 // ============================================================================================
 // backward, pass 1: dQ (+ delta)
 // ============================================================================================
-// one 32-key half tile (ring slot SLOT, half KB) of the dQ pass
-template <class TR, bool MASK, int SLOT, int KB>
-__device__ __forceinline__ void dq_half(const FragAddr& fa, const typename TR::vec8 (&qf)[4], const typename TR::vec8 (&dof)[4],
-                                        f32x16& dq0, f32x16& dq1, float c, float lse2, float delta, int key0, int n, int hh) {
+// One pipelined stage of the dQ pass over FULL key tiles (no masking): the score products of half (SLOT, KB), then --
+// behind them on the matrix pipe -- dQ^T += K^T dS^T of the PREVIOUS half (PSLOT, PKB, its dS in `dw`), while the
+// vector ALU turns the new scores into the next dS.
+template <class TR, int SLOT, int KB, int PSLOT, int PKB, bool ACC>
+__device__ __forceinline__ void dq_stage(const FragAddr& fa, const typename TR::vec8 (&qf)[4], const typename TR::vec8 (&dof)[4],
+                                         f32x16& dq0, f32x16& dq1, float c, float lse2, float delta, u32x4 (&dw)[2]) {
+    using V8 = typename TR::vec8;
+    constexpr int KT = SLOT * 16384 + KB * 4096, VT = KT + 8192, PK = PSLOT * 16384;
+    u32x4 kr[4], vr[4];
+    kr[0] = lds_b128_issue<KT>(fa.row[0]); vr[0] = lds_b128_issue<VT>(fa.row[0]);
+    kr[1] = lds_b128_issue<KT>(fa.row[1]); vr[1] = lds_b128_issue<VT>(fa.row[1]);
+    kr[2] = lds_b128_issue<KT>(fa.row[2]); vr[2] = lds_b128_issue<VT>(fa.row[2]);
+    kr[3] = lds_b128_issue<KT>(fa.row[3]); vr[3] = lds_b128_issue<VT>(fa.row[3]);
+    tr_wait();
+    f32x16 s0 = {0}, d0 = {0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        s0 = TR::mfma32(__builtin_bit_cast(V8, kr[s]), qf[s], s0);
+        d0 = TR::mfma32(__builtin_bit_cast(V8, vr[s]), dof[s], d0);
+    }
+    TrPair kt[2][2];
+    if (ACC) {
+        __builtin_amdgcn_sched_barrier(0);
+        kt[0][0] = tr_issue_at<PK, PKB * 2>(fa, 0);     kt[0][1] = tr_issue_at<PK, PKB * 2>(fa, 1);
+        kt[1][0] = tr_issue_at<PK, PKB * 2 + 1>(fa, 0); kt[1][1] = tr_issue_at<PK, PKB * 2 + 1>(fa, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int s = 2; s < 4; ++s) {
+        s0 = TR::mfma32(__builtin_bit_cast(V8, kr[s]), qf[s], s0);
+        d0 = TR::mfma32(__builtin_bit_cast(V8, vr[s]), dof[s], d0);
+    }
+    if (ACC) {
+        tr_wait();
+        dq0 = TR::mfma32(tr_vec<TR>(kt[0][0]), __builtin_bit_cast(V8, dw[0]), dq0);
+        dq1 = TR::mfma32(tr_vec<TR>(kt[0][1]), __builtin_bit_cast(V8, dw[0]), dq1);
+        dq0 = TR::mfma32(tr_vec<TR>(kt[1][0]), __builtin_bit_cast(V8, dw[1]), dq0);
+        dq1 = TR::mfma32(tr_vec<TR>(kt[1][1]), __builtin_bit_cast(V8, dw[1]), dq1);
+    }
+    u32x4 nw[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[2 * j], c, -lse2)), p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[2 * j + 1], c, -lse2));
+        nw[j >> 2][j & 3] = pack2<TR>(p0 * (d0[2 * j] - delta), p1 * (d0[2 * j + 1] - delta));
+    }
+    dw[0] = nw[0];
+    dw[1] = nw[1];
+}
+template <class TR, int PSLOT, int PKB>
+__device__ __forceinline__ void dq_flush(const FragAddr& fa, f32x16& dq0, f32x16& dq1, const u32x4 (&dw)[2]) {
+    using V8 = typename TR::vec8;
+    constexpr int PK = PSLOT * 16384;
+    TrPair kt[2][2];
+    kt[0][0] = tr_issue_at<PK, PKB * 2>(fa, 0);     kt[0][1] = tr_issue_at<PK, PKB * 2>(fa, 1);
+    kt[1][0] = tr_issue_at<PK, PKB * 2 + 1>(fa, 0); kt[1][1] = tr_issue_at<PK, PKB * 2 + 1>(fa, 1);
+    tr_wait();
+    dq0 = TR::mfma32(tr_vec<TR>(kt[0][0]), __builtin_bit_cast(V8, dw[0]), dq0);
+    dq1 = TR::mfma32(tr_vec<TR>(kt[0][1]), __builtin_bit_cast(V8, dw[0]), dq1);
+    dq0 = TR::mfma32(tr_vec<TR>(kt[1][0]), __builtin_bit_cast(V8, dw[1]), dq0);
+    dq1 = TR::mfma32(tr_vec<TR>(kt[1][1]), __builtin_bit_cast(V8, dw[1]), dq1);
+}
+
+// K/V ring of the pipelined dQ pass (same protocol as the dK/dV pass): tile t+1 is awaited and tile t+2 requested (into
+// the slot of tile t-1) in the MIDDLE of tile t, after the first stage of tile t has read the last fragments of tile t-1.
+template <class E, int SLOT>
+__device__ __forceinline__ void dq_mid(unsigned char* smem, const E* kb, const E* vb, int64_t sn, int t, int nt, int n, int wave, int lane,
+                                       const DmaLane& dl) {
+    NPCD_DMA_WAIT_BARRIER(0);
+    if (t + 2 < nt) {
+        if ((t + 3) * 64 <= n) dma_tile_pair_fast<E, (SLOT + 2) % 3>(smem, kb, vb, sn, (t + 2) * 64, wave, dl);
+        else dma_tile_pair(smem + ((SLOT + 2) % 3) * 16384, kb, sn, vb, sn, (t + 2) * 64, n, wave, lane);
+    }
+}
+template <class TR, int SLOT>
+__device__ __forceinline__ void dq_step(unsigned char* smem, const FragAddr& fa, const DmaLane& dl, const typename TR::elem* kb,
+                                        const typename TR::elem* vb, int64_t sn, int t, int nt, int n, int wave, int lane,
+                                        const typename TR::vec8 (&qf)[4], const typename TR::vec8 (&dof)[4], f32x16& dq0, f32x16& dq1,
+                                        float c, float lse2, float delta, u32x4 (&dw)[2]) {
+    constexpr int PREV = (SLOT + 2) % 3;
+    dq_stage<TR, SLOT, 0, PREV, 1, true>(fa, qf, dof, dq0, dq1, c, lse2, delta, dw);
+    dq_mid<typename TR::elem, SLOT>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
+    dq_stage<TR, SLOT, 1, SLOT, 0, true>(fa, qf, dof, dq0, dq1, c, lse2, delta, dw);
+}
+
+// the ragged last key tile (fewer than 64 keys): simple, masked, not pipelined
+template <class TR, int SLOT, int KB>
+__device__ __forceinline__ void dq_tail_half(const FragAddr& fa, const typename TR::vec8 (&qf)[4], const typename TR::vec8 (&dof)[4],
+                                             f32x16& dq0, f32x16& dq1, float c, float lse2, float delta, int key0, int n, int hh) {
     using V8 = typename TR::vec8;
     constexpr int KT = SLOT * 16384 + KB * 4096, VT = KT + 8192, KTR = SLOT * 16384;
     f32x16 s0 = {0}, d0 = {0};
@@ -503,18 +587,14 @@ __device__ __forceinline__ void dq_half(const FragAddr& fa, const typename TR::v
         d0 = TR::mfma32(lds_frag_at<TR, VT>(fa.row[s]), dof[s], d0);
     }
     TrPair kt[2][2];
-    kt[0][0] = tr_issue_at<KTR, KB * 2>(fa, 0);
-    kt[0][1] = tr_issue_at<KTR, KB * 2>(fa, 1);
-    kt[1][0] = tr_issue_at<KTR, KB * 2 + 1>(fa, 0);
-    kt[1][1] = tr_issue_at<KTR, KB * 2 + 1>(fa, 1);
+    kt[0][0] = tr_issue_at<KTR, KB * 2>(fa, 0);     kt[0][1] = tr_issue_at<KTR, KB * 2>(fa, 1);
+    kt[1][0] = tr_issue_at<KTR, KB * 2 + 1>(fa, 0); kt[1][1] = tr_issue_at<KTR, KB * 2 + 1>(fa, 1);
     u32x4 dw[2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[2 * j], c, -lse2)), p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[2 * j + 1], c, -lse2));
-        if (MASK) {
-            if (key0 + KB * 32 + acc_row(2 * j, hh) >= n) p0 = 0.f;
-            if (key0 + KB * 32 + acc_row(2 * j + 1, hh) >= n) p1 = 0.f;
-        }
+        if (key0 + KB * 32 + acc_row(2 * j, hh) >= n) p0 = 0.f;
+        if (key0 + KB * 32 + acc_row(2 * j + 1, hh) >= n) p1 = 0.f;
         dw[j >> 2][j & 3] = pack2<TR>(p0 * (d0[2 * j] - delta), p1 * (d0[2 * j + 1] - delta));
     }
     tr_wait();
@@ -523,21 +603,11 @@ __device__ __forceinline__ void dq_half(const FragAddr& fa, const typename TR::v
     dq0 = TR::mfma32(tr_vec<TR>(kt[1][0]), __builtin_bit_cast(V8, dw[1]), dq0);
     dq1 = TR::mfma32(tr_vec<TR>(kt[1][1]), __builtin_bit_cast(V8, dw[1]), dq1);
 }
-
 template <class TR, int SLOT>
-__device__ __forceinline__ void dq_step(unsigned char* smem, const FragAddr& fa, const DmaLane& dl, const typename TR::elem* kb,
-                                        const typename TR::elem* vb, int64_t sn, int t, int nt, int n, int wave, int lane,
-                                        const typename TR::vec8 (&qf)[4], const typename TR::vec8 (&dof)[4], f32x16& dq0, f32x16& dq1,
-                                        float c, float lse2, float delta) {
-    kv_prefetch<typename TR::elem, SLOT>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
-    if (t * 64 + 64 <= n) {
-        dq_half<TR, false, SLOT, 0>(fa, qf, dof, dq0, dq1, c, lse2, delta, t * 64, n, lane >> 5);
-        dq_half<TR, false, SLOT, 1>(fa, qf, dof, dq0, dq1, c, lse2, delta, t * 64, n, lane >> 5);
-    } else {
-        dq_half<TR, true, SLOT, 0>(fa, qf, dof, dq0, dq1, c, lse2, delta, t * 64, n, lane >> 5);
-        if (t * 64 + 32 < n) dq_half<TR, true, SLOT, 1>(fa, qf, dof, dq0, dq1, c, lse2, delta, t * 64, n, lane >> 5);
-    }
-    NPCD_KV_ADVANCE(t, nt);
+__device__ __forceinline__ void dq_tail(const FragAddr& fa, const typename TR::vec8 (&qf)[4], const typename TR::vec8 (&dof)[4], f32x16& dq0,
+                                        f32x16& dq1, float c, float lse2, float delta, int key0, int n, int hh) {
+    dq_tail_half<TR, SLOT, 0>(fa, qf, dof, dq0, dq1, c, lse2, delta, key0, n, hh);
+    if (key0 + 32 < n) dq_tail_half<TR, SLOT, 1>(fa, qf, dof, dq0, dq1, c, lse2, delta, key0, n, hh);
 }
 
 #ifndef NPCD_DQ_WAVES
@@ -550,7 +620,7 @@ __global__ __launch_bounds__(256, NPCD_DQ_WAVES) void attn_bwd_dq_kernel(AttnPar
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 16384];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = p.n, nt = (n + 63) >> 6;
+    const int n = p.n, nt = (n + 63) >> 6, nfull = n >> 6;
     const int nqt = (n + 127) >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = bid % nqt, bh = bid / nqt, h = bh % p.H, b = bh / p.H;
@@ -594,19 +664,48 @@ __global__ __launch_bounds__(256, NPCD_DQ_WAVES) void attn_bwd_dq_kernel(AttnPar
     }
     const float lse2 = lse_row * kLog2e;
     f32x16 dq0 = {0}, dq1 = {0};
-    if (nt > 1) NPCD_DMA_WAIT_BARRIER(4);
-    else NPCD_DMA_WAIT_BARRIER(0);
-    if (!wave_active) {                                          // wave-uniform
-        kv_idle_loop<E>(smem, kb, vb, p.sn, nt, n, wave, lane, dl);
+    // the row operands have arrived: tell the compiler's wait-count tracking here, not inside the loop
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]), "+v"(dof[s]));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (!wave_active) {      // wave-uniform: no query rows (ragged last query tile): keep the stream and the barriers going
+        for (int t = 0; t < nfull; ++t) {
+            if (t % 3 == 0) dq_mid<E, 0>(smem, kb, vb, p.sn, t, nt, n, wave, lane, dl);
+            else if (t % 3 == 1) dq_mid<E, 1>(smem, kb, vb, p.sn, t, nt, n, wave, lane, dl);
+            else dq_mid<E, 2>(smem, kb, vb, p.sn, t, nt, n, wave, lane, dl);
+        }
+        if (nfull == 0) NPCD_DMA_WAIT_BARRIER(0);
+        __builtin_amdgcn_s_barrier();
         return;
     }
     const FragAddr fa = frag_addr(smem, lane);
-    for (int t = 0; t < nt; t += 3) {
-        dq_step<TR, 0>(smem, fa, dl, kb, vb, p.sn, t, nt, n, wave, lane, qf, dof, dq0, dq1, c, lse2, delta);
-        if (t + 1 < nt) dq_step<TR, 1>(smem, fa, dl, kb, vb, p.sn, t + 1, nt, n, wave, lane, qf, dof, dq0, dq1, c, lse2, delta);
-        if (t + 2 < nt) dq_step<TR, 2>(smem, fa, dl, kb, vb, p.sn, t + 2, nt, n, wave, lane, qf, dof, dq0, dq1, c, lse2, delta);
+    u32x4 dw[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+    if (nfull > 0) {
+        // tile 0 (slot 0) is peeled: its first stage has no predecessor
+        dq_stage<TR, 0, 0, 2, 1, false>(fa, qf, dof, dq0, dq1, c, lse2, delta, dw);
+        dq_mid<E, 0>(smem, kb, vb, p.sn, 0, nt, n, wave, lane, dl);
+        dq_stage<TR, 0, 1, 0, 0, true>(fa, qf, dof, dq0, dq1, c, lse2, delta, dw);
+        for (int t = 1; t < nfull; t += 3) {
+            dq_step<TR, 1>(smem, fa, dl, kb, vb, p.sn, t, nt, n, wave, lane, qf, dof, dq0, dq1, c, lse2, delta, dw);
+            if (t + 1 < nfull) dq_step<TR, 2>(smem, fa, dl, kb, vb, p.sn, t + 1, nt, n, wave, lane, qf, dof, dq0, dq1, c, lse2, delta, dw);
+            if (t + 2 < nfull) dq_step<TR, 0>(smem, fa, dl, kb, vb, p.sn, t + 2, nt, n, wave, lane, qf, dof, dq0, dq1, c, lse2, delta, dw);
+        }
+        const int last = (nfull - 1) % 3;
+        if (last == 0) dq_flush<TR, 0, 1>(fa, dq0, dq1, dw);
+        else if (last == 1) dq_flush<TR, 1, 1>(fa, dq0, dq1, dw);
+        else dq_flush<TR, 2, 1>(fa, dq0, dq1, dw);
+    } else {
+        NPCD_DMA_WAIT_BARRIER(0);
     }
-    // every wave has left the ring (last barrier of the loop): 4 KiB of it per wave stage the gradient rows
+    if (nfull < nt) {        // ragged last tile: landed at the mid-point of tile nfull-1 (or just above)
+        const int slot = nfull % 3;
+        if (slot == 0) dq_tail<TR, 0>(fa, qf, dof, dq0, dq1, c, lse2, delta, nfull * 64, n, hh);
+        else if (slot == 1) dq_tail<TR, 1>(fa, qf, dof, dq0, dq1, c, lse2, delta, nfull * 64, n, hh);
+        else dq_tail<TR, 2>(fa, qf, dof, dq0, dq1, c, lse2, delta, nfull * 64, n, hh);
+    }
+    __builtin_amdgcn_s_barrier();     // every wave has left the ring: 4 KiB of it per wave stage the gradient rows
     E* grow0 = static_cast<E*>(p.dq) + b * p.gsb + (int64_t)q0 * p.gsn + h * p.gsh;
     store_rows_staged<TR>(smem + wave * 4096, grow0, p.gsn, n - q0, dq0, dq1, p.scale, lane);
 }
