@@ -387,49 +387,120 @@ __device__ __forceinline__ void fwd_half(const FragAddr& fa, const typename TR::
     }
 }
 
-// Stream control shared by the forward and the dQ kernel: before computing on tile t (ring slot SLOT), start
-// the LDS-DMA of tile t+2 into slot SLOT+2 (last read in iteration t-1, which every wave has left).
+// K/V ring of the pipelined forward / dQ kernels: tile t+1 is awaited and tile t+2 requested (into the slot of tile
+// t-1) in the MIDDLE of tile t, after the first stage of tile t has read the last fragments of tile t-1.  At most
+// one tile is in flight; it has a whole tile time to land.
 template <class E, int SLOT>
-__device__ __forceinline__ void kv_prefetch(unsigned char* smem, const E* kb, const E* vb, int64_t sn, int t, int nt, int n, int wave,
-                                            int lane, const DmaLane& dl) {
+__device__ __forceinline__ void kv_mid(unsigned char* smem, const E* kb, const E* vb, int64_t sn, int t, int nt, int n, int wave, int lane,
+                                       const DmaLane& dl) {
+    NPCD_DMA_WAIT_BARRIER(0);
     if (t + 2 < nt) {
         if ((t + 3) * 64 <= n) dma_tile_pair_fast<E, (SLOT + 2) % 3>(smem, kb, vb, sn, (t + 2) * 64, wave, dl);
         else dma_tile_pair(smem + ((SLOT + 2) % 3) * 16384, kb, sn, vb, sn, (t + 2) * 64, n, wave, lane);
     }
 }
-// tile t+1 has landed for every wave and tile t is fully consumed (tile t+2, if any, stays in flight)
-#define NPCD_KV_ADVANCE(t, nt)                     \
-    do {                                           \
-        if ((t) + 2 < (nt)) NPCD_DMA_WAIT_BARRIER(4); \
-        else NPCD_DMA_WAIT_BARRIER(0);             \
-    } while (0)
+// a wave without query rows (last query tile of a ragged sequence) only keeps the K/V stream and the barriers going
+template <class E>
+__device__ __forceinline__ void kv_idle_loop(unsigned char* smem, const E* kb, const E* vb, int64_t sn, int nfull, int nt, int n, int wave,
+                                             int lane, const DmaLane& dl) {
+    for (int t = 0; t < nfull; ++t) {
+        if (t % 3 == 0) kv_mid<E, 0>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
+        else if (t % 3 == 1) kv_mid<E, 1>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
+        else kv_mid<E, 2>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
+    }
+    if (nfull == 0) NPCD_DMA_WAIT_BARRIER(0);
+    __builtin_amdgcn_s_barrier();       // the one before the row stores
+}
 
+// online-softmax update of one 32-key half from its raw scores; returns the 16-bit P operands
+template <class TR>
+__device__ __forceinline__ void fwd_softmax(const f32x16& s0, f32x16& o0, f32x16& o1, float& m, float& l, float c, u32x4 (&pw)[2]) {
+    float mx = fmaxf(s0[0], s0[1]);
+#pragma unroll
+    for (int i = 2; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s0[i]), s0[i + 1]);
+    mx = half_max(mx) * c;   // c = scale * log2(e) > 0: m lives in the exp2 domain
+    if (__any(mx > m + kDeferLog2)) {
+        const float mn = (mx > m + kDeferLog2) ? mx : m;
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            o0[i] *= alpha;
+            o1[i] *= alpha;
+        }
+    }
+    float rs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float a = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[2 * j], c, -m)), b2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[2 * j + 1], c, -m));
+        rs += a + b2;
+        pw[j >> 2][j & 3] = pack2<TR>(a, b2);
+    }
+    l += rs;
+}
+
+// One pipelined stage of the forward over FULL key tiles: the score products of half (SLOT, KB), then -- behind them on
+// the matrix pipe -- O^T += V^T P^T of the PREVIOUS half (PSLOT, PKB, its P in `pw`), while the vector ALU runs the
+// online softmax of the new scores.  A rescale of O (rare, deferred maximum) waits for those products by data dependence.
+template <class TR, int SLOT, int KB, int PSLOT, int PKB, bool ACC>
+__device__ __forceinline__ void fwd_stage(const FragAddr& fa, const typename TR::vec8 (&qf)[4], f32x16& o0, f32x16& o1, float& m, float& l,
+                                          float c, u32x4 (&pw)[2]) {
+    using V8 = typename TR::vec8;
+    constexpr int KT = SLOT * 16384 + KB * 4096, PV = PSLOT * 16384 + 8192;
+    u32x4 kr[4];
+    kr[0] = lds_b128_issue<KT>(fa.row[0]);
+    kr[1] = lds_b128_issue<KT>(fa.row[1]);
+    kr[2] = lds_b128_issue<KT>(fa.row[2]);
+    kr[3] = lds_b128_issue<KT>(fa.row[3]);
+    TrPair vt[2][2];
+    if (ACC) {
+        vt[0][0] = tr_issue_at<PV, PKB * 2>(fa, 0);     vt[0][1] = tr_issue_at<PV, PKB * 2>(fa, 1);
+        vt[1][0] = tr_issue_at<PV, PKB * 2 + 1>(fa, 0); vt[1][1] = tr_issue_at<PV, PKB * 2 + 1>(fa, 1);
+    }
+    tr_wait();
+    f32x16 s0 = {0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) s0 = TR::mfma32(__builtin_bit_cast(V8, kr[s]), qf[s], s0);
+    if (ACC) {
+        o0 = TR::mfma32(tr_vec<TR>(vt[0][0]), __builtin_bit_cast(V8, pw[0]), o0);
+        o1 = TR::mfma32(tr_vec<TR>(vt[0][1]), __builtin_bit_cast(V8, pw[0]), o1);
+        o0 = TR::mfma32(tr_vec<TR>(vt[1][0]), __builtin_bit_cast(V8, pw[1]), o0);
+        o1 = TR::mfma32(tr_vec<TR>(vt[1][1]), __builtin_bit_cast(V8, pw[1]), o1);
+    }
+    u32x4 nw[2];
+    fwd_softmax<TR>(s0, o0, o1, m, l, c, nw);
+    pw[0] = nw[0];
+    pw[1] = nw[1];
+}
+template <class TR, int PSLOT, int PKB>
+__device__ __forceinline__ void fwd_flush(const FragAddr& fa, f32x16& o0, f32x16& o1, const u32x4 (&pw)[2]) {
+    using V8 = typename TR::vec8;
+    constexpr int PV = PSLOT * 16384 + 8192;
+    TrPair vt[2][2];
+    vt[0][0] = tr_issue_at<PV, PKB * 2>(fa, 0);     vt[0][1] = tr_issue_at<PV, PKB * 2>(fa, 1);
+    vt[1][0] = tr_issue_at<PV, PKB * 2 + 1>(fa, 0); vt[1][1] = tr_issue_at<PV, PKB * 2 + 1>(fa, 1);
+    tr_wait();
+    o0 = TR::mfma32(tr_vec<TR>(vt[0][0]), __builtin_bit_cast(V8, pw[0]), o0);
+    o1 = TR::mfma32(tr_vec<TR>(vt[0][1]), __builtin_bit_cast(V8, pw[0]), o1);
+    o0 = TR::mfma32(tr_vec<TR>(vt[1][0]), __builtin_bit_cast(V8, pw[1]), o0);
+    o1 = TR::mfma32(tr_vec<TR>(vt[1][1]), __builtin_bit_cast(V8, pw[1]), o1);
+}
 template <class TR, int SLOT>
 __device__ __forceinline__ void fwd_step(unsigned char* smem, const FragAddr& fa, const DmaLane& dl, const typename TR::elem* kb,
                                          const typename TR::elem* vb, int64_t sn, int t, int nt, int n, int wave, int lane,
-                                         const typename TR::vec8 (&qf)[4], f32x16& o0, f32x16& o1, float& m, float& l, float c) {
-    kv_prefetch<typename TR::elem, SLOT>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
-    if (t * 64 + 64 <= n) {
-        fwd_half<TR, false, SLOT, 0>(fa, qf, o0, o1, m, l, c, t * 64, n, lane >> 5);
-        fwd_half<TR, false, SLOT, 1>(fa, qf, o0, o1, m, l, c, t * 64, n, lane >> 5);
-    } else {
-        fwd_half<TR, true, SLOT, 0>(fa, qf, o0, o1, m, l, c, t * 64, n, lane >> 5);
-        if (t * 64 + 32 < n) fwd_half<TR, true, SLOT, 1>(fa, qf, o0, o1, m, l, c, t * 64, n, lane >> 5);
-    }
-    NPCD_KV_ADVANCE(t, nt);
+                                         const typename TR::vec8 (&qf)[4], f32x16& o0, f32x16& o1, float& m, float& l, float c, u32x4 (&pw)[2]) {
+    constexpr int PREV = (SLOT + 2) % 3;
+    fwd_stage<TR, SLOT, 0, PREV, 1, true>(fa, qf, o0, o1, m, l, c, pw);
+    kv_mid<typename TR::elem, SLOT>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
+    fwd_stage<TR, SLOT, 1, SLOT, 0, true>(fa, qf, o0, o1, m, l, c, pw);
 }
-// a wave without query rows (last query tile of a ragged sequence) only keeps the K/V stream and the barriers going
-template <class E>
-__device__ __forceinline__ void kv_idle_loop(unsigned char* smem, const E* kb, const E* vb, int64_t sn, int nt, int n, int wave, int lane,
-                                             const DmaLane& dl) {
-    int slot = 0;
-    for (int t = 0; t < nt; ++t) {
-        if (slot == 0) kv_prefetch<E, 0>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
-        else if (slot == 1) kv_prefetch<E, 1>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
-        else kv_prefetch<E, 2>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
-        NPCD_KV_ADVANCE(t, nt);
-        slot = slot == 2 ? 0 : slot + 1;
-    }
+// the ragged last key tile (fewer than 64 keys): simple, masked, not pipelined
+template <class TR, int SLOT>
+__device__ __forceinline__ void fwd_tail(const FragAddr& fa, const typename TR::vec8 (&qf)[4], f32x16& o0, f32x16& o1, float& m, float& l, float c,
+                                         int key0, int n, int hh) {
+    fwd_half<TR, true, SLOT, 0>(fa, qf, o0, o1, m, l, c, key0, n, hh);
+    if (key0 + 32 < n) fwd_half<TR, true, SLOT, 1>(fa, qf, o0, o1, m, l, c, key0, n, hh);
 }
 
 #ifndef NPCD_FWD_WAVES
@@ -442,21 +513,20 @@ __global__ __launch_bounds__(256, NPCD_FWD_WAVES) void attn_fwd_kernel(AttnParam
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 16384];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nqt = (p.n + 127) >> 7;
+    const int n = p.n, nt = (n + 63) >> 6, nfull = n >> 6;
+    const int nqt = (n + 127) >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = bid % nqt, bh = bid / nqt, h = bh % p.H, b = bh / p.H;
     const E* qb = static_cast<const E*>(p.q) + b * p.sb + h * p.sh;
     const E* kb = static_cast<const E*>(p.k) + b * p.sb + h * p.sh;
     const E* vb = static_cast<const E*>(p.v) + b * p.sb + h * p.sh;
     const int q0 = qt * 128 + wave * 32;
-    const bool wave_active = q0 < p.n;
+    const bool wave_active = q0 < n;
     const int qrow = q0 + r;
     const float c = p.scale_log2;
-    const int n = p.n, nt = (n + 63) >> 6;
     const DmaLane dl = dma_lane<E>(p.sn, lane);
-    const FragAddr fa = frag_addr(smem, lane);
 
-    // 3-deep LDS ring filled by LDS-DMA, two tiles ahead of the compute.
+    // 3-deep LDS ring filled by LDS-DMA
     dma_tile_pair(smem, kb, p.sn, vb, p.sn, 0, n, wave, lane);
     if (nt > 1) dma_tile_pair(smem + 16384, kb, p.sn, vb, p.sn, 64, n, wave, lane);
 
@@ -468,20 +538,43 @@ __global__ __launch_bounds__(256, NPCD_FWD_WAVES) void attn_fwd_kernel(AttnParam
         qf[s] = *reinterpret_cast<const V8*>(qb + (int64_t)min(qrow, n - 1) * p.sn + 16 * s + 8 * hh);
     f32x16 o0 = {0}, o1 = {0};
     float m = -INFINITY, l = 0.f;
-    if (nt > 1) NPCD_DMA_WAIT_BARRIER(4);                        // tile 0 has landed (tile 1 may still be in flight)
-    else NPCD_DMA_WAIT_BARRIER(0);
+    // the row operands have arrived: tell the compiler's wait-count tracking here, not inside the loop
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     if (!wave_active) {                                          // wave-uniform
-        kv_idle_loop<E>(smem, kb, vb, p.sn, nt, n, wave, lane, dl);
+        kv_idle_loop<E>(smem, kb, vb, p.sn, nfull, nt, n, wave, lane, dl);
         return;
     }
-    // the ring position is a compile-time constant inside each step: three steps per trip
-    for (int t = 0; t < nt; t += 3) {
-        fwd_step<TR, 0>(smem, fa, dl, kb, vb, p.sn, t, nt, n, wave, lane, qf, o0, o1, m, l, c);
-        if (t + 1 < nt) fwd_step<TR, 1>(smem, fa, dl, kb, vb, p.sn, t + 1, nt, n, wave, lane, qf, o0, o1, m, l, c);
-        if (t + 2 < nt) fwd_step<TR, 2>(smem, fa, dl, kb, vb, p.sn, t + 2, nt, n, wave, lane, qf, o0, o1, m, l, c);
+    const FragAddr fa = frag_addr(smem, lane);
+    u32x4 pw[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+    if (nfull > 0) {
+        // tile 0 (slot 0) is peeled: its first stage has no predecessor
+        fwd_stage<TR, 0, 0, 2, 1, false>(fa, qf, o0, o1, m, l, c, pw);
+        kv_mid<E, 0>(smem, kb, vb, p.sn, 0, nt, n, wave, lane, dl);
+        fwd_stage<TR, 0, 1, 0, 0, true>(fa, qf, o0, o1, m, l, c, pw);
+        for (int t = 1; t < nfull; t += 3) {
+            fwd_step<TR, 1>(smem, fa, dl, kb, vb, p.sn, t, nt, n, wave, lane, qf, o0, o1, m, l, c, pw);
+            if (t + 1 < nfull) fwd_step<TR, 2>(smem, fa, dl, kb, vb, p.sn, t + 1, nt, n, wave, lane, qf, o0, o1, m, l, c, pw);
+            if (t + 2 < nfull) fwd_step<TR, 0>(smem, fa, dl, kb, vb, p.sn, t + 2, nt, n, wave, lane, qf, o0, o1, m, l, c, pw);
+        }
+        const int last = (nfull - 1) % 3;
+        if (last == 0) fwd_flush<TR, 0, 1>(fa, o0, o1, pw);
+        else if (last == 1) fwd_flush<TR, 1, 1>(fa, o0, o1, pw);
+        else fwd_flush<TR, 2, 1>(fa, o0, o1, pw);
+    } else {
+        NPCD_DMA_WAIT_BARRIER(0);
+    }
+    if (nfull < nt) {        // ragged last tile: landed at the mid-point of tile nfull-1 (or in the prologue)
+        const int slot = nfull % 3;
+        if (slot == 0) fwd_tail<TR, 0>(fa, qf, o0, o1, m, l, c, nfull * 64, n, hh);
+        else if (slot == 1) fwd_tail<TR, 1>(fa, qf, o0, o1, m, l, c, nfull * 64, n, hh);
+        else fwd_tail<TR, 2>(fa, qf, o0, o1, m, l, c, nfull * 64, n, hh);
     }
     l = half_sum(l);
-    // every wave has left the ring (last barrier of the loop): 4 KiB of it per wave stage the output rows
+    __builtin_amdgcn_s_barrier();     // every wave has left the ring: 4 KiB of it per wave stage the output rows
     E* orow0 = static_cast<E*>(p.o_w) + b * p.osb + (int64_t)q0 * p.osn + h * p.osh;
     store_rows_staged<TR>(smem + wave * 4096, orow0, p.osn, n - q0, o0, o1, 1.f / l, lane);
     if (qrow < n && hh == 0) p.lse[(int64_t)(b * p.H + h) * n + qrow] = m * kLn2 + logf(l);
@@ -552,17 +645,6 @@ __device__ __forceinline__ void dq_flush(const FragAddr& fa, f32x16& dq0, f32x16
     dq1 = TR::mfma32(tr_vec<TR>(kt[1][1]), __builtin_bit_cast(V8, dw[1]), dq1);
 }
 
-// K/V ring of the pipelined dQ pass (same protocol as the dK/dV pass): tile t+1 is awaited and tile t+2 requested (into
-// the slot of tile t-1) in the MIDDLE of tile t, after the first stage of tile t has read the last fragments of tile t-1.
-template <class E, int SLOT>
-__device__ __forceinline__ void dq_mid(unsigned char* smem, const E* kb, const E* vb, int64_t sn, int t, int nt, int n, int wave, int lane,
-                                       const DmaLane& dl) {
-    NPCD_DMA_WAIT_BARRIER(0);
-    if (t + 2 < nt) {
-        if ((t + 3) * 64 <= n) dma_tile_pair_fast<E, (SLOT + 2) % 3>(smem, kb, vb, sn, (t + 2) * 64, wave, dl);
-        else dma_tile_pair(smem + ((SLOT + 2) % 3) * 16384, kb, sn, vb, sn, (t + 2) * 64, n, wave, lane);
-    }
-}
 template <class TR, int SLOT>
 __device__ __forceinline__ void dq_step(unsigned char* smem, const FragAddr& fa, const DmaLane& dl, const typename TR::elem* kb,
                                         const typename TR::elem* vb, int64_t sn, int t, int nt, int n, int wave, int lane,
@@ -570,7 +652,7 @@ __device__ __forceinline__ void dq_step(unsigned char* smem, const FragAddr& fa,
                                         float c, float lse2, float delta, u32x4 (&dw)[2]) {
     constexpr int PREV = (SLOT + 2) % 3;
     dq_stage<TR, SLOT, 0, PREV, 1, true>(fa, qf, dof, dq0, dq1, c, lse2, delta, dw);
-    dq_mid<typename TR::elem, SLOT>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
+    kv_mid<typename TR::elem, SLOT>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
     dq_stage<TR, SLOT, 1, SLOT, 0, true>(fa, qf, dof, dq0, dq1, c, lse2, delta, dw);
 }
 
@@ -671,13 +753,7 @@ __global__ __launch_bounds__(256, NPCD_DQ_WAVES) void attn_bwd_dq_kernel(AttnPar
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (!wave_active) {      // wave-uniform: no query rows (ragged last query tile): keep the stream and the barriers going
-        for (int t = 0; t < nfull; ++t) {
-            if (t % 3 == 0) dq_mid<E, 0>(smem, kb, vb, p.sn, t, nt, n, wave, lane, dl);
-            else if (t % 3 == 1) dq_mid<E, 1>(smem, kb, vb, p.sn, t, nt, n, wave, lane, dl);
-            else dq_mid<E, 2>(smem, kb, vb, p.sn, t, nt, n, wave, lane, dl);
-        }
-        if (nfull == 0) NPCD_DMA_WAIT_BARRIER(0);
-        __builtin_amdgcn_s_barrier();
+        kv_idle_loop<E>(smem, kb, vb, p.sn, nfull, nt, n, wave, lane, dl);
         return;
     }
     const FragAddr fa = frag_addr(smem, lane);
@@ -685,7 +761,7 @@ __global__ __launch_bounds__(256, NPCD_DQ_WAVES) void attn_bwd_dq_kernel(AttnPar
     if (nfull > 0) {
         // tile 0 (slot 0) is peeled: its first stage has no predecessor
         dq_stage<TR, 0, 0, 2, 1, false>(fa, qf, dof, dq0, dq1, c, lse2, delta, dw);
-        dq_mid<E, 0>(smem, kb, vb, p.sn, 0, nt, n, wave, lane, dl);
+        kv_mid<E, 0>(smem, kb, vb, p.sn, 0, nt, n, wave, lane, dl);
         dq_stage<TR, 0, 1, 0, 0, true>(fa, qf, dof, dq0, dq1, c, lse2, delta, dw);
         for (int t = 1; t < nfull; t += 3) {
             dq_step<TR, 1>(smem, fa, dl, kb, vb, p.sn, t, nt, n, wave, lane, qf, dof, dq0, dq1, c, lse2, delta, dw);
