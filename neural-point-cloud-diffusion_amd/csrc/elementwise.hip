@@ -86,11 +86,17 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
 // Linear whose output was added to the residual stream right before this LayerNorm).
 // Workgroup = 4 waves x kRowsPerWave rows; partials [gridDim.x][W] are summed by colsum_finalize.
 // ============================================================================================
-// rows per wave are chosen per launch so that the grid keeps >= ~1000 workgroups also at small token counts
-static inline int ln_rows_per_wave(int T) { int r = T / (4 * 1024); return r < 1 ? 1 : (r > 8 ? 8 : r); }
+// Rows per wave are chosen per launch: 2 workgroups are resident per CU (180 VGPRs with the double-buffered row
+// loads), i.e. 512 on the chip; the grid is sized to ONE such round when that needs <= 32 rows per wave (cfg-D: 17
+// rows, 483 workgroups), otherwise 16 rows per wave.  Small token counts (strong scaling) keep one row per wave.
+static inline int ln_rows_per_wave(int T) {
+    const int one_round = (T + 4 * 512 - 1) / (4 * 512);
+    if (one_round <= 32) return one_round < 1 ? 1 : one_round;
+    return 16;
+}
 
 template <int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+__global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const __bf16* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      const float* __restrict__ dres, float* __restrict__ dx, __bf16* __restrict__ dxb,
                                                      float* __restrict__ part_gamma, float* __restrict__ part_beta,
@@ -102,11 +108,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) ag[ch] = ab[ch] = ac[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int row0 = (blockIdx.x * 4 + wave) * rows_per_wave;
-    for (int rr = 0; rr < rows_per_wave; ++rr) {
-        const int row = row0 + rr;
-        if (row >= T) break;
+    const int nrows = min(rows_per_wave, T - row0);
+    // The row loop is software-pipelined: the loads of row r+1 are issued before row r is reduced and stored, so that
+    // every wave keeps ~10 KB of reads in flight all the time (the kernel is a pure HBM stream: 536 MB per call at cfg-D).
+    bf16x4 dyA[NCH], dyB[NCH];
+    f32x4 xA[NCH], xB[NCH], rA[NCH], rB[NCH];
+    float muA = 0.f, rsA = 0.f, muB = 0.f, rsB = 0.f;
+    auto load_row = [&](int row, bf16x4 (&dyr)[NCH], f32x4 (&xr)[NCH], f32x4 (&rr2)[NCH], float& mu, float& rs) {
         const int64_t base = (int64_t)row * W;
-        const float mu = mean[row], rs = rstd[row];
+        mu = mean[row];
+        rs = rstd[row];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = ch * 256 + lane * 4;
+            if (c < W) {
+                dyr[ch] = *reinterpret_cast<const bf16x4*>(dy + base + c);
+                xr[ch] = *reinterpret_cast<const f32x4*>(x + base + c);
+                if (dres) rr2[ch] = *reinterpret_cast<const f32x4*>(dres + base + c);
+            }
+        }
+    };
+    if (nrows > 0) load_row(row0, dyA, xA, rA, muA, rsA);
+    for (int rr = 0; rr < nrows; ++rr) {
+        const int row = row0 + rr;
+        const int64_t base = (int64_t)row * W;
+        if (rr + 1 < nrows) load_row(row + 1, dyB, xB, rB, muB, rsB);
+        const float mu = muA, rs = rsA;
         f32x4 gy[NCH], xh[NCH];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -114,8 +141,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
             const int c = ch * 256 + lane * 4;
             gy[ch] = xh[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (c < W) {
-                const f32x4 d = bf16x4_to_f32(*reinterpret_cast<const bf16x4*>(dy + base + c));
-                xh[ch] = (*reinterpret_cast<const f32x4*>(x + base + c) - mu) * rs;
+                const f32x4 d = bf16x4_to_f32(dyA[ch]);
+                xh[ch] = (xA[ch] - mu) * rs;
                 ag[ch] += d * xh[ch];
                 ab[ch] += d;
                 gy[ch] = d * *reinterpret_cast<const f32x4*>(gamma + c);
@@ -130,12 +157,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const __bf16* __restrict__ 
             const int c = ch * 256 + lane * 4;
             if (c < W) {
                 f32x4 o = (gy[ch] - c1 - xh[ch] * c2) * rs;
-                if (dres) o += *reinterpret_cast<const f32x4*>(dres + base + c);
+                if (dres) o += rA[ch];
                 *reinterpret_cast<f32x4*>(dx + base + c) = o;
                 if (dxb) *reinterpret_cast<bf16x4*>(dxb + base + c) = f32_to_bf16x4(o);
                 ac[ch] += o;
             }
         }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            dyA[ch] = dyB[ch];
+            xA[ch] = xB[ch];
+            rA[ch] = rB[ch];
+        }
+        muA = muB;
+        rsA = rsB;
     }
     // cross-wave reduction of the column partials
 #pragma unroll
