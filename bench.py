@@ -27,6 +27,7 @@ import torch.distributed as dist
 
 CFG = dict(coords_dim=3, feats_dim=128, num_points=512, width=1024, layers=24, heads=16, global_batch=64)
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0          # HBM3E, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 
 
@@ -174,6 +175,7 @@ def main():
         use_tuned = bool(tun.read_file(tuned))
 
     from npcd.hip import attention as hattn
+    from npcd.hip import elementwise as hew
     trainer = build_trainer(device, per)
     coords, feats = synthetic_batch(CFG["global_batch"], rank, world, device)
 
@@ -186,12 +188,14 @@ def main():
         trainer.step(coords, feats)
     barrier()
     hattn.KERNEL_EVENTS = {"fwd": [], "dq": [], "dkdv": []}
+    hew.KERNEL_EVENTS = {"add_ln_fwd": [], "ln_bwd": [], "gelu_fwd": [], "gelu_bwd": []}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = trainer.step(coords, feats)
     barrier()
     elapsed = time.perf_counter() - t0
     events, hattn.KERNEL_EVENTS = hattn.KERNEL_EVENTS, None
+    ew_events, hew.KERNEL_EVENTS = hew.KERNEL_EVENTS, None
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -213,6 +217,22 @@ def main():
     if per == 64 and os.path.exists(tfile):
         traffic = json.load(open(tfile)).get(kname, {}).get("hbm_bytes")
 
+    # the HBM-bound kernels of the step (residual stream fp32, activations bf16; T tokens x W / 4W columns), priced at their
+    # algorithmic bytes: every operand read once, every result written once
+    T, Wd = per * n, CFG["width"]
+    ew_bytes = {"add_ln_fwd": T * Wd * (4 + 2 + 4 + 2), "ln_bwd": T * Wd * (2 + 4 + 4 + 4 + 2),
+                "gelu_fwd": T * 4 * Wd * (2 + 2), "gelu_bwd": T * 4 * Wd * (2 + 2 + 2)}
+    ew_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in ew_events.items() if v}
+    hbm = None
+    if ew_ms:
+        dom = max(ew_ms, key=lambda k: ew_ms[k] * len(ew_events[k]))
+        gbs = {k: ew_bytes[k] / (ew_ms[k] * 1e-3) / 1e9 for k in ew_ms}
+        hbm = {"kernel": {"add_ln_fwd": "add_ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel", "gelu_fwd": "gelu_fwd_kernel",
+                          "gelu_bwd": "colsum_kernel<GELU>"}[dom],
+               "bound": "hbm", "achieved": gbs[dom], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs[dom] / PEAK_HBM_GBS,
+               "traffic": None, "algorithmic_bytes_per_launch": ew_bytes[dom], "avg_ms": ew_ms[dom], "launches": len(ew_events[dom]),
+               "all_elementwise_kernels_ms": ew_ms, "all_elementwise_kernels_gbs": gbs}
+
     result = {
         "metric": "denoiser train steps/sec (+ rendered rays/sec under 'render'), SRN-Cars 512pt x 128d",
         "value": args.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -232,6 +252,7 @@ def main():
                      "avg_ms": kern_ms[dominant], "launches": len(events[dominant]),
                      "all_attention_kernels_ms": kern_ms,
                      "all_attention_kernels_tflops": {k: alg[k] / (kern_ms[k] * 1e-3) / 1e12 for k in kern_ms}},
+        "roofline_hbm": hbm,
         "loss": float(loss),
         "tuned_gemm_file": "profiles/tunableop_gfx950.csv" if use_tuned else None,
     }

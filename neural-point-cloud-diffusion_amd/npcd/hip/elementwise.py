@@ -8,6 +8,21 @@ from . import check, lib, ptr, require_gpu, stream_ptr
 _f32, _bf16 = torch.float32, torch.bfloat16
 MAX_JOBS = 8          # NPCD_COLSUM_MAX_JOBS
 
+# When set to a dict {"add_ln_fwd": [], "ln_bwd": [], "gelu_fwd": [], "gelu_bwd": []}, the main launch of each of these
+# kernels is bracketed by HIP events recorded on the launch stream (bench.py measures the kernels in situ with it).
+KERNEL_EVENTS = None
+
+
+def _timed(tag, fn):
+    if KERNEL_EVENTS is None or tag not in KERNEL_EVENTS:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn()
+    e1.record()
+    KERNEL_EVENTS[tag].append((e0, e1))
+    return rc
+
 
 class ColsumJob(ctypes.Structure):
     """NpcdColsumJob (include/npcd_hip.h)."""
@@ -52,8 +67,9 @@ def add_ln_fwd(x_in, delta, gamma, beta, eps=1e-5, want_sum=True):
     y = torch.empty((T, W), dtype=_bf16, device=dev)
     mean = torch.empty(T, dtype=_f32, device=dev)
     rstd = torch.empty(T, dtype=_f32, device=dev)
-    check(lib().npcd_add_ln_fwd(ptr(x_in), ptr(delta), ptr(gamma), ptr(beta), ptr(x_out), ptr(y), ptr(mean), ptr(rstd), T, W,
-                                float(eps), stream_ptr()), "npcd_add_ln_fwd")
+    check(_timed("add_ln_fwd" if delta is not None and want_sum else "ln_fwd",
+                 lambda: lib().npcd_add_ln_fwd(ptr(x_in), ptr(delta), ptr(gamma), ptr(beta), ptr(x_out), ptr(y), ptr(mean), ptr(rstd), T, W,
+                                               float(eps), stream_ptr())), "npcd_add_ln_fwd")
     return x_out, y, mean, rstd
 
 
@@ -67,8 +83,11 @@ def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma_out, dbeta_out, dcol_out=None,
     dx = torch.empty((T, W), dtype=_f32, device=dev)
     dxb = torch.empty((T, W), dtype=_bf16, device=dev) if want_bf16 else None
     parts = torch.empty((3, nblk + L.npcd_colsum_scratch_rows(), W), dtype=_f32, device=dev)
-    check(L.npcd_ln_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(dxb), ptr(parts[0]), ptr(parts[1]),
-                        ptr(parts[2]) if dcol_out is not None else ptr(None), T, W, stream_ptr()), "npcd_ln_bwd")
+    full = dres is not None and want_bf16          # the shape bench.py prices: dy, x, dres read; dx, dx(bf16) written
+    check(_timed("ln_bwd" if full else "ln_bwd_partial",
+                 lambda: L.npcd_ln_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(dxb), ptr(parts[0]),
+                                       ptr(parts[1]), ptr(parts[2]) if dcol_out is not None else ptr(None), T, W, stream_ptr())),
+          "npcd_ln_bwd")
     _finish(batch, parts[0], nblk, W, dgamma_out)
     _finish(batch, parts[1], nblk, W, dbeta_out)
     if dcol_out is not None:
@@ -78,7 +97,7 @@ def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma_out, dbeta_out, dcol_out=None,
 
 def gelu_fwd(h):
     g = torch.empty_like(h)
-    check(lib().npcd_gelu_fwd(ptr(h), ptr(g), h.numel(), stream_ptr()), "npcd_gelu_fwd")
+    check(_timed("gelu_fwd", lambda: lib().npcd_gelu_fwd(ptr(h), ptr(g), h.numel(), stream_ptr())), "npcd_gelu_fwd")
     return g
 
 
@@ -89,7 +108,7 @@ def gelu_bwd(dg, h, dbias_out, batch=None):
     nblk = L.npcd_colsum_blocks(T)
     dh = torch.empty_like(h)
     part = torch.empty((nblk + L.npcd_colsum_scratch_rows(), N), dtype=_f32, device=h.device)
-    check(L.npcd_gelu_bwd(ptr(dg), ptr(h), ptr(dh), ptr(part), T, N, stream_ptr()), "npcd_gelu_bwd")
+    check(_timed("gelu_bwd", lambda: L.npcd_gelu_bwd(ptr(dg), ptr(h), ptr(dh), ptr(part), T, N, stream_ptr())), "npcd_gelu_bwd")
     _finish(batch, part, nblk, N, dbias_out)
     return dh
 
