@@ -729,7 +729,9 @@ extern "C" int npcd_grid_query(const npcd_grid_params* g, const void* workspace,
     int rc = grid_check(g, B, N);
     if (rc != NPCD_OK) return rc;
     if (!points || !sample_idx || !sample_loc || !slot_sample || !nsel) return NPCD_ERR_ARG;
-    if (R <= 0 || S <= 1 || M <= 0 || k <= 0 || !(r > 0.f)) return NPCD_ERR_ARG;
+    // explicit positions may come one per "ray" (the TV loss queries every point's own neighbourhood); depth sampling along
+    // rays needs at least two samples
+    if (R <= 0 || S <= 0 || (!x && S <= 1) || M <= 0 || k <= 0 || !(r > 0.f)) return NPCD_ERR_ARG;
     if (M > 64 || k > 8) return NPCD_ERR_UNSUPPORTED;
     if (!x && (!rays_o || !rays_d || !t0 || !t1)) return NPCD_ERR_ARG;
     if (mode == 0 && !workspace) return NPCD_ERR_ARG;

@@ -77,13 +77,14 @@ class VariationalEmbedding(Embedding):
         self.sample_embedding = mode
         return self
 
-    def forward(self, idx):
+    def forward(self, idx, eps=None):
+        """`eps` replays a given standard-normal draw (tests); by default it is drawn here (reparametrisation trick)."""
         rows = self._rows(idx)
         mean = rows[:, :, :self.out_dim]
         if not self.sample_embedding:
             return mean
         std = torch.exp(0.5 * rows[:, :, self.out_dim:])
-        return mean + std * torch.randn_like(std)
+        return mean + std * (torch.randn_like(std) if eps is None else eps.to(std))
 
     def get_mean_log_var_std(self, idx):
         rows = self._rows(idx)

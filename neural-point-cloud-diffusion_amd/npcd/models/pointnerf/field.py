@@ -55,6 +55,31 @@ class Aggregator(nn.Module):
         valid = idx[..., 0] >= 0                                  # lists are sorted: slot valid iff first entry valid
         return idx[valid].long(), loc[valid], valid.view(B, T, R, M, 1)
 
+    def select_valid_rays(self, slot_valid: torch.Tensor, valid_perm: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """slot_valid [I, R, M] bool -> ray_sample_mask [I, R] bool: the same number min(min_i #valid_i, ray_subsamples) of
+        rays per instance, drawn from a random shuffle of each instance's rays that have a valid shading slot
+        (aggregator.py:88-108).  `valid_perm` replays a given shuffle of the row-major (instance, ray) list."""
+        valid = slot_valid.any(dim=-1)
+        pairs = torch.nonzero(valid)
+        perm = torch.randperm(pairs.shape[0], device=valid.device) if valid_perm is None else valid_perm.to(valid.device).long()
+        pairs = pairs[perm]
+        rays = pairs[torch.sort(pairs[:, 0], stable=True).indices, 1]          # regrouped by instance, shuffled order kept
+        num_valid = valid.sum(dim=-1)
+        n = int(min(int(num_valid.min()), self.ray_subsamples))
+        start = torch.cumsum(num_valid, 0) - num_valid
+        sel = rays[(start[:, None] + torch.arange(n, device=valid.device)[None, :]).reshape(-1)].reshape(valid.shape[0], n)
+        return torch.zeros_like(valid).scatter_(1, sel, True)
+
+    def subsample_valid_rays(self, neighbor_idx, shading_pts, mask, valid_perm=None):
+        """Reference signature (aggregator.py:78-119): neighbor_idx [P,k], shading_pts [P,3], mask [B,T,R,M,1] ->
+        (neighbor_idx_samples, shading_pts_samples, sampled_mask [B,T,n,M,1], ray_sample_mask [B,T,R])."""
+        B, T, R, M = mask.shape[:4]
+        flat = mask.reshape(B * T, R, M)
+        ray_sel = self.select_valid_rays(flat, valid_perm)
+        pts_sel = ray_sel[:, :, None].expand_as(flat)[flat]                     # per valid shading point: is its ray kept?
+        n = int(ray_sel[0].sum())
+        return neighbor_idx[pts_sel], shading_pts[pts_sel], flat[ray_sel].view(B, T, n, M, 1), ray_sel.view(B, T, R)
+
     @staticmethod
     def get_keypoint_data(neighbor_idx, mask, kp_pos=None, kp_feat=None) -> Dict[str, torch.Tensor]:
         data = torch.cat([t for t in (kp_pos, kp_feat) if t is not None], dim=-1)

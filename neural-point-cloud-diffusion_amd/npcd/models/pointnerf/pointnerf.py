@@ -73,9 +73,11 @@ class PointNeRF(nn.Module):
         counts = torch.full((B,), self.opt.model.kp.num, device=coords.device, dtype=torch.int)
         self.voxel_grid.set_pointset(coords.detach(), counts)
 
-    def forward(self, obj_idx, intrinsics, extrinsics, sample_rays: bool):
-        """reference pointnerf.py:56-105 -> (pred AttrDict, aux dict)."""
-        feats = self.feats(idx=obj_idx)
+    def forward(self, obj_idx, intrinsics, extrinsics, sample_rays: bool, rng=None):
+        """reference pointnerf.py:56-105 -> (pred AttrDict, aux dict).  `rng` (tests) replays given random draws:
+        eps (feature reparametrisation), ray_perm, jitter, valid_perm (npcd.models.pointnerf.train_path)."""
+        rng = rng or {}
+        feats = self.feats(idx=obj_idx, eps=rng["eps"]) if "eps" in rng else self.feats(idx=obj_idx)
         coords = self.coords(idx=obj_idx)
         self._set_pointset(coords)
         if hasattr(self.feats, "get_mean_log_var_std"):
@@ -84,7 +86,7 @@ class PointNeRF(nn.Module):
         else:
             aux = {"coords": coords, "feats": feats}
         pred = self.renderer(coords, feats, extrinsics, intrinsics, resolution=self.opt.sizes.default_resolution,
-                             sample=sample_rays, return_channels=True)
+                             sample=sample_rays, return_channels=True, rng=rng)
         return pred, aux
 
     def render(self, coords, feats, extrinsics, intrinsics, resolution=128, max_shading_points=None, sample_rays=False):

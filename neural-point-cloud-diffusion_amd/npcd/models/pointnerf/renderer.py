@@ -21,12 +21,15 @@ class VolumeRenderer(nn.Module):
         self.count_pairs = True            # report the number of (point, neighbour) pairs (one extra reduction)
 
     def forward(self, kp_pos, kp_feat, extr, intr, resolution: int, sample: bool, return_channels: bool = True,
-                return_kp_weights: bool = False, knn_mode: int = 0):
+                return_kp_weights: bool = False, knn_mode: int = 0, rng=None):
         """kp_pos [B,N,3], kp_feat [B,N,F], extr [B,T,4,4] world2cam, intr [B,T,3,3] ->
         AttrDict(mask [B,T,R,1], depth [B,T,R,1], channels [B,T,R,3])   (renderer.py:202-268)."""
         if sample or self.randomize_depth_samples:
-            raise NotImplementedError("training-mode rendering (ray subsampling, jittered depths; renderer.py:74-76,"
-                                      "232-238) is not part of the inference hot path yet")
+            # training mode (random ray subset, jittered depths, gradients): npcd.models.pointnerf.train_path
+            if return_kp_weights or not return_channels:
+                raise NotImplementedError("training-mode rendering returns channels and no key-point weights")
+            from .train_path import render_train
+            return render_train(self, kp_pos, kp_feat, extr, intr, resolution, sample, rng=rng, knn_mode=knn_mode)
         if return_kp_weights:
             raise NotImplementedError("return_kp_weights")
         B, T = extr.shape[:2]

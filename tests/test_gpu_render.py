@@ -255,5 +255,4 @@ def test_pointnerf_forward_surface():
     assert float((r2.channels.cpu() - ref2["channels"]).abs().max()) < 5e-3
     assert net.pointnerf.field.aggregator.max_shading_pts == 50
     assert net.pointnerf.get_all_coords().shape == (5, 512, 3) and net.pointnerf.get_all_feats().shape == (5, 512, 32)
-    with pytest.raises(NotImplementedError):
-        net.pointnerf(torch.tensor([0]).cuda(), intr[:1].cuda(), extr[:1].cuda(), sample_rays=True)
+    # sample_rays=True (training mode) is covered by tests/test_gpu_train_render.py
