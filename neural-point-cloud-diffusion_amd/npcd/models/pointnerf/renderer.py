@@ -18,7 +18,7 @@ class VolumeRenderer(nn.Module):
         self.ray_subsamples, self.white_back = ray_subsamples, white_back
         self.randomize_depth_samples = False
         self.capacity_fraction = 0.25      # compact shading-point buffers: fraction of rays*slots reserved up front
-        self.count_pairs = True            # report the number of (point, neighbour) pairs (one extra reduction)
+        self.count_pairs = False           # also report the number of (point, neighbour) pairs (an extra reduction + sync, ~8 % of a view)
 
     def forward(self, kp_pos, kp_feat, extr, intr, resolution: int, sample: bool, return_channels: bool = True,
                 return_kp_weights: bool = False, knn_mode: int = 0, rng=None):

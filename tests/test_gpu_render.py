@@ -219,6 +219,7 @@ def test_render_vs_oracle_grid(res, B, views):
         if "shape_net.2" in kname:
             p[kname] = p[kname] * 8 + 1.0                 # raise densities so the object is opaque-ish
     m = _model(32, 512, p)
+    m.renderer.count_pairs = True
     with torch.no_grad():
         out = m.render(coords.cuda(), feats.cuda(), extr.cuda(), intr.cuda(), res)
     ref = orr.render(p, coords, feats, extr, intr, res=res, mode="grid", return_aux=True)

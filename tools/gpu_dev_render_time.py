@@ -5,7 +5,7 @@ import torch
 from oracle import renderer as orr
 from npcd.models.pointnerf import PointNeRF
 coords, feats = orr.synthetic_cloud(512, 32, 1, seed=0)
-model = PointNeRF(1, 32, 512, False); model.field.load_state_dict(orr.init_field_params(32, seed=0)); model = model.cuda().eval()
+model = PointNeRF(1, 32, 512, False); model.field.load_state_dict(orr.init_field_params(32, seed=0)); model = model.cuda().eval(); model.renderer.count_pairs = bool(int(os.environ.get("COUNT_PAIRS", "0")))
 extr = orr.look_at_pose(30, 20)[None, None].cuda(); intr = orr.srn_intrinsics()[None, None].cuda()
 c, f = coords.cuda(), feats.cuda()
 with torch.no_grad():
