@@ -91,7 +91,7 @@ def bench_render(device, n_iters=10, burn_in=3):
         dt8 = (time.perf_counter() - t0) / 5
         net.renderer.count_pairs = True            # workload statistics (FLOP accounting), outside the timed region
         out = net.render(c, f, extr, intr, 128)
-    P, Q = out["num_shading_points"], out["num_pairs"]
+    P, Q = int(out["num_shading_points"]), int(out["num_pairs"])
     flops = Q * 2 * (95 * 256 + 3 * 256 * 256) + P * 2 * (256 * 256 * 6 + 256 + 3 * 256)   # as executed (last agg layer on points)
     return {"rays_per_s": 128 * 128 / dt, "rays_per_s_8_views_per_call": 8 * 128 * 128 / dt8, "ms_per_view": dt * 1e3, "resolution": 128, "depth_samples": 128, "k": 8,
             "shading_points": P, "pairs": Q, "mlp_tflops": flops / dt / 1e12,

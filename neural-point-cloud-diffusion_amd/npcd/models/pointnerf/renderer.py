@@ -17,7 +17,9 @@ class VolumeRenderer(nn.Module):
         self.cube_scale, self.depth_resolution = cube_scale, depth_resolution
         self.ray_subsamples, self.white_back = ray_subsamples, white_back
         self.randomize_depth_samples = False
-        self.capacity_fraction = 0.25      # compact shading-point buffers: fraction of rays*slots reserved up front
+        self.capacity_fraction = 0.25      # compact shading-point buffers: fraction of rays*slots reserved up front ...
+        self.sync_free_points = 1 << 20    # ... unless the worst case is at most this many points (one 128^2 view: 819,200):
+        #                                    then the buffers take the worst case (44 B of lists + 512 B of workspace per point)
         self.count_pairs = False           # also report the number of (point, neighbour) pairs (an extra reduction + sync, ~8 % of a view)
 
     def forward(self, kp_pos, kp_feat, extr, intr, resolution: int, sample: bool, return_channels: bool = True,
@@ -42,7 +44,9 @@ class VolumeRenderer(nn.Module):
         if knn_mode == 0:
             # fused path: compact shading-point lists are produced on the device; the shading kernels read the
             # point count from device memory, so nothing round-trips through the host until the result is used
-            capacity = max(4096, int(B * T * R * M * self.capacity_fraction))
+            worst = B * T * R * M                              # every slot of every ray valid
+            sync_free = worst <= self.sync_free_points
+            capacity = worst if sync_free else max(4096, int(worst * self.capacity_fraction))
             while True:
                 counter, ray_base, _, ray_bits, nb, pts = grid.query_compact(agg.k, agg.r, M, rays, self.depth_resolution, capacity,
                                                                            points=kp_pos)
@@ -51,11 +55,16 @@ class VolumeRenderer(nn.Module):
                                              hidden=self.field.hid_dim)
                 mask, depth, chan = hr.ray_march_compact(sigma, rgb, ray_bits, pts, ray_base, o.view(-1, 3), d.view(-1, 3), t1.reshape(-1),
                                                          M, self.white_back)
+                if sync_free:
+                    # buffers sized for the worst case cannot overflow: nothing to check, the call returns without a host
+                    # round trip (the point count stays a device scalar) and the next call's launches overlap this one
+                    P = counter[0]
+                    break
                 P, overflow = counter.tolist()
                 if not overflow:
                     break
-                capacity = B * T * R * M                       # worst case: every slot of every ray is valid
-            n_pairs = int((nb[:P] >= 0).sum()) if self.count_pairs else -1
+                capacity = worst
+            n_pairs = int((nb[:int(P)] >= 0).sum()) if self.count_pairs else -1
         else:
             idx, loc, _, _ = grid.query_dense(agg.k, agg.scaled_r, M, rays=rays, S=self.depth_resolution, mode=knn_mode, points=kp_pos)
             valid = (idx[..., 0] >= 0).view(B * T * R, M)
