@@ -29,7 +29,7 @@ SOURCES = {
     # mis-pairs the 16-bit packing (MI355X_MICROARCH.md, per-instruction cycle constants)
     "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-fno-slp-vectorize"],
     "geometry.hip": ["-ffp-contract=off"],
-    "shade.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+    "shade.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "elementwise.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",

@@ -32,7 +32,7 @@ constexpr int kHidden = 256;
 constexpr int kNFreqs = 10;
 constexpr int kEncBlock = 64;          // 3 + 60 positional-encoding columns + 1 zero pad
 constexpr int kRows = 128;             // rows per tile
-constexpr int kRowBytes = kHidden * 2; // 512
+constexpr int kRowBytes = kHidden * 2 + 16; // 528: rows padded by one 16-byte chunk instead of an XOR swizzle (below)
 constexpr int kFragBytes = 1024;       // one 32(out) x 16(in) fp16 weight fragment
 constexpr float kLeaky = 0.01f;
 
@@ -59,13 +59,16 @@ __host__ __device__ inline ShadeLayout shade_layout(int feat_dim) {
     return L;
 }
 
-// LDS address of 16-byte chunk `chunk` (0..31) of activation row `row`
-__device__ __forceinline__ int act_off(int row, int chunk) { return row * kRowBytes + ((chunk ^ (row & 15)) << 4); }
+// LDS byte offset of 16-byte chunk `chunk` (0..31) of activation row `row`.  The row pitch is 512 + 16 bytes: consecutive rows
+// start 4 banks apart, so the 16 rows a ds_read_b128 lane group touches (same chunk) cover all 64 banks -- conflict-free like
+// an XOR swizzle, but every address is "per-lane base + compile-time constant": no vector arithmetic inside the layer loops
+// (the kernel is bound by vector-instruction issue, not by the matrix pipe).
+__device__ __forceinline__ int act_off(int row, int chunk) { return row * kRowBytes + (chunk << 4); }
 
 // One layer:  acc[oi][cb] (+)= W[(2*wave+oi)*32.., :] . H^T[:, cb*32..]   for oi in {0,1}, cb in 0..3
-template <int KSTEPS>
+template <int KSTEPS, int UNROLL = 4>
 __device__ __forceinline__ void layer_mfma(const unsigned char* H, const unsigned char* wfrag, const float* bias, int wave, int lane,
-                                           f32x16 (&acc)[2][4]) {
+                                           f32x16 (&acc)[2][4], int nblk = 4) {
     const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int oi = 0; oi < 2; ++oi) {
@@ -82,8 +85,9 @@ __device__ __forceinline__ void layer_mfma(const unsigned char* H, const unsigne
     }
     const f16x8* w0 = reinterpret_cast<const f16x8*>(wfrag + (int64_t)(2 * wave) * KSTEPS * kFragBytes) + lane;
     const f16x8* w1 = reinterpret_cast<const f16x8*>(wfrag + (int64_t)(2 * wave + 1) * KSTEPS * kFragBytes) + lane;
+    const unsigned char* hb = H + r * kRowBytes + hh * 16;      // B operand: row (cb*32 + r), chunk 2s + hh -> hb + const
     f16x8 a0 = w0[0], a1 = w1[0];
-#pragma unroll 4
+#pragma unroll UNROLL
     for (int s = 0; s < KSTEPS; ++s) {
         f16x8 n0 = a0, n1 = a1;
         if (s + 1 < KSTEPS) {
@@ -92,9 +96,11 @@ __device__ __forceinline__ void layer_mfma(const unsigned char* H, const unsigne
         }
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
-            const f16x8 b = *reinterpret_cast<const f16x8*>(H + act_off(cb * 32 + r, 2 * s + hh));
-            acc[0][cb] = F16::mfma32(a0, b, acc[0][cb]);
-            acc[1][cb] = F16::mfma32(a1, b, acc[1][cb]);
+            if (cb < nblk) {                         // wave-uniform: 32-row blocks past the tile's packed rows are skipped
+                const f16x8 b = *reinterpret_cast<const f16x8*>(hb + cb * 32 * kRowBytes + s * 32);
+                acc[0][cb] = F16::mfma32(a0, b, acc[0][cb]);
+                acc[1][cb] = F16::mfma32(a1, b, acc[1][cb]);
+            }
         }
         a0 = n0;
         a1 = n1;
@@ -103,23 +109,30 @@ __device__ __forceinline__ void layer_mfma(const unsigned char* H, const unsigne
 
 // epilogue: optional LeakyReLU, convert to fp16, write back in place (4 consecutive channels = 8 bytes)
 template <bool ACT>
-__device__ __forceinline__ void layer_store(unsigned char* H, int wave, int lane, const f32x16 (&acc)[2][4]) {
+__device__ __forceinline__ void layer_store(unsigned char* H, int wave, int lane, const f32x16 (&acc)[2][4], int nblk = 4) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     const int r = lane & 31, hh = lane >> 5;
+    unsigned char* sb = H + r * kRowBytes + hh * 8 + wave * 128;      // row (cb*32 + r), channels (2 wave + oi)*32 + 8 g + 4 hh ..
 #pragma unroll
     for (int oi = 0; oi < 2; ++oi)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f16x4 v;
+                if (cb >= nblk) continue;
+                u32x2 v;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    float x = acc[oi][cb][4 * g + b];
-                    if (ACT) x = x > 0.f ? x : kLeaky * x;
-                    v[b] = (_Float16)x;
+                for (int b = 0; b < 2; ++b) {
+                    float x0 = acc[oi][cb][4 * g + 2 * b], x1 = acc[oi][cb][4 * g + 2 * b + 1];
+                    if (ACT) {                       // LeakyReLU(0.01): max(x, 0.01 x)
+                        x0 = fmaxf(x0, kLeaky * x0);
+                        x1 = fmaxf(x1, kLeaky * x1);
+                    }
+                    const f32x2 f = {x0, x1};
+                    v[b] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2));
                 }
-                const int row = cb * 32 + r, chunk = (2 * wave + oi) * 4 + g;
-                *reinterpret_cast<f16x4*>(H + act_off(row, chunk) + 8 * hh) = v;
+                *reinterpret_cast<u32x2*>(sb + cb * 32 * kRowBytes + (oi * 4 + g) * 16) = v;
             }
 }
 
@@ -152,7 +165,9 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
     constexpr int K0 = FEAT + kEncBlock;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
     unsigned char* H = dsmem;
-    float* wrow = reinterpret_cast<float*>(dsmem + kRows * kRowBytes);  // [128]
+    float* wrow = reinterpret_cast<float*>(dsmem + kRows * kRowBytes);  // [128] inverse distances of the packed rows
+    int* pstart = reinterpret_cast<int*>(wrow + kRows);                 // [16] first packed row of each point of the tile
+    int* pcount = pstart + 16;                                          // [16] its number of valid neighbours
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ShadeLayout L = shade_layout(FEAT);
     const int P = *a.n_points;
@@ -160,79 +175,94 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // ---- prologue: build the layer-0 input rows -------------------------------------------
+        // The tile's 16 x 8 (point, slot) candidates are PACKED: a valid pair takes the row number "valid pairs before
+        // it", so the rows of a point stay consecutive and the unused rows collect at the end of the tile, where whole
+        // 32-row MFMA blocks are skipped (typically one in four: ~29 % of the slots are empty).
+        int nblk;
         {
             const int row = tid & 127, half = tid >> 7;  // half is wave-uniform
             const int p = tile * 16 + (row >> 3), slot = row & 7;
-            int gi = -1;
+            int gi = -1, gi_other = -1;
             if (p < P && slot < a.k) gi = a.nb_idx[(int64_t)p * a.k + slot];
+            const int po = tile * 16 + ((row ^ 64) >> 3);
+            if (po < P && slot < a.k) gi_other = a.nb_idx[(int64_t)po * a.k + slot];
+            const unsigned long long mine = __ballot(gi >= 0), other = __ballot(gi_other >= 0);
+            const int n_mine = __popcll(mine), n_other = __popcll(other);
+            const int before = __popcll(mine & ((1ull << lane) - 1ull)) + ((row & 64) ? n_other : 0);
+            const int V = n_mine + n_other;
+            nblk = (V + 31) >> 5;
+            const int prow = before;                                        // packed row of this candidate (if valid)
+            if (half == 0 && slot == 0) {
+                pstart[row >> 3] = before;
+                pcount[row >> 3] = __popcll((mine >> (lane & ~7)) & 0xffull);
+            }
             float rel[3] = {0.f, 0.f, 0.f};
             if (gi >= 0) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) rel[c] = a.pts[(int64_t)p * 3 + c] - a.kp_pos[(int64_t)gi * 3 + c];
             }
-            if (half == 0)
-                wrow[row] = gi >= 0 ? 1.f / (sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]) + 1e-5f) : 0.f;
-            // features: this half converts FEAT/2 channels
+            if (half == 0 && gi >= 0) wrow[prow] = 1.f / (sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]) + 1e-5f);
             constexpr int FH = FEAT / 2;
-            const float* fp = a.kp_feat + (int64_t)(gi >= 0 ? gi : 0) * FEAT + half * FH;
+            if (gi >= 0) {
+                // features: this half converts FEAT/2 channels
+                const float* fp = a.kp_feat + (int64_t)gi * FEAT + half * FH;
 #pragma unroll
-            for (int c8 = 0; c8 < FH / 8; ++c8) {
-                f16x8 v;
-                if (gi >= 0) {
+                for (int c8 = 0; c8 < FH / 8; ++c8) {
+                    f16x8 v;
                     const f32x4 x0 = *reinterpret_cast<const f32x4*>(fp + c8 * 8);
                     const f32x4 x1 = *reinterpret_cast<const f32x4*>(fp + c8 * 8 + 4);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] = (_Float16)x0[j]; v[4 + j] = (_Float16)x1[j]; }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
+                    *reinterpret_cast<f16x8*>(H + act_off(prow, half * (FH / 8) + c8)) = v;
                 }
-                *reinterpret_cast<f16x8*>(H + act_off(row, half * (FH / 8) + c8)) = v;
+                // positional encoding: this half fills 32 of the 64 columns (the select on `half` is wave-uniform)
+#pragma unroll
+                for (int c8 = 0; c8 < 4; ++c8) {
+                    f16x8 v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (_Float16)(half == 0 ? enc_value(c8 * 8 + j, rel) : enc_value(32 + c8 * 8 + j, rel));
+                    *reinterpret_cast<f16x8*>(H + act_off(prow, FEAT / 8 + half * 4 + c8)) = v;
+                }
             }
-            // positional encoding: this half fills 32 of the 64 columns
+            // rows V .. 32 nblk - 1 are computed (whole MFMA blocks) but never aggregated: give them defined inputs
+            if (row >= V && row < 32 * nblk) {
+                f16x8 z;
 #pragma unroll
-            for (int c8 = 0; c8 < 4; ++c8) {
-                f16x8 v;
+                for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int q = half * 32 + c8 * 8 + j;
-                    // both halves are compiled; the select on `half` below is wave-uniform
-                    v[j] = (_Float16)0.f;
-                    if (gi >= 0) v[j] = (_Float16)(half == 0 ? enc_value(c8 * 8 + j, rel) : enc_value(32 + c8 * 8 + j, rel));
-                    (void)q;
-                }
-                *reinterpret_cast<f16x8*>(H + act_off(row, FEAT / 8 + half * 4 + c8)) = v;
+                for (int c8 = 0; c8 < FH / 8; ++c8) *reinterpret_cast<f16x8*>(H + act_off(row, half * (FH / 8) + c8)) = z;
+#pragma unroll
+                for (int c8 = 0; c8 < 4; ++c8) *reinterpret_cast<f16x8*>(H + act_off(row, FEAT / 8 + half * 4 + c8)) = z;
             }
         }
         __syncthreads();
         // ---- four non-linear layers ---------------------------------------------------------
         f32x16 acc[2][4];
-        layer_mfma<K0 / 16>(H, a.wpack + L.w[0], reinterpret_cast<const float*>(a.wpack + L.bias[0]), wave, lane, acc);
+        layer_mfma<K0 / 16, K0 / 16>(H, a.wpack + L.w[0], reinterpret_cast<const float*>(a.wpack + L.bias[0]), wave, lane, acc, nblk);
         __syncthreads();
-        layer_store<true>(H, wave, lane, acc);
+        layer_store<true>(H, wave, lane, acc, nblk);
         __syncthreads();
 #pragma unroll 1
         for (int l = 1; l < 4; ++l) {
-            layer_mfma<kHidden / 16>(H, a.wpack + L.w[l], reinterpret_cast<const float*>(a.wpack + L.bias[l]), wave, lane, acc);
+            layer_mfma<kHidden / 16, kHidden / 16>(H, a.wpack + L.w[l], reinterpret_cast<const float*>(a.wpack + L.bias[l]), wave, lane, acc, nblk);
             __syncthreads();
-            layer_store<true>(H, wave, lane, acc);
+            layer_store<true>(H, wave, lane, acc, nblk);
             __syncthreads();
         }
         // ---- inverse-distance aggregation over the 8 neighbour slots ------------------------
         {
             const int pl = tid >> 4, cc = tid & 15;  // point, 16-channel chunk
             const int p = tile * 16 + pl;
-            float w[8], wsum = 0.f;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) { w[s] = wrow[pl * 8 + s]; wsum += w[s]; }
+            const int r0 = pstart[pl], cnt = pcount[pl];             // the point's packed rows
+            float wsum = 0.f;
+            for (int s2 = 0; s2 < cnt; ++s2) wsum += wrow[r0 + s2];
             const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
             float out[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) out[j] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int row = pl * 8 + s;
-                const float ws = w[s] * inv;
+            for (int s2 = 0; s2 < cnt; ++s2) {
+                const int row = r0 + s2;
+                const float ws = wrow[row] * inv;
                 const f16x8 v0 = *reinterpret_cast<const f16x8*>(H + act_off(row, 2 * cc));
                 const f16x8 v1 = *reinterpret_cast<const f16x8*>(H + act_off(row, 2 * cc + 1));
 #pragma unroll
@@ -437,7 +467,7 @@ extern "C" int npcd_shade_points(const void* wpack, int feat_dim, int n_freqs, i
     a.G = static_cast<_Float16*>(workspace);
     a.sigma = sigma; a.rgb = rgb;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int ldsA = kRows * kRowBytes + kRows * 4;
+    const int ldsA = kRows * kRowBytes + kRows * 4 + 32 * 4;   // activations, row weights, per-point packed-row ranges
     const int ldsB = kRows * kRowBytes + 4 * kRows * 4 * 4;
     static bool attr_done = false;
     if (!attr_done) {
