@@ -18,7 +18,7 @@ class VolumeRenderer(nn.Module):
         self.ray_subsamples, self.white_back = ray_subsamples, white_back
         self.randomize_depth_samples = False
         self.capacity_fraction = 0.25      # compact shading-point buffers: fraction of rays*slots reserved up front ...
-        self.sync_free_points = 1 << 20    # ... unless the worst case is at most this many points (one 128^2 view: 819,200):
+        self.sync_free_points = 1 << 23    # ... unless the worst case is at most this many points (eight 128^2 views: 6.6 M):
         #                                    then the buffers take the worst case (44 B of lists + 512 B of workspace per point)
         self.count_pairs = False           # also report the number of (point, neighbour) pairs (an extra reduction + sync, ~8 % of a view)
 

@@ -147,6 +147,12 @@ class DiffusionTrainer:
         self.ema = self.flat.flat.clone() if ema_decay is not None else None
         self.max_grad_norm = max_grad_norm
         self.iteration = 0
+        # float16 autocast (the reference's default --dtype, train_diffusion.py:78) trains with dynamic loss scaling
+        # (torch.cuda.amp.GradScaler defaults, diffusion_training.py:62,156,169-170): scale 2^16, halved when a gradient
+        # overflows (that step is skipped), doubled after 2000 clean steps
+        self.loss_scale = 65536.0 if dtype == torch.float16 else None
+        self._clean_steps = 0
+        self.skipped_steps = 0
         self.native = self.flat.flat.is_cuda and fused
         if self.native:
             # HIP path: one fused AdamW+EMA kernel over the flat buffers, a bf16 shadow of the parameters for
@@ -182,15 +188,17 @@ class DiffusionTrainer:
         dev_type = "cuda" if coords.is_cuda else "cpu"
         with torch.autocast(dev_type, dtype=self.dtype, enabled=self.dtype is not None):
             loss, sub, _ = self.model.compute_loss(coords, feats, t=t, coords_noise=coords_noise, feats_noise=feats_noise)
-        loss.backward()
+        (loss if self.loss_scale is None else loss * self.loss_scale).backward()
         self.iteration += 1
         pipelined = False
-        if self.native and self.max_grad_norm is None:
+        if self.native and self.max_grad_norm is None and self.loss_scale is None:
             # multi-GPU: update each bucket's slice as soon as ITS all-reduce is done, under the remaining collectives
             pipelined = self.reducer.finish(self._adamw_range)
         else:
             self.reducer.finish()
         if pipelined:
+            return loss.detach(), sub
+        if self.loss_scale is not None and not self._unscale_or_skip():
             return loss.detach(), sub
         if self.max_grad_norm is not None:
             if self.native:
@@ -205,6 +213,26 @@ class DiffusionTrainer:
             if self.ema is not None:
                 self.ema.lerp_(self.flat.flat, 1.0 - self.ema_decay)
         return loss.detach(), sub
+
+    def _unscale_or_skip(self) -> bool:
+        """GradScaler.step/update: returns False (step skipped, scale halved) when the reduced gradient holds an inf / nan
+        -- every rank sees the same all-reduced values, hence takes the same decision."""
+        g = self.flat.grad
+        if not bool(torch.isfinite(g).all()):
+            g.zero_()
+            self.loss_scale *= 0.5
+            self._clean_steps = 0
+            self.skipped_steps += 1
+            self.iteration -= 1                       # the optimizer's bias correction counts applied steps only
+            if self.ema is not None:                  # the reference updates the EMA after every iteration (:172-174)
+                self.ema.lerp_(self.flat.flat, 1.0 - self.ema_decay)
+            return False
+        g.mul_(1.0 / self.loss_scale)
+        self._clean_steps += 1
+        if self._clean_steps == 2000:
+            self.loss_scale *= 2.0
+            self._clean_steps = 0
+        return True
 
     def _adamw_range(self, s0, e0):
         ema = None if self.ema is None else self.ema[s0:e0]

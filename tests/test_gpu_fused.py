@@ -139,3 +139,30 @@ def test_fused_backbone_matches_module_path():
     assert abs(float(la) - float(lb)) < 5e-3 * abs(float(lb))
     assert rel(ta.flat.flat, tb.flat.flat) < 1e-3
     assert rel(ta.ema, tb.ema) < 1e-4
+
+
+def test_float16_training_with_dynamic_loss_scale():
+    """dtype=float16 (the reference's default --dtype): scaled backward, overflow -> skipped step and halved scale."""
+    from npcd.train import DiffusionTrainer
+    a, b = _models()
+    tr = DiffusionTrainer(a, dtype=torch.float16)
+    ref = DiffusionTrainer(b, dtype=torch.bfloat16, fused=False)
+    assert tr.loss_scale == 65536.0 and a.denoiser.backbone.fused_engine is None        # fp16 runs the module path
+    g = torch.Generator().manual_seed(2)
+    B, N, F_ = 3, 48, 32
+    c0, f0 = torch.randn(B, 3, N, generator=g).cuda(), torch.randn(B, F_, N, generator=g).cuda()
+    t = torch.tensor([7, 400, 900]).cuda()
+    cn, fn = torch.randn(B, 3, N, generator=g).cuda(), torch.randn(B, F_, N, generator=g).cuda()
+    l16, _ = tr.step(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
+    lref, _ = ref.step(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
+    assert torch.isfinite(l16) and abs(float(l16) - float(lref)) < 2e-2 * abs(float(lref))
+    assert tr.skipped_steps == 0 and tr.iteration == 1
+    # after one applied step the two trainers' parameters moved the same way (AdamW's first step is +-lr per element)
+    moved = [(pa - pb).abs().max() for pa, pb in zip(a.parameters(), b.parameters())]
+    assert float(max(moved)) < 3 * tr.lr
+    # force an overflow: the step must be skipped, the scale halved, parameters and step count untouched
+    before = tr.flat.flat.clone()
+    tr.loss_scale = 2.0 ** 40
+    tr.step(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
+    assert tr.skipped_steps == 1 and tr.loss_scale == 2.0 ** 39 and tr.iteration == 1
+    assert torch.equal(tr.flat.flat, before) and float(tr.flat.grad.abs().max()) == 0.0
