@@ -24,6 +24,56 @@ _BLOCK_PARAMS = ("ln_1.weight", "ln_1.bias", "attn.c_qkv.weight", "attn.c_qkv.bi
                  "ln_2.weight", "ln_2.bias", "mlp.c_fc.weight", "mlp.c_fc.bias", "mlp.c_proj.weight", "mlp.c_proj.bias")
 
 
+# ---- token-dimension split of the forward / data-gradient GEMMs ---------------------------------------------------------------
+# The token count of a step is B x (N + 1): the time token makes it 64 x 513 = 32,832 = 128.25 tiles of 256 rows, and hipBLASLt
+# loses 12 % on that quarter tile (measured with tuned solutions, tools/gpu_dev_gemm_m.py: 1683 -> 1475 us per block for the
+# eight GEMMs).  A GEMM does not care which rows it gets, so every [T, K] x [K, N] product is issued as one call on the first
+# T - T % 256 rows and one on the remaining < 256 rows.  The small call runs on a side stream under the large one.
+import os
+
+_SPLIT = 0 if os.environ.get("NPCD_NO_GEMM_SPLIT") else 256       # (the env switch exists for A/B measurements)
+_side_stream = None
+
+
+def _tail_stream():
+    global _side_stream
+    if _side_stream is None:
+        _side_stream = torch.cuda.Stream()
+    return _side_stream
+
+
+def _split_gemm(fn_main, fn_tail, T):
+    """fn_main(slice) / fn_tail(slice) enqueue the product for a row range into a shared output."""
+    Tm = T - T % _SPLIT if _SPLIT else T
+    if Tm == 0 or Tm == T:
+        fn_main(slice(0, T))
+        return
+    main = torch.cuda.current_stream()
+    side = _tail_stream()
+    side.wait_stream(main)                      # the tail's input rows were produced on the main stream
+    with torch.cuda.stream(side):
+        fn_tail(slice(Tm, T))
+    fn_main(slice(0, Tm))
+    main.wait_stream(side)                      # consumers on the main stream see both parts
+
+
+def _linear(bias, x, w16):
+    """x [T, K] bf16, w16 [N, K] bf16, bias [N] bf16 -> x @ w16^T + bias, [T, N] bf16."""
+    T = x.shape[0]
+    out = torch.empty((T, w16.shape[0]), dtype=x.dtype, device=x.device)
+    wt = w16.t()
+    _split_gemm(lambda r: torch.addmm(bias, x[r], wt, out=out[r]), lambda r: torch.addmm(bias, x[r], wt, out=out[r]), T)
+    return out
+
+
+def _dgrad(dy, w16):
+    """dy [T, N] bf16, w16 [N, K] bf16 -> dy @ w16, [T, K] bf16."""
+    T = dy.shape[0]
+    out = torch.empty((T, w16.shape[1]), dtype=dy.dtype, device=dy.device)
+    _split_gemm(lambda r: torch.mm(dy[r], w16, out=out[r]), lambda r: torch.mm(dy[r], w16, out=out[r]), T)
+    return out
+
+
 def _wgrad(dy, x, out):
     """out (fp32 view of the flat gradient) = dy^T @ x, fp32 accumulate AND fp32 output.
 
@@ -83,15 +133,15 @@ class _BackboneFn(torch.autograd.Function):
             for e in eng.blocks:
                 x1, y1, mean1, rstd1 = ew.add_ln_fwd(xs, delta, e["ln_1_weight"], e["ln_1_bias"])
                 x_cur = xs if x1 is None else x1
-                qkv = torch.addmm(e["attn_c_qkv_bias_16"], y1, e["attn_c_qkv_weight_16"].t())
+                qkv = _linear(e["attn_c_qkv_bias_16"], y1, e["attn_c_qkv_weight_16"])
                 q4 = qkv.view(B, n, H, 3 * d)
                 a, lse = hattn._fwd(q4[..., :d], q4[..., d:2 * d], q4[..., 2 * d:], scale)
                 a = a.view(T, W)
-                o = torch.addmm(e["attn_c_proj_bias_16"], a, e["attn_c_proj_weight_16"].t())
+                o = _linear(e["attn_c_proj_bias_16"], a, e["attn_c_proj_weight_16"])
                 x2, y2, mean2, rstd2 = ew.add_ln_fwd(x_cur, o, e["ln_2_weight"], e["ln_2_bias"])
-                h = torch.addmm(e["mlp_c_fc_bias_16"], y2, e["mlp_c_fc_weight_16"].t())
+                h = _linear(e["mlp_c_fc_bias_16"], y2, e["mlp_c_fc_weight_16"])
                 g = ew.gelu_fwd(h)
-                delta = torch.addmm(e["mlp_c_proj_bias_16"], g, e["mlp_c_proj_weight_16"].t())
+                delta = _linear(e["mlp_c_proj_bias_16"], g, e["mlp_c_proj_weight_16"])
                 saved.append((x_cur, mean1, rstd1, y1, qkv, a, lse, x2, mean2, rstd2, y2, h, g))
                 xs = x2
             out = xs + delta                       # fp32 + bf16 -> fp32
@@ -113,18 +163,18 @@ class _BackboneFn(torch.autograd.Function):
                 ctx.saved[bi] = None
                 sums = ew.ColsumBatch()            # this block's 8 bias / LN-affine column sums: one finalize
                 # ---- MLP branch: x3 = x2 + c_proj(gelu(c_fc(ln_2(x2)))) ------------------------------
-                dg = torch.mm(dxb, e["mlp_c_proj_weight_16"])
+                dg = _dgrad(dxb, e["mlp_c_proj_weight_16"])
                 _wgrad(dxb, g, e["mlp_c_proj_weight_g"])
                 dh = ew.gelu_bwd(dg, h, e["mlp_c_fc_bias_g"], batch=sums)
                 del dg, g, h
-                dy2 = torch.mm(dh, e["mlp_c_fc_weight_16"])
+                dy2 = _dgrad(dh, e["mlp_c_fc_weight_16"])
                 _wgrad(dh, y2, e["mlp_c_fc_weight_g"])
                 del dh, y2
                 dx2, dx2b = ew.ln_bwd(dy2, x2, mean2, rstd2, e["ln_2_weight"], dx, e["ln_2_weight_g"], e["ln_2_bias_g"],
                                       e["attn_c_proj_bias_g"], batch=sums)
                 del dy2, x2, dx, dxb
                 # ---- attention branch: x2 = x + c_proj(attn(c_qkv(ln_1(x)))) ---------------------------
-                da = torch.mm(dx2b, e["attn_c_proj_weight_16"])
+                da = _dgrad(dx2b, e["attn_c_proj_weight_16"])
                 _wgrad(dx2b, a, e["attn_c_proj_weight_g"])
                 dqkv = torch.empty_like(qkv)
                 q4, g4 = qkv.view(B, n, H, 3 * d), dqkv.view(B, n, H, 3 * d)
@@ -132,7 +182,7 @@ class _BackboneFn(torch.autograd.Function):
                            g4[..., :d], g4[..., d:2 * d], g4[..., 2 * d:], scale)
                 del da, a, qkv, dx2b
                 ew.colsum_bf16(dqkv, e["attn_c_qkv_bias_g"], batch=sums)
-                dy1 = torch.mm(dqkv, e["attn_c_qkv_weight_16"])
+                dy1 = _dgrad(dqkv, e["attn_c_qkv_weight_16"])
                 _wgrad(dqkv, y1, e["attn_c_qkv_weight_g"])
                 del dqkv, y1
                 prev_bias_g = eng.blocks[bi - 1]["mlp_c_proj_bias_g"] if bi > 0 else None
