@@ -26,35 +26,23 @@ _BLOCK_PARAMS = ("ln_1.weight", "ln_1.bias", "attn.c_qkv.weight", "attn.c_qkv.bi
 
 # ---- token-dimension split of the forward / data-gradient GEMMs ---------------------------------------------------------------
 # The token count of a step is B x (N + 1): the time token makes it 64 x 513 = 32,832 = 128.25 tiles of 256 rows, and hipBLASLt
-# loses 12 % on that quarter tile (measured with tuned solutions, tools/gpu_dev_gemm_m.py: 1683 -> 1475 us per block for the
-# eight GEMMs).  A GEMM does not care which rows it gets, so every [T, K] x [K, N] product is issued as one call on the first
-# T - T % 256 rows and one on the remaining < 256 rows.  The small call runs on a side stream under the large one.
+# loses 12 % on that quarter tile (tools/gpu_dev_gemm_m.py: 1683 -> 1475 us per block for the eight GEMMs).  A GEMM does not
+# care which rows it gets, so every [T, K] x [K, N] product is issued as one call on the last T % 256 rows and one on the rest.
+# Measured in situ (same box, tuned solutions for both): 10.78 -> 11.13 steps/s.  (Tried: the small call on a second stream --
+# its workgroups queue behind the large GEMM's and the join waits for them: no gain at either stream priority.)
 import os
 
 _SPLIT = 0 if os.environ.get("NPCD_NO_GEMM_SPLIT") else 256       # (the env switch exists for A/B measurements)
-_side_stream = None
 
 
-def _tail_stream():
-    global _side_stream
-    if _side_stream is None:
-        _side_stream = torch.cuda.Stream()
-    return _side_stream
-
-
-def _split_gemm(fn_main, fn_tail, T):
-    """fn_main(slice) / fn_tail(slice) enqueue the product for a row range into a shared output."""
+def _split_gemm(fn, T):
+    """fn(rows) enqueues the product for a row range into a shared output."""
     Tm = T - T % _SPLIT if _SPLIT else T
     if Tm == 0 or Tm == T:
-        fn_main(slice(0, T))
+        fn(slice(0, T))
         return
-    main = torch.cuda.current_stream()
-    side = _tail_stream()
-    side.wait_stream(main)                      # the tail's input rows were produced on the main stream
-    with torch.cuda.stream(side):
-        fn_tail(slice(Tm, T))
-    fn_main(slice(0, Tm))
-    main.wait_stream(side)                      # consumers on the main stream see both parts
+    fn(slice(Tm, T))
+    fn(slice(0, Tm))
 
 
 def _linear(bias, x, w16):
@@ -62,7 +50,7 @@ def _linear(bias, x, w16):
     T = x.shape[0]
     out = torch.empty((T, w16.shape[0]), dtype=x.dtype, device=x.device)
     wt = w16.t()
-    _split_gemm(lambda r: torch.addmm(bias, x[r], wt, out=out[r]), lambda r: torch.addmm(bias, x[r], wt, out=out[r]), T)
+    _split_gemm(lambda r: torch.addmm(bias, x[r], wt, out=out[r]), T)
     return out
 
 
@@ -70,7 +58,7 @@ def _dgrad(dy, w16):
     """dy [T, N] bf16, w16 [N, K] bf16 -> dy @ w16, [T, K] bf16."""
     T = dy.shape[0]
     out = torch.empty((T, w16.shape[1]), dtype=dy.dtype, device=dy.device)
-    _split_gemm(lambda r: torch.mm(dy[r], w16, out=out[r]), lambda r: torch.mm(dy[r], w16, out=out[r]), T)
+    _split_gemm(lambda r: torch.mm(dy[r], w16, out=out[r]), T)
     return out
 
 
