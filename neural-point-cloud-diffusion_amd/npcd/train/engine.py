@@ -55,9 +55,12 @@ class GradReducer:
     produces them); a bucket's collective is launched from the post-accumulate-grad hook of its last
     parameter to become ready.  `finish()` waits for all of them."""
 
-    def __init__(self, flat: FlatBuffers, group=None, bucket_bytes: int = 64 << 20):
+    def __init__(self, flat: FlatBuffers, group=None, bucket_bytes: int = 64 << 20, always_reduce: bool = False):
+        """always_reduce: run the collectives also on a one-rank group (lets a single-GPU box exercise the RCCL code path:
+        ReduceOp.AVG, async work handles, stream ordering -- RCCL refuses two ranks on one device)."""
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.active = self.world > 1 or (always_reduce and dist.is_available() and dist.is_initialized())
         self.handles = []
         self.buckets = []           # (start, end) element ranges
         self.param_bucket = {}      # id(param) -> bucket index
@@ -74,7 +77,7 @@ class GradReducer:
         if members:
             self._close(members, start_of, end)
         self._avg = None
-        if self.world > 1:
+        if self.active:
             for p in flat.params:
                 p.register_post_accumulate_grad_hook(self._hook)
 
@@ -103,7 +106,7 @@ class GradReducer:
 
     def mark_ready(self, p):
         """For gradients written outside autograd (the fused backbone backward)."""
-        if self.world > 1:
+        if self.active:
             self._hook(p)
 
     def _hook(self, p):
@@ -116,7 +119,7 @@ class GradReducer:
         """Wait for every bucket's collective.  `on_bucket_ready(start, end)` is called right after the wait of
         each bucket (in launch order): work it enqueues on the current stream only depends on THAT bucket's
         all-reduce, so it overlaps with the collectives still in flight (used to pipeline the optimizer)."""
-        if self.world == 1:
+        if not self.active:
             return False
         for b, left in enumerate(self._left):     # parameters that received no gradient this step
             if left > 0:
@@ -137,11 +140,11 @@ class DiffusionTrainer:
 
     def __init__(self, diffusion: nn.Module, lr: float = 7e-5, weight_decay: float = 0.01, ema_decay: Optional[float] = 0.9999,
                  dtype: Optional[torch.dtype] = torch.bfloat16, group=None, bucket_bytes: int = 64 << 20, max_grad_norm=None,
-                 fused: bool = True):
+                 fused: bool = True, always_reduce: bool = False):
         self.model = diffusion
         self.dtype = dtype
         self.flat = FlatBuffers(diffusion)
-        self.reducer = GradReducer(self.flat, group, bucket_bytes)
+        self.reducer = GradReducer(self.flat, group, bucket_bytes, always_reduce)
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, (0.9, 0.999), 1e-8
         self.ema_decay = ema_decay
         self.ema = self.flat.flat.clone() if ema_decay is not None else None

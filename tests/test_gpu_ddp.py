@@ -75,3 +75,37 @@ def test_two_ranks_equal_one_rank_full_batch():
     cos = float((upd_ref * upd_ddp).sum() / (upd_ref.norm() * upd_ddp.norm()))
     assert cos > 0.98, cos
     assert float(upd_ddp.norm()) == pytest.approx(float(upd_ref.norm()), rel=0.05)
+
+
+def _nccl_worker(rank, world, port, out):
+    from conftest import PKG, ROOT  # noqa: F401
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    try:
+        from npcd.train import DiffusionTrainer
+        tr = DiffusionTrainer(_build(), bucket_bytes=256 << 10, always_reduce=True)
+        assert tr.reducer.active and tr.reducer.world == 1 and len(tr.reducer.buckets) > 2
+        c0, f0, t, cn, fn = (x.cuda() for x in _batch())
+        for _ in range(2):
+            loss, _ = tr.step(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
+        assert len(tr.reducer.launched) == len(tr.reducer.buckets)
+        torch.cuda.synchronize()
+        out[0] = (tr.flat.flat.cpu(), tr.ema.cpu(), float(loss))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_code_path_on_a_one_rank_group():
+    """The bucketed async all-reduce (ReduceOp.AVG) + pipelined optimizer on a real RCCL communicator of one rank must
+    reproduce the plain single-process trainer bit for bit."""
+    from npcd.train import DiffusionTrainer
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_nccl_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    p0, e0, l0 = out[0]
+    tr = DiffusionTrainer(_build())
+    c0, f0, t, cn, fn = (x.cuda() for x in _batch())
+    for _ in range(2):
+        loss, _ = tr.step(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
+    assert torch.equal(tr.flat.flat.cpu(), p0) and torch.equal(tr.ema.cpu(), e0) and float(loss) == l0
