@@ -537,7 +537,82 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
             if (lane == 0) out_ss[slot] = s;
         }
     };
-    for (int slot = 0; slot < nsel; ++slot) process(slot, u32x2{0u, 0u});
+    // Table path with a window of <= 32 voxels (the reference's 3^3): TWO slots per trip, one per 32-lane half.  Lanes 0..26 of
+    // a half fetch its slot's window voxels, the sorted list of a half lives in its lanes 0..7, and one trip of the insertion
+    // loop takes one candidate of each half.  Same arithmetic per slot as `process`, i.e. the same bits out.
+    auto process2 = [&](int pair) {
+        const int h = lane >> 5, l32 = lane & 31;
+        const int slot = 2 * pair + h;
+        const bool live = slot < nsel;                                  // uniform per half
+        const int s = mysel[live ? slot : 2 * pair];
+        float p[3];
+        sample_pos(a, ray, s, o, d, t0, t1, p);
+        const FineCoord fc = fine_coord(a.g, p[0], p[1], p[2]);
+        uint32_t key_hi = 0xffffffffu, key_lo = 0xffffffffu;
+        auto insert2 = [&](unsigned long long cm, float d2, int jj) {
+            uint32_t c0 = (uint32_t)cm, c1 = (uint32_t)(cm >> 32);
+            while (c0 | c1) {                                           // wave-uniform
+                const bool v0 = c0 != 0u, v1 = c1 != 0u;
+                const int b0 = v0 ? __ffs((int)c0) - 1 : 0, b1 = v1 ? __ffs((int)c1) - 1 : 0;
+                c0 &= c0 - 1u;                                          // (0 stays 0)
+                c1 &= c1 - 1u;
+                const uint32_t ch0 = __builtin_amdgcn_readlane(__float_as_uint(d2), b0), cl0 = (uint32_t)__builtin_amdgcn_readlane(jj, b0);
+                const uint32_t ch1 = __builtin_amdgcn_readlane(__float_as_uint(d2), 32 + b1), cl1 = (uint32_t)__builtin_amdgcn_readlane(jj, 32 + b1);
+                const uint32_t ch = h ? ch1 : ch0, cl = h ? cl1 : cl0;
+                const bool vv = h ? v1 : v0;
+                const bool le = (key_hi < ch) || (key_hi == ch && key_lo < cl);
+                const unsigned long long lm = __ballot(le);
+                const int pos = h ? __popc((uint32_t)(lm >> 32) & 0xffu) : __popc((uint32_t)lm & 0xffu);
+                const uint32_t up_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key_hi, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+                const uint32_t up_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key_lo, 0x111, 0xf, 0xf, false);
+                if (vv && pos < 8) {
+                    if (l32 == pos) { key_hi = ch; key_lo = cl; }
+                    else if (l32 > pos) { key_hi = up_hi; key_lo = up_lo; }
+                }
+            }
+        };
+        const int ky = a.g.kernel_size[1], kz = a.g.kernel_size[2], nk = a.g.kernel_size[0] * ky * kz;
+        int cand_idx[4] = {-1, -1, -1, -1};
+        if (live && l32 < nk) {
+            const int vx = fc.c[0] + l32 / (ky * kz) - hx, vy = fc.c[1] + (l32 / kz) % ky - hy, vz = fc.c[2] + l32 % kz - hz;
+            if (vx >= 0 && vy >= 0 && vz >= 0 && vx < a.g.dims[0] && vy < a.g.dims[1] && vz < a.g.dims[2]) {
+                const int64_t vox = (int64_t)b * a.g.dims[0] * a.g.dims[1] * a.g.dims[2] + ((int64_t)vx * a.g.dims[1] + vy) * a.g.dims[2] + vz;
+                const u32x2 raw = *reinterpret_cast<const u32x2*>(a.table + vox * 4);
+                cand_idx[0] = (int)(int16_t)(raw[0] & 0xffffu); cand_idx[1] = (int)(int16_t)(raw[0] >> 16);
+                cand_idx[2] = (int)(int16_t)(raw[1] & 0xffffu); cand_idx[3] = (int)(int16_t)(raw[1] >> 16);
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+            const int j = cand_idx[qi];
+            bool cand = false;
+            float d2 = 0.f;
+            if (j >= 0) {
+                const float4 q = pts[j];
+                const float dx = p[0] - q.x, dy = p[1] - q.y, dz = p[2] - q.z;
+                d2 = (dx * dx + dy * dy) + dz * dz;
+                cand = d2 < a.r2;
+            }
+            insert2(__ballot(cand), d2, j);
+        }
+        const bool has = key_lo != 0xffffffffu;
+        const unsigned long long hm = __ballot(has);
+        if (COMPACT) {
+            if (live && l32 < 8) stage_idx[(wave * 64 + slot) * 8 + l32] = has ? gbase + (int)key_lo : -1;
+            if (live && l32 < 3) stage_pos[(wave * 64 + slot) * 4 + l32] = l32 == 0 ? p[0] : (l32 == 1 ? p[1] : p[2]);
+            if (hm & 1ull) valid_bits |= (1ull << (2 * pair));
+            if ((hm >> 32) & 1ull) valid_bits |= (1ull << (2 * pair + 1));          // a dead upper half has no entries
+        } else {
+            if (live && l32 < a.k) out_idx[slot * a.k + l32] = has ? gbase + (int)key_lo : -1;
+            if (live && l32 < 3) out_loc[slot * 3 + l32] = l32 == 0 ? p[0] : (l32 == 1 ? p[1] : p[2]);
+            if (live && l32 == 0) out_ss[slot] = s;
+        }
+    };
+    if (a.table && a.g.kernel_size[0] * a.g.kernel_size[1] * a.g.kernel_size[2] <= 32) {
+        for (int pair = 0; 2 * pair < nsel; ++pair) process2(pair);
+    } else {
+        for (int slot = 0; slot < nsel; ++slot) process(slot, u32x2{0u, 0u});
+    }
     if (COMPACT) {
         const int cnt = __popcll(valid_bits);
         int base = 0;
