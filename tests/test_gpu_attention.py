@@ -73,7 +73,7 @@ def test_attention_golden(golden, tag, dtype):
     assert rel_l2(out, torch.from_numpy(g["out"])) < 2e-2
 
 
-@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 192, 513, 700])
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 192, 193, 256, 384, 448, 513, 576, 700, 1025])
 def test_attention_ragged_lengths(n):
     gen = torch.Generator().manual_seed(n)
     B, H = 2, 3
