@@ -221,3 +221,19 @@ def test_generate_reverse_step_and_sampler(golden):
     assert all(torch.isfinite(x).all() for x in coords + feats)
     with pytest.raises(AssertionError):
         model.train().generate(1)
+
+
+def test_attention_is_bitwise_reproducible():
+    """No atomics and fixed summation orders in all three kernels: two runs give identical bits (full BASELINE cfg 2 size)."""
+    from npcd.hip.attention import attention_qkvpacked
+    B, n, H, d = 64, 513, 16, 64
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    qkv = torch.randn(B, n, 3 * H * d, device="cuda", generator=gen).bfloat16()
+    gout = torch.randn(B, n, H * d, device="cuda", generator=gen).bfloat16()
+    res = []
+    for _ in range(2):
+        x = qkv.clone().requires_grad_(True)
+        out = attention_qkvpacked(x, H)
+        out.backward(gout)
+        res.append((out.detach().clone(), x.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
