@@ -208,6 +208,17 @@ int npcd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* sha
                    float ema_decay, int zero_grad, void* stream);
 int npcd_cast_f32_bf16(const float* src, void* dst, int64_t numel, void* stream);
 
+/* One DDPM reverse step of the sampler, fused (reference gaussian_diffusion.py:100-146: _predict_xstart_from_eps :127-129,
+ * clamp :111-113, posterior mean :88-98, noise add :138-144):
+ *   x0 = recip[t] x_t - recipm1[t] eps (clamped to [clip_lo, clip_hi] if has_clip); x_prev = coef1[t] x0 + coef2[t] x_t
+ *        + [t > 0] exp(logvar[t] / 2) noise.
+ * x_t, noise, x_prev (and x0_out, may be NULL) are fp32 [B, per_sample]; eps is fp32 or bf16 (eps_dtype); t is int64 [B];
+ * the five tables are the process's fp32 [num_timesteps] device arrays. */
+int npcd_ddpm_reverse_step(const float* x_t, const void* eps, int eps_dtype, const float* noise, float* x_prev, float* x0_out,
+                           const int64_t* t, int B, int64_t per_sample, const float* tab_recip, const float* tab_recipm1,
+                           const float* tab_coef1, const float* tab_coef2, const float* tab_logvar, float clip_lo, float clip_hi,
+                           int has_clip, void* stream);
+
 /* ray march on the compact layout of npcd_grid_query_compact (same math as npcd_ray_march) */
 int npcd_ray_march_compact(const float* sigma, const float* rgb, const uint64_t* ray_bits, const float* pts,
                            const int32_t* ray_base, const float* rays_o, const float* rays_d, const float* t1,

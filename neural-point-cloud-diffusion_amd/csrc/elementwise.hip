@@ -344,6 +344,29 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const f32x4* __restrict_
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) dst[i] = f32_to_bf16x4(src[i]);
 }
 
+// DDPM reverse step (gaussian_diffusion.py:100-146 of the reference): x0 = a x_t - b eps (clamped), mean = c1 x0 + c2 x_t,
+// x_{t-1} = mean + [t > 0] exp(logvar / 2) noise; the five per-sample coefficients are looked up from the 1000-entry tables.
+struct DdpmTables {
+    const float *recip, *recipm1, *c1, *c2, *logvar;
+};
+template <class EPS>
+__global__ __launch_bounds__(256) void ddpm_reverse_kernel(const float* __restrict__ x_t, const EPS* __restrict__ eps, const float* __restrict__ noise,
+                                                           float* __restrict__ x_prev, float* __restrict__ x0_out, const int64_t* __restrict__ t,
+                                                           int64_t per_sample, DdpmTables tab, float lo, float hi, int has_clip) {
+    const int b = blockIdx.y;
+    const int64_t ts = t[b];
+    const float a = tab.recip[ts], bb = tab.recipm1[ts], c1 = tab.c1[ts], c2 = tab.c2[ts];
+    const float sd = ts != 0 ? expf(0.5f * tab.logvar[ts]) : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
+        const int64_t j = (int64_t)b * per_sample + i;
+        const float x = x_t[j];
+        float x0 = a * x - bb * (float)eps[j];
+        if (has_clip) x0 = fminf(fmaxf(x0, lo), hi);
+        if (x0_out) x0_out[j] = x0;
+        x_prev[j] = (c1 * x0 + c2 * x) + sd * noise[j];
+    }
+}
+
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace npcd
@@ -479,6 +502,26 @@ extern "C" int npcd_adamw_ema(float* p, float* g, float* m, float* v, float* ema
     hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<f32x4*>(p),
                        reinterpret_cast<f32x4*>(g), reinterpret_cast<f32x4*>(m), reinterpret_cast<f32x4*>(v), reinterpret_cast<f32x4*>(ema),
                        static_cast<bf16x4*>(shadow_bf16), n4, a, zero_grad);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int npcd_ddpm_reverse_step(const float* x_t, const void* eps, int eps_dtype, const float* noise, float* x_prev, float* x0_out,
+                                      const int64_t* t, int B, int64_t per_sample, const float* tab_recip, const float* tab_recipm1,
+                                      const float* tab_coef1, const float* tab_coef2, const float* tab_logvar, float clip_lo, float clip_hi,
+                                      int has_clip, void* stream) {
+    if (!x_t || !eps || !noise || !x_prev || !t || B <= 0 || per_sample <= 0) return NPCD_ERR_ARG;
+    if (!tab_recip || !tab_recipm1 || !tab_coef1 || !tab_coef2 || !tab_logvar) return NPCD_ERR_ARG;
+    if (eps_dtype != NPCD_F32 && eps_dtype != NPCD_BF16) return NPCD_ERR_UNSUPPORTED;
+    const DdpmTables tab{tab_recip, tab_recipm1, tab_coef1, tab_coef2, tab_logvar};
+    const int gx = (int)((per_sample + 255) / 256 < 1024 ? (per_sample + 255) / 256 : 1024);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (eps_dtype == NPCD_F32)
+        hipLaunchKernelGGL(ddpm_reverse_kernel<float>, dim3(gx, B), dim3(256), 0, st, x_t, static_cast<const float*>(eps), noise, x_prev, x0_out, t,
+                           per_sample, tab, clip_lo, clip_hi, has_clip);
+    else
+        hipLaunchKernelGGL(ddpm_reverse_kernel<__bf16>, dim3(gx, B), dim3(256), 0, st, x_t, static_cast<const __bf16*>(eps), noise, x_prev, x0_out, t,
+                           per_sample, tab, clip_lo, clip_hi, has_clip);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }

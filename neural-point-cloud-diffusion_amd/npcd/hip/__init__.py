@@ -50,6 +50,7 @@ SIGNATURES = {
     "npcd_colsum_scratch_rows": (c_int, []),
     "npcd_colsum_finalize": (c_int, [_P, c_int, c_int, _P, c_int, _P]),
     "npcd_colsum_finalize_batch": (c_int, [_P, c_int, _P]),
+    "npcd_ddpm_reverse_step": (c_int, [_P, _P, c_int, _P, _P, _P, _P, c_int, c_int64, _P, _P, _P, _P, _P, c_float, c_float, c_int, _P]),
     "npcd_gelu_fwd": (c_int, [_P, _P, c_int64, _P]),
     "npcd_colsum_blocks": (c_int, [c_int]),
     "npcd_gelu_bwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),

@@ -134,3 +134,19 @@ def adamw_ema(p, g, m, v, ema, shadow, lr, beta1, beta2, eps, weight_decay, step
 def cast_f32_bf16(src, dst):
     check(lib().npcd_cast_f32_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr()), "npcd_cast_f32_bf16")
     return dst
+
+
+def ddpm_reverse_step(x_t, eps, noise, t, tables, clip=None, want_x0=False):
+    """Fused reverse step of the sampler.  x_t / noise fp32 [B, ...], eps fp32 or bf16 (same shape), t int64 [B], tables = the five
+    fp32 device tables (sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_mean_coef1, posterior_mean_coef2,
+    posterior_log_variance_clipped), clip = (lo, hi) floats or None -> x_{t-1} (and the clamped x0 when want_x0)."""
+    require_gpu(x_t)
+    x_t, noise, eps = x_t.contiguous(), noise.contiguous(), eps.contiguous()
+    B = x_t.shape[0]
+    out = torch.empty_like(x_t)
+    x0 = torch.empty_like(x_t) if want_x0 else None
+    code = {torch.float32: 2, torch.bfloat16: 0}[eps.dtype]
+    lo, hi = (float(clip[0]), float(clip[1])) if clip is not None else (0.0, 0.0)
+    check(lib().npcd_ddpm_reverse_step(ptr(x_t), ptr(eps), code, ptr(noise), ptr(out), ptr(x0), ptr(t), B, x_t.numel() // B,
+                                       *[ptr(tb) for tb in tables], lo, hi, int(clip is not None), stream_ptr()), "npcd_ddpm_reverse_step")
+    return out, x0

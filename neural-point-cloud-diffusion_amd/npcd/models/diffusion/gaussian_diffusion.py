@@ -97,17 +97,80 @@ class GaussianDiffusion(nn.Module):
         f_next, f_rec = self._reverse_one(feats_t, eps_f.float(), t, feats_clipping_range)
         return c_next, c_rec, f_next, f_rec
 
+    # ---- fused sampler (device-resident tables, one HIP kernel per tensor for the posterior update) -------------
+    def _device_tables(self, device):
+        key = str(device)
+        if getattr(self, "_tab_key", None) != key:
+            self._tab = [tb.to(device=device, dtype=torch.float32).contiguous() for tb in
+                         (self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1,
+                          self.posterior_mean_coef2, self.posterior_log_variance_clipped)]
+            self._tab_key = key
+        return self._tab
+
+    @staticmethod
+    def _scalar_clip(clip):
+        """(lo, hi) floats when the clip range is one scalar pair (the reference's default, clip_per_axis=False), else None"""
+        if clip is None:
+            return False, None
+        lo, hi = clip
+        if torch.is_tensor(lo) and (lo.numel() != 1 or hi.numel() != 1):
+            return True, None
+        return True, (float(lo), float(hi))
+
+    def p_sample_fused(self, denoise_fn, coords_t, feats_t, t, coords_clip, feats_clip):
+        """Same step as p_sample with the elementwise posterior update of each tensor in ONE kernel (npcd_ddpm_reverse_step);
+        clip ranges are (lo, hi) float pairs or None.  eps may stay bf16 (autocast)."""
+        from ...hip import elementwise as ew
+        tabs = self._device_tables(coords_t.device)
+        eps_c, eps_f = denoise_fn(coords_t, feats_t, t)
+        eps_c = eps_c if eps_c.dtype in (torch.float32, torch.bfloat16) else eps_c.float()
+        eps_f = eps_f if eps_f.dtype in (torch.float32, torch.bfloat16) else eps_f.float()
+        c_next, _ = ew.ddpm_reverse_step(coords_t, eps_c, torch.randn_like(coords_t), t, tabs, coords_clip)
+        f_next, _ = ew.ddpm_reverse_step(feats_t, eps_f, torch.randn_like(feats_t), t, tabs, feats_clip)
+        return c_next, f_next
+
     def p_sample_loop(self, denoise_fn, coords_start, feats_start, coords_clip_range=None, feats_clip_range=None,
-                      progress=False):
+                      progress=False, use_graph=False):
+        """1000 reverse steps (reference :148-177 without the trajectory lists).  On the GPU with scalar clip ranges every step
+        runs the fused posterior update; `use_graph` additionally captures one whole step (denoiser forward + update, fixed
+        batch) in a HIP graph and replays it -- the per-step launch work (~600 launches at 24 layers) leaves the host."""
         steps = range(self.num_timesteps - 1, -1, -1)
         if progress:
             from tqdm.auto import tqdm
             steps = tqdm(steps)
         c, f = coords_start, feats_start
+        has_c, clip_c = self._scalar_clip(coords_clip_range)
+        has_f, clip_f = self._scalar_clip(feats_clip_range)
+        fused = c.is_cuda and c.dtype == torch.float32 and not (has_c and clip_c is None) and not (has_f and clip_f is None)
+        if not fused:
+            for i in steps:
+                t = torch.full((c.shape[0],), i, device=c.device, dtype=torch.long)
+                c, _, f, _ = self.p_sample(denoise_fn, c, f, t, coords_clip_range, feats_clip_range)
+            return c, f
+        t = torch.empty((c.shape[0],), device=c.device, dtype=torch.long)
+        if not use_graph:
+            for i in steps:
+                t.fill_(i)
+                c, f = self.p_sample_fused(denoise_fn, c, f, t, clip_c, clip_f)
+            return c, f
+        # graph replay: static input / output buffers, the timestep is a device tensor updated between replays
+        sc, sf = c.clone(), f.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            t.fill_(self.num_timesteps - 1)
+            for _ in range(2):                                  # warm-up outside capture (lazy initialisations)
+                self.p_sample_fused(denoise_fn, sc, sf, t, clip_c, clip_f)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            oc, of = self.p_sample_fused(denoise_fn, sc, sf, t, clip_c, clip_f)
         for i in steps:
-            t = torch.full((c.shape[0],), i, device=c.device, dtype=torch.long)
-            c, _, f, _ = self.p_sample(denoise_fn, c, f, t, coords_clip_range, feats_clip_range)
-        return c, f
+            t.fill_(i)
+            graph.replay()
+            sc.copy_(oc)
+            sf.copy_(of)
+        return sc.clone(), sf.clone()
 
     def p_sample_loop_trajectory(self, denoise_fn, coords_start, feats_start, coords_clip_range=None,
                                  feats_clip_range=None, progress=False):

@@ -212,6 +212,11 @@ def test_generate_reverse_step_and_sampler(golden):
     rf1, rf0 = odf.p_sample_step(tab, f_t, ef, t, nf.cpu(), clip_f)
     for a, b in ((c1, rc1), (c0, rc0), (f1, rf1), (f0, rf0)):
         assert float((a.cpu() - b).abs().max()) < 2e-4
+    # the fused posterior update (one kernel per tensor) draws the same noise in the same order: same step
+    torch.manual_seed(77)
+    with torch.no_grad():
+        fc1, ff1 = gd.p_sample_fused(model.denoiser, c_t.cuda(), f_t.cuda(), t.cuda(), (-2.0, 2.5), (-1.0, 1.0))
+    assert float((fc1 - c1).abs().max()) < 1e-5 and float((ff1 - f1).abs().max()) < 1e-5
     # full sampling loop on a shortened chain
     gd.num_timesteps = 12
     model.coords_normalization.min.fill_(-3); model.coords_normalization.max.fill_(3)
@@ -219,6 +224,22 @@ def test_generate_reverse_step_and_sampler(golden):
     coords, feats = model.generate(3, batch_size=2, progress=False)
     assert len(coords) == 3 and coords[0].shape == (3, N) and feats[0].shape == (F_, N)
     assert all(torch.isfinite(x).all() for x in coords + feats)
+    # same seed: the fused loop reproduces the step-by-step reference formulation
+    torch.manual_seed(5)
+    a_c, a_f = model.generate(2, batch_size=2, progress=False)
+    torch.manual_seed(5)
+    c = torch.randn(2, 3, N, device="cuda"); f = torch.randn(2, F_, N, device="cuda")
+    with torch.no_grad():
+        for i in range(11, -1, -1):
+            tt = torch.full((2,), i, device="cuda", dtype=torch.long)
+            c, _, f, _ = gd.p_sample(model.denoiser, c, f, tt, (model.coords_normalization.min, model.coords_normalization.max),
+                                     (model.feats_normalization.min, model.feats_normalization.max))
+    assert float((torch.stack(a_c) - model.coords_normalization(c)).abs().max()) < 1e-4
+    assert float((torch.stack(a_f) - model.feats_normalization(f)).abs().max()) < 1e-4
+    # bf16 autocast + HIP-graph replay of the reverse step
+    coords, feats = model.generate(4, batch_size=4, progress=False, dtype=torch.bfloat16, use_graph=True)
+    assert len(coords) == 4 and all(torch.isfinite(x).all() for x in coords + feats)
+    assert float(torch.stack(coords).abs().max()) <= 3.0 + 1e-5          # x0 clipping was applied on the last step
     with pytest.raises(AssertionError):
         model.train().generate(1)
 
