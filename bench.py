@@ -229,10 +229,14 @@ def main():
     if ew_ms:
         dom = max(ew_ms, key=lambda k: ew_ms[k] * len(ew_events[k]))
         gbs = {k: ew_bytes[k] / (ew_ms[k] * 1e-3) / 1e9 for k in ew_ms}
-        hbm = {"kernel": {"add_ln_fwd": "add_ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel", "gelu_fwd": "gelu_fwd_kernel",
-                          "gelu_bwd": "colsum_kernel<GELU>"}[dom],
+        hname = {"add_ln_fwd": "add_ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel", "gelu_fwd": "gelu_fwd_kernel", "gelu_bwd": "colsum_kernel<true>"}[dom]
+        htraffic, hfile = None, os.path.join(ROOT, "profiles", "r1_elementwise_hbm_traffic_pmc.json")
+        if per == 64 and os.path.exists(hfile):         # PMC-measured bytes per launch at exactly this shape (rocprofv3 --pmc passes)
+            htraffic = json.load(open(hfile)).get(hname, {}).get("hbm_bytes")
+        hbm = {"kernel": hname,
                "bound": "hbm", "achieved": gbs[dom], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs[dom] / PEAK_HBM_GBS,
-               "traffic": None, "algorithmic_bytes_per_launch": ew_bytes[dom], "avg_ms": ew_ms[dom], "launches": len(ew_events[dom]),
+               "traffic": htraffic, "traffic_source": "profiles/r1_elementwise_hbm_traffic_pmc.json" if htraffic else None,
+               "algorithmic_bytes_per_launch": ew_bytes[dom], "avg_ms": ew_ms[dom], "launches": len(ew_events[dom]),
                "all_elementwise_kernels_ms": ew_ms, "all_elementwise_kernels_gbs": gbs}
 
     result = {
