@@ -160,6 +160,12 @@ __device__ __forceinline__ float enc_value(int q, const float rel[3]) {
 // ============================================================================================
 // kernel A: (point, neighbour) pairs.  tile = 16 points x 8 neighbour slots = 128 rows
 // ============================================================================================
+#ifdef NPCD_SHADE_TL
+__device__ long long g_shade_tl[64];
+#define NPCD_STS(i) do { if (tl_on && tile == tl_tile) tl[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NPCD_STS(i) do { } while (0)
+#endif
 template <int FEAT>
 __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
     constexpr int K0 = FEAT + kEncBlock;
@@ -173,7 +179,14 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
     const int P = *a.n_points;
     const int ntiles = (P + 15) / 16;
 
+#ifdef NPCD_SHADE_TL
+    const bool tl_on = blockIdx.x == NPCD_SHADE_TL && wave == 0;
+    const int tl_tile = blockIdx.x + 3 * gridDim.x;
+    long long tl[16];
+    for (int i = 0; i < 16; ++i) tl[i] = 0;
+#endif
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        NPCD_STS(0);
         // ---- prologue: build the layer-0 input rows -------------------------------------------
         // The tile's 16 x 8 (point, slot) candidates are PACKED: a valid pair takes the row number "valid pairs before
         // it", so the rows of a point stay consecutive and the unused rows collect at the end of the tile, where whole
@@ -235,20 +248,31 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
                 for (int c8 = 0; c8 < 4; ++c8) *reinterpret_cast<f16x8*>(H + act_off(row, FEAT / 8 + half * 4 + c8)) = z;
             }
         }
+        NPCD_STS(1);
         __syncthreads();
+        NPCD_STS(2);
         // ---- four non-linear layers ---------------------------------------------------------
         f32x16 acc[2][4];
         layer_mfma<K0 / 16, K0 / 16>(H, a.wpack + L.w[0], reinterpret_cast<const float*>(a.wpack + L.bias[0]), wave, lane, acc, nblk);
+        NPCD_STS(3);
         __syncthreads();
+        NPCD_STS(4);
         layer_store<true>(H, wave, lane, acc, nblk);
+        NPCD_STS(5);
         __syncthreads();
+        NPCD_STS(6);
 #pragma unroll 1
         for (int l = 1; l < 4; ++l) {
             layer_mfma<kHidden / 16, kHidden / 16>(H, a.wpack + L.w[l], reinterpret_cast<const float*>(a.wpack + L.bias[l]), wave, lane, acc, nblk);
+            if (l == 1) NPCD_STS(7);
             __syncthreads();
+            if (l == 1) NPCD_STS(8);
             layer_store<true>(H, wave, lane, acc, nblk);
+            if (l == 1) NPCD_STS(9);
             __syncthreads();
+            if (l == 1) NPCD_STS(10);
         }
+        NPCD_STS(11);
         // ---- inverse-distance aggregation over the 8 neighbour slots ------------------------
         {
             const int pl = tid >> 4, cc = tid & 15;  // point, 16-channel chunk
@@ -277,9 +301,22 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
                 gp[1] = o1;
             }
         }
+        NPCD_STS(12);
         __syncthreads();
+        NPCD_STS(13);
     }
+#ifdef NPCD_SHADE_TL
+    if (tl_on && lane == 0)
+        for (int i = 0; i < 16; ++i) g_shade_tl[i] = tl[i];
+#endif
 }
+#ifdef NPCD_SHADE_TL
+}
+extern "C" int npcd_shade_debug_read(long long* out, int count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(npcd::g_shade_tl), sizeof(long long) * count);
+}
+namespace npcd {
+#endif
 
 // ============================================================================================
 // kernel B: points.  tile = 128 points

@@ -1,0 +1,21 @@
+"""Dev probe (diagnostic build -DNPCD_SHADE_TL=<block>): s_memtime stamps of one tile of one workgroup of shade_pairs."""
+import sys, os, ctypes
+R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R_); sys.path.insert(0, os.path.join(R_, "neural-point-cloud-diffusion_amd"))
+import torch
+from oracle import renderer as orr
+from npcd.models.pointnerf import PointNeRF
+from npcd.hip import lib
+coords, feats = orr.synthetic_cloud(512, 32, 1, seed=0)
+model = PointNeRF(1, 32, 512, False); model.field.load_state_dict(orr.init_field_params(32, seed=0)); model = model.cuda().eval()
+extr = orr.look_at_pose(30, 20)[None, None].cuda(); intr = orr.srn_intrinsics()[None, None].cuda()
+with torch.no_grad():
+    for _ in range(5): model.render(coords.cuda(), feats.cuda(), extr, intr, 128)
+torch.cuda.synchronize()
+buf = (ctypes.c_longlong * 16)()
+L = lib(); L.npcd_shade_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+L.npcd_shade_debug_read(ctypes.cast(buf, ctypes.c_void_p), 16)
+names = ["tile start", "prologue done", "barrier", "L0 mfma", "barrier", "L0 store", "barrier", "L1 mfma", "barrier", "L1 store", "barrier", "L2,L3 done", "aggregation", "barrier"]
+t = list(buf); prev = t[0]
+for i, x in enumerate(t[:14]):
+    print(f"{i:2d} {names[i]:16s} +{x - prev:7d}  (={x - t[0]})"); prev = x
