@@ -98,6 +98,35 @@ def bench_render(device, n_iters=10, burn_in=3):
             "mlp_frac_of_f16_mfma_peak": flops / dt / 1e12 / PEAK_BF16_TFLOPS}
 
 
+def bench_stage1(device, n_iters=5, burn_in=2):
+    """Stage-1 (PointNeRF autodecoder) training step at the reference's configuration (configs/npcd_srncars.yaml:13-16,
+    data/srn.py:45: 8 objects x 50 views per step, 112 random rays per view, 128 depth samples, Adam lr 1e-3): secondary
+    figure for SURVEY §8(f) rank 2.  Synthetic clouds / poses / target images."""
+    from npcd.models import NPCD
+    from npcd.train import PointNeRFTrainer
+    from npcd.utils import synthetic as orr
+    B, T, N, F_, res = 8, 50, 512, 32, 128
+    torch.manual_seed(0)
+    net = NPCD(n_obj=B, coords_dim=3, feats_dim=F_, num_points=N, use_view_dir=False, width=64, layers=1, heads=1, pointnerf_only=True).to(device)
+    coords, _ = orr.ellipsoid_cloud(N, F_, B, seed=0)
+    net.pointnerf.set_all_coords(coords.to(device))
+    extr = torch.stack([orr.look_at_pose(7.2 * i, 20 - 0.5 * i) for i in range(T)])[None].expand(B, -1, -1, -1).contiguous().to(device)
+    intr = orr.srn_intrinsics()[None, None].expand(B, T, 3, 3).contiguous().to(device)
+    sample = {"images": torch.rand(B, T, 3, res, res, device=device), "intrinsics": intr, "extrinsics": extr,
+              "obj_idx": torch.arange(B, device=device)}
+    tr = PointNeRFTrainer(net)
+    for _ in range(burn_in):
+        tr.step(sample)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_iters):
+        loss, _ = tr.step(sample)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n_iters
+    return {"steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "objects": B, "views_per_object": T, "rays_per_view": net.pointnerf.renderer.ray_subsamples,
+            "loss": float(loss), "differentiable_part": "torch autograd on the device (first version); ray generation and both neighbour queries: HIP"}
+
+
 def cpu_baseline():
     """The CPU oracle (a restatement of the reference, `kind: port`) timed on this box's host cores:
     one fp32 denoiser train step (fwd + bwd + AdamW) at B=2 of the same architecture, scaled to the
@@ -273,6 +302,10 @@ def main():
             dist.all_reduce(tt)
             r["rays_per_s_all_gpus"] = float(tt)
         result["render"] = r
+        try:
+            result["stage1_pointnerf_training"] = bench_stage1(device)
+        except Exception as e:                      # noqa: BLE001
+            result["stage1_pointnerf_training"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -137,6 +137,10 @@ int npcd_grid_query_compact(const npcd_grid_params* g, const void* workspace, co
  * ------------------------------------------------------------------------------------------ */
 int npcd_ray_gen(const float* extr, const float* intr, int V, int res, float box,
                  float* rays_o, float* rays_d, float* t0, float* t1, float* limits_ws, void* stream);
+/* Same for a subset of the pixels: pixel_ids [n_ids] int32 row-major pixel numbers (i * res + j), the same for every view
+ * (the training path renders ~100 random pixels per view: renderer.py:232-238) -> rays_o/rays_d [V,n_ids,3], t0/t1 [V,n_ids]. */
+int npcd_ray_gen_subset(const float* extr, const float* intr, int V, int res, float box, const int32_t* pixel_ids, int n_ids,
+                        float* rays_o, float* rays_d, float* t0, float* t1, float* limits_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused shading of compact shading points (aggregators/mlp.py:36-125, fields/mlp.py:38-72,

@@ -36,15 +36,18 @@ __global__ void limits_init_kernel(uint32_t* ws) {
     ws[3] = 0u;
 }
 
+// pixel_ids (may be NULL): the n_ids pixels (row-major ids, the same for every view) to generate rays for -- the training
+// path renders ~100 random pixels per view; without it all res^2 pixels of every view are generated
 __global__ __launch_bounds__(256) void ray_gen_kernel(const float* __restrict__ extr, const float* __restrict__ intr, int V, int res,
-                                                      float box, float* __restrict__ rays_o, float* __restrict__ rays_d,
-                                                      float* __restrict__ t0, float* __restrict__ t1, uint32_t* ws) {
-    const int R = res * res;
+                                                      float box, const int32_t* __restrict__ pixel_ids, int n_ids, float* __restrict__ rays_o,
+                                                      float* __restrict__ rays_d, float* __restrict__ t0, float* __restrict__ t1, uint32_t* ws) {
+    const int R = pixel_ids ? n_ids : res * res;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool hit = false;
     float tmin = -1.f, tmax = -2.f;
     if (gid < (int64_t)V * R) {
-        const int v = (int)(gid / R), ray = (int)(gid % R);
+        const int v = (int)(gid / R);
+        const int ray = pixel_ids ? pixel_ids[gid % R] : (int)(gid % R);
         const float* E = extr + v * 16;
         const float* K = intr + v * 9;
         const float fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
@@ -737,18 +740,30 @@ __global__ __launch_bounds__(256) void depth_clamp_kernel(int Nr, float* __restr
 using namespace npcd;
 
 // --------------------------------------------------------------------------------------------
-extern "C" int npcd_ray_gen(const float* extr, const float* intr, int V, int res, float box, float* rays_o, float* rays_d,
-                            float* t0, float* t1, float* limits_ws, void* stream) {
+static int ray_gen_launch(const float* extr, const float* intr, int V, int res, float box, const int32_t* pixel_ids, int n_ids, float* rays_o,
+                          float* rays_d, float* t0, float* t1, float* limits_ws, void* stream) {
     if (!extr || !intr || !rays_o || !rays_d || !t0 || !t1 || !limits_ws || V <= 0 || res <= 0) return NPCD_ERR_ARG;
+    if (pixel_ids && n_ids <= 0) return NPCD_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int64_t n = (int64_t)V * res * res;
+    const int64_t n = (int64_t)V * (pixel_ids ? (int64_t)n_ids : (int64_t)res * res);
     const int grid = (int)((n + 255) / 256);
     uint32_t* ws = reinterpret_cast<uint32_t*>(limits_ws);
     hipLaunchKernelGGL(limits_init_kernel, dim3(1), dim3(1), 0, st, ws);
-    hipLaunchKernelGGL(ray_gen_kernel, dim3(grid), dim3(256), 0, st, extr, intr, V, res, box, rays_o, rays_d, t0, t1, ws);
+    hipLaunchKernelGGL(ray_gen_kernel, dim3(grid), dim3(256), 0, st, extr, intr, V, res, box, pixel_ids, n_ids, rays_o, rays_d, t0, t1, ws);
     hipLaunchKernelGGL(ray_limits_fix_kernel, dim3(grid), dim3(256), 0, st, n, t0, t1, ws);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
+}
+
+extern "C" int npcd_ray_gen(const float* extr, const float* intr, int V, int res, float box, float* rays_o, float* rays_d,
+                            float* t0, float* t1, float* limits_ws, void* stream) {
+    return ray_gen_launch(extr, intr, V, res, box, nullptr, 0, rays_o, rays_d, t0, t1, limits_ws, stream);
+}
+
+extern "C" int npcd_ray_gen_subset(const float* extr, const float* intr, int V, int res, float box, const int32_t* pixel_ids, int n_ids,
+                                   float* rays_o, float* rays_d, float* t0, float* t1, float* limits_ws, void* stream) {
+    if (!pixel_ids) return NPCD_ERR_ARG;
+    return ray_gen_launch(extr, intr, V, res, box, pixel_ids, n_ids, rays_o, rays_d, t0, t1, limits_ws, stream);
 }
 
 static int grid_check(const npcd_grid_params* g, int B, int N) {

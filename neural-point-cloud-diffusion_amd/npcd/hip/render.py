@@ -24,14 +24,27 @@ def make_grid_params(voxel_size, voxel_scale, kernel_size, max_points_per_voxel,
     return g
 
 
-def ray_gen(extr: torch.Tensor, intr: torch.Tensor, res: int, box: float = 1.0):
-    """extr [V,4,4] world2cam, intr [V,3,3] -> rays_o, rays_d [V,R,3], t0, t1 [V,R] (R = res*res).
-    ray_sampler.py:10-49 + renderer.py:36-47 (rays that miss the cube get the global limits)."""
+def ray_gen(extr: torch.Tensor, intr: torch.Tensor, res: int, box: float = 1.0, pixel_ids=None):
+    """extr [V,4,4] world2cam, intr [V,3,3] -> rays_o, rays_d [V,R,3], t0, t1 [V,R] (R = res*res, or len(pixel_ids) when a
+    subset of row-major pixel numbers is given).  ray_sampler.py:10-49 + renderer.py:36-47 (rays that miss the cube get the
+    global limits of the generated set)."""
     require_gpu(extr, intr)
     extr = extr.to(_f32).contiguous()
     intr = intr.to(_f32).contiguous()
-    V, R = extr.shape[0], res * res
+    V = extr.shape[0]
     dev = extr.device
+    if pixel_ids is not None:
+        ids = pixel_ids.to(device=dev, dtype=_i32).contiguous()
+        R = ids.numel()
+        o = torch.empty((V, R, 3), dtype=_f32, device=dev)
+        d = torch.empty((V, R, 3), dtype=_f32, device=dev)
+        t0 = torch.empty((V, R), dtype=_f32, device=dev)
+        t1 = torch.empty((V, R), dtype=_f32, device=dev)
+        ws = torch.empty(4, dtype=_f32, device=dev)
+        check(lib().npcd_ray_gen_subset(ptr(extr), ptr(intr), V, res, float(box), ptr(ids), R, ptr(o), ptr(d), ptr(t0), ptr(t1), ptr(ws),
+                                        stream_ptr()), "npcd_ray_gen_subset")
+        return o, d, t0, t1
+    R = res * res
     o = torch.empty((V, R, 3), dtype=_f32, device=dev)
     d = torch.empty((V, R, 3), dtype=_f32, device=dev)
     t0 = torch.empty((V, R), dtype=_f32, device=dev)

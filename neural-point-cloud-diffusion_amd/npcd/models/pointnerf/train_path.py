@@ -2,8 +2,8 @@
 per view with jittered depth samples, differentiable w.r.t. the neural-point features and the field weights.
 
 First version of this row.  Geometry -- ray generation and the neighbour query -- runs on the HIP kernels
-(npcd.hip.render); the differentiable part (per-pair MLP, aggregation, heads, ray march: ~1e5 pairs per step, three
-orders of magnitude less work than one evaluation view) is written with torch operators on the device so that autograd
+(npcd.hip.render); the differentiable part (per-pair MLP, aggregation, heads, ray march: ~1e6 (point, neighbour) pairs per
+step at the reference's 8 objects x 50 views x 112 rays) is written with torch operators on the device so that autograd
 provides the backward; its GEMMs are library calls.  Nothing here runs on the CPU: the neighbour query fails loudly
 without the HIP library.
 
@@ -116,14 +116,15 @@ def render_train(renderer, kp_pos, kp_feat, extr, intr, resolution: int, sample:
     field, agg = renderer.field, renderer.field.aggregator
     B, T = extr.shape[:2]
     dev = kp_pos.device
-    o, d, _, _ = hr.ray_gen(extr.flatten(0, 1), intr.flatten(0, 1), resolution, renderer.cube_scale)
-    R = o.shape[1]
-    o, d = o.view(B, T, R, 3), d.view(B, T, R, 3)
-    ray_ids = torch.arange(R, device=dev)
+    R = resolution * resolution
     if renderer.ray_subsamples and sample:          # the same random rays for every (object, view) instance
         perm = rng["ray_perm"].to(dev) if "ray_perm" in rng else torch.randperm(R, device=dev)
         ray_ids = perm[:renderer.ray_subsamples].long()
-        o, d = o[:, :, ray_ids], d[:, :, ray_ids]
+        o, d, _, _ = hr.ray_gen(extr.flatten(0, 1), intr.flatten(0, 1), resolution, renderer.cube_scale, pixel_ids=ray_ids)
+    else:
+        ray_ids = torch.arange(R, device=dev)
+        o, d, _, _ = hr.ray_gen(extr.flatten(0, 1), intr.flatten(0, 1), resolution, renderer.cube_scale)
+    o, d = o.view(B, T, -1, 3), d.view(B, T, -1, 3)
     Rs = o.shape[2]
     start, end = box_limits(o, d, renderer.cube_scale)
     S = renderer.depth_resolution
