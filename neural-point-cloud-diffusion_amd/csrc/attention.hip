@@ -11,13 +11,16 @@
 // as the B operand of O^T = V^T P^T -- no LDS round trip for P (cdna_hip_programming.md §3,
 // "An accumulator tile as the next MFMA's operand").
 //
-//   fwd  : one wave = 32 query rows, workgroup = 4 waves = 128 rows; 64-key K / V^T tiles are
-//          double-buffered in LDS (32 KiB) and shared by the 4 waves.
-//   dq   : same decomposition; per key tile S^T, dP^T = V dO^T, dQ^T += K^T dS^T; also emits
-//          delta = rowsum(dO * O).
-//   dkdv : one wave = 32 keys (on the lanes), workgroup = 128 keys; loops over 64-row query
-//          tiles; S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS.  No atomics: dq and
-//          dk/dv come from two passes that each own their outputs (deterministic).
+//   fwd  : one wave = 32 query rows, workgroup = 4 waves = 128 rows; 64-key K / V tiles stream through a 3-slot LDS ring
+//          (LDS-DMA) shared by the 4 waves.
+//   dq   : same decomposition; per key half S^T, dP^T = V dO^T, dQ^T += K^T dS^T; also writes the per-row constants of the
+//          dK/dV pass (-lse/scale, -rowsum(dO * O)).
+//   dkdv : one wave = 32 keys (on the lanes), workgroup = 128 keys; Q / dO tiles of 64 rows stream through the ring;
+//          S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS.  No atomics: dq and dk/dv come from two passes that each
+//          own their outputs (deterministic).
+// All three run the same software pipeline (a stage = one 32-row half tile; the products consuming the previous half's P / dS
+// are issued behind the next half's score products) and the same ring protocol (see kv_mid); DESIGN.md 5.1 has the details
+// and the measurements.
 #include <math.h>
 
 #include "common.h"
@@ -47,25 +50,8 @@ struct AttnParams {
     float scale, scale_log2;
 };
 
-// ---- tile staging (256 threads, 64 rows x 64 sixteen-bit elements) --------------------------
-// thread t loads rows 2(t>>3), 2(t>>3)+1, 16-byte element chunk t&7 (8 lanes cover one 128-byte row);
-// the same registers feed the row-major image and/or the transposed image.
-// Rows past the end are CLAMPED to the last valid row instead of being predicated: the loads stay
-// branch-free (so the compiler can use counted s_waitcnt vmcnt(N) and keep a later tile in flight) and
-// the duplicated rows are neutralised downstream (masked scores / P = 0 / outputs never stored).
-template <class E>
-__device__ __forceinline__ void pair_load(u32x4 (&reg)[2], const E* base, int64_t row_stride, int row0, int nrows, int tid) {
-    const int grow = row0 + 2 * (tid >> 3);
-    const int r0 = min(grow, nrows - 1), r1 = min(grow + 1, nrows - 1);
-    reg[0] = *reinterpret_cast<const u32x4*>(base + r0 * row_stride + (tid & 7) * 8);
-    reg[1] = *reinterpret_cast<const u32x4*>(base + r1 * row_stride + (tid & 7) * 8);
-}
-// row-major image [row][64]
-__device__ __forceinline__ void rm_store(unsigned char* lds, const u32x4 (&reg)[2], int tid) {
-    const int row = 2 * (tid >> 3), dc = tid & 7;
-    *reinterpret_cast<u32x4*>(lds + tile_off(row, dc)) = reg[0];
-    *reinterpret_cast<u32x4*>(lds + tile_off(row + 1, dc)) = reg[1];
-}
+// Rows past the end of a sequence are CLAMPED to the last valid row instead of being predicated (the duplicated rows are
+// neutralised downstream: masked scores / P = 0 / outputs never stored).
 // ---- LDS-DMA staging ----------------------------------------------------------------------------
 // Two 64x64 tiles (A at buf, B at buf+8192) are filled by 16 global_load_lds_dwordx4 pieces of 1 KiB
 // (8 rows x 128 B); wave w issues 4 of them (waves 0,1: tile A, waves 2,3: tile B).  The LDS destination of
@@ -213,63 +199,14 @@ __device__ __forceinline__ TrPair tr_issue_at(const FragAddr& fa, int db) {
     t.hi = tr_issue_imm<TILE + G16 * 2048>(fa.tr[db][1]);
     return t;
 }
-__device__ __forceinline__ TrPair tr_issue(const unsigned char* tile, int g16, int db, int lane) {
-    const int grp = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h = grp >> 1;
-    const int col = db * 32 + 16 * (grp & 1) + 4 * pp;
-    const int r0 = 16 * g16 + 4 * h + q;
-    TrPair t;
-    t.lo = tr_issue_one(lds_addr(tile + tile_off(r0, col >> 3) + (col & 7) * 2));
-    t.hi = tr_issue_one(lds_addr(tile + tile_off(r0 + 8, col >> 3) + (col & 7) * 2));
-    return t;
-}
 __device__ __forceinline__ void tr_wait() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
-// compiler-scheduled variant (ds_read_tr builtin) for kernels without LDS-DMA in flight
-template <class TR>
-__device__ __forceinline__ typename TR::vec8 tr_frag(const unsigned char* tile, int g16, int db, int lane) {
-    const int grp = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, h = grp >> 1;
-    const int col = db * 32 + 16 * (grp & 1) + 4 * pp;
-    const int r0 = 16 * g16 + 4 * h + q;
-    const typename TR::vec4 lo = TR::tr_read(tile + tile_off(r0, col >> 3) + (col & 7) * 2);
-    const typename TR::vec4 hi = TR::tr_read(tile + tile_off(r0 + 8, col >> 3) + (col & 7) * 2);
-    typename TR::vec8 v;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        v[j] = lo[j];
-        v[4 + j] = hi[j];
-    }
-    return v;
-}
-
 template <class TR>
 __device__ __forceinline__ typename TR::vec8 tr_vec(const TrPair& t) {
     const u32x4 x = {t.lo[0], t.lo[1], t.hi[0], t.hi[1]};
     return __builtin_bit_cast(typename TR::vec8, x);
-}
-
-template <class TR>
-__device__ __forceinline__ typename TR::vec8 lds_frag(const unsigned char* tile, int row, int chunk) {
-    return *reinterpret_cast<const typename TR::vec8*>(tile + tile_off(row, chunk));
-}
-
-// store one wave's 64(d) x 32(rows on lanes) transposed accumulator pair as rows of [.., 64]
-template <class TR>
-__device__ __forceinline__ void store_rows(typename TR::elem* row_ptr, const f32x16& a0, const f32x16& a1, float mul, int hh) {
-    using V4 = typename TR::vec4;
-    using E = typename TR::elem;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        V4 x, y;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            x[b] = (E)(a0[4 * g + b] * mul);
-            y[b] = (E)(a1[4 * g + b] * mul);
-        }
-        *reinterpret_cast<V4*>(row_ptr + 8 * g + 4 * hh) = x;
-        *reinterpret_cast<V4*>(row_ptr + 32 + 8 * g + 4 * hh) = y;
-    }
 }
 
 // two fp32 -> one packed 16-bit pair (v_cvt_pk_*)
@@ -793,10 +730,6 @@ __global__ __launch_bounds__(256, NPCD_DQ_WAVES) void attn_bwd_dq_kernel(AttnPar
 // constants of the 64 query rows written by the dQ pass: -lse/scale [64] and -delta [64] (fp32).
 constexpr int kDkdvSlot = 2 * 8192 + 512;
 
-__device__ __forceinline__ f32x4 lds_f32x4_at(uint32_t addr) {
-    typedef __attribute__((address_space(3))) const f32x4 lds_f4;
-    return *reinterpret_cast<lds_f4*>((uintptr_t)addr);
-}
 
 // per-wave LDS-DMA context of the dK/dV pass: waves 0,1 stream the Q tile, waves 2,3 the dO tile (32 rows each);
 // waves with an even / odd index also fetch the 64 -lse/scale / -delta values of the tile (4 bytes per lane).
