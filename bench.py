@@ -184,11 +184,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # NPCD_BENCH_DRYRUN_ONE_GPU=1 (tests only): all ranks share cuda:0 and talk through gloo, so that the multi-rank code path
+    # of this script can be exercised on a one-GPU box (RCCL refuses two ranks on one device)
+    dryrun = bool(os.environ.get("NPCD_BENCH_DRYRUN_ONE_GPU"))
+    if dryrun:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)     # "nccl" is RCCL on ROCm
+        if dryrun:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)     # "nccl" is RCCL on ROCm
     if CFG["global_batch"] % world:
         raise SystemExit("global batch 64 must be divisible by the number of GPUs")
     per = CFG["global_batch"] // world

@@ -31,6 +31,24 @@ def test_bench_json_contract():
     assert "error" not in d["render"] and d["render"]["rays_per_s"] > 1e6
 
 
+def test_bench_multi_rank_code_path_dry_run():
+    """The driver's N > 1 launch line (torch.distributed.run, one rank per GPU) on a ONE-GPU box: two ranks share cuda:0 over
+    gloo (NPCD_BENCH_DRYRUN_ONE_GPU).  Checks the rank-0-only JSON line, the whole-job aggregation and strong scaling."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, NPCD_BENCH_DRYRUN_ONE_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == 64 and d["config"]["per_gpu_batch"] == 32
+    assert d["config"]["parallelism"] == "dp2" and d["value"] == pytest.approx(1000.0 / d["ms_per_step"], rel=1e-6)
+    assert "rays_per_s_all_gpus" in d["render"]
+
+
 def test_smoke_entry():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py"), "smoke"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])

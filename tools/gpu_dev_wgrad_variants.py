@@ -1,6 +1,7 @@
 """Dev probe: weight-gradient GEMM formulations (bf16 in, fp32 out) for the four Linear shapes of a block at T = 32832."""
 import torch
-T = 32832
+import sys
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 32832
 dev = "cuda"
 f32 = torch.float32
 def timeit(fn, reps=20):
