@@ -12,6 +12,7 @@ nn.Parameter is a view), likewise gradients, Adam moments and the EMA copy.  The
 EMA are then single elementwise passes over 310 M contiguous floats and the gradient all-reduce
 works on slices of one buffer -- no per-tensor launches, no flatten/unflatten copies.
 """
+import os
 from typing import List, Optional
 
 import torch
@@ -21,16 +22,19 @@ import torch.nn as nn
 
 class FlatBuffers:
     """Re-home the trainable parameters of `module` into one flat buffer (+ flat grads)."""
+    ALIGN = 256
 
     def __init__(self, module: nn.Module):
         self.params: List[nn.Parameter] = [p for p in module.parameters() if p.requires_grad]
         assert self.params, "no trainable parameters"
         dev, dt = self.params[0].device, self.params[0].dtype
         assert all(p.dtype == dt and p.device == dev for p in self.params)
+        # every view starts on a multiple of ALIGN elements: 16-byte aligned for the vector kernels, and every bucket of the
+        # gradient reducer (a union of whole parameters) then splits into equal, 16-byte aligned shards for up to 64 ranks
         self.offsets, n = [], 0
         for p in self.params:
             self.offsets.append(n)
-            n += (p.numel() + 3) // 4 * 4                 # keep every view 16-byte aligned
+            n += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.numel = n
         self.flat = torch.zeros(n, dtype=dt, device=dev)
         self.grad = torch.zeros(n, dtype=dt, device=dev)
@@ -61,6 +65,11 @@ class GradReducer:
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.active = self.world > 1 or (always_reduce and dist.is_available() and dist.is_initialized())
+        self.rank = dist.get_rank(group) if self.active else 0
+        # sharded mode (set by the trainer): reduce-scatter the gradient buckets, every rank updates 1/world of each bucket,
+        # all-gather the parameters -- the optimizer pass (38 bytes per parameter) shrinks by the number of ranks
+        self.shard = False
+        self.gshard = None
         self.handles = []
         self.buckets = []           # (start, end) element ranges
         self.param_bucket = {}      # id(param) -> bucket index
@@ -88,6 +97,18 @@ class GradReducer:
             self.param_bucket[id(p)] = b
         self.pending.append(len(members))
 
+    def enable_sharding(self) -> bool:
+        """Needs equal 16-byte aligned shards: (bucket length) % (4 * world) == 0 for every bucket."""
+        if not self.active or any((e - s) % (4 * self.world) for s, e in self.buckets):
+            return False
+        self.shard = True
+        self.gshard = torch.empty(self.flat.numel // self.world, dtype=self.flat.grad.dtype, device=self.flat.grad.device)
+        return True
+
+    def shard_range(self, s, e):
+        n = (e - s) // self.world
+        return s + self.rank * n, s + (self.rank + 1) * n
+
     def start_step(self):
         self.handles = []
         self.launched = []          # bucket index of every handle, in launch order
@@ -99,6 +120,11 @@ class GradReducer:
         buf = self.flat.grad[s:e]
         if self._avg is None:       # RCCL has a native average; gloo (CPU tests) does not
             self._avg = dist.get_backend(self.group) == "nccl"
+        if self.shard:
+            out = self.gshard[s // self.world:e // self.world]
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            self.handles.append((dist.reduce_scatter_tensor(out, buf, op=op, group=self.group, async_op=True), None if self._avg else out))
+            return
         if self._avg:
             self.handles.append((dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
         else:
@@ -140,7 +166,10 @@ class DiffusionTrainer:
 
     def __init__(self, diffusion: nn.Module, lr: float = 7e-5, weight_decay: float = 0.01, ema_decay: Optional[float] = 0.9999,
                  dtype: Optional[torch.dtype] = torch.bfloat16, group=None, bucket_bytes: int = 64 << 20, max_grad_norm=None,
-                 fused: bool = True, always_reduce: bool = False):
+                 fused: bool = True, always_reduce: bool = False, shard_optimizer: Optional[bool] = None):
+        """shard_optimizer (default: on whenever gradients are exchanged on the native path without clipping / loss scaling):
+        ZeRO-1 style -- reduce-scatter instead of all-reduce, each rank runs AdamW + EMA on 1/world of every bucket, the updated
+        parameters are all-gathered.  Same bytes on the wire as the all-reduce, optimizer pass divided by the number of ranks."""
         self.model = diffusion
         self.dtype = dtype
         self.flat = FlatBuffers(diffusion)
@@ -168,8 +197,16 @@ class DiffusionTrainer:
             self.shadow = torch.empty(self.flat.numel, dtype=torch.bfloat16, device=self.flat.flat.device)
             ew.cast_f32_bf16(self.flat.flat, self.shadow)
             denoiser = getattr(diffusion, "denoiser", None)
+            fused_ids = set()
             if denoiser is not None and dtype == torch.bfloat16 and denoiser.backbone.width // denoiser.backbone.resblocks[0].attn.heads == 64:
                 denoiser.backbone.fused_engine = FusedBackboneEngine(denoiser.backbone, self.flat, self.shadow, self.reducer)
+                fused_ids = {id(p) for e in denoiser.backbone.fused_engine.blocks for p in e["params"]}
+            # parameters whose gradients ACCUMULATE through autograd (everything outside the fused backbone, which overwrites):
+            # their gradient ranges must be zeroed every step when the fused optimizer kernel only sees a shard of them
+            self._accum_ranges = [(off, p.numel()) for p, off in zip(self.flat.params, self.flat.offsets) if id(p) not in fused_ids]
+            want = shard_optimizer if shard_optimizer is not None else not os.environ.get("NPCD_NO_SHARD_OPTIMIZER")
+            if want and self.reducer.active and max_grad_norm is None and self.loss_scale is None:
+                self.reducer.enable_sharding()
         else:
             # reference path (CPU tests / ablation): torch AdamW over ONE flat "parameter"
             self.master = nn.Parameter(self.flat.flat, requires_grad=True)
@@ -178,6 +215,7 @@ class DiffusionTrainer:
 
     def ema_state_dict(self):
         """state_dict of the EMA model: same keys as the running model (utils/ema.py:80), buffers copied."""
+        self.gather_ema()
         sd = {k: v.clone() for k, v in self.model.state_dict().items()}
         names = {id(p): n for n, p in self.model.named_parameters()}
         for p, off in zip(self.flat.params, self.flat.offsets):
@@ -194,7 +232,12 @@ class DiffusionTrainer:
         (loss if self.loss_scale is None else loss * self.loss_scale).backward()
         self.iteration += 1
         pipelined = False
-        if self.native and self.max_grad_norm is None and self.loss_scale is None:
+        if self.native and self.reducer.shard:
+            self._gathers = []
+            pipelined = self.reducer.finish(self._adamw_shard)
+            if pipelined:
+                self._finish_shards()
+        elif self.native and self.max_grad_norm is None and self.loss_scale is None:
             # multi-GPU: update each bucket's slice as soon as ITS all-reduce is done, under the remaining collectives
             pipelined = self.reducer.finish(self._adamw_range)
         else:
@@ -242,6 +285,36 @@ class DiffusionTrainer:
         self._ew.adamw_ema(self.flat.flat[s0:e0], self.flat.grad[s0:e0], self.exp_avg[s0:e0], self.exp_avg_sq[s0:e0], ema,
                            self.shadow[s0:e0], self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.iteration,
                            self.ema_decay, zero_grad=True)
+
+    # ---- sharded optimizer (ZeRO-1 style) ---------------------------------------------------------------------------
+    def _adamw_shard(self, s0, e0):
+        """called when bucket [s0, e0)'s reduce-scatter is done: update this rank's shard, start the parameter all-gather"""
+        red = self.reducer
+        a, b = red.shard_range(s0, e0)
+        g = red.gshard[s0 // red.world:e0 // red.world]
+        ema = None if self.ema is None else self.ema[a:b]
+        self._ew.adamw_ema(self.flat.flat[a:b], g, self.exp_avg[a:b], self.exp_avg_sq[a:b], ema, self.shadow[a:b], self.lr, self.betas[0],
+                           self.betas[1], self.eps, self.weight_decay, self.iteration, self.ema_decay, zero_grad=False)
+        mine = self.flat.flat[a:b].clone()            # out-of-place gather: the output range contains the input range
+        h = dist.all_gather_into_tensor(self.flat.flat[s0:e0], mine, group=red.group, async_op=True)
+        self._gathers.append((h, mine, s0, e0))
+
+    def _finish_shards(self):
+        for h, _, s0, e0 in self._gathers:            # parameters of the other ranks' shards have arrived: refresh the bf16 shadow
+            h.wait()
+            self._ew.cast_f32_bf16(self.flat.flat[s0:e0], self.shadow[s0:e0])
+        self._gathers = []
+        for off, n in self._accum_ranges:             # (the fused backbone overwrites its gradients; these accumulate)
+            self.flat.grad[off:off + n].zero_()
+
+    def gather_ema(self):
+        """EMA shards -> the full EMA vector on every rank (before exporting / evaluating the EMA model)."""
+        red = self.reducer
+        if self.ema is None or not red.shard or red.world == 1:
+            return
+        for s0, e0 in red.buckets:
+            a, b = red.shard_range(s0, e0)
+            dist.all_gather_into_tensor(self.ema[s0:e0], self.ema[a:b].clone(), group=red.group)
 
     def _clip_native(self):
         norm = torch.linalg.vector_norm(self.flat.grad)

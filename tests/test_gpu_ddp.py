@@ -43,14 +43,21 @@ def _worker(rank, world, port, out):
     try:
         from npcd.train import DiffusionTrainer
         torch.cuda.set_device(0)
-        tr = DiffusionTrainer(_build(), bucket_bytes=256 << 10)
-        assert tr.reducer.world == 2 and len(tr.reducer.buckets) > 2
         c0, f0, t, cn, fn = (x.cuda() for x in _batch())
         sl = slice(rank * 2, rank * 2 + 2)
-        for _ in range(2):
-            loss, _ = tr.step(c0[sl], f0[sl], t=t[sl], coords_noise=cn[sl], feats_noise=fn[sl])
-        torch.cuda.synchronize()
-        out[rank] = (tr.flat.flat.cpu(), tr.ema.cpu(), float(loss))
+        res = {}
+        for shard in (True, False):           # sharded optimizer (reduce-scatter / all-gather, the default) vs plain all-reduce
+            tr = DiffusionTrainer(_build(), bucket_bytes=256 << 10, shard_optimizer=shard)
+            assert tr.reducer.world == 2 and len(tr.reducer.buckets) > 2 and tr.reducer.shard == shard
+            for _ in range(2):
+                loss, _ = tr.step(c0[sl], f0[sl], t=t[sl], coords_noise=cn[sl], feats_noise=fn[sl])
+            torch.cuda.synchronize()
+            tr.gather_ema()
+            res[shard] = (tr.flat.flat.cpu(), tr.ema.cpu(), float(loss), tr.shadow.float().cpu())
+        assert torch.equal(res[True][0], res[False][0]), "sharded optimizer diverged from the all-reduce path (parameters)"
+        assert torch.equal(res[True][1], res[False][1]), "sharded optimizer diverged from the all-reduce path (EMA)"
+        assert torch.equal(res[True][3], res[False][3]), "bf16 shadow of the parameters differs"
+        out[rank] = res[True][:3]
     finally:
         dist.destroy_process_group()
 
@@ -85,7 +92,7 @@ def _nccl_worker(rank, world, port, out):
     try:
         from npcd.train import DiffusionTrainer
         tr = DiffusionTrainer(_build(), bucket_bytes=256 << 10, always_reduce=True)
-        assert tr.reducer.active and tr.reducer.world == 1 and len(tr.reducer.buckets) > 2
+        assert tr.reducer.active and tr.reducer.world == 1 and len(tr.reducer.buckets) > 2 and tr.reducer.shard
         c0, f0, t, cn, fn = (x.cuda() for x in _batch())
         for _ in range(2):
             loss, _ = tr.step(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
