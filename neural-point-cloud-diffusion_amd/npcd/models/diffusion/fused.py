@@ -109,6 +109,53 @@ class FusedBackboneEngine:
         return _BackboneFn.apply(x, self)
 
 
+class InferenceWeights:
+    """bf16 copies of the block weights for the forward-only path of a backbone that is not attached to a trainer
+    (sampling from a loaded checkpoint).  Rebuilt when a parameter was written to or replaced since the copy was taken."""
+
+    def __init__(self, backbone):
+        self.heads = backbone.resblocks[0].attn.heads
+        self.params = [[dict(blk.named_parameters())[n] for n in _BLOCK_PARAMS] for blk in backbone.resblocks]
+        self.stamp, self.blocks = None, None
+
+    def current(self):
+        stamp = [(p._version, p.data_ptr()) for ps in self.params for p in ps]
+        if stamp != self.stamp:
+            self.blocks = []
+            for ps in self.params:
+                e = {}
+                for n, p in zip(_BLOCK_PARAMS, ps):
+                    key = n.replace(".", "_")
+                    e[key] = p.data
+                    if not n.startswith("ln_"):
+                        e[key + "_16"] = p.data.to(_bf16)
+                self.blocks.append(e)
+            self.stamp = stamp
+        return self.blocks
+
+
+def backbone_forward(x, blocks, heads):
+    """Forward only (sampler, evaluation): the kernels of the training forward, nothing kept for a backward.
+    x [B, n, W] fp32 -> [B, n, W] fp32."""
+    B, n, W = x.shape
+    T, d = B * n, W // heads
+    scale = 1.0 / math.sqrt(d)
+    with torch.autocast("cuda", enabled=False):
+        xs = x.reshape(T, W).contiguous()
+        delta = None
+        for e in blocks:
+            x1, y1, _, _ = ew.add_ln_fwd(xs, delta, e["ln_1_weight"], e["ln_1_bias"])
+            x_cur = xs if x1 is None else x1
+            q4 = _linear(e["attn_c_qkv_bias_16"], y1, e["attn_c_qkv_weight_16"]).view(B, n, heads, 3 * d)
+            a, _ = hattn._fwd(q4[..., :d], q4[..., d:2 * d], q4[..., 2 * d:], scale)
+            o = _linear(e["attn_c_proj_bias_16"], a.view(T, W), e["attn_c_proj_weight_16"])
+            xs, y2, _, _ = ew.add_ln_fwd(x_cur, o, e["ln_2_weight"], e["ln_2_bias"])
+            g = ew.gelu_fwd(_linear(e["mlp_c_fc_bias_16"], y2, e["mlp_c_fc_weight_16"]))
+            delta = _linear(e["mlp_c_proj_bias_16"], g, e["mlp_c_proj_weight_16"])
+        out = xs + delta
+    return out.view(B, n, W)
+
+
 class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, eng):

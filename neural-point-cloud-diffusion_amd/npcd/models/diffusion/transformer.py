@@ -98,12 +98,23 @@ class Transformer(nn.Module):
             ResidualAttentionBlock(width=width, heads=heads, init_scale=std, use_flash_attn=use_flash_attn)
             for _ in range(layers))
         self.fused_engine = None        # set by npcd.train.DiffusionTrainer (explicit fwd/bwd over flat buffers)
+        self._infer_weights = None      # bf16 weight copies of the forward-only path (sampler), built on first use
 
     def forward(self, x):
         eng = self.fused_engine
-        if (eng is not None and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
-                and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
-            return eng(x)
+        if (x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+            if torch.is_grad_enabled():
+                if eng is not None:
+                    return eng(x)
+            else:
+                # sampling / evaluation under bf16 autocast: fused forward-only kernels (fused.backbone_forward)
+                from . import fused
+                if eng is not None:
+                    return fused.backbone_forward(x, eng.blocks, eng.heads)
+                if self._infer_weights is None:
+                    self._infer_weights = fused.InferenceWeights(self)
+                return fused.backbone_forward(x, self._infer_weights.current(), self._infer_weights.heads)
         for blk in self.resblocks:
             x = blk(x)
         return x

@@ -141,6 +141,49 @@ def test_fused_backbone_matches_module_path():
     assert rel(ta.ema, tb.ema) < 1e-4
 
 
+def test_forward_only_backbone_for_sampling():
+    """no_grad + bf16 autocast (the sampler / evaluation): fused forward-only kernels vs the module path and vs fp32; the
+    bf16 weight copies follow in-place parameter updates; with a trainer attached the trainer's shadow weights are used."""
+    a, b = _models()
+    a.eval(); b.eval()
+    g = torch.Generator().manual_seed(2)
+    B, N, F_ = 3, 48, 32
+    c, f = torch.randn(B, 3, N, generator=g).cuda(), torch.randn(B, F_, N, generator=g).cuda()
+    t = torch.tensor([3, 400, 999]).cuda()
+    bb = a.denoiser.backbone
+    with torch.no_grad():
+        ref32 = torch.cat(b.denoiser(c, f, t), dim=1)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got = torch.cat(a.denoiser(c, f, t), dim=1)
+            assert bb._infer_weights is not None                  # the forward-only path ran
+            h = torch.randn(B, N + 1, bb.width, generator=g).cuda()
+            fused_out = bb(h)
+            x = h
+            for blk in bb.resblocks:                              # the nn.Module path under the same autocast
+                x = blk(x)
+            assert rel(fused_out, x) < 1e-2
+    assert rel(got, ref32) < 2e-2
+    # in-place update of a weight -> the bf16 copy is refreshed
+    with torch.no_grad():
+        bb.resblocks[0].mlp.c_fc.weight.mul_(1.5)
+        b.denoiser.backbone.resblocks[0].mlp.c_fc.weight.mul_(1.5)
+        ref2 = torch.cat(b.denoiser(c, f, t), dim=1)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got2 = torch.cat(a.denoiser(c, f, t), dim=1)
+    assert rel(got2, ref2) < 2e-2 and rel(got2, got) > 1e-3
+    # attached to a trainer: evaluation uses the trainer's bf16 shadow, which follows the optimizer steps
+    from npcd.train import DiffusionTrainer
+    a.train()
+    tr = DiffusionTrainer(a, fused=True)
+    tr.step(c, f, t=t, coords_noise=torch.randn_like(c), feats_noise=torch.randn_like(f))
+    a.eval()
+    with torch.no_grad():
+        ref3 = torch.cat(a.denoiser(c, f, t), dim=1)              # fp32 module path on the updated master weights
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got3 = torch.cat(a.denoiser(c, f, t), dim=1)
+    assert rel(got3, ref3) < 2e-2
+
+
 def test_float16_training_with_dynamic_loss_scale():
     """dtype=float16 (the reference's default --dtype): scaled backward, overflow -> skipped step and halved scale."""
     from npcd.train import DiffusionTrainer
