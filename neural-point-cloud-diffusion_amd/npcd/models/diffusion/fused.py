@@ -71,7 +71,10 @@ def _wgrad(dy, x, out):
     elements, i.e. 16-64 tiles of 256x256 for 256 CUs: the GEMM is split along T into S batched slices
     (hipBLASLt batched GEMM, S x more tiles in flight) whose fp32 partials are summed straight into the
     gradient view.  Measured on MI355X: c_qkv 350 -> 250 us, attn.c_proj 200 -> 87 us, c_fc 327 -> 259 us,
-    mlp.c_proj 308 -> 255 us."""
+    mlp.c_proj 308 -> 255 us.
+    (Tried: the weight gradients on a second HIP stream, so that they run beside the HBM-bound GELU / LayerNorm backward
+    kernels of the critical path -- 84.39 -> 84.14 ms per step on the same box, i.e. nothing: the GEMM's workgroups hold
+    every CU and the other stream's kernels are dispatched as they drain.)"""
     T = dy.shape[0]
     S = 8 if out.numel() <= (1 << 20) else 4
     S = min(S, max(1, T // 4096))          # keep >= 4096 rows per slice: short reductions need no split
