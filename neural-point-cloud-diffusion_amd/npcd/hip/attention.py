@@ -55,12 +55,8 @@ def _bwd(q, k, v, out, dout, lse, dq, dk, dv, scale):
 
 def _check_input(x):
     require_gpu(x)
-    if x.dtype == torch.float32:
-        if x.requires_grad and torch.is_grad_enabled():
-            raise RuntimeError("fp32 HIP attention is inference-only (exact fp32 forward for sampling); training runs the "
-                               "bf16/f16 MFMA kernels: use autocast(bfloat16) as train_diffusion.py does for --dtype bfloat16.")
-    elif x.dtype not in (torch.bfloat16, torch.float16):
-        raise RuntimeError(f"HIP attention supports bf16/f16 (MFMA, fwd+bwd) and fp32 (forward only); got {x.dtype}")
+    if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise RuntimeError(f"HIP attention supports bf16/f16 (MFMA kernels) and fp32; got {x.dtype}")
 
 
 def _fwd_f32(q, k, v, scale):
@@ -69,6 +65,43 @@ def _fwd_f32(q, k, v, scale):
     check(lib().npcd_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(None), B, n, H, d, q.stride(0), q.stride(1), q.stride(2),
                               out.stride(0), out.stride(1), out.stride(2), scale, dtype_code(q), stream_ptr()), "npcd_attn_fwd(f32)")
     return out
+
+
+class _AttnF32(torch.autograd.Function):
+    """fp32 attention with gradients (`--dtype float32` training, where the reference runs its einsum path in fp32,
+    transformer.py:77-83).  Forward: the exact-fp32 HIP kernel.  Backward: NOT a hand-written kernel -- the probabilities are
+    recomputed and the four products are fp32 library GEMMs on the device (B*H*n^2 floats of workspace: 1.1 GB at cfg-D).
+    The benchmarked training configuration is bf16 autocast and never comes here."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        if not (q.stride() == k.stride() == v.stride() and q.stride(3) == 1):
+            q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        out = _fwd_f32(q, k, v, scale)
+        ctx.save_for_backward(q, k, v, out)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        q, k, v, out = ctx.saved_tensors
+        scale = ctx.scale
+        p = torch.softmax(torch.einsum("bthd,bshd->bhts", q, k) * scale, dim=-1)
+        dv = torch.einsum("bhts,bthd->bshd", p, gout)
+        dp = torch.einsum("bthd,bshd->bhts", gout, v)
+        delta = (gout * out).sum(dim=-1).permute(0, 2, 1).unsqueeze(-1)          # [B, H, n, 1]
+        ds = p * (dp - delta) * scale
+        dq = torch.einsum("bhts,bshd->bthd", ds, k)
+        dk = torch.einsum("bhts,bthd->bshd", ds, q)
+        return dq, dk, dv, None
+
+
+def _f32(q, k, v, scale):
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        return _AttnF32.apply(q, k, v, scale)
+    if not (q.stride() == k.stride() == v.stride() and q.stride(3) == 1):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    return _fwd_f32(q.detach(), k.detach(), v.detach(), scale)
 
 
 class _AttnPacked(torch.autograd.Function):
@@ -106,8 +139,8 @@ def attention_qkvpacked(qkv: torch.Tensor, heads: int) -> torch.Tensor:
     if qkv.dtype == torch.float32:
         B, n, w3 = qkv.shape
         d = w3 // heads // 3
-        x = qkv.detach().contiguous().view(B, n, heads, 3 * d)
-        return _fwd_f32(x[..., :d], x[..., d:2 * d], x[..., 2 * d:], 1.0 / math.sqrt(d)).view(B, n, heads * d)
+        x = qkv.contiguous().view(B, n, heads, 3 * d)
+        return _f32(x[..., :d], x[..., d:2 * d], x[..., 2 * d:], 1.0 / math.sqrt(d)).reshape(B, n, heads * d)
     return _AttnPacked.apply(qkv, heads)
 
 
@@ -144,7 +177,5 @@ def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, **
         _check_input(t)
     scale = 1.0 / math.sqrt(q.shape[-1]) if softmax_scale is None else float(softmax_scale)
     if q.dtype == torch.float32:
-        if not (q.stride() == k.stride() == v.stride() and q.stride(3) == 1):
-            q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        return _fwd_f32(q.detach(), k.detach(), v.detach(), scale)
+        return _f32(q, k, v, scale)
     return _AttnQKV.apply(q, k, v, scale)

@@ -178,7 +178,8 @@ class DiffusionTrainer:
         self.ema_decay = ema_decay
         self.ema = self.flat.flat.clone() if ema_decay is not None else None
         self.max_grad_norm = max_grad_norm
-        self.iteration = 0
+        self.iteration = 0                 # optimizer steps applied (AdamW bias correction)
+        self.finished_iterations = 0       # loop iterations, including those a float16 overflow skipped (diffusion_training.py:190)
         # float16 autocast (the reference's default --dtype, train_diffusion.py:78) trains with dynamic loss scaling
         # (torch.cuda.amp.GradScaler defaults, diffusion_training.py:62,156,169-170): scale 2^16, halved when a gradient
         # overflows (that step is skipped), doubled after 2000 clean steps
@@ -226,26 +227,31 @@ class DiffusionTrainer:
         if not self.native or self.iteration == 0:
             self.flat.zero_grad()                 # afterwards the fused optimizer kernel leaves the gradients zeroed
         self.reducer.start_step()
+        self.finished_iterations += 1
         dev_type = "cuda" if coords.is_cuda else "cpu"
         with torch.autocast(dev_type, dtype=self.dtype, enabled=self.dtype is not None):
             loss, sub, _ = self.model.compute_loss(coords, feats, t=t, coords_noise=coords_noise, feats_noise=feats_noise)
         (loss if self.loss_scale is None else loss * self.loss_scale).backward()
+        self.apply_gradients()
+        return loss.detach(), sub
+
+    def apply_gradients(self):
+        """Second half of an iteration: finish the gradient exchange, then AdamW + EMA on what the flat gradient buffer holds
+        (diffusion_training.py:169-174).  step() calls this after backward."""
         self.iteration += 1
-        pipelined = False
         if self.native and self.reducer.shard:
             self._gathers = []
-            pipelined = self.reducer.finish(self._adamw_shard)
-            if pipelined:
+            if self.reducer.finish(self._adamw_shard):
                 self._finish_shards()
+                return
         elif self.native and self.max_grad_norm is None and self.loss_scale is None:
             # multi-GPU: update each bucket's slice as soon as ITS all-reduce is done, under the remaining collectives
-            pipelined = self.reducer.finish(self._adamw_range)
+            if self.reducer.finish(self._adamw_range):
+                return
         else:
             self.reducer.finish()
-        if pipelined:
-            return loss.detach(), sub
         if self.loss_scale is not None and not self._unscale_or_skip():
-            return loss.detach(), sub
+            return
         if self.max_grad_norm is not None:
             if self.native:
                 self._clip_native()
@@ -258,7 +264,6 @@ class DiffusionTrainer:
             self.optimizer.step()
             if self.ema is not None:
                 self.ema.lerp_(self.flat.flat, 1.0 - self.ema_decay)
-        return loss.detach(), sub
 
     def _unscale_or_skip(self) -> bool:
         """GradScaler.step/update: returns False (step skipped, scale halved) when the reduced gradient holds an inf / nan
@@ -307,14 +312,33 @@ class DiffusionTrainer:
         for off, n in self._accum_ranges:             # (the fused backbone overwrites its gradients; these accumulate)
             self.flat.grad[off:off + n].zero_()
 
+    def _gather(self, bufs):
+        red = self.reducer
+        if not red.shard or red.world == 1:
+            return
+        for buf in bufs:
+            for s0, e0 in red.buckets:
+                a, b = red.shard_range(s0, e0)
+                dist.all_gather_into_tensor(buf[s0:e0], buf[a:b].clone(), group=red.group)
+
     def gather_ema(self):
         """EMA shards -> the full EMA vector on every rank (before exporting / evaluating the EMA model)."""
-        red = self.reducer
-        if self.ema is None or not red.shard or red.world == 1:
-            return
-        for s0, e0 in red.buckets:
-            a, b = red.shard_range(s0, e0)
-            dist.all_gather_into_tensor(self.ema[s0:e0], self.ema[a:b].clone(), group=red.group)
+        if self.ema is not None:
+            self._gather([self.ema])
+
+    def gather_state(self):
+        """EMA and Adam-moment shards -> full vectors on every rank (before writing a checkpoint; collective)."""
+        if self.native:
+            self._gather([self.exp_avg, self.exp_avg_sq] + ([self.ema] if self.ema is not None else []))
+
+    # ---- train-state checkpoints in the reference's layout (npcd.train.checkpoint) -----------------------------------
+    def state_dict(self, full_model=None):
+        from .checkpoint import trainer_state_dict
+        return trainer_state_dict(self, full_model)
+
+    def load_state_dict(self, ckpt):
+        from .checkpoint import load_trainer_state
+        load_trainer_state(self, ckpt)
 
     def _clip_native(self):
         norm = torch.linalg.vector_norm(self.flat.grad)

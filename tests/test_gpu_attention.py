@@ -141,8 +141,23 @@ def test_unsupported_shapes_fail_loudly():
     from npcd.hip.attention import attention_qkvpacked
     with pytest.raises(RuntimeError, match="unsupported"):
         attention_qkvpacked(torch.zeros(1, 8, 3 * 2 * 32, device="cuda", dtype=torch.bfloat16), 2)   # d = 32
-    with pytest.raises(RuntimeError, match="inference-only"):
-        attention_qkvpacked(torch.zeros(1, 8, 192, device="cuda", requires_grad=True), 1)           # fp32 training
+    with pytest.raises(RuntimeError, match="supports"):
+        attention_qkvpacked(torch.zeros(1, 8, 192, device="cuda", dtype=torch.float64), 1)
+
+
+@pytest.mark.parametrize("name", ["attention_n130_h4_d64", "attention_n513_h1_d64"])
+def test_attention_fp32_training_matches_reference_golden(golden, name):
+    """`--dtype float32` training: exact-fp32 HIP forward, gradients from fp32 library GEMMs on the device, against the
+    reference's own fp32 attention output and qkv gradient (fixture G1)."""
+    from npcd.hip.attention import attention_qkvpacked
+    g = golden(name)
+    H = int(g["heads"])
+    qkv = torch.from_numpy(g["qkv"]).cuda().requires_grad_(True)
+    out = attention_qkvpacked(qkv, H)
+    (out * torch.from_numpy(g["gout"]).cuda()).sum().backward()
+    ref_o, ref_g = torch.from_numpy(g["out"]), torch.from_numpy(g["dqkv"])
+    assert float((out.detach().cpu() - ref_o).abs().max()) < 2e-5 * max(1.0, float(ref_o.abs().max()))
+    assert float((qkv.grad.cpu() - ref_g).abs().max()) < 2e-5 * max(1.0, float(ref_g.abs().max()))
 
 
 @pytest.mark.parametrize("tag", ["f32_w64", "f128_w64"])
