@@ -15,7 +15,10 @@ class PointNeRFTrainer:
         """model: NPCD (uses model.pointnerf); loss: a PointNeRFLoss (default weights of train_pointnerf.py:56-59)."""
         self.model = model
         self.loss = loss if loss is not None else PointNeRFLoss(model, 1, 1e-7, 3.5e-7)
-        self.optimizer = torch.optim.Adam([p for p in model.pointnerf.parameters() if p.requires_grad], lr=lr)
+        # every parameter is handed to Adam like the reference does (:102): frozen ones never get a gradient or a state, but
+        # keep their index, so optimizer state dictionaries are interchangeable with the reference's
+        self.optimizer = torch.optim.Adam(model.pointnerf.parameters(), lr=lr)
+        self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=1, gamma=1.0)       # constant (:105)
         self.iteration = 0
 
     def step(self, sample, rng=None):
@@ -26,5 +29,37 @@ class PointNeRFTrainer:
         loss, sub, _ = self.loss(sample=sample, pred=pred, aux=aux, iteration=self.iteration)
         loss.backward()
         self.optimizer.step()
+        self.scheduler.step()
         self.iteration += 1
         return loss.detach(), {k: v.detach() for k, v in sub.items()}
+
+    # ---- train state in the reference's layout (utils/checkpoint_utils.py:196-236, pointnerf_training.py:180-187,212-215) ----
+    def state_dict(self):
+        return {"model_state_dict": self.model.state_dict(), "optimizer_state_dict": self.optimizer.state_dict(),
+                "scheduler_state_dict": self.scheduler.state_dict()}
+
+    def load_state_dict(self, ckpt):
+        self.model.load_state_dict(ckpt["model_state_dict"])
+        self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+        self.scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+        self.iteration = int(self.scheduler.last_epoch)
+
+    def save(self, base_path: str, base_name: str = "pointnerf_training", max_to_keep=None) -> str:
+        import os
+        from .checkpoint import checkpoint_name, list_checkpoints
+        os.makedirs(base_path, exist_ok=True)
+        path = os.path.join(base_path, checkpoint_name(base_name, self.iteration))
+        torch.save(self.state_dict(), path)
+        if max_to_keep is not None:
+            files = list_checkpoints(base_path, base_name)
+            for _, old in files[:max(0, len(files) - max_to_keep)]:
+                os.remove(old)
+        return path
+
+    def resume_latest(self, base_path: str, base_name: str = "pointnerf_training"):
+        from .checkpoint import list_checkpoints
+        found = list_checkpoints(base_path, base_name)
+        if not found:
+            return None
+        self.load_state_dict(torch.load(found[-1][1], map_location=next(self.model.parameters()).device, weights_only=False))
+        return found[-1][1]

@@ -158,3 +158,41 @@ def test_resume_continues_bit_for_bit_gpu(tmp_path):
         lb, _ = b.step(c, f, t=t, coords_noise=cn, feats_noise=fn)
     assert float(la) == float(lb)
     assert torch.equal(a.flat.flat, b.flat.flat) and torch.equal(a.ema, b.ema) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
+
+
+def test_stage1_train_state_roundtrip_cpu(tmp_path, golden):
+    """PointNeRFTrainer: {model, optimizer, scheduler}_state_dict over the whole model / Adam on every pointnerf parameter
+    (pointnerf_training.py:102,180-187), `pointnerf_training-iter-%09d.pt`, resume restores optimizer moments and iteration."""
+    from npcd.models import NPCD
+    from npcd.train import PointNeRFTrainer
+    cfg = _cfg(golden("train_state_format"))
+    torch.manual_seed(0)
+    net = NPCD(**cfg)
+    tr = PointNeRFTrainer(net)
+    all_params = list(net.pointnerf.parameters())
+    assert tr.optimizer.state_dict()["param_groups"][0]["params"] == list(range(len(all_params)))
+    g = torch.Generator().manual_seed(1)
+    for _ in range(2):                                       # two Adam steps on made-up gradients (no renderer on the CPU)
+        for p in all_params:
+            if p.requires_grad:
+                p.grad = torch.randn(p.shape, generator=g) * 0.01
+        tr.optimizer.step(); tr.scheduler.step(); tr.iteration += 1
+    path = tr.save(str(tmp_path))
+    assert os.path.basename(path) == "pointnerf_training-iter-000000002.pt"
+    ckpt = torch.load(path, weights_only=False)
+    assert list(ckpt.keys()) == ["model_state_dict", "optimizer_state_dict", "scheduler_state_dict"]
+    assert list(ckpt["model_state_dict"].keys()) == list(net.state_dict().keys())
+    torch.manual_seed(1)
+    net2 = NPCD(**cfg)
+    tr2 = PointNeRFTrainer(net2)
+    assert tr2.resume_latest(str(tmp_path)) == path and tr2.iteration == 2
+    for (ka, va), (kb, vb) in zip(net.state_dict().items(), net2.state_dict().items()):
+        assert ka == kb
+        if torch.is_tensor(va):
+            assert torch.equal(va, vb), ka
+        else:
+            assert torch.equal(va["emb"]["weight"], vb["emb"]["weight"]), ka
+    sa, sb = tr.optimizer.state_dict()["state"], tr2.optimizer.state_dict()["state"]
+    assert list(sa.keys()) == list(sb.keys()) and len(sa) > 0
+    for i in sa:
+        assert torch.equal(sa[i]["exp_avg"], sb[i]["exp_avg"]) and float(sa[i]["step"]) == float(sb[i]["step"]) == 2.0
