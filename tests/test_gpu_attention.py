@@ -73,8 +73,8 @@ def test_attention_golden(golden, tag, dtype):
     assert rel_l2(out, torch.from_numpy(g["out"])) < 2e-2
 
 
-@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 192, 193, 256, 384, 448, 513, 576, 700, 1025])
-def test_attention_ragged_lengths(n):
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 192, 193, 256, 384, 448, 513, 576, 700, 1025, 2049])
+def test_attention_ragged_lengths(n):      # 513 = BASELINE configs[1] (512 points + time token), 2049 = configs[4] (2048 points)
     gen = torch.Generator().manual_seed(n)
     B, H = 2, 3
     qkv = (torch.randn(B, n, 3 * H * 64, generator=gen) * 1.5).bfloat16()

@@ -184,6 +184,31 @@ def test_forward_only_backbone_for_sampling():
     assert rel(got3, ref3) < 2e-2
 
 
+def test_stress_config_shape_step():
+    """BASELINE configs[4] shape: 2048 points x 256-d latents, 8-layer denoiser (width 1024, 16 heads -> sequence 2049),
+    a small batch of it: the fused engine's step against the nn.Module / autograd path with the same weights and draws."""
+    import copy
+    from npcd.models.diffusion import DiffusionModel
+    from npcd.train import DiffusionTrainer
+    torch.manual_seed(0)
+    a = DiffusionModel(3, 256, 2048, 1024, 8, 16, True)
+    with torch.no_grad():
+        a.denoiser.output_proj.weight.normal_(0, 0.02)
+    b = copy.deepcopy(a)
+    ta, tb = DiffusionTrainer(a.cuda(), fused=True), DiffusionTrainer(b.cuda(), fused=False)
+    assert a.denoiser.backbone.fused_engine is not None
+    g = torch.Generator().manual_seed(1)
+    B = 2
+    c, f = torch.randn(B, 3, 2048, generator=g).cuda(), torch.randn(B, 256, 2048, generator=g).cuda()
+    t = torch.tensor([10, 900]).cuda()
+    cn, fn = torch.randn(B, 3, 2048, generator=g).cuda(), torch.randn(B, 256, 2048, generator=g).cuda()
+    for _ in range(2):
+        la, _ = ta.step(c, f, t=t, coords_noise=cn, feats_noise=fn)
+        lb, _ = tb.step(c, f, t=t, coords_noise=cn, feats_noise=fn)
+        assert math.isfinite(float(la)) and abs(float(la) - float(lb)) < 5e-3 * abs(float(lb))
+    assert rel(ta.flat.flat, tb.flat.flat) < 1e-3
+
+
 def test_float16_training_with_dynamic_loss_scale():
     """dtype=float16 (the reference's default --dtype): scaled backward, overflow -> skipped step and halved scale."""
     from npcd.train import DiffusionTrainer

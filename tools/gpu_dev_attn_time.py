@@ -6,7 +6,7 @@ sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-di
 import torch
 from npcd.hip import attention as A
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-B, n, H, d = 64, (int(sys.argv[2]) if len(sys.argv) > 2 else 513), 16, 64
+B, n, H, d = (int(sys.argv[3]) if len(sys.argv) > 3 else 64), (int(sys.argv[2]) if len(sys.argv) > 2 else 513), 16, 64
 torch.manual_seed(0)
 qkv = torch.randn(B, n, H, 3 * d, device="cuda").bfloat16()
 q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
