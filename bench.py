@@ -98,7 +98,7 @@ def bench_render(device, n_iters=10, burn_in=3):
             "mlp_frac_of_f16_mfma_peak": flops / dt / 1e12 / PEAK_BF16_TFLOPS}
 
 
-def bench_stage1(device, n_iters=5, burn_in=2):
+def bench_stage1(device, n_iters=5, burn_in=2, mlp_dtype=None):
     """Stage-1 (PointNeRF autodecoder) training step at the reference's configuration (configs/npcd_srncars.yaml:13-16,
     data/srn.py:45: 8 objects x 50 views per step, 112 random rays per view, 128 depth samples, Adam lr 1e-3): secondary
     figure for SURVEY §8(f) rank 2.  Synthetic clouds / poses / target images."""
@@ -114,7 +114,7 @@ def bench_stage1(device, n_iters=5, burn_in=2):
     intr = orr.srn_intrinsics()[None, None].expand(B, T, 3, 3).contiguous().to(device)
     sample = {"images": torch.rand(B, T, 3, res, res, device=device), "intrinsics": intr, "extrinsics": extr,
               "obj_idx": torch.arange(B, device=device)}
-    tr = PointNeRFTrainer(net)
+    tr = PointNeRFTrainer(net, mlp_dtype=mlp_dtype)
     for _ in range(burn_in):
         tr.step(sample)
     torch.cuda.synchronize()
@@ -312,6 +312,8 @@ def main():
         result["render"] = r
         try:
             result["stage1_pointnerf_training"] = bench_stage1(device)
+            opt_in = bench_stage1(device, mlp_dtype=torch.bfloat16)
+            result["stage1_pointnerf_training"]["opt_in_bf16_mlp"] = {k: opt_in[k] for k in ("steps_per_s", "ms_per_step", "loss")}
         except Exception as e:                      # noqa: BLE001
             result["stage1_pointnerf_training"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:

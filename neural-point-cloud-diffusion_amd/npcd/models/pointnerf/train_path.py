@@ -37,9 +37,12 @@ def box_limits(o: torch.Tensor, d: torch.Tensor, half: float):
     t0 = torch.where(ok, t0, torch.full_like(t0, -1.0))
     t1 = torch.where(ok, t1, torch.full_like(t1, -2.0))
     hit = t1 > t0
-    if bool(hit.any()):
-        t0 = torch.where(hit, t0, t0[hit].min())
-        t1 = torch.where(hit, t1, t1[hit].max())
+    # (no host round trip: with no hit at all the fills are the miss markers themselves, i.e. nothing changes)
+    any_hit = hit.any()
+    lo = torch.where(any_hit, torch.where(hit, t0, torch.full_like(t0, math.inf)).min(), torch.full_like(t0[..., :1].sum(), -1.0))
+    hi = torch.where(any_hit, torch.where(hit, t1, torch.full_like(t1, -math.inf)).max(), torch.full_like(t1[..., :1].sum(), -2.0))
+    t0 = torch.where(hit, t0, lo)
+    t1 = torch.where(hit, t1, hi)
     return t0.unsqueeze(-1), t1.unsqueeze(-1)
 
 
@@ -66,18 +69,23 @@ def shade_autograd(field, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch
     coordinates are frozen in stage 1: pointnerf.py:24,68, aggregators/mlp.py:58-59)."""
     agg = field.aggregator
     P, k = nb_idx.shape
-    valid = nb_idx >= 0
-    owner = torch.arange(P, device=pts.device)[:, None].expand(P, k)[valid]
-    flat = nb_idx[valid]
+    owner, col = torch.nonzero(nb_idx >= 0, as_tuple=True)        # (point, neighbour) pairs, row-major; one host round trip
+    flat = nb_idx[owner, col]
     pos = kp_pos.detach().reshape(-1, 3)[flat]
     feat = kp_feat.reshape(-1, kp_feat.shape[-1])[flat]
     rel = pts[owner] - pos
     w = 1.0 / (torch.linalg.norm(rel, dim=-1) + 1e-5)
-    local = agg.local_field(torch.cat((feat, positional_encoding(rel, agg.n_freqs)), dim=-1))
+    # the reference trains stage 1 in fp32; `field.train_mlp_dtype = torch.bfloat16` (PointNeRFTrainer(mlp_dtype=...)) is an
+    # opt-in that runs the Linear layers of the three MLPs under autocast (MFMA instead of fp32 matrix instructions)
+    mlp_dtype = getattr(field, "train_mlp_dtype", None)
+    with torch.autocast("cuda", dtype=mlp_dtype or torch.bfloat16, enabled=mlp_dtype is not None):
+        local = agg.local_field(torch.cat((feat, positional_encoding(rel, agg.n_freqs)), dim=-1)).float()
     w = w / torch.zeros(P, device=pts.device, dtype=w.dtype).index_add_(0, owner, w)[owner]
     agg_feat = torch.zeros(P, local.shape[1], device=pts.device, dtype=local.dtype).index_add_(0, owner, w[:, None] * local)
-    sigma = F.softplus(field.shape_net(agg_feat) - 1.0)[:, 0]
-    rgb = torch.sigmoid(field.channel_net(agg_feat))
+    with torch.autocast("cuda", dtype=mlp_dtype or torch.bfloat16, enabled=mlp_dtype is not None):
+        shape, chan = field.shape_net(agg_feat).float(), field.channel_net(agg_feat).float()
+    sigma = F.softplus(shape - 1.0)[:, 0]
+    rgb = torch.sigmoid(chan)
     return sigma, rgb
 
 
@@ -144,20 +152,22 @@ def render_train(renderer, kp_pos, kp_feat, extr, intr, resolution: int, sample:
         ray_sel = agg.select_valid_rays(slot_valid, rng.get("valid_perm"))      # [B*T, Rs] bool, same count per instance
     else:
         ray_sel = torch.ones(B * T, Rs, dtype=torch.bool, device=dev)
-    n = int(ray_sel[0].sum())
-    idx_s, loc_s, valid_s = idx[ray_sel], loc[ray_sel], slot_valid[ray_sel]      # [B*T*n, M, ...] in ascending ray order
-    nb, pts = idx_s[valid_s], loc_s[valid_s]
+    # compaction with ONE host round trip per list (boolean indexing would take one per indexed tensor)
+    sel = torch.nonzero(ray_sel.view(-1)).squeeze(1)                             # selected rays, ascending
+    n = sel.numel() // (B * T)
+    idx_s, loc_s, valid_s = idx.view(-1, M, agg.k)[sel], loc.view(-1, M, 3)[sel], slot_valid.view(-1, M)[sel]
+    rows = torch.nonzero(valid_s, as_tuple=True)                                 # valid (ray, slot) cells, row-major
+    nb, pts = idx_s[rows], loc_s[rows]
     sigma_c, rgb_c = shade_autograd(field, nb, pts, kp_pos, kp_feat)
-    rows = torch.nonzero(valid_s, as_tuple=True)
     sigma = torch.zeros(valid_s.shape, device=dev, dtype=sigma_c.dtype).index_put(rows, sigma_c)
     rgb = torch.zeros(valid_s.shape + (3,), device=dev, dtype=rgb_c.dtype).index_put(rows, rgb_c)
     dense_pts = torch.zeros(valid_s.shape + (3,), device=dev).index_put(rows, pts)
-    o_s, d_s, end_s = o.reshape(B * T, Rs, 3)[ray_sel], d.reshape(B * T, Rs, 3)[ray_sel], end.reshape(B * T, Rs, 1)[ray_sel]
+    o_s, d_s, end_s = o.reshape(-1, 3)[sel], d.reshape(-1, 3)[sel], end.reshape(-1, 1)[sel]
     depths = depths_from_points(dense_pts, valid_s, o_s, d_s, end_s)
     total, cdepth, chan = ray_march(sigma, depths, rgb, valid_s, renderer.white_back)
     out = AttrDict(mask=total.view(B, T, n, 1), depth=cdepth.view(B, T, n, 1), channels=chan.view(B, T, n, 3))
     if sample:
-        out["ray_idx"] = ray_ids[None, :].expand(B * T, Rs)[ray_sel].view(B, T, n, 1)
+        out["ray_idx"] = ray_ids[None, :].expand(B * T, Rs).reshape(-1)[sel].view(B, T, n, 1)
     out["num_shading_points"] = int(nb.shape[0])
-    out["num_pairs"] = int((nb >= 0).sum())
+    out["num_pairs"] = (nb >= 0).sum()                                           # device scalar (no host round trip here)
     return out

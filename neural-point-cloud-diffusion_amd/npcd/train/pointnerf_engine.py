@@ -11,9 +11,11 @@ from ..losses import PointNeRFLoss
 
 
 class PointNeRFTrainer:
-    def __init__(self, model, loss=None, lr: float = 1e-3):
-        """model: NPCD (uses model.pointnerf); loss: a PointNeRFLoss (default weights of train_pointnerf.py:56-59)."""
+    def __init__(self, model, loss=None, lr: float = 1e-3, mlp_dtype=None):
+        """model: NPCD (uses model.pointnerf); loss: a PointNeRFLoss (default weights of train_pointnerf.py:56-59).
+        mlp_dtype: None = fp32 like the reference; torch.bfloat16 runs the field's Linear layers under autocast (opt-in)."""
         self.model = model
+        model.pointnerf.field.train_mlp_dtype = mlp_dtype
         self.loss = loss if loss is not None else PointNeRFLoss(model, 1, 1e-7, 3.5e-7)
         # every parameter is handed to Adam like the reference does (:102): frozen ones never get a gradient or a state, but
         # keep their index, so optimizer state dictionaries are interchangeable with the reference's

@@ -109,7 +109,7 @@ def test_train_render_grid_mode_own_draws():
     ref = otr.render_train(po, coords, fo, extr, intr, res, 64, agg.max_shading_pts, agg.k, agg.r, "grid", ren.ray_subsamples,
                            agg.ray_subsamples, rng["ray_perm"], rng["jitter"], rng["valid_perm"], stable_regroup=True)
     assert out["channels"].shape == ref["channels"].shape and (out["ray_idx"].cpu() == ref["ray_idx"]).all()
-    assert (out["num_shading_points"], out["num_pairs"]) == (ref["num_shading_points"], ref["num_pairs"])
+    assert (int(out["num_shading_points"]), int(out["num_pairs"])) == (ref["num_shading_points"], ref["num_pairs"])
     assert float(ref["mask"].max()) > 0.05
     for key in ("mask", "channels"):
         _close(out[key], ref[key], 2e-4, key)
