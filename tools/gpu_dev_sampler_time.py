@@ -29,7 +29,8 @@ def loop(n, dtype, graph):
     ctx = torch.autocast("cuda", dtype=dtype) if dtype else contextlib.nullcontext()
     with torch.no_grad(), ctx:
         return dp.p_sample_loop(m.denoiser, c, f, (-3.0, 3.0), (-1.0, 1.0), use_graph=graph)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 for name, dtype, graph in (("bf16 fused", torch.bfloat16, False), ("bf16 fused+graph", torch.bfloat16, True)):
-    loop(4, dtype, graph); torch.cuda.synchronize(); t0 = time.time(); out = loop(24, dtype, graph)[0]; torch.cuda.synchronize()
-    dt = (time.time() - t0) / 24
-    print(f"{name:18s} B={B}: {dt * 1e3:7.2f} ms per reverse step (incl. capture amortised over 24 steps); finite={bool(torch.isfinite(out).all())}", flush=True)
+    loop(4, dtype, graph); torch.cuda.synchronize(); t0 = time.time(); out = loop(N, dtype, graph)[0]; torch.cuda.synchronize()
+    dt = (time.time() - t0) / N
+    print(f"{name:18s} B={B}: {dt * 1e3:7.2f} ms per reverse step (incl. capture amortised over {N} steps); finite={bool(torch.isfinite(out).all())}", flush=True)
