@@ -9,8 +9,12 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 B, n, H, d = (int(sys.argv[3]) if len(sys.argv) > 3 else 64), (int(sys.argv[2]) if len(sys.argv) > 2 else 513), 16, 64
 torch.manual_seed(0)
 qkv = torch.randn(B, n, H, 3 * d, device="cuda").bfloat16()
+if os.environ.get("NPCD_ZERO_DATA"):      # clock check: all-zero operands draw less power (MI355X_MICROARCH.md, DVFS give-back)
+    qkv.zero_()
 q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
 dout = torch.randn(B, n, H, d, device="cuda").bfloat16()
+if os.environ.get("NPCD_ZERO_DATA"):
+    dout.zero_()
 scale = 1 / math.sqrt(d)
 # correctness on a slice (fp32 reference)
 out, lse = A._fwd(q, k, v, scale)
