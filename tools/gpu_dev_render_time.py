@@ -8,9 +8,14 @@ coords, feats = orr.synthetic_cloud(512, 32, 1, seed=0)
 model = PointNeRF(1, 32, 512, False); model.field.load_state_dict(orr.init_field_params(32, seed=0)); model = model.cuda().eval(); model.renderer.count_pairs = bool(int(os.environ.get("COUNT_PAIRS", "0")))
 extr = orr.look_at_pose(30, 20)[None, None].cuda(); intr = orr.srn_intrinsics()[None, None].cuda()
 c, f = coords.cuda(), feats.cuda()
+if os.environ.get("NPCD_ZERO_DATA"):      # clock check: all-zero weights and features (same instruction stream, less power)
+    with torch.no_grad():
+        for p_ in model.field.parameters(): p_.zero_()
+    f.zero_()
+N_ = int(os.environ.get("NPCD_RENDERS", "10"))
 with torch.no_grad():
     for _ in range(3): out = model.render(c, f, extr, intr, 128)
     torch.cuda.synchronize(); t = time.time()
-    for _ in range(10): out = model.render(c, f, extr, intr, 128)
-    torch.cuda.synchronize(); dt = (time.time() - t) / 10
+    for _ in range(N_): out = model.render(c, f, extr, intr, 128)
+    torch.cuda.synchronize(); dt = (time.time() - t) / N_
 print("128^2 view: %.3f ms  %.2f Mrays/s  P=%d Q=%d" % (dt*1e3, 16384/dt/1e6, out["num_shading_points"], out["num_pairs"]))
