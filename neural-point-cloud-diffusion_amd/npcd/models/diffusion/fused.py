@@ -29,7 +29,10 @@ _BLOCK_PARAMS = ("ln_1.weight", "ln_1.bias", "attn.c_qkv.weight", "attn.c_qkv.bi
 # loses 12 % on that quarter tile (tools/gpu_dev_gemm_m.py: 1683 -> 1475 us per block for the eight GEMMs).  A GEMM does not
 # care which rows it gets, so every [T, K] x [K, N] product is issued as one call on the last T % 256 rows and one on the rest.
 # Measured in situ (same box, tuned solutions for both): 10.78 -> 11.13 steps/s.  (Tried: the small call on a second stream --
-# its workgroups queue behind the large GEMM's and the join waits for them: no gain at either stream priority.)
+# its workgroups queue behind the large GEMM's and the join waits for them: no gain at either stream priority.  Tried: a
+# hand-written kernel for the 64 left-over rows of the forward -- one pass over the weights straight into MFMA fragments,
+# split-K over 8 waves: 11.5 us per call in situ against the tuned library's 12.8 us, 0.2-0.5 % of a step; both are bound by
+# pulling 2-8 MB of cold weights through a launch that is over before it has filled the chip.  Not kept.)
 import os
 
 _SPLIT = 0 if os.environ.get("NPCD_NO_GEMM_SPLIT") else 256       # (the env switch exists for A/B measurements)
