@@ -229,6 +229,20 @@ int npcd_ray_march_compact(const float* sigma, const float* rgb, const uint64_t*
                            int Nr, int M, int white_back, float* mask, float* depth, float* channels,
                            float* depth_ws, void* stream);
 
+/* ---- stage-1 training path: the data movement around the per-pair MLP (aggregators/mlp.py:36-125,
+ * positional_encoder.py:16-20, aggregator.py:122-144).  Pairs (shading point, neighbour) are compact and ordered by point:
+ * flat [Q] = global neighbour index, owner [Q] = shading-point index, off / cnt [P] = first pair and number of pairs of a point.
+ *   npcd_pair_input_fwd : x0 [Q, F + 3 + 6 nf] = [feat[flat] | rel | sin / cos bands of rel], w [Q] = 1 / (|rel| + 1e-5),
+ *                         rel = pts[owner] - kp_pos[flat]
+ *   npcd_pair_input_bwd : dfeat [B*N, F] += dx0[:, :F] scattered by flat (float atomics; dfeat must be zeroed by the caller)
+ *   npcd_pair_aggregate : backward == 0: dst = agg [P, C] = sum over a point's pairs of w / (sum w) * src[q]  (src = local [Q, C]);
+ *                         backward != 0: dst = dlocal [Q, C] = w / (sum w) * src[p]                      (src = dagg [P, C]) */
+int npcd_pair_input_fwd(const int64_t* flat, const int64_t* owner, const float* pts, const float* kp_pos, const float* kp_feat,
+                        int feat_dim, int n_freqs, int64_t n_pairs, float* x0, float* w, void* stream);
+int npcd_pair_input_bwd(const int64_t* flat, const float* dx0, int feat_dim, int n_cols, int64_t n_pairs, float* dfeat, void* stream);
+int npcd_pair_aggregate(int backward, const float* src, const float* w, const int64_t* off, const int64_t* cnt, int channels,
+                        int64_t n_points, float* dst, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

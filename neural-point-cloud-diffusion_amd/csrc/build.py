@@ -31,6 +31,7 @@ SOURCES = {
     "geometry.hip": ["-ffp-contract=off"],
     "shade.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "elementwise.hip": [],
+    "pairs.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-fno-gpu-rdc", "-ffast-math" if False else "-fno-fast-math"]

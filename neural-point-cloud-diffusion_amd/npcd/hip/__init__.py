@@ -31,6 +31,9 @@ SIGNATURES = {
     "npcd_error_string": (c_char_p, [c_int]),
     "npcd_last_hip_error": (c_char_p, []),
     "npcd_attn_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int] + [c_int64] * 6 + [c_float, c_int, _P]),
+    "npcd_pair_input_fwd": (c_int, [_P] * 5 + [c_int, c_int, c_int64, _P, _P, _P]),
+    "npcd_pair_input_bwd": (c_int, [_P, _P, c_int, c_int, c_int64, _P, _P]),
+    "npcd_pair_aggregate": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int64, _P, _P]),
     "npcd_attn_bwd": (c_int, [_P] * 10 + [c_int] * 4 + [c_int64] * 9 + [c_float, c_int, _P]),
     "npcd_attn_bwd_pass": (c_int, [c_int] + [_P] * 10 + [c_int] * 4 + [c_int64] * 9 + [c_float, c_int, _P]),
     "npcd_grid_workspace_bytes": (c_int64, [POINTER(GridParams), c_int, c_int]),

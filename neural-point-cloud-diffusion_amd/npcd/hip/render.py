@@ -212,3 +212,65 @@ def ray_march(sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1, 
                                ptr(t1.contiguous()), Nr, M, int(bool(white_back)), ptr(mask), ptr(depth), ptr(chan), ptr(ws),
                                stream_ptr()), "npcd_ray_march")
     return mask, depth, chan
+
+
+# ---- stage-1 training path: pair inputs and aggregation with hand-written forward AND backward (csrc/pairs.hip) -------------
+class _PairInput(torch.autograd.Function):
+    """feat table [Nt, F] (differentiable), flat / owner [Q] int64, pts [P, 3], pos table [Nt, 3] -> x0 [Q, F + 3 + 6 nf], w [Q]"""
+
+    @staticmethod
+    def forward(ctx, feat, flat, owner, pts, pos, n_freqs):
+        require_gpu(feat, flat, owner, pts, pos)
+        feat, pts, pos = feat.contiguous(), pts.contiguous(), pos.contiguous()
+        Q, F_ = flat.numel(), feat.shape[1]
+        ncol = F_ + 3 + 6 * n_freqs
+        x0 = torch.empty((Q, ncol), dtype=_f32, device=feat.device)
+        w = torch.empty(Q, dtype=_f32, device=feat.device)
+        check(lib().npcd_pair_input_fwd(ptr(flat), ptr(owner), ptr(pts), ptr(pos), ptr(feat), F_, n_freqs, Q, ptr(x0), ptr(w), stream_ptr()),
+              "npcd_pair_input_fwd")
+        ctx.save_for_backward(flat)
+        ctx.dims = (feat.shape[0], F_, ncol)
+        ctx.mark_non_differentiable(w)
+        return x0, w
+
+    @staticmethod
+    def backward(ctx, dx0, _dw):
+        (flat,) = ctx.saved_tensors
+        Nt, F_, ncol = ctx.dims
+        dx0 = dx0.contiguous()
+        dfeat = torch.zeros((Nt, F_), dtype=_f32, device=dx0.device)
+        check(lib().npcd_pair_input_bwd(ptr(flat), ptr(dx0), F_, ncol, flat.numel(), ptr(dfeat), stream_ptr()), "npcd_pair_input_bwd")
+        return dfeat, None, None, None, None, None
+
+
+class _PairAggregate(torch.autograd.Function):
+    """local [Q, C] (differentiable), w [Q], off / cnt [P] int64 -> agg [P, C] = inverse-distance weighted mean over a point's pairs"""
+
+    @staticmethod
+    def forward(ctx, local, w, off, cnt):
+        require_gpu(local, w, off, cnt)
+        local = local.contiguous()
+        P, C = off.numel(), local.shape[1]
+        agg = torch.empty((P, C), dtype=_f32, device=local.device)
+        check(lib().npcd_pair_aggregate(0, ptr(local), ptr(w), ptr(off), ptr(cnt), C, P, ptr(agg), stream_ptr()), "npcd_pair_aggregate")
+        ctx.save_for_backward(w, off, cnt)
+        ctx.shape = tuple(local.shape)
+        return agg
+
+    @staticmethod
+    def backward(ctx, dagg):
+        w, off, cnt = ctx.saved_tensors
+        dagg = dagg.contiguous()
+        dlocal = torch.empty(ctx.shape, dtype=_f32, device=dagg.device)
+        check(lib().npcd_pair_aggregate(1, ptr(dagg), ptr(w), ptr(off), ptr(cnt), ctx.shape[1], off.numel(), ptr(dlocal), stream_ptr()),
+              "npcd_pair_aggregate(bwd)")
+        return dlocal, None, None, None
+
+
+def pair_input(feat, flat, owner, pts, pos, n_freqs):
+    return _PairInput.apply(feat, flat, owner, pts, pos, n_freqs)
+
+
+def pair_aggregate(local, w, off, cnt):
+    return _PairAggregate.apply(local, w, off, cnt)
+

@@ -63,27 +63,85 @@ def positional_encoding(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
     return torch.cat((x, torch.cat((spec.sin(), spec.cos()), dim=-1).flatten(start_dim=-2)), dim=-1)
 
 
+class _RowSplitLinear(torch.autograd.Function):
+    """y = x W^T + b for x of ~10^6 rows and a few hundred columns.  The forward and the data gradient are plain library GEMMs;
+    the WEIGHT gradient dW = dy^T x reduces over the ~10^6 rows into a 256 x 256 output, which the library runs on 16 tiles
+    (830 us per layer, a third of the whole step): here the rows are split into slices of 16384, the slices go through one
+    batched GEMM with fp32 partial outputs, and the partials are summed (150 us).  `dtype` = None: fp32 like the reference;
+    torch.bfloat16: operands rounded to bf16, fp32 accumulation, fp32 weight gradient (what autocast would compute)."""
+    SLICE = 16384
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dtype):
+        xx = x if dtype is None else x.to(dtype)
+        ww = weight if dtype is None else weight.to(dtype)
+        bb = bias if dtype is None else bias.to(dtype)
+        ctx.save_for_backward(xx, ww)
+        ctx.in_dtype = x.dtype
+        return torch.addmm(bb, xx, ww.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        xx, ww = ctx.saved_tensors
+        dy = dy.to(xx.dtype).contiguous()
+        dx = torch.mm(dy, ww).to(ctx.in_dtype) if ctx.needs_input_grad[0] else None
+        rows, c = dy.shape[0], _RowSplitLinear.SLICE
+        S = rows // c
+        f32 = torch.float32
+        mixed = xx.dtype != f32
+        if S >= 2:
+            head, tail = S * c, rows > S * c
+            part = torch.empty((S + int(tail), dy.shape[1], xx.shape[1]), dtype=f32, device=dy.device)
+            a, b = dy[:head].view(S, c, -1).transpose(1, 2), xx[:head].view(S, c, -1)
+            if mixed:
+                torch.bmm(a, b, out_dtype=f32, out=part[:S])
+            else:
+                torch.bmm(a, b, out=part[:S])
+            if tail:
+                if mixed:
+                    torch.mm(dy[head:].t(), xx[head:], out_dtype=f32, out=part[S])
+                else:
+                    torch.mm(dy[head:].t(), xx[head:], out=part[S])
+            dw = part.sum(dim=0)
+        else:
+            dw = torch.mm(dy.t(), xx, out_dtype=f32) if mixed else torch.mm(dy.t(), xx)
+        return dx, dw, dy.sum(dim=0, dtype=f32), None
+
+
+def _mlp(seq, x, dtype):
+    """nn.Sequential of Linear / LeakyReLU (utils/model.py:22-36).  With several hundred thousand rows (the per-pair network) the
+    Linear layers run as _RowSplitLinear; below that the plain modules (under autocast for the bf16 opt-in) -- the step is
+    bound by launch count on the host, and the split costs three more launches per layer."""
+    if x.shape[0] < 262144:
+        with torch.autocast("cuda", dtype=dtype or torch.bfloat16, enabled=dtype is not None):
+            return seq(x)
+    for m in seq:
+        if isinstance(m, torch.nn.Linear):
+            x = _RowSplitLinear.apply(x, m.weight, m.bias, dtype)
+        else:
+            x = m(x)
+    return x
+
+
 def shade_autograd(field, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch.Tensor, kp_feat: torch.Tensor):
     """Compact shading points -> sigma [P] (softplus(x - 1)), rgb [P, 3] (sigmoid), differentiable w.r.t. kp_feat and the
     field's parameters.  nb_idx [P, k] global point indices (-1 pad), pts [P, 3]; positions are constants (the point
     coordinates are frozen in stage 1: pointnerf.py:24,68, aggregators/mlp.py:58-59)."""
     agg = field.aggregator
     P, k = nb_idx.shape
-    owner, col = torch.nonzero(nb_idx >= 0, as_tuple=True)        # (point, neighbour) pairs, row-major; one host round trip
+    valid = nb_idx >= 0
+    owner, col = torch.nonzero(valid, as_tuple=True)              # (point, neighbour) pairs, row-major; one host round trip
     flat = nb_idx[owner, col]
-    pos = kp_pos.detach().reshape(-1, 3)[flat]
-    feat = kp_feat.reshape(-1, kp_feat.shape[-1])[flat]
-    rel = pts[owner] - pos
-    w = 1.0 / (torch.linalg.norm(rel, dim=-1) + 1e-5)
+    cnt = valid.sum(dim=1)
+    off = torch.cumsum(cnt, 0) - cnt                             # a point's pairs are rows off[p] .. off[p] + cnt[p]
+    # MLP input of every pair and its inverse-distance weight: one HIP kernel forward, one backward (csrc/pairs.hip)
+    x0, w = hr.pair_input(kp_feat.reshape(-1, kp_feat.shape[-1]), flat, owner, pts, kp_pos.detach().reshape(-1, 3), agg.n_freqs)
     # the reference trains stage 1 in fp32; `field.train_mlp_dtype = torch.bfloat16` (PointNeRFTrainer(mlp_dtype=...)) is an
     # opt-in that runs the Linear layers of the three MLPs under autocast (MFMA instead of fp32 matrix instructions)
     mlp_dtype = getattr(field, "train_mlp_dtype", None)
-    with torch.autocast("cuda", dtype=mlp_dtype or torch.bfloat16, enabled=mlp_dtype is not None):
-        local = agg.local_field(torch.cat((feat, positional_encoding(rel, agg.n_freqs)), dim=-1)).float()
-    w = w / torch.zeros(P, device=pts.device, dtype=w.dtype).index_add_(0, owner, w)[owner]
-    agg_feat = torch.zeros(P, local.shape[1], device=pts.device, dtype=local.dtype).index_add_(0, owner, w[:, None] * local)
-    with torch.autocast("cuda", dtype=mlp_dtype or torch.bfloat16, enabled=mlp_dtype is not None):
-        shape, chan = field.shape_net(agg_feat).float(), field.channel_net(agg_feat).float()
+    local = _mlp(agg.local_field, x0, mlp_dtype).float()
+    agg_feat = hr.pair_aggregate(local, w, off, cnt)             # weighted mean over each point's pairs (HIP fwd + bwd)
+    shape, chan = _mlp(field.shape_net, agg_feat, mlp_dtype).float(), _mlp(field.channel_net, agg_feat, mlp_dtype).float()
     sigma = F.softplus(shape - 1.0)[:, 0]
     rgb = torch.sigmoid(chan)
     return sigma, rgb
