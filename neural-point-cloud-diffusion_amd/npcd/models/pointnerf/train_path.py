@@ -23,29 +23,6 @@ from ...utils import AttrDict
 
 
 # ------------------------------------------------------------------------------------------------- rays
-def box_limits(o: torch.Tensor, d: torch.Tensor, half: float):
-    """Slab test of rays against the cube [-half, half]^3.  o, d [..., 3] -> start, end [..., 1]; rays that miss get the
-    smallest start / largest end among the rays that hit (one global reduction, as the reference does)."""
-    inv = 1.0 / d
-    near = (torch.where(inv < 0, half, -half) - o) * inv
-    far = (torch.where(inv < 0, -half, half) - o) * inv
-    t0, t1 = near[..., 0], far[..., 0]
-    ok = torch.ones_like(t0, dtype=torch.bool)
-    for a in (1, 2):
-        ok = ok & ~((t0 > far[..., a]) | (near[..., a] > t1))
-        t0, t1 = torch.maximum(t0, near[..., a]), torch.minimum(t1, far[..., a])
-    t0 = torch.where(ok, t0, torch.full_like(t0, -1.0))
-    t1 = torch.where(ok, t1, torch.full_like(t1, -2.0))
-    hit = t1 > t0
-    # (no host round trip: with no hit at all the fills are the miss markers themselves, i.e. nothing changes)
-    any_hit = hit.any()
-    lo = torch.where(any_hit, torch.where(hit, t0, torch.full_like(t0, math.inf)).min(), torch.full_like(t0[..., :1].sum(), -1.0))
-    hi = torch.where(any_hit, torch.where(hit, t1, torch.full_like(t1, -math.inf)).max(), torch.full_like(t1[..., :1].sum(), -2.0))
-    t0 = torch.where(hit, t0, lo)
-    t1 = torch.where(hit, t1, hi)
-    return t0.unsqueeze(-1), t1.unsqueeze(-1)
-
-
 def jittered_depths(start: torch.Tensor, end: torch.Tensor, S: int, jitter: Optional[torch.Tensor]):
     """start/end [..., 1] -> depths [..., S]: S evenly spaced samples, each moved forward by U(0,1) of one spacing."""
     steps = torch.arange(S, dtype=torch.float32, device=start.device) / (S - 1)
@@ -183,16 +160,17 @@ def render_train(renderer, kp_pos, kp_feat, extr, intr, resolution: int, sample:
     B, T = extr.shape[:2]
     dev = kp_pos.device
     R = resolution * resolution
+    # rays and their cube limits (misses filled with the global limits of the generated set) come out of one kernel
     if renderer.ray_subsamples and sample:          # the same random rays for every (object, view) instance
         perm = rng["ray_perm"].to(dev) if "ray_perm" in rng else torch.randperm(R, device=dev)
         ray_ids = perm[:renderer.ray_subsamples].long()
-        o, d, _, _ = hr.ray_gen(extr.flatten(0, 1), intr.flatten(0, 1), resolution, renderer.cube_scale, pixel_ids=ray_ids)
+        o, d, t0, t1 = hr.ray_gen(extr.flatten(0, 1), intr.flatten(0, 1), resolution, renderer.cube_scale, pixel_ids=ray_ids)
     else:
         ray_ids = torch.arange(R, device=dev)
-        o, d, _, _ = hr.ray_gen(extr.flatten(0, 1), intr.flatten(0, 1), resolution, renderer.cube_scale)
+        o, d, t0, t1 = hr.ray_gen(extr.flatten(0, 1), intr.flatten(0, 1), resolution, renderer.cube_scale)
     o, d = o.view(B, T, -1, 3), d.view(B, T, -1, 3)
     Rs = o.shape[2]
-    start, end = box_limits(o, d, renderer.cube_scale)
+    start, end = t0.view(B, T, Rs, 1), t1.view(B, T, Rs, 1)
     S = renderer.depth_resolution
     jitter = None
     if renderer.randomize_depth_samples:
