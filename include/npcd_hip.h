@@ -171,6 +171,14 @@ int npcd_ray_march(const float* sigma, const float* rgb, const uint8_t* slot_val
                    int Nr, int M, int white_back, float* mask, float* depth, float* channels,
                    float* depth_ws, void* stream);
 
+/* Backward of npcd_ray_march w.r.t. sigma and rgb (stage-1 training: positions and rays are constants).  depth_ws is the
+ * scratch the forward call left (global depth limits); g_mask / g_depth [Nr], g_chan [Nr,3] are the upstream gradients;
+ * dsigma [P], drgb [P,3] are written for every compact point.  M <= 64. */
+int npcd_ray_march_bwd(const float* sigma, const float* rgb, const uint8_t* slot_valid, const float* slot_loc,
+                       const int32_t* point_base, const float* rays_o, const float* rays_d, const float* t1,
+                       int Nr, int M, int white_back, const float* depth_ws, const float* g_mask, const float* g_depth,
+                       const float* g_chan, float* dsigma, float* drgb, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Elementwise / normalisation / optimizer kernels of the denoiser training step (HBM-bound).
  * They fuse the eager op chains of transformer.py:169-172,136-137 (under autocast) and of

@@ -725,6 +725,87 @@ __global__ __launch_bounds__(256) void ray_march_kernel(const float* __restrict_
     }
 }
 
+// Backward of the ray march w.r.t. the compact densities and colours (stage-1 training; slot positions, ray geometry and hence
+// all depths are constants there).  One thread per ray, three passes over its <= 64 slots: slot depths; alpha_i, T_i, w_i
+// (kept in thread-private arrays); then in reverse, with G_i = dL/dw_i and the suffix sum S_i = sum_{j>i} G_j w_j,
+//     dL/dalpha_i = G_i T_i - S_i / (1 - alpha_i + 1e-10),   dsigma_i = dL/dalpha_i * delta_i * exp(-sigma_i delta_i),
+//     drgb_i = g_chan * w_i,    G_i = g_mask + g_depth (d_i - depth) / mask [only where the output depth is the unclamped,
+//     finite ratio] + sum_c g_chan_c (rgb_ic [valid] - white_back).
+// A ray without any weight (mask == 0) gets no depth gradient (torch's autograd gives NaN there; the reference's loss does
+// not use the depth).
+__global__ __launch_bounds__(64) void ray_march_bwd_kernel(const float* __restrict__ sigma, const float* __restrict__ rgb,
+                                                           const uint8_t* __restrict__ slot_valid, const float* __restrict__ slot_loc,
+                                                           const int32_t* __restrict__ point_base, const float* __restrict__ rays_o,
+                                                           const float* __restrict__ rays_d, const float* __restrict__ t1, int Nr, int M,
+                                                           int white_back, const uint32_t* __restrict__ ws, const float* __restrict__ g_mask,
+                                                           const float* __restrict__ g_depth, const float* __restrict__ g_chan,
+                                                           float* __restrict__ dsigma, float* __restrict__ drgb) {
+    const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= Nr) return;
+    const float o[3] = {rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2]};
+    const float d[3] = {rays_d[ray * 3], rays_d[ray * 3 + 1], rays_d[ray * 3 + 2]};
+    const float ray_end = t1[ray];
+    const uint8_t* sv = slot_valid + (int64_t)ray * M;
+    const float* sl = slot_loc + (int64_t)ray * M * 3;
+    const int cp0 = point_base[ray];
+    float dep[64], al[64], Tt[64];
+    // pass 1: per-slot depths (renderer.py:96-110)
+    float run_max = -INFINITY;
+    for (int j = 0; j < M; ++j) {
+        if (sv[j]) {
+            float acc = 0.f;
+            int cnt = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float q = (sl[j * 3 + c] - o[c]) / d[c];
+                if (q == q) { acc += q; ++cnt; }
+            }
+            run_max = fmaxf(run_max, acc / (float)cnt);
+        }
+        dep[j] = (run_max == -INFINITY) ? ray_end : run_max;
+    }
+    // pass 2: alpha, transmittance, the two sums of the forward
+    float T = 1.f, total = 0.f, wd = 0.f;
+    int cp = cp0;
+    for (int j = 0; j < M; ++j) {
+        const float sg = sv[j] ? sigma[cp] : 0.f;
+        cp += sv[j] ? 1 : 0;
+        const float delta = j + 1 < M ? dep[j + 1] - dep[j] : 0.f;
+        const float alpha = 1.f - expf(-(sg * delta));
+        al[j] = alpha;
+        Tt[j] = T;
+        total += alpha * T;
+        wd += alpha * T * dep[j];
+        T *= (1.f - alpha + 1e-10f);
+    }
+    const float lo = fkey_inv(ws[0]), hi = fkey_inv(ws[1]);
+    const float draw = wd / total;
+    const bool depth_live = (total != 0.f) && (draw == draw) && draw >= lo && draw <= hi && fabsf(draw) != INFINITY;
+    const float gm = g_mask[ray], gd = depth_live ? g_depth[ray] / total : 0.f;
+    const float gc[3] = {g_chan[ray * 3], g_chan[ray * 3 + 1], g_chan[ray * 3 + 2]};
+    const float gbg = white_back ? gc[0] + gc[1] + gc[2] : 0.f;
+    // pass 3: reverse
+    float S = 0.f;
+    for (int j = M - 1; j >= 0; --j) {
+        const bool valid = sv[j] != 0;
+        cp -= valid ? 1 : 0;                                     // compact index of slot j
+        const float w = al[j] * Tt[j];
+        float G = gm - gbg;
+        if (depth_live) G += gd * (dep[j] - draw);               // (not a multiplication by 0: draw is NaN on an empty ray)
+        if (valid) {
+            const float r_ = rgb[cp * 3], g_ = rgb[cp * 3 + 1], b_ = rgb[cp * 3 + 2];
+            G += gc[0] * r_ + gc[1] * g_ + gc[2] * b_;
+            const float dalpha = G * Tt[j] - S / (1.f - al[j] + 1e-10f);
+            const float delta = j + 1 < M ? dep[j + 1] - dep[j] : 0.f;
+            dsigma[cp] = dalpha * delta * (1.f - al[j]);         // exp(-sigma delta) = 1 - alpha
+            drgb[cp * 3 + 0] = gc[0] * w;
+            drgb[cp * 3 + 1] = gc[1] * w;
+            drgb[cp * 3 + 2] = gc[2] * w;
+        }
+        S += G * w;
+    }
+}
+
 // nan -> +inf -> clamp to the global [min, max] of the per-slot depths (renderer.py:151-156)
 __global__ __launch_bounds__(256) void depth_clamp_kernel(int Nr, float* __restrict__ depth, const uint32_t* ws) {
     const int ray = blockIdx.x * blockDim.x + threadIdx.x;
@@ -880,6 +961,22 @@ extern "C" int npcd_ray_march(const float* sigma, const float* rgb, const uint8_
     hipLaunchKernelGGL(ray_march_kernel<false>, dim3(grid), dim3(256), 0, st, sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1,
                        Nr, M, white_back, mask, depth, channels, ws);
     hipLaunchKernelGGL(depth_clamp_kernel, dim3(grid), dim3(256), 0, st, Nr, depth, ws);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int npcd_ray_march_bwd(const float* sigma, const float* rgb, const uint8_t* slot_valid, const float* slot_loc,
+                                  const int32_t* point_base, const float* rays_o, const float* rays_d, const float* t1, int Nr, int M,
+                                  int white_back, const float* depth_ws, const float* g_mask, const float* g_depth, const float* g_chan,
+                                  float* dsigma, float* drgb, void* stream) {
+    if (!sigma || !rgb || !slot_valid || !slot_loc || !point_base || !rays_o || !rays_d || !t1 || !depth_ws || !g_mask || !g_depth || !g_chan ||
+        !dsigma || !drgb)
+        return NPCD_ERR_ARG;
+    if (Nr <= 0 || M <= 0) return NPCD_ERR_ARG;
+    if (M > 64) return NPCD_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(ray_march_bwd_kernel, dim3((Nr + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), sigma, rgb, slot_valid, slot_loc,
+                       point_base, rays_o, rays_d, t1, Nr, M, white_back, reinterpret_cast<const uint32_t*>(depth_ws), g_mask, g_depth, g_chan,
+                       dsigma, drgb);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }

@@ -267,6 +267,44 @@ class _PairAggregate(torch.autograd.Function):
         return dlocal, None, None, None
 
 
+class _RayMarch(torch.autograd.Function):
+    """ray_march with a hand-written backward w.r.t. the compact densities / colours (everything else is constant in stage 1)"""
+
+    @staticmethod
+    def forward(ctx, sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1, white_back):
+        require_gpu(sigma, slot_valid, slot_loc)
+        Nr, M = slot_valid.shape
+        dev = slot_loc.device
+        sv = slot_valid.to(torch.uint8).contiguous()
+        sigma, rgb, slot_loc = sigma.contiguous(), rgb.contiguous(), slot_loc.contiguous()
+        base, o, d, t1 = point_base.to(_i32).contiguous(), rays_o.contiguous(), rays_d.contiguous(), t1.contiguous()
+        mask = torch.empty(Nr, dtype=_f32, device=dev)
+        depth = torch.empty(Nr, dtype=_f32, device=dev)
+        chan = torch.empty((Nr, 3), dtype=_f32, device=dev)
+        ws = torch.empty(4, dtype=_f32, device=dev)
+        check(lib().npcd_ray_march(ptr(sigma), ptr(rgb), ptr(sv), ptr(slot_loc), ptr(base), ptr(o), ptr(d), ptr(t1), Nr, M,
+                                   int(bool(white_back)), ptr(mask), ptr(depth), ptr(chan), ptr(ws), stream_ptr()), "npcd_ray_march")
+        ctx.save_for_backward(sigma, rgb, sv, slot_loc, base, o, d, t1, ws)
+        ctx.white_back = int(bool(white_back))
+        return mask, depth, chan
+
+    @staticmethod
+    def backward(ctx, g_mask, g_depth, g_chan):
+        sigma, rgb, sv, slot_loc, base, o, d, t1, ws = ctx.saved_tensors
+        Nr, M = sv.shape
+        dsigma = torch.empty_like(sigma)
+        drgb = torch.empty_like(rgb)
+        check(lib().npcd_ray_march_bwd(ptr(sigma), ptr(rgb), ptr(sv), ptr(slot_loc), ptr(base), ptr(o), ptr(d), ptr(t1), Nr, M, ctx.white_back,
+                                       ptr(ws), ptr(g_mask.contiguous()), ptr(g_depth.contiguous()), ptr(g_chan.contiguous()), ptr(dsigma),
+                                       ptr(drgb), stream_ptr()), "npcd_ray_march_bwd")
+        return dsigma, drgb, None, None, None, None, None, None, None
+
+
+def ray_march_train(sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1, white_back):
+    """differentiable (sigma, rgb) form of ray_march: HIP forward and backward"""
+    return _RayMarch.apply(sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1, white_back)
+
+
 def pair_input(feat, flat, owner, pts, pos, n_freqs):
     return _PairInput.apply(feat, flat, owner, pts, pos, n_freqs)
 

@@ -195,12 +195,11 @@ def render_train(renderer, kp_pos, kp_feat, extr, intr, resolution: int, sample:
     rows = torch.nonzero(valid_s, as_tuple=True)                                 # valid (ray, slot) cells, row-major
     nb, pts = idx_s[rows], loc_s[rows]
     sigma_c, rgb_c = shade_autograd(field, nb, pts, kp_pos, kp_feat)
-    sigma = torch.zeros(valid_s.shape, device=dev, dtype=sigma_c.dtype).index_put(rows, sigma_c)
-    rgb = torch.zeros(valid_s.shape + (3,), device=dev, dtype=rgb_c.dtype).index_put(rows, rgb_c)
-    dense_pts = torch.zeros(valid_s.shape + (3,), device=dev).index_put(rows, pts)
-    o_s, d_s, end_s = o.reshape(-1, 3)[sel], d.reshape(-1, 3)[sel], end.reshape(-1, 1)[sel]
-    depths = depths_from_points(dense_pts, valid_s, o_s, d_s, end_s)
-    total, cdepth, chan = ray_march(sigma, depths, rgb, valid_s, renderer.white_back)
+    # ray march on the compact densities / colours, HIP forward and backward (no dense scatter, no per-slot depth tensors)
+    per_ray = valid_s.sum(dim=1, dtype=torch.int32)
+    base = torch.cumsum(per_ray, 0, dtype=torch.int32) - per_ray
+    o_s, d_s, end_s = o.reshape(-1, 3)[sel], d.reshape(-1, 3)[sel], end.reshape(-1)[sel]
+    total, cdepth, chan = hr.ray_march_train(sigma_c, rgb_c, valid_s, loc_s, base, o_s, d_s, end_s, renderer.white_back)
     out = AttrDict(mask=total.view(B, T, n, 1), depth=cdepth.view(B, T, n, 1), channels=chan.view(B, T, n, 3))
     if sample:
         out["ray_idx"] = ray_ids[None, :].expand(B * T, Rs).reshape(-1)[sel].view(B, T, n, 1)

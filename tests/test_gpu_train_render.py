@@ -226,3 +226,43 @@ def test_pointnerf_forward_training_surface():
     assert pn.renderer.randomize_depth_samples and pn.feats.sample_embedding
     pn.eval()
     assert not pn.renderer.randomize_depth_samples and not pn.feats.sample_embedding
+
+
+@pytest.mark.parametrize("white_back", [True, False])
+def test_ray_march_backward_kernel_vs_autograd(white_back):
+    """npcd_ray_march_bwd (hand-written) against torch autograd through the dense-tensor formulation of the same march
+    (train_path.depths_from_points / ray_march): densities, colours, and all three outputs incl. the depth."""
+    from npcd.hip import render as hr
+    from npcd.models.pointnerf import train_path as tp
+    g = torch.Generator().manual_seed(7)
+    Nr, M = 300, 50
+    valid = torch.rand(Nr, M, generator=g) < 0.4
+    valid[0] = False                                   # a ray without any shading point
+    valid[1, :20] = False                              # leading invalid slots
+    o = torch.randn(Nr, 3, generator=g) * 0.1 + torch.tensor([0.0, 0.0, -1.3])
+    d = torch.nn.functional.normalize(torch.randn(Nr, 3, generator=g) * 0.2 + torch.tensor([0.0, 0.0, 1.0]), dim=-1)
+    tdep = torch.sort(torch.rand(Nr, M, generator=g) * 1.5 + 0.5, dim=1).values
+    loc = (o[:, None] + tdep[..., None] * d[:, None]) * valid[..., None]
+    end = torch.full((Nr,), 2.2)
+    P = int(valid.sum())
+    sigma = (torch.rand(P, generator=g) * 6).cuda().requires_grad_(True)
+    rgb = torch.rand(P, 3, generator=g).cuda().requires_grad_(True)
+    gm, gd, gc = torch.randn(Nr, generator=g).cuda(), torch.randn(Nr, generator=g).cuda(), torch.randn(Nr, 3, generator=g).cuda()
+    valid, loc, o, d, end = valid.cuda(), loc.cuda(), o.cuda(), d.cuda(), end.cuda()
+    per_ray = valid.sum(1, dtype=torch.int32)
+    base = torch.cumsum(per_ray, 0, dtype=torch.int32) - per_ray
+    m1, d1, c1 = hr.ray_march_train(sigma, rgb, valid, loc, base, o, d, end, white_back)
+    live = m1.detach() > 1e-6                          # torch's own backward of 0/0 is NaN on empty rays: leave those out of the depth term
+    ((m1 * gm).sum() + (d1 * gd * live).sum() + (c1 * gc).sum()).backward()
+    gs1, gr1 = sigma.grad.clone(), rgb.grad.clone()
+    sigma.grad = rgb.grad = None
+    rows = torch.nonzero(valid, as_tuple=True)
+    sd = torch.zeros(Nr, M, device="cuda").index_put(rows, sigma)
+    rd = torch.zeros(Nr, M, 3, device="cuda").index_put(rows, rgb)
+    depths = tp.depths_from_points(loc, valid, o, d, end[:, None])
+    m2, d2, c2 = tp.ray_march(sd, depths, rd, valid, white_back)
+    ((m2[:, 0] * gm).sum() + (torch.where(live, d2[:, 0], torch.zeros_like(gd)) * gd).sum() + (c2 * gc).sum()).backward()
+    assert torch.allclose(m1, m2[:, 0], atol=1e-6) and torch.allclose(c1, c2, atol=1e-6)
+    assert torch.allclose(d1[live], d2[live, 0], atol=1e-5)
+    assert float((gs1 - sigma.grad).abs().max()) < 1e-4 * max(1.0, float(sigma.grad.abs().max()))
+    assert float((gr1 - rgb.grad).abs().max()) < 1e-5 * max(1.0, float(rgb.grad.abs().max()))
