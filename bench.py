@@ -125,7 +125,7 @@ def bench_stage1(device, n_iters=5, burn_in=2, mlp_dtype=None):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n_iters
     return {"steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "objects": B, "views_per_object": T, "rays_per_view": net.pointnerf.renderer.ray_subsamples,
-            "loss": float(loss), "differentiable_part": "HIP: ray generation, both neighbour queries, pair inputs and aggregation (forward + backward); library GEMMs (row-split weight gradients) and torch autograd for the MLP layers and the ray march"}
+            "loss": float(loss), "differentiable_part": "HIP: ray generation, both neighbour queries, pair inputs, aggregation and ray march (forward + backward); library GEMMs (row-split weight gradients) and torch autograd for the MLP layers"}
 
 
 def cpu_baseline():
