@@ -91,3 +91,30 @@ def test_normalizers_host(golden):
     np.testing.assert_allclose(un(T(g["xc"])).numpy(), g["c_train"], atol=1e-6)
     un.eval(); mm.eval()
     np.testing.assert_allclose(mm(T(g["xf"])).numpy(), g["f_eval"], atol=1e-6)
+
+
+def test_row_split_linear_matches_plain_linear():
+    """train_path._RowSplitLinear (weight gradient summed over row slices, with and without a remainder slice) against
+    F.linear + autograd in fp32 on the CPU."""
+    import torch.nn.functional as F
+    from npcd.models.pointnerf.train_path import _RowSplitLinear
+    g = torch.Generator().manual_seed(0)
+    old = _RowSplitLinear.SLICE
+    _RowSplitLinear.SLICE = 64
+    try:
+        for rows in (64 * 3, 64 * 3 + 17, 100, 5):
+            x = torch.randn(rows, 24, generator=g, requires_grad=True)
+            w = torch.randn(16, 24, generator=g, requires_grad=True)
+            b = torch.randn(16, generator=g, requires_grad=True)
+            gy = torch.randn(rows, 16, generator=g)
+            y = _RowSplitLinear.apply(x, w, b, None)
+            y.backward(gy)
+            got = (y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone())
+            x.grad = w.grad = b.grad = None
+            y2 = F.linear(x, w, b)
+            y2.backward(gy)
+            for a, r in zip(got, (y2.detach(), x.grad, w.grad, b.grad)):
+                assert torch.allclose(a, r, atol=2e-5, rtol=1e-5), rows
+            x.grad = w.grad = b.grad = None
+    finally:
+        _RowSplitLinear.SLICE = old
