@@ -896,11 +896,7 @@ __device__ __forceinline__ void dkdv_flush(const FragAddr& fa, DkdvState& a, con
 // One 64-row query tile t >= 1 in ring slot SLOT.  Ring protocol: tile t+1 is awaited (and tile t+2 requested, into
 // the slot of tile t-1) in the MIDDLE of tile t, after the last reads of tile t-1 (the transposed fragments read by the
 // first stage of tile t).  Returns false when the tile's second sub-block lies completely past the sequence.
-#ifdef NPCD_EXP_NOBARRIER
-#define NPCD_DKDV_MID() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#else
 #define NPCD_DKDV_MID() NPCD_DMA_WAIT_BARRIER(0)
-#endif
 template <class TR, int SLOT>
 __device__ __forceinline__ bool dkdv_step(unsigned char* smem, const FragAddr& fa, uint32_t st_addr, const QdoStream<typename TR::elem>& qs,
                                           int t, int nt, int n, int wave, int lane, const typename TR::vec8 (&kf)[4],
@@ -1207,11 +1203,7 @@ static int attn_bwd_launch(int passes, const void* q, const void* k, const void*
     p.scale = scale; p.scale_log2 = scale * kLog2e;
     const int grid = B * H * ceil_div(n, 128);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    #ifdef NPCD_EXP_LDS
-    const int dyn = NPCD_EXP_LDS;
-#else
     const int dyn = 3 * kDkdvSlot;
-#endif
     static bool attr_set = false;
     if (!attr_set) {
         NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<BF16>),
