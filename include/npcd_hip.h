@@ -248,6 +248,12 @@ int npcd_ray_march_compact(const float* sigma, const float* rgb, const uint64_t*
 int npcd_pair_input_fwd(const int64_t* flat, const int64_t* owner, const float* pts, const float* kp_pos, const float* kp_feat,
                         int feat_dim, int n_freqs, int64_t n_pairs, float* x0, float* w, void* stream);
 int npcd_pair_input_bwd(const int64_t* flat, const float* dx0, int feat_dim, int n_cols, int64_t n_pairs, float* dfeat, void* stream);
+/* LeakyReLU backward fused with the bias-gradient column partials (stage-1 MLPs, utils/model.py:22-36): dy = dz * (z > 0 ? 1 :
+ * slope) with z the activation output, part [npcd_leaky_bwd_blocks(rows) + npcd_colsum_scratch_rows()][N] = column partials of
+ * dy for npcd_colsum_finalize.  dtype NPCD_F32 or NPCD_BF16; N * element size a multiple of 16 bytes that divides 4096. */
+int npcd_leaky_bwd_blocks(int64_t rows);
+int npcd_leaky_bwd_colsum(const void* dz, const void* z, void* dy, float* part, int64_t rows, int N, float slope, int dtype,
+                          void* stream);
 int npcd_pair_aggregate(int backward, const float* src, const float* w, const int64_t* off, const int64_t* cnt, int channels,
                         int64_t n_points, float* dst, void* stream);
 

@@ -74,9 +74,76 @@ __global__ __launch_bounds__(256) void aggregate_kernel(const float* __restrict_
     }
 }
 
+// LeakyReLU backward + bias-gradient column partials in one pass (utils/model.py:22-36: Linear -> LeakyReLU(0.01)):
+//   dy = dz * (z > 0 ? 1 : slope)   (z = the activation OUTPUT: same sign as its input for slope > 0),
+//   part[workgroup][c] = sum over the workgroup's rows of dy[:, c]  (then npcd_colsum_finalize: fixed order).
+// A thread owns 16 bytes of a row; the workgroup's 256 threads are (N * sizeof(T) / 16) column threads x row lanes, the row
+// lanes of all workgroups interleave over the rows (one contiguous band at a time, cf. the column-sum kernels of the denoiser).
+template <class T>
+__global__ __launch_bounds__(256) void leaky_bwd_colsum_kernel(const T* __restrict__ dz, const T* __restrict__ z, T* __restrict__ dy,
+                                                               float* __restrict__ part, int64_t R, int N, float slope) {
+    constexpr int VEC = 16 / sizeof(T);
+    typedef T TV __attribute__((ext_vector_type(VEC)));
+    extern __shared__ float red[];                   // [row lanes][N]
+    const int CT = N / VEC, RL = 256 / CT;
+    const int ct = threadIdx.x % CT, rl = threadIdx.x / CT, col = ct * VEC;
+    const int64_t slots = (int64_t)gridDim.x * RL;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * RL + rl; row < R; row += slots) {
+        const TV g = *reinterpret_cast<const TV*>(dz + row * N + col);
+        const TV a = *reinterpret_cast<const TV*>(z + row * N + col);
+        TV o;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            o[j] = (T)((float)g[j] * ((float)a[j] > 0.f ? 1.f : slope));
+            acc[j] += (float)o[j];
+        }
+        *reinterpret_cast<TV*>(dy + row * N + col) = o;
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) red[rl * N + col + j] = acc[j];
+    __syncthreads();
+    if (rl == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float v = 0.f;
+            for (int q = 0; q < RL; ++q) v += red[q * N + col + j];
+            part[(int64_t)blockIdx.x * N + col + j] = v;
+        }
+    }
+}
+
 }  // namespace npcd
 
 using namespace npcd;
+
+extern "C" int npcd_leaky_bwd_blocks(int64_t rows) {
+    const int64_t b = (rows + 63) / 64;
+    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+extern "C" int npcd_leaky_bwd_colsum(const void* dz, const void* z, void* dy, float* part, int64_t rows, int N, float slope, int dtype,
+                                     void* stream) {
+    if (!dz || !z || !dy || !part || rows <= 0 || N <= 0) return NPCD_ERR_ARG;
+    const int esz = dtype == NPCD_F32 ? 4 : 2;
+    if (dtype != NPCD_F32 && dtype != NPCD_BF16) return NPCD_ERR_UNSUPPORTED;
+    const int ct = N * esz / 16;
+    if ((N * esz) % 16 != 0 || ct < 1 || ct > 256 || 256 % ct != 0) return NPCD_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(dz) & 15) || (reinterpret_cast<uintptr_t>(z) & 15) || (reinterpret_cast<uintptr_t>(dy) & 15)) return NPCD_ERR_UNSUPPORTED;
+    const dim3 grid(npcd_leaky_bwd_blocks(rows));
+    const size_t lds = (size_t)(256 / ct) * N * sizeof(float);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == NPCD_F32)
+        hipLaunchKernelGGL(leaky_bwd_colsum_kernel<float>, grid, dim3(256), lds, st, static_cast<const float*>(dz), static_cast<const float*>(z),
+                           static_cast<float*>(dy), part, rows, N, slope);
+    else
+        hipLaunchKernelGGL(leaky_bwd_colsum_kernel<__bf16>, grid, dim3(256), lds, st, static_cast<const __bf16*>(dz), static_cast<const __bf16*>(z),
+                           static_cast<__bf16*>(dy), part, rows, N, slope);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
 
 extern "C" int npcd_pair_input_fwd(const int64_t* flat, const int64_t* owner, const float* pts, const float* kp_pos, const float* kp_feat,
                                    int feat_dim, int n_freqs, int64_t n_pairs, float* x0, float* w, void* stream) {

@@ -32,6 +32,8 @@ SIGNATURES = {
     "npcd_last_hip_error": (c_char_p, []),
     "npcd_attn_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int] + [c_int64] * 6 + [c_float, c_int, _P]),
     "npcd_ray_march_bwd": (c_int, [_P] * 8 + [c_int, c_int, c_int] + [_P] * 6 + [_P]),
+    "npcd_leaky_bwd_blocks": (c_int, [c_int64]),
+    "npcd_leaky_bwd_colsum": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_float, c_int, _P]),
     "npcd_pair_input_fwd": (c_int, [_P] * 5 + [c_int, c_int, c_int64, _P, _P, _P]),
     "npcd_pair_input_bwd": (c_int, [_P, _P, c_int, c_int, c_int64, _P, _P]),
     "npcd_pair_aggregate": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int64, _P, _P]),

@@ -305,6 +305,26 @@ def ray_march_train(sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d
     return _RayMarch.apply(sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1, white_back)
 
 
+def leaky_bwd_colsum(dz, z, slope):
+    """dy = dz * (z > 0 ? 1 : slope), dbias [N] (fp32) = column sum of dy: one pass + a fixed-order finalize (csrc/pairs.hip).
+    dz, z [R, N] contiguous, fp32 or bf16.  Returns None when the shape is not covered (the caller falls back to torch)."""
+    from . import dtype_code
+    R, N = z.shape
+    esz = z.element_size()
+    ct = N * esz // 16
+    if z.dtype not in (_f32, torch.bfloat16) or (N * esz) % 16 or ct < 1 or ct > 256 or 256 % ct:
+        return None
+    L = lib()
+    dz, z = dz.contiguous(), z.contiguous()
+    nblk = L.npcd_leaky_bwd_blocks(R)
+    dy = torch.empty_like(z)
+    part = torch.empty((nblk + L.npcd_colsum_scratch_rows(), N), dtype=_f32, device=z.device)
+    db = torch.empty(N, dtype=_f32, device=z.device)
+    check(L.npcd_leaky_bwd_colsum(ptr(dz), ptr(z), ptr(dy), ptr(part), R, N, float(slope), dtype_code(z), stream_ptr()), "npcd_leaky_bwd_colsum")
+    check(L.npcd_colsum_finalize(ptr(part), nblk, N, ptr(db), 0, stream_ptr()), "npcd_colsum_finalize")
+    return dy, db
+
+
 def pair_input(feat, flat, owner, pts, pos, n_freqs):
     return _PairInput.apply(feat, flat, owner, pts, pos, n_freqs)
 

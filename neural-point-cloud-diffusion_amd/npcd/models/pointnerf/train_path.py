@@ -49,18 +49,32 @@ class _RowSplitLinear(torch.autograd.Function):
     SLICE = 16384
 
     @staticmethod
-    def forward(ctx, x, weight, bias, dtype):
+    def forward(ctx, x, weight, bias, dtype, slope=None):
+        """slope: negative slope of a LeakyReLU applied to the output (in place), or None"""
         xx = x if dtype is None else x.to(dtype)
         ww = weight if dtype is None else weight.to(dtype)
         bb = bias if dtype is None else bias.to(dtype)
-        ctx.save_for_backward(xx, ww)
-        ctx.in_dtype = x.dtype
-        return torch.addmm(bb, xx, ww.t())
+        y = torch.addmm(bb, xx, ww.t())
+        if slope is not None:
+            y = F.leaky_relu(y, slope, inplace=True)
+            ctx.save_for_backward(xx, ww, y)         # the activation OUTPUT carries the sign its backward needs
+        else:
+            ctx.save_for_backward(xx, ww)
+        ctx.in_dtype, ctx.slope = x.dtype, slope
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        xx, ww = ctx.saved_tensors
+        xx, ww = ctx.saved_tensors[:2]
         dy = dy.to(xx.dtype).contiguous()
+        db = None
+        if ctx.slope is not None:
+            z = ctx.saved_tensors[2]
+            fused = hr.leaky_bwd_colsum(dy, z, ctx.slope) if dy.is_cuda else None    # activation backward + bias gradient: one pass
+            if fused is not None:
+                dy, db = fused
+            else:
+                dy = dy * torch.where(z > 0, 1.0, ctx.slope).to(dy.dtype)
         dx = torch.mm(dy, ww).to(ctx.in_dtype) if ctx.needs_input_grad[0] else None
         rows, c = dy.shape[0], _RowSplitLinear.SLICE
         S = rows // c
@@ -82,7 +96,9 @@ class _RowSplitLinear(torch.autograd.Function):
             dw = part.sum(dim=0)
         else:
             dw = torch.mm(dy.t(), xx, out_dtype=f32) if mixed else torch.mm(dy.t(), xx)
-        return dx, dw, dy.sum(dim=0, dtype=f32), None
+        if db is None:
+            db = dy.sum(dim=0, dtype=f32)
+        return dx, dw, db, None, None
 
 
 def _mlp(seq, x, dtype):
@@ -92,11 +108,16 @@ def _mlp(seq, x, dtype):
     if x.shape[0] < 262144:
         with torch.autocast("cuda", dtype=dtype or torch.bfloat16, enabled=dtype is not None):
             return seq(x)
-    for m in seq:
+    mods, i = list(seq), 0
+    while i < len(mods):
+        m = mods[i]
         if isinstance(m, torch.nn.Linear):
-            x = _RowSplitLinear.apply(x, m.weight, m.bias, dtype)
+            act = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.LeakyReLU) else None
+            x = _RowSplitLinear.apply(x, m.weight, m.bias, dtype, None if act is None else act.negative_slope)
+            i += 2 if act is not None else 1
         else:
             x = m(x)
+            i += 1
     return x
 
 

@@ -266,3 +266,22 @@ def test_ray_march_backward_kernel_vs_autograd(white_back):
     assert torch.allclose(d1[live], d2[live, 0], atol=1e-5)
     assert float((gs1 - sigma.grad).abs().max()) < 1e-4 * max(1.0, float(sigma.grad.abs().max()))
     assert float((gr1 - rgb.grad).abs().max()) < 1e-5 * max(1.0, float(rgb.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R", [1, 777, 300001])
+def test_leaky_bwd_colsum_kernel(dtype, R):
+    """LeakyReLU backward fused with the bias-gradient column sum (csrc/pairs.hip) against torch"""
+    from npcd.hip import render as hr
+    g = torch.Generator().manual_seed(R)
+    z = torch.randn(R, 256, generator=g).to(dtype).cuda()
+    z[0, :5] = 0.0                                     # z == 0 takes the negative slope like torch's leaky_relu_backward (x > 0 ? 1 : slope)
+    dz = torch.randn(R, 256, generator=g).to(dtype).cuda()
+    dy, db = hr.leaky_bwd_colsum(dz, z, 0.01)
+    ref = (dz.float() * torch.where(z.float() > 0, 1.0, 0.01)).to(dtype)
+    assert torch.equal(dy, ref)
+    refb = ref.float().sum(0)
+    assert float((db - refb).abs().max()) <= 1e-5 * max(1.0, float(refb.abs().max())) * (R ** 0.5)
+    dy2, db2 = hr.leaky_bwd_colsum(dz, z, 0.01)
+    assert torch.equal(db, db2)                        # fixed summation order
+    assert hr.leaky_bwd_colsum(dz[:, :100].contiguous(), z[:, :100].contiguous(), 0.01) is None    # shape not covered -> caller falls back

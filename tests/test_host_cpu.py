@@ -107,11 +107,14 @@ def test_row_split_linear_matches_plain_linear():
             w = torch.randn(16, 24, generator=g, requires_grad=True)
             b = torch.randn(16, generator=g, requires_grad=True)
             gy = torch.randn(rows, 16, generator=g)
-            y = _RowSplitLinear.apply(x, w, b, None)
+            slope = 0.01 if rows % 2 else None                     # with and without the fused LeakyReLU
+            y = _RowSplitLinear.apply(x, w, b, None, slope)
             y.backward(gy)
             got = (y.detach().clone(), x.grad.clone(), w.grad.clone(), b.grad.clone())
             x.grad = w.grad = b.grad = None
             y2 = F.linear(x, w, b)
+            if slope is not None:
+                y2 = F.leaky_relu(y2, slope)
             y2.backward(gy)
             for a, r in zip(got, (y2.detach(), x.grad, w.grad, b.grad)):
                 assert torch.allclose(a, r, atol=2e-5, rtol=1e-5), rows
