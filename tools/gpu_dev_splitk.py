@@ -1,3 +1,4 @@
+"""Dev probe: split-K variants of the weight-gradient GEMMs."""
 import torch
 T, W = 64 * 513, 1024
 def tm(fn, n=20):
