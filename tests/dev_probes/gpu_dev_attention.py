@@ -1,7 +1,7 @@
 """Developer probe (not a pytest file): print attention kernel errors for several shapes."""
 import sys, os, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neural-point-cloud-diffusion_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "neural-point-cloud-diffusion_amd"))
 import torch
 from oracle import denoiser as od
 from npcd.hip.attention import attention_qkvpacked

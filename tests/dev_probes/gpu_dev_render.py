@@ -1,6 +1,6 @@
 """Developer probe (not a pytest file): renderer kernels vs the oracle, with error printouts."""
 import sys, os, time
-R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R_ = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R_); sys.path.insert(0, os.path.join(R_, "neural-point-cloud-diffusion_amd"))
 import numpy as np, torch
 from oracle import renderer as orr, voxel_grid as ovg

@@ -3,11 +3,11 @@ import sys, os, time
 R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R_); sys.path.insert(0, os.path.join(R_, "neural-point-cloud-diffusion_amd"))
 import torch
-from oracle import renderer as orr
+from npcd.utils import synthetic as orr
 from npcd.models.pointnerf import PointNeRF
 from npcd.hip import render as hr
-coords, feats = orr.synthetic_cloud(512, 32, 1, seed=0)
-model = PointNeRF(1, 32, 512, False); model.field.load_state_dict(orr.init_field_params(32, seed=0)); model = model.cuda().eval()
+coords, feats = orr.ellipsoid_cloud(512, 32, 1, seed=0)
+torch.manual_seed(0); model = PointNeRF(1, 32, 512, False).cuda().eval()      # field MLPs: PyTorch default init, as in bench.py
 extr = orr.look_at_pose(30, 20)[None, None].cuda(); intr = orr.srn_intrinsics()[None, None].cuda()
 c, f = coords.cuda(), feats.cuda()
 def T(): torch.cuda.synchronize(); return time.time()

@@ -3,10 +3,10 @@ import sys, os, time
 R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R_); sys.path.insert(0, os.path.join(R_, "neural-point-cloud-diffusion_amd"))
 import torch
-from oracle import renderer as orr
+from npcd.utils import synthetic as orr
 from npcd.models.pointnerf import PointNeRF
-coords, feats = orr.synthetic_cloud(512, 32, 1, seed=0)
-model = PointNeRF(1, 32, 512, False); model.field.load_state_dict(orr.init_field_params(32, seed=0)); model = model.cuda().eval(); model.renderer.count_pairs = bool(int(os.environ.get("COUNT_PAIRS", "0")))
+coords, feats = orr.ellipsoid_cloud(512, 32, 1, seed=0)
+torch.manual_seed(0); model = PointNeRF(1, 32, 512, False).cuda().eval()      # field MLPs: PyTorch default init, as in bench.py; model.renderer.count_pairs = bool(int(os.environ.get("COUNT_PAIRS", "0")))
 extr = orr.look_at_pose(30, 20)[None, None].cuda(); intr = orr.srn_intrinsics()[None, None].cuda()
 c, f = coords.cuda(), feats.cuda()
 if os.environ.get("NPCD_ZERO_DATA"):      # clock check: all-zero weights and features (same instruction stream, less power)
