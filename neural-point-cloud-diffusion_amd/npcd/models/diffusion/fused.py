@@ -35,14 +35,15 @@ _BLOCK_PARAMS = ("ln_1.weight", "ln_1.bias", "attn.c_qkv.weight", "attn.c_qkv.bi
 # pulling 2-8 MB of cold weights through a launch that is over before it has filled the chip.  Not kept.)
 import os
 
-_SPLIT = 0 if os.environ.get("NPCD_NO_GEMM_SPLIT") else 256       # (the env switch exists for A/B measurements)
+_SPLIT = 0 if os.environ.get("NPCD_NO_GEMM_SPLIT") else 256       # (the env switches exist for A/B measurements)
+_SPLIT_MIN = int(os.environ.get("NPCD_GEMM_SPLIT_MIN", "16000"))
 
 
 def _split_gemm(fn, T):
     """fn(rows) enqueues the product for a row range into a shared output."""
-    # below ~20 k tokens the large call is short enough that the extra launch costs what the quarter tile did (measured at
-    # per-GPU batch 8 and 16: 19.9 vs 20.2 ms and 30.8 vs 31.1 ms per step)
-    Tm = T - T % _SPLIT if (_SPLIT and T >= 20000) else T
+    # below ~16 k tokens the large call is short enough that the extra launch costs what the quarter tile did (measured at
+    # per-GPU batch 8 and 16: 19.9 vs 20.2 ms and 30.8 vs 31.1 ms per step; at per-GPU batch 32 the split wins: 50.4 -> 48.9 ms)
+    Tm = T - T % _SPLIT if (_SPLIT and T >= _SPLIT_MIN) else T
     if Tm == 0 or Tm == T:
         fn(slice(0, T))
         return
