@@ -1,11 +1,12 @@
 """Training-mode rendering (stage-1 autodecoder training): a few hundred randomly chosen rays
 per view with jittered depth samples, differentiable w.r.t. the neural-point features and the field weights.
 
-First version of this row.  Geometry -- ray generation and the neighbour query -- runs on the HIP kernels
-(npcd.hip.render); the differentiable part (per-pair MLP, aggregation, heads, ray march: ~1e6 (point, neighbour) pairs per
-step at the reference's 8 objects x 50 views x 112 rays) is written with torch operators on the device so that autograd
-provides the backward; its GEMMs are library calls.  Nothing here runs on the CPU: the neighbour query fails loudly
-without the HIP library.
+Where things run: ray generation with its cube limits, the neighbour query, the MLP input of every (point, neighbour) pair,
+the inverse-distance aggregation, the LeakyReLU backward + bias gradients of the per-pair layers and the ray march are HIP
+kernels with hand-written backward (npcd.hip.render, csrc/geometry.hip, csrc/pairs.hip); the Linear layers are library GEMMs
+(weight gradients split along the ~1e6 rows, _RowSplitLinear); the point-level heads, the ray selection and the losses are
+torch operators on the device.  `positional_encoding`, `depths_from_points` and `ray_march` below are the torch formulations
+the kernels are tested against.  Nothing here runs on the CPU: the neighbour query fails loudly without the HIP library.
 
 Reference: renderers/renderer.py:49-77,96-110,120-185,202-268; renderers/volume_renderer.py:23-92; fields/field.py:77-152;
 fields/aggregators/aggregator.py:78-119; fields/aggregators/mlp.py:36-125; fields/positional_encoder.py:7-23;
