@@ -285,3 +285,47 @@ def test_leaky_bwd_colsum_kernel(dtype, R):
     dy2, db2 = hr.leaky_bwd_colsum(dz, z, 0.01)
     assert torch.equal(db, db2)                        # fixed summation order
     assert hr.leaky_bwd_colsum(dz[:, :100].contiguous(), z[:, :100].contiguous(), 0.01) is None    # shape not covered -> caller falls back
+
+
+def test_pair_input_and_aggregate_kernels_vs_torch():
+    """csrc/pairs.hip (forward and backward) against the torch formulation of the same two steps: gather + relative position
+    + positional encoding + inverse-distance weights, and the weighted mean over each point's pairs."""
+    from npcd.hip import render as hr
+    from npcd.models.pointnerf.train_path import positional_encoding
+    g = torch.Generator().manual_seed(11)
+    Nt, F_, P, k, nf, C = 200, 32, 500, 8, 10, 256
+    nb = torch.randint(0, Nt, (P, k), generator=g)
+    nb[torch.rand(P, k, generator=g) < 0.3] = -1
+    nb = torch.sort(nb, dim=1, descending=True).values            # valid entries first (only the order within a row matters)
+    nb[7] = -1                                                     # a point without neighbours
+    nb = nb.cuda()
+    feat = torch.randn(Nt, F_, generator=g).cuda().requires_grad_(True)
+    pos = (torch.rand(Nt, 3, generator=g) - 0.5).cuda()
+    pts = (torch.rand(P, 3, generator=g) - 0.5).cuda()
+    valid = nb >= 0
+    owner, col = torch.nonzero(valid, as_tuple=True)
+    flat = nb[owner, col]
+    cnt = valid.sum(1)
+    off = torch.cumsum(cnt, 0) - cnt
+    gx = torch.randn(flat.numel(), F_ + 3 + 6 * nf, generator=g).cuda()
+    # pair inputs
+    x0, w = hr.pair_input(feat, flat, owner, pts, pos, nf)
+    (x0 * gx).sum().backward()
+    g1 = feat.grad.clone(); feat.grad = None
+    rel = pts[owner] - pos[flat]
+    x0r = torch.cat((feat[flat], positional_encoding(rel, nf)), dim=-1)
+    wr = 1.0 / (torch.linalg.norm(rel, dim=-1) + 1e-5)
+    (x0r * gx).sum().backward()
+    assert torch.allclose(x0, x0r, atol=2e-6) and torch.allclose(w, wr, rtol=1e-6)
+    assert torch.allclose(g1, feat.grad, atol=1e-4, rtol=1e-5)
+    # aggregation
+    local = torch.randn(flat.numel(), C, generator=g).cuda().requires_grad_(True)
+    ga = torch.randn(P, C, generator=g).cuda()
+    agg = hr.pair_aggregate(local, w, off, cnt)
+    (agg * ga).sum().backward()
+    g2 = local.grad.clone(); local.grad = None
+    wn = w / torch.zeros(P, device="cuda").index_add_(0, owner, w)[owner]
+    aggr = torch.zeros(P, C, device="cuda").index_add_(0, owner, wn[:, None] * local)
+    (aggr * ga).sum().backward()
+    assert torch.allclose(agg, aggr, atol=1e-5) and torch.allclose(g2, local.grad, atol=1e-6)
+    assert float(agg[7].abs().max()) == 0.0
