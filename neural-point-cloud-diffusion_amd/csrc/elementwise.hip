@@ -31,51 +31,78 @@ __device__ __forceinline__ bf16x4 f32_to_bf16x4(f32x4 v) { return bf16x4{(__bf16
 // x_out = x_in (+ delta);  y = LayerNorm(x_out) * gamma + beta  (bf16);  mean / rstd saved
 // one wave per row
 // ============================================================================================
+// A wave walks rows g, g + NW, g + 2 NW, ... (NW waves in the grid: the grid streams one contiguous band of rows at a time) and
+// loads row r + NW before it reduces and stores row r; the affine parameters stay in registers.
 template <int NCH>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ x_in, const __bf16* __restrict__ delta,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* __restrict__ x_out, __bf16* __restrict__ y, float* __restrict__ mean,
                                                          float* __restrict__ rstd, int T, int W, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
+    const int NW = gridDim.x * 4;
+    int row = blockIdx.x * 4 + wave;
     if (row >= T) return;
-    const int64_t base = (int64_t)row * W;
-    f32x4 v[NCH];
-    float s = 0.f;
+    f32x4 gm[NCH], bt[NCH], v[NCH], nx[NCH];
+    bf16x4 nd[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int c = ch * 256 + lane * 4;
-        v[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gm[ch] = bt[ch] = nx[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+        nd[ch] = bf16x4{0, 0, 0, 0};
         if (c < W) {
-            v[ch] = *reinterpret_cast<const f32x4*>(x_in + base + c);
-            if (delta) v[ch] += bf16x4_to_f32(*reinterpret_cast<const bf16x4*>(delta + base + c));
-            if (x_out) *reinterpret_cast<f32x4*>(x_out + base + c) = v[ch];
-            s += (v[ch][0] + v[ch][1]) + (v[ch][2] + v[ch][3]);
+            gm[ch] = *reinterpret_cast<const f32x4*>(gamma + c);
+            bt[ch] = *reinterpret_cast<const f32x4*>(beta + c);
         }
     }
-    const float mu = wave_sum(s) / (float)W;
-    float q = 0.f;
+    auto load_row = [&](int r) {
+        const int64_t base = (int64_t)r * W;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int c = ch * 256 + lane * 4;
-        if (c < W) {
-            const f32x4 d = v[ch] - mu;
-            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = ch * 256 + lane * 4;
+            if (c < W) {
+                nx[ch] = *reinterpret_cast<const f32x4*>(x_in + base + c);
+                if (delta) nd[ch] = *reinterpret_cast<const bf16x4*>(delta + base + c);
+            }
         }
-    }
-    const float rs = rsqrtf(wave_sum(q) / (float)W + eps);
+    };
+    load_row(row);
+    for (; row < T; row += NW) {
+        const int64_t base = (int64_t)row * W;
+        float s = 0.f;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int c = ch * 256 + lane * 4;
-        if (c < W) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
-            *reinterpret_cast<bf16x4*>(y + base + c) = f32_to_bf16x4((v[ch] - mu) * rs * g + b);
+        for (int ch = 0; ch < NCH; ++ch) {
+            v[ch] = nx[ch];
+            if (delta) v[ch] += bf16x4_to_f32(nd[ch]);
         }
-    }
-    if (lane == 0) {
-        mean[row] = mu;
-        rstd[row] = rs;
+        if (row + NW < T) load_row(row + NW);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = ch * 256 + lane * 4;
+            if (c < W) {
+                if (x_out) *reinterpret_cast<f32x4*>(x_out + base + c) = v[ch];
+                s += (v[ch][0] + v[ch][1]) + (v[ch][2] + v[ch][3]);
+            }
+        }
+        const float mu = wave_sum(s) / (float)W;
+        float q = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = ch * 256 + lane * 4;
+            if (c < W) {
+                const f32x4 d = v[ch] - mu;
+                q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) / (float)W + eps);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int c = ch * 256 + lane * 4;
+            if (c < W) *reinterpret_cast<bf16x4*>(y + base + c) = f32_to_bf16x4((v[ch] - mu) * rs * gm[ch] + bt[ch]);
+        }
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
     }
 }
 
@@ -401,6 +428,9 @@ static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 
 using namespace npcd;
 
+// rows are interleaved over the waves of a grid of at most 2048 workgroups (8 per CU)
+static inline int ln_fwd_blocks(int T) { const int b = (T + 3) / 4; return b < 2048 ? b : 2048; }
+
 extern "C" int npcd_add_ln_fwd(const float* x_in, const void* delta, const float* gamma, const float* beta, float* x_out, void* y,
                                float* mean, float* rstd, int T, int W, float eps, void* stream) {
     if (!x_in || !gamma || !beta || !y || !mean || !rstd || T <= 0 || W <= 0) return NPCD_ERR_ARG;
@@ -409,7 +439,7 @@ extern "C" int npcd_add_ln_fwd(const float* x_in, const void* delta, const float
         (delta && (reinterpret_cast<uintptr_t>(delta) & 7)))
         return NPCD_ERR_ARG;
 #define NPCD_LAUNCH_LN_FWD(NCH)                                                                                               \
-    hipLaunchKernelGGL(add_ln_fwd_kernel<NCH>, dim3((T + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), x_in,        \
+    hipLaunchKernelGGL(add_ln_fwd_kernel<NCH>, dim3(ln_fwd_blocks(T)), dim3(256), 0, static_cast<hipStream_t>(stream), x_in,        \
                        static_cast<const __bf16*>(delta), gamma, beta, x_out, static_cast<__bf16*>(y), mean, rstd, T, W, eps)
     if (W <= 256) NPCD_LAUNCH_LN_FWD(1);
     else if (W <= 512) NPCD_LAUNCH_LN_FWD(2);
