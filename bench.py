@@ -28,7 +28,6 @@ import torch.distributed as dist
 CFG = dict(coords_dim=3, feats_dim=128, num_points=512, width=1024, layers=24, heads=16, global_batch=64)
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0          # HBM3E, MI355X_MICROARCH.md
-PEAK_HBM_GBS = 8000.0
 
 
 def denoiser_flops_per_sample():
@@ -46,7 +45,11 @@ def build_trainer(device, per_rank_batch):
     model = DiffusionModel(CFG["coords_dim"], CFG["feats_dim"], CFG["num_points"], CFG["width"], CFG["layers"], CFG["heads"], True)
     torch.nn.init.normal_(model.denoiser.output_proj.weight, std=0.02)    # non-zero so grads are non-trivial
     model = model.to(device).train()
-    return DiffusionTrainer(model, lr=7e-5, weight_decay=0.01, ema_decay=0.9999, dtype=torch.bfloat16)
+    trainer = DiffusionTrainer(model, lr=7e-5, weight_decay=0.01, ema_decay=0.9999, dtype=torch.bfloat16)
+    # the number below is only valid for the native path: fused AdamW/EMA kernel, bf16 shadow, hand-written backbone node
+    assert trainer.native, "DiffusionTrainer fell back to the torch optimizer: libnpcd_hip.so path not engaged"
+    assert model.denoiser.backbone.fused_engine is not None, "fused HIP backbone (FusedBackboneEngine) not engaged"
+    return trainer
 
 
 def synthetic_batch(global_batch, rank, world, device):
@@ -60,7 +63,8 @@ def synthetic_batch(global_batch, rank, world, device):
 
 def bench_render(device, n_iters=100, burn_in=5):
     """pointnerf_evaluation.py:217-224 protocol: sync, t0, render, sync, t1; burn-in renders discarded (the reference drops 3
-    and then renders 251 views per object: the timed region here is 100 back-to-back renders, i.e. the sustained rate)."""
+    and then renders 251 views per object: the timed region here is 100 back-to-back renders, i.e. the sustained rate).
+    Depth samples per ray: 128 is the reference's code (pointnerf.py:184), 64 is what BASELINE.json configs[2] names: both."""
     from npcd.models.pointnerf import PointNeRF
     from npcd.utils import synthetic as orr
     coords, feats = orr.ellipsoid_cloud(512, 32, 1, seed=0)
@@ -70,39 +74,45 @@ def bench_render(device, n_iters=100, burn_in=5):
     extr = orr.look_at_pose(30, 20)[None, None].to(device)
     intr = orr.srn_intrinsics()[None, None].to(device)
     c, f = coords.to(device), feats.to(device)
+    poses = torch.stack([orr.look_at_pose(30 + 45 * i, 20 - 5 * i) for i in range(8)])[None].to(device)
+    intr8 = orr.srn_intrinsics()[None, None].expand(1, 8, 3, 3).contiguous().to(device)
+
+    def timed(fn, iters, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters
+
+    per_s = {}
     with torch.no_grad():
-        for _ in range(burn_in):
+        for S in (128, 64):
+            net.renderer.depth_resolution = S
+            net.renderer.count_pairs = False
+            dt = timed(lambda: net.render(c, f, extr, intr, 128), n_iters, burn_in)
+            # throughput form: 8 views of the same object in one call (launch / sync overhead amortised)
+            dt8 = timed(lambda: net.render(c, f, poses, intr8, 128), 20, 2)
+            net.renderer.count_pairs = True        # workload statistics (FLOP accounting), outside the timed region
             out = net.render(c, f, extr, intr, 128)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n_iters):
-            out = net.render(c, f, extr, intr, 128)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / n_iters
-        # throughput form: 8 views of the same object in one call (launch / sync overhead amortised)
-        poses = torch.stack([orr.look_at_pose(30 + 45 * i, 20 - 5 * i) for i in range(8)])[None].to(device)
-        intr8 = orr.srn_intrinsics()[None, None].expand(1, 8, 3, 3).contiguous().to(device)
-        for _ in range(2):
-            net.render(c, f, poses, intr8, 128)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            net.render(c, f, poses, intr8, 128)
-        torch.cuda.synchronize()
-        dt8 = (time.perf_counter() - t0) / 20
-        net.renderer.count_pairs = True            # workload statistics (FLOP accounting), outside the timed region
-        out = net.render(c, f, extr, intr, 128)
-    P, Q = int(out["num_shading_points"]), int(out["num_pairs"])
-    flops = Q * 2 * (95 * 256 + 3 * 256 * 256) + P * 2 * (256 * 256 * 6 + 256 + 3 * 256)   # as executed (last agg layer on points)
-    return {"rays_per_s": 128 * 128 / dt, "rays_per_s_8_views_per_call": 8 * 128 * 128 / dt8, "ms_per_view": dt * 1e3, "timed_renders": n_iters, "resolution": 128, "depth_samples": 128, "k": 8,
-            "shading_points": P, "pairs": Q, "mlp_tflops": flops / dt / 1e12,
-            "mlp_frac_of_f16_mfma_peak": flops / dt / 1e12 / PEAK_BF16_TFLOPS}
+            P, Q = int(out["num_shading_points"]), int(out["num_pairs"])
+            flops = Q * 2 * (95 * 256 + 3 * 256 * 256) + P * 2 * (256 * 256 * 6 + 256 + 3 * 256)   # as executed (last agg layer on points)
+            per_s[S] = {"rays_per_s": 128 * 128 / dt, "rays_per_s_8_views_per_call": 8 * 128 * 128 / dt8, "ms_per_view": dt * 1e3,
+                        "shading_points": P, "pairs": Q, "mlp_tflops_whole_view": flops / dt / 1e12}
+    r = dict(per_s[128])
+    r.update({"timed_renders": n_iters, "resolution": 128, "depth_samples": 128, "k": 8,
+              "depth_samples_64": per_s[64],
+              "note": "mlp_tflops_whole_view = shading FLOPs / whole-view wall time (all kernels of the view), not a per-kernel roofline"})
+    return r
 
 
-def bench_stage1(device, n_iters=5, burn_in=2, mlp_dtype=None):
+def bench_stage1(device, n_iters=20, burn_in=3, mlp_dtype=None):
     """Stage-1 (PointNeRF autodecoder) training step at the reference's configuration (configs/npcd_srncars.yaml:13-16,
     data/srn.py:45: 8 objects x 50 views per step, 112 random rays per view, 128 depth samples, Adam lr 1e-3): secondary
-    figure for SURVEY §8(f) rank 2.  Synthetic clouds / poses / target images."""
+    figure for SURVEY §8(f) rank 2.  Synthetic clouds / poses / target images.  20 timed iterations, per-iteration spread
+    reported (HIP events around every step)."""
     from npcd.models import NPCD
     from npcd.train import PointNeRFTrainer
     from npcd.utils import synthetic as orr
@@ -119,24 +129,55 @@ def bench_stage1(device, n_iters=5, burn_in=2, mlp_dtype=None):
     for _ in range(burn_in):
         tr.step(sample)
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_iters + 1)]
     t0 = time.perf_counter()
-    for _ in range(n_iters):
+    marks[0].record()
+    for i in range(n_iters):
         loss, _ = tr.step(sample)
+        marks[i + 1].record()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n_iters
-    return {"steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "objects": B, "views_per_object": T, "rays_per_view": net.pointnerf.renderer.ray_subsamples,
-            "loss": float(loss), "differentiable_part": "HIP: ray generation, both neighbour queries, pair inputs, aggregation and ray march (forward + backward); library GEMMs (row-split weight gradients) and torch autograd for the MLP layers"}
+    per_it = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n_iters))
+    return {"steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "ms_per_step_min_median_max": [per_it[0], per_it[n_iters // 2], per_it[-1]],
+            "timed_iterations": n_iters, "objects": B, "views_per_object": T, "rays_per_view": net.pointnerf.renderer.ray_subsamples,
+            "loss": float(loss), "differentiable_part": getattr(tr, "describe", lambda: "HIP geometry / pair / ray-march kernels (fwd + bwd); MLP layers: see DESIGN.md")()}
+
+
+def host_cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, affinity
+
+
+PARITY_PARAMS = ("input_proj.weight", "time_embed.c_fc.weight", "backbone.resblocks.0.attn.c_qkv.weight", "backbone.resblocks.0.ln_1.weight",
+                 "backbone.resblocks.11.mlp.c_fc.weight", "backbone.resblocks.23.attn.c_proj.weight", "backbone.resblocks.23.mlp.c_proj.bias",
+                 "ln_post.weight", "output_proj.weight")
 
 
 def cpu_baseline():
-    """The CPU oracle (a restatement of the reference, `kind: port`) timed on this box's host cores:
-    one fp32 denoiser train step (fwd + bwd + AdamW) at B=2 of the same architecture, scaled to the
-    B=64 step; plus one 64x64 render (grid semantics) for the rays/s half."""
+    """The CPU oracle (oracle/: an fp32 PyTorch restatement of the reference, pinned by the golden fixtures; `kind: port`) timed on
+    this box's host cores on a BOUNDED sample of the benchmark workload: full-width denoiser train steps (W 1024 / L 24 / H 16,
+    forward + backward + AdamW) on B = 4 of the 64 samples of a step -- one untimed warm-up step, then THREE timed steps, the
+    median scaled by 64 / 4 -- plus one 128 x 128 render with the voxel-grid semantics for the rays/s half.
+    The warm-up step's loss and gradient norms are returned too: bench.py feeds the same samples, timesteps and noise through
+    the GPU trainer and reports the differences (`parity_full_width`)."""
     from oracle import denoiser as od, diffusion as odf, renderer as orr
-    cores = min(os.cpu_count() or 1, 32)          # more threads only add contention for these op sizes
-    torch.set_num_threads(cores)
-    B, L_sample = 8, CFG["layers"]                # bounded sample: 8 of the 64 samples of the step, all 24 blocks
-    params = od.init_params(CFG["coords_dim"], CFG["feats_dim"], CFG["width"], L_sample, CFG["heads"], seed=0)
+    model_name, logical, affinity = host_cpu_info()
+    threads = min(affinity, 32)                   # more threads only add contention for these op sizes
+    torch.set_num_threads(threads)
+    B = 4
+    params = od.init_params(CFG["coords_dim"], CFG["feats_dim"], CFG["width"], CFG["layers"], CFG["heads"], seed=0)
     leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     opt = torch.optim.AdamW(list(leaves.values()), lr=7e-5, weight_decay=0.01)
     g = torch.Generator().manual_seed(42)
@@ -144,31 +185,108 @@ def cpu_baseline():
     f0 = torch.rand(B, CFG["feats_dim"], CFG["num_points"], generator=g) * 2 - 1
     tab = odf.schedule_tables()
     t = torch.randint(0, 1000, (B,), generator=g)
-    cn, fn = torch.randn_like(c0), torch.randn_like(f0)
+    cn, fn = torch.randn(c0.shape, generator=g), torch.randn(f0.shape, generator=g)
 
-    def step():
+    def fwd_bwd():
         opt.zero_grad()
         loss, _, _ = odf.p_losses(tab, lambda c, f, tt: od.denoiser_forward(leaves, c, f, tt, CFG["heads"]), c0, f0, t, cn, fn)
         loss.backward()
-        opt.step()
+        return loss
 
-    step()                                        # untimed: thread-pool / allocator warm-up
-    t0 = time.perf_counter(); step(); dt_sample = time.perf_counter() - t0
-    dt = dt_sample * CFG["layers"] / L_sample     # transformer blocks are > 99 % of the step
+    loss0 = fwd_bwd()                             # untimed: thread-pool / allocator warm-up; also the parity reference
+    ref = {"loss": float(loss0.detach()), "grad_norm": {k: float(leaves[k].grad.norm()) for k in PARITY_PARAMS},
+           "inputs": (params, c0, f0, t, cn, fn)}
+    opt.step()
+    samples = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        fwd_bwd()
+        opt.step()
+        samples.append(time.perf_counter() - t0)
+    dt = sorted(samples)[1]
     steps_per_s = (B / dt) / CFG["global_batch"]
     fp = orr.init_field_params(32, seed=0)
     coords, feats = orr.synthetic_cloud(512, 32, 1, seed=0)
     res = 128
-    K = orr.srn_intrinsics().clone(); K[0, 0] = K[1, 1] = 131.25 * res / 128; K[0, 2] = K[1, 2] = res / 2
     t0 = time.perf_counter()
     with torch.no_grad():
-        orr.render(fp, coords, feats, orr.look_at_pose(30, 20)[None, None], K[None, None], res=res)
+        orr.render(fp, coords, feats, orr.look_at_pose(30, 20)[None, None], orr.srn_intrinsics()[None, None], res=res)
     dtr = time.perf_counter() - t0
-    return {"value": steps_per_s, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle (fp32 PyTorch CPU restatement of the reference), {cores} threads: 1 denoiser train step (fwd+bwd+AdamW) "
-                      f"at B={B} of {CFG['global_batch']} with {L_sample} of {CFG['layers']} blocks = {dt_sample:.1f} s, scaled x{CFG['layers'] // L_sample} "
-                      f"(blocks) and x{CFG['global_batch'] // B} (batch) ; render: one {res}x{res} view = {dtr:.1f} s",
-            "render_rays_per_s": res * res / dtr}
+    out = {"value": steps_per_s, "unit": "steps/s", "cores": threads, "kind": "port",
+           "cpu_model": model_name, "host_logical_cpus": logical, "affinity_cpus": affinity,
+           "sample": f"oracle (fp32 PyTorch CPU restatement of the reference) on {threads} threads of '{model_name}' "
+                     f"({logical} logical CPUs, {affinity} usable): full-width denoiser train step (fwd + bwd + AdamW, "
+                     f"{CFG['layers']} blocks) at B = {B} of {CFG['global_batch']}: 1 warm-up + 3 timed steps = "
+                     f"{', '.join(f'{x:.2f}' for x in samples)} s, median x {CFG['global_batch'] // B} (batch); "
+                     f"render: one {res} x {res} view (grid semantics, 128 depth samples) = {dtr:.1f} s",
+           "timed_step_seconds": samples, "render_rays_per_s": res * res / dtr}
+    return out, ref
+
+
+def parity_full_width(device, ref):
+    """The full-width model (W 1024 / L 24 / H 16, 310.8 M parameters) on the GPU trainer against the CPU oracle on the SAME
+    weights, samples, timesteps and noise (those of the cpu_baseline leg): loss and a few parameter-gradient norms.  The
+    oracle is the checker here, the timed region is long over.  Bars: loss within 2e-2 relative, gradient norms within 5e-2
+    (bf16 GEMM operands and attention against fp32)."""
+    from npcd.models.diffusion import DiffusionModel
+    from npcd.train import DiffusionTrainer
+    params, c0, f0, t, cn, fn = ref["inputs"]
+    model = DiffusionModel(CFG["coords_dim"], CFG["feats_dim"], CFG["num_points"], CFG["width"], CFG["layers"], CFG["heads"], True)
+    model.denoiser.load_state_dict(params)
+    model = model.to(device).train()
+    tr = DiffusionTrainer(model, dtype=torch.bfloat16)
+    assert tr.native and model.denoiser.backbone.fused_engine is not None
+    tr.flat.zero_grad()
+    tr.reducer.start_step()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss, _, _ = model.compute_loss(c0.to(device), f0.to(device), t=t.to(device), coords_noise=cn.to(device), feats_noise=fn.to(device))
+    loss.backward()
+    torch.cuda.synchronize()
+    named = dict(model.denoiser.named_parameters())
+    gn = {k: float(named[k].grad.norm()) for k in PARITY_PARAMS}
+    rel = {k: abs(gn[k] - ref["grad_norm"][k]) / max(ref["grad_norm"][k], 1e-30) for k in PARITY_PARAMS}
+    loss_rel = abs(float(loss) - ref["loss"]) / abs(ref["loss"])
+    return {"loss_gpu": float(loss), "loss_oracle": ref["loss"], "loss_rel_diff": loss_rel,
+            "grad_norm_gpu": gn, "grad_norm_oracle": ref["grad_norm"], "grad_norm_rel_diff": rel,
+            "bars": {"loss_rel": 2e-2, "grad_norm_rel": 5e-2},
+            "ok": bool(loss_rel < 2e-2 and max(rel.values()) < 5e-2),
+            "config": "W 1024 / L 24 / H 16, B = 4, same weights / samples / t / noise on both sides; GPU = fused engine under bf16 autocast"}
+
+
+def strong_scaling_proxy(trainer, coords, feats, steps=8, warmup=3):
+    """One-GPU proxy of the strong-scaling curve (global batch 64 fixed): the step at per-GPU batch 64 / 32 / 16 / 8, i.e. what
+    one rank of a 1 / 2 / 4 / 8-GPU job computes, WITHOUT communication.  The optimizer pass is timed on its own: with the
+    sharded optimizer a rank runs 1/ranks of it, so `ms_per_rank_step` = step - optimizer * (1 - 1/ranks).  Upper bound of the
+    speed-up = ms(64) / ms_per_rank_step(b)."""
+    out = {}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        trainer._adamw_range(0, trainer.flat.numel, zero_grad=False)
+    e1.record()
+    torch.cuda.synchronize()
+    opt_ms = e0.elapsed_time(e1) / 5
+    trainer.flat.grad.zero_()
+    base = None
+    for b in (64, 32, 16, 8):
+        c, f = coords[:b], feats[:b]
+        if c.shape[0] < b:
+            continue
+        for _ in range(warmup):
+            trainer.step(c, f)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            trainer.step(c, f)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        ranks = 64 // b
+        per_rank = ms - opt_ms * (1 - 1 / ranks)
+        base = base or per_rank
+        out[str(b)] = {"ranks": ranks, "ms_per_step_one_gpu": ms, "ms_per_rank_step": per_rank, "speedup_bound": base / per_rank}
+    out["optimizer_pass_ms"] = opt_ms
+    return out
 
 
 def main():
@@ -178,6 +296,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-render", action="store_true")
+    ap.add_argument("--no-proxy", action="store_true", help="skip the one-GPU strong-scaling proxy (per-GPU batch 64/32/16/8)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -218,6 +337,10 @@ def main():
     from npcd.hip import elementwise as hew
     trainer = build_trainer(device, per)
     coords, feats = synthetic_batch(CFG["global_batch"], rank, world, device)
+    # weights are identical on every rank (seed above); the per-step draws (timesteps, noise) are not: seed + rank, as a
+    # DistributedSampler-style job would
+    torch.manual_seed(42 + rank)
+    torch.cuda.manual_seed(42 + rank)
 
     def barrier():
         if world > 1:
@@ -227,7 +350,7 @@ def main():
     for _ in range(args.warmup):
         trainer.step(coords, feats)
     barrier()
-    hattn.KERNEL_EVENTS = {"fwd": [], "dq": [], "dkdv": []}
+    hattn.KERNEL_EVENTS = {k: [] for k in hattn.KERNEL_TAGS}
     hew.KERNEL_EVENTS = {"add_ln_fwd": [], "ln_bwd": [], "gelu_fwd": [], "gelu_bwd": []}
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -242,20 +365,49 @@ def main():
         elapsed = float(tt)
     assert torch.isfinite(loss), "training diverged"
 
-    kern_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / max(1, len(v))) for k, v in events.items()}
+    # ---- attention roofline (MFMA-bound), on the ALGORITHMIC FLOPs of SURVEY 8(d) ---------------------------------------
+    # unit U = one B x H x n x n x d product = 2 B H n^2 d FLOP.  Forward = 2 U (QK^T, PV).  Backward = 5 U (S, dP, dV, dK, dQ)
+    # however many products the kernels execute: a two-pass backward (dq pass: S, dP, dQ; dk/dv pass: S, dP, dV, dK)
+    # EXECUTES 7 U -- the two recomputed products are not credited.  "Launch" of the backward = the kernel(s) of one
+    # attention backward; durations are HIP-event averages over the timed region, on the launch stream.
+    kern_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in events.items() if v}
     n = CFG["num_points"] + 1
-    unit_flops = 2 * per * CFG["heads"] * n * n * 64          # one B x H x n x n x d product
-    alg = {"fwd": 2 * unit_flops, "dq": 3 * unit_flops, "dkdv": 4 * unit_flops}
-    dominant = max(kern_ms, key=lambda k: kern_ms[k])
-    achieved = alg[dominant] / (kern_ms[dominant] * 1e-3) / 1e12
-
-    # HBM traffic of the dominant kernel: measured with rocprofv3 PMC counters (FETCH_SIZE/WRITE_SIZE, separate passes,
-    # gfx950 x2 read correction) on this exact kernel and shape -- bench.py itself cannot collect PMC counters
+    U = 2 * per * CFG["heads"] * n * n * 64
+    bwd_tags = [k for k in kern_ms if k != "fwd"]
+    bwd_ms = sum(kern_ms[k] for k in bwd_tags)
+    executed = {"fwd": 2 * U, "dq": 3 * U, "dkdv": 4 * U, "bwd": 5 * U}
+    tf = lambda fl, ms: fl / (ms * 1e-3) / 1e12
+    bwd_tf, fwd_tf, all_tf = tf(5 * U, bwd_ms), tf(2 * U, kern_ms["fwd"]), tf(7 * U, bwd_ms + kern_ms["fwd"])
+    knames = {"fwd": "attn_fwd_kernel", "dq": "attn_bwd_dq_kernel", "dkdv": "attn_bwd_dkdv_kernel", "bwd": "attn_bwd_kernel"}
+    # HBM traffic and MFMA-busy: rocprofv3 PMC passes on these exact kernels and this shape (tools/make_traffic_json.py,
+    # tools/pmc_summary.py); bench.py itself cannot collect PMC counters
+    def newest(*names):
+        for nm in names:
+            fp = os.path.join(ROOT, "profiles", nm)
+            if os.path.exists(fp):
+                return nm, json.load(open(fp))
+        return None, {}
+    tname, tjson = newest("r2_attention_hbm_traffic_pmc.json", "r1_attention_hbm_traffic_pmc.json")
+    sname, sjson = newest("r2_attention_sq_pmc.json")
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r1_attention_hbm_traffic_pmc.json")
-    kname = {"fwd": "attn_fwd_kernel", "dq": "attn_bwd_dq_kernel", "dkdv": "attn_bwd_dkdv_kernel"}[dominant]
-    if per == 64 and os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get(kname, {}).get("hbm_bytes")
+    if per == 64 and tjson and all(knames[k] in tjson for k in bwd_tags):
+        traffic = sum(tjson[knames[k]]["hbm_bytes"] for k in bwd_tags)
+    roofline = {
+        "kernel": " + ".join(knames[k] for k in bwd_tags) + " (one attention backward)",
+        "bound": "mfma", "achieved": bwd_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": bwd_tf / PEAK_BF16_TFLOPS,
+        "traffic": traffic, "traffic_source": f"profiles/{tname} (rocprofv3 --pmc, bytes per launch, summed over the kernels)" if traffic else None,
+        "basis": "ALGORITHMIC FLOPs, SURVEY 8(d): backward = 5 products = 5 U, U = 2 B H n^2 d; recomputed products are not credited",
+        "algorithmic_flops_per_launch": 5 * U, "avg_ms": bwd_ms, "launches": len(events[bwd_tags[0]]),
+        "executed_flops_per_launch": sum(executed[k] for k in bwd_tags),
+        "achieved_on_executed_flops": tf(sum(executed[k] for k in bwd_tags), bwd_ms),
+        "forward": {"kernel": knames["fwd"], "achieved": fwd_tf, "frac": fwd_tf / PEAK_BF16_TFLOPS, "algorithmic_flops_per_launch": 2 * U,
+                    "avg_ms": kern_ms["fwd"]},
+        "forward_plus_backward": {"achieved": all_tf, "frac": all_tf / PEAK_BF16_TFLOPS, "algorithmic_flops": 7 * U, "avg_ms": bwd_ms + kern_ms["fwd"]},
+        "per_kernel_ms": kern_ms,
+        "per_kernel_tflops_executed": {k: tf(executed[k], kern_ms[k]) for k in kern_ms},
+        "mfma_busy": {k: sjson[knames[k]] for k in kern_ms if knames[k] in sjson} or None,
+        "mfma_busy_source": f"profiles/{sname} (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES etc., rocprofv3 --pmc on the same kernels)" if sjson else None,
+    }
 
     # the HBM-bound kernels of the step (residual stream fp32, activations bf16; T tokens x W / 4W columns), priced at their
     # algorithmic bytes: every operand read once, every result written once
@@ -268,12 +420,11 @@ def main():
         dom = max(ew_ms, key=lambda k: ew_ms[k] * len(ew_events[k]))
         gbs = {k: ew_bytes[k] / (ew_ms[k] * 1e-3) / 1e9 for k in ew_ms}
         hname = {"add_ln_fwd": "add_ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel", "gelu_fwd": "gelu_fwd_kernel", "gelu_bwd": "colsum_kernel<true>"}[dom]
-        htraffic, hfile = None, os.path.join(ROOT, "profiles", "r1_elementwise_hbm_traffic_pmc.json")
-        if per == 64 and os.path.exists(hfile):         # PMC-measured bytes per launch at exactly this shape (rocprofv3 --pmc passes)
-            htraffic = json.load(open(hfile)).get(hname, {}).get("hbm_bytes")
+        hfile, hjson = newest("r2_elementwise_hbm_traffic_pmc.json", "r1_elementwise_hbm_traffic_pmc.json")
+        htraffic = hjson.get(hname, {}).get("hbm_bytes") if per == 64 else None   # PMC-measured bytes per launch at exactly this shape
         hbm = {"kernel": hname,
                "bound": "hbm", "achieved": gbs[dom], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs[dom] / PEAK_HBM_GBS,
-               "traffic": htraffic, "traffic_source": "profiles/r1_elementwise_hbm_traffic_pmc.json" if htraffic else None,
+               "traffic": htraffic, "traffic_source": f"profiles/{hfile}" if htraffic else None,
                "algorithmic_bytes_per_launch": ew_bytes[dom], "avg_ms": ew_ms[dom], "launches": len(ew_events[dom]),
                "all_elementwise_kernels_ms": ew_ms, "all_elementwise_kernels_gbs": gbs}
 
@@ -284,22 +435,22 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: denoiser fwd/bwd + AdamW + EMA, 512 points x 128-d latents, "
                                "width 1024 / 24 layers / 16 heads (seq 513), bf16 autocast",
-                   "global_batch": CFG["global_batch"], "per_gpu_batch": per, "parallelism": f"dp{world}"},
+                   "global_batch": CFG["global_batch"], "per_gpu_batch": per, "parallelism": f"dp{world}",
+                   "rng": "weights seed 1234 on every rank; timestep / noise draws seed 42 + rank"},
+        "native_path": {"fused_backbone_engine": True, "fused_adamw_ema": True, "sharded_optimizer": bool(trainer.reducer.shard)},
         "step_tflops": denoiser_flops_per_sample() * CFG["global_batch"] / (elapsed / args.steps) / 1e12,
         "step_frac_of_bf16_mfma_peak": denoiser_flops_per_sample() * CFG["global_batch"] / (elapsed / args.steps) / 1e12
                                        / (PEAK_BF16_TFLOPS * world),
-        "roofline": {"kernel": kname,
-                     "bound": "mfma", "achieved": achieved, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_BF16_TFLOPS, "traffic": traffic,
-                     "traffic_source": "profiles/r1_attention_hbm_traffic_pmc.json (rocprofv3 --pmc, bytes per launch)" if traffic else None,
-                     "algorithmic_flops_per_launch": alg[dominant],
-                     "avg_ms": kern_ms[dominant], "launches": len(events[dominant]),
-                     "all_attention_kernels_ms": kern_ms,
-                     "all_attention_kernels_tflops": {k: alg[k] / (kern_ms[k] * 1e-3) / 1e12 for k in kern_ms}},
+        "roofline": roofline,
         "roofline_hbm": hbm,
         "loss": float(loss),
         "tuned_gemm_file": "profiles/tunableop_gfx950.csv" if use_tuned else None,
     }
+    if world == 1 and not args.no_proxy:
+        try:
+            result["strong_scaling_proxy"] = strong_scaling_proxy(trainer, coords, feats)
+        except Exception as e:                      # noqa: BLE001
+            result["strong_scaling_proxy"] = {"error": f"{type(e).__name__}: {e}"}
     # the secondary measurements must never take the headline line down with them
     if not args.no_render:
         try:
@@ -314,18 +465,25 @@ def main():
         try:
             result["stage1_pointnerf_training"] = bench_stage1(device)
             opt_in = bench_stage1(device, mlp_dtype=torch.bfloat16)
-            result["stage1_pointnerf_training"]["opt_in_bf16_mlp"] = {k: opt_in[k] for k in ("steps_per_s", "ms_per_step", "loss")}
+            result["stage1_pointnerf_training"]["opt_in_bf16_mlp"] = {k: opt_in[k] for k in ("steps_per_s", "ms_per_step", "ms_per_step_min_median_max", "loss")}
         except Exception as e:                      # noqa: BLE001
             result["stage1_pointnerf_training"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline()
+                result["cpu_baseline"], ref = cpu_baseline()
                 result["gpu_over_cpu"] = {"denoiser_steps": result["value"] / result["cpu_baseline"]["value"]}
                 if result.get("render", {}).get("rays_per_s"):
                     result["gpu_over_cpu"]["render_rays"] = result["render"]["rays_per_s"] / result["cpu_baseline"]["render_rays_per_s"]
             except Exception as e:                  # noqa: BLE001
-                result["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
+                result["cpu_baseline"], ref = {"error": f"{type(e).__name__}: {e}"}, None
+            if ref is not None:
+                try:
+                    del trainer
+                    torch.cuda.empty_cache()
+                    result["parity_full_width"] = parity_full_width(device, ref)
+                except Exception as e:              # noqa: BLE001
+                    result["parity_full_width"] = {"error": f"{type(e).__name__}: {e}", "ok": False}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()

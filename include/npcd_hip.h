@@ -149,7 +149,8 @@ int npcd_ray_gen_subset(const float* extr, const float* intr, int V, int res, fl
  * Weights are packed once by npcd_shade_pack_weights into `wpack`.
  *   nb_idx [P,k] int32 (-1 pad), pts [P,3] fp32, kp_pos [B*N,3] fp32, kp_feat [B*N,F] fp32
  *   -> sigma [P] fp32, rgb [P,3] fp32.  n_points_dev: device int32 holding P (so that P may be
- *   produced on the device without a host round trip); max_points bounds the launch.
+ *   produced on the device without a host round trip); max_points = rows allocated in every
+ *   per-point array: it bounds the launch and the kernels clamp the device-side count to it.
  * ------------------------------------------------------------------------------------------ */
 int64_t npcd_shade_wpack_bytes(int feat_dim, int n_freqs, int hidden);
 int64_t npcd_shade_workspace_bytes(int max_points, int hidden);
@@ -231,10 +232,12 @@ int npcd_ddpm_reverse_step(const float* x_t, const void* eps, int eps_dtype, con
                            const float* tab_coef1, const float* tab_coef2, const float* tab_logvar, float clip_lo, float clip_hi,
                            int has_clip, void* stream);
 
-/* ray march on the compact layout of npcd_grid_query_compact (same math as npcd_ray_march) */
+/* ray march on the compact layout of npcd_grid_query_compact (same math as npcd_ray_march).  `capacity` = rows allocated in
+ * sigma / rgb / pts: when the compact lists overflowed (counter[1] != 0) a ray whose rows lie past it is marched as empty --
+ * the caller discards that result and retries with larger lists, nothing is read out of bounds meanwhile. */
 int npcd_ray_march_compact(const float* sigma, const float* rgb, const uint64_t* ray_bits, const float* pts,
                            const int32_t* ray_base, const float* rays_o, const float* rays_d, const float* t1,
-                           int Nr, int M, int white_back, float* mask, float* depth, float* channels,
+                           int Nr, int M, int capacity, int white_back, float* mask, float* depth, float* channels,
                            float* depth_ws, void* stream);
 
 /* ---- stage-1 training path: the data movement around the per-pair MLP (aggregators/mlp.py:36-125,

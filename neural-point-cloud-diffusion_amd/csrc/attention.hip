@@ -1204,14 +1204,9 @@ static int attn_bwd_launch(int passes, const void* q, const void* k, const void*
     const int grid = B * H * ceil_div(n, 128);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int dyn = 3 * kDkdvSlot;
-    static bool attr_set = false;
-    if (!attr_set) {
-        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<BF16>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<F16>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
-        attr_set = true;
-    }
+    static DynLds lds_bf16, lds_f16;
+    NPCD_HIP_CHECK(lds_bf16.ensure(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<BF16>), dyn));
+    NPCD_HIP_CHECK(lds_f16.ensure(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<F16>), dyn));
     if (dtype == NPCD_BF16) {
         if (passes & 1) hipLaunchKernelGGL(attn_bwd_dq_kernel<BF16>, dim3(grid), dim3(256), 0, st, p);
         if (passes & 2) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<BF16>, dim3(grid), dim3(256), dyn, st, p);

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/npcd_hip.h"
 
 namespace npcd {
@@ -85,5 +87,23 @@ void set_hip_error(hipError_t e);
             return NPCD_ERR_HIP;                      \
         }                                             \
     } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: remember, per device, the largest size set
+// so far.  Two host threads (autograd's backward thread and the main thread) may race here: both then set the same value.
+struct DynLds {
+    static constexpr int kMaxDevices = 64;
+    std::atomic<size_t> set[kMaxDevices];
+    DynLds() { for (auto& s : set) s.store(0); }
+    hipError_t ensure(const void* kernel, size_t bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+        if (bytes <= set[dev].load(std::memory_order_acquire)) return hipSuccess;
+        e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) set[dev].store(bytes, std::memory_order_release);
+        return e;
+    }
+};
 
 }  // namespace npcd

@@ -460,11 +460,8 @@ extern "C" int npcd_ln_bwd(const void* dy, const float* x, const float* mean, co
     const int nblk = npcd_ln_bwd_blocks(T);
     const size_t lds = (size_t)3 * 4 * W * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static bool attr_set = false;
-    if (!attr_set) {   // W = 2048 needs 96 KiB of dynamic LDS
-        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ln_bwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 4 * 2048 * 4));
-        attr_set = true;
-    }
+    static DynLds lds_attr;   // W = 2048 needs 96 KiB of dynamic LDS
+    NPCD_HIP_CHECK(lds_attr.ensure(reinterpret_cast<const void*>(ln_bwd_kernel<8>), 3 * 4 * 2048 * 4));
 #define NPCD_LAUNCH_LN_BWD(NCH)                                                                                                \
     hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3(nblk), dim3(256), lds, st, static_cast<const __bf16*>(dy), x, mean, rstd, gamma, \
                        dres, dx, static_cast<__bf16*>(dxb), part_gamma, part_beta, part_col, T, W, ln_rows_per_wave(T))

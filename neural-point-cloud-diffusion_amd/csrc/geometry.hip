@@ -659,7 +659,7 @@ template <bool COMPACT>
 __global__ __launch_bounds__(256) void ray_march_kernel(const float* __restrict__ sigma, const float* __restrict__ rgb, const uint8_t* __restrict__ slot_valid,
                                                         const float* __restrict__ slot_loc, const int32_t* __restrict__ point_base,
                                                         const float* __restrict__ rays_o, const float* __restrict__ rays_d, const float* __restrict__ t1,
-                                                        int Nr, int M, int white_back, float* __restrict__ mask, float* __restrict__ depth,
+                                                        int Nr, int M, int capacity, int white_back, float* __restrict__ mask, float* __restrict__ depth,
                                                         float* __restrict__ channels, uint32_t* ws) {
     const int ray = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t kmin = 0xffffffffu, kmax = 0u;
@@ -669,8 +669,11 @@ __global__ __launch_bounds__(256) void ray_march_kernel(const float* __restrict_
         const float ray_end = t1[ray];
         const uint8_t* sv = COMPACT ? nullptr : slot_valid + (int64_t)ray * M;
         const float* sl = COMPACT ? nullptr : slot_loc + (int64_t)ray * M * 3;
-        const unsigned long long bits = COMPACT ? reinterpret_cast<const unsigned long long*>(slot_valid)[ray] : 0ull;
+        unsigned long long bits = COMPACT ? reinterpret_cast<const unsigned long long*>(slot_valid)[ray] : 0ull;
         int cp = point_base[ray];
+        // compact lists that overflowed (grid_query_wave_kernel sets the flag, the host retries with larger buffers): a ray
+        // whose rows do not all exist is marched as empty instead of reading past the lists
+        if (COMPACT && cp + __popcll(bits) > capacity) bits = 0ull;
         float run_max = -INFINITY;
         float T = 1.f, total = 0.f, wd = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
         float pd = 0.f, ps = 0.f, pr = 0.f, pg = 0.f, pb = 0.f;  // previous slot
@@ -878,11 +881,8 @@ extern "C" int npcd_grid_build(const npcd_grid_params* g, const float* points, c
     uint32_t* occ = reinterpret_cast<uint32_t*>(pcoord + (int64_t)B * N);
     const size_t lds = (size_t)N * 8 + (size_t)nwords * 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static size_t lds_set = 0;
-    if (lds > 65536 && lds > lds_set) {
-        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
+    static DynLds lds_attr;
+    if (lds > 65536) NPCD_HIP_CHECK(lds_attr.ensure(reinterpret_cast<const void*>(grid_build_kernel), lds));
     int16_t* table = nullptr;
     if (table_ok(*g)) {
         table = reinterpret_cast<int16_t*>(static_cast<unsigned char*>(workspace) + table_offset(*g, B, N));
@@ -929,18 +929,12 @@ extern "C" int npcd_grid_query(const npcd_grid_params* g, const void* workspace,
     const int bpe = (R + 3) / 4;
     const size_t lds = (size_t)N * 16 + (size_t)a.nwords * 4 + 4 * 64 * 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static size_t lds_set = 0;
-    if (mode == 1 && lds > 65536 && lds > lds_set) {
-        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_query_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
+    static DynLds lds_attr;
+    if (mode == 1 && lds > 65536) NPCD_HIP_CHECK(lds_attr.ensure(reinterpret_cast<const void*>(grid_query_kernel<false>), lds));
     if (mode == 0) {
         const size_t lds2 = lds + 4 * 64 * 8 * 4 + 4 * 64 * 4 * 4;
-        static size_t lds2_set = 0;
-        if (lds2 > 65536 && lds2 > lds2_set) {
-            NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_query_wave_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            lds2_set = lds2;
-        }
+        static DynLds lds2_attr;
+        if (lds2 > 65536) NPCD_HIP_CHECK(lds2_attr.ensure(reinterpret_cast<const void*>(grid_query_wave_kernel<false>), lds2));
         hipLaunchKernelGGL(grid_query_wave_kernel<false>, dim3(B * bpe), dim3(256), lds2, st, a, CompactOut{}, bpe);
     }
     else hipLaunchKernelGGL(grid_query_kernel<false>, dim3(B * bpe), dim3(256), lds, st, a, bpe);
@@ -959,7 +953,7 @@ extern "C" int npcd_ray_march(const float* sigma, const float* rgb, const uint8_
     const int grid = (Nr + 255) / 256;
     hipLaunchKernelGGL(march_init_kernel, dim3(1), dim3(1), 0, st, ws);
     hipLaunchKernelGGL(ray_march_kernel<false>, dim3(grid), dim3(256), 0, st, sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1,
-                       Nr, M, white_back, mask, depth, channels, ws);
+                       Nr, M, 0, white_back, mask, depth, channels, ws);
     hipLaunchKernelGGL(depth_clamp_kernel, dim3(grid), dim3(256), 0, st, Nr, depth, ws);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
@@ -1014,11 +1008,8 @@ extern "C" int npcd_grid_query_compact(const npcd_grid_params* g, const void* wo
     const int bpe = (R + 3) / 4;
     const size_t lds = (size_t)N * 16 + (size_t)a.nwords * 4 + 4 * 64 * 4 + 4 * 64 * 8 * 4 + 4 * 64 * 4 * 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static size_t lds_set = 0;
-    if (lds > 65536 && lds > lds_set) {
-        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(grid_query_wave_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        lds_set = lds;
-    }
+    static DynLds lds_attr;
+    if (lds > 65536) NPCD_HIP_CHECK(lds_attr.ensure(reinterpret_cast<const void*>(grid_query_wave_kernel<true>), lds));
     NPCD_HIP_CHECK(hipMemsetAsync(counter, 0, 2 * sizeof(int32_t), st));
     hipLaunchKernelGGL(grid_query_wave_kernel<true>, dim3(B * bpe), dim3(256), lds, st, a, co, bpe);
     NPCD_HIP_CHECK(hipGetLastError());
@@ -1027,17 +1018,17 @@ extern "C" int npcd_grid_query_compact(const npcd_grid_params* g, const void* wo
 
 // Ray march on the compact layout produced by npcd_grid_query_compact.
 extern "C" int npcd_ray_march_compact(const float* sigma, const float* rgb, const uint64_t* ray_bits, const float* pts, const int32_t* ray_base,
-                                      const float* rays_o, const float* rays_d, const float* t1, int Nr, int M, int white_back, float* mask,
-                                      float* depth, float* channels, float* depth_ws, void* stream) {
+                                      const float* rays_o, const float* rays_d, const float* t1, int Nr, int M, int capacity, int white_back,
+                                      float* mask, float* depth, float* channels, float* depth_ws, void* stream) {
     if (!sigma || !rgb || !ray_bits || !pts || !ray_base || !rays_o || !rays_d || !t1 || !mask || !depth || !channels || !depth_ws)
         return NPCD_ERR_ARG;
-    if (Nr <= 0 || M <= 0 || M > 64) return NPCD_ERR_ARG;
+    if (Nr <= 0 || M <= 0 || M > 64 || capacity <= 0) return NPCD_ERR_ARG;
     hipStream_t st = static_cast<hipStream_t>(stream);
     uint32_t* ws = reinterpret_cast<uint32_t*>(depth_ws);
     const int grid = (Nr + 255) / 256;
     hipLaunchKernelGGL(march_init_kernel, dim3(1), dim3(1), 0, st, ws);
     hipLaunchKernelGGL(ray_march_kernel<true>, dim3(grid), dim3(256), 0, st, sigma, rgb, reinterpret_cast<const uint8_t*>(ray_bits), pts, ray_base,
-                       rays_o, rays_d, t1, Nr, M, white_back, mask, depth, channels, ws);
+                       rays_o, rays_d, t1, Nr, M, capacity, white_back, mask, depth, channels, ws);
     hipLaunchKernelGGL(depth_clamp_kernel, dim3(grid), dim3(256), 0, st, Nr, depth, ws);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;

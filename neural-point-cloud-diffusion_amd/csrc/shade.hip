@@ -142,6 +142,7 @@ struct ShadeArgs {
     const int32_t* nb_idx;
     const float *pts, *kp_pos, *kp_feat;
     const int32_t* n_points;
+    int max_points;  // rows allocated in nb_idx / pts / G / sigma / rgb: the device-side count is clamped to it
     _Float16* G;  // [max_points][256] aggregated hidden features (workspace)
     float *sigma, *rgb;
 };
@@ -176,7 +177,9 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
     int* pcount = pstart + 16;                                          // [16] its number of valid neighbours
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const ShadeLayout L = shade_layout(FEAT);
-    const int P = *a.n_points;
+    // the count comes from device memory (the compact query's counter); that counter keeps counting past the capacity of the
+    // lists when they overflow (the host then retries with larger buffers), so it is clamped to the rows that exist
+    const int P = min(*a.n_points, a.max_points);
     const int ntiles = (P + 15) / 16;
 
 #ifdef NPCD_SHADE_TL
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void shade_points_kernel(ShadeArgs a) {
     float* red = reinterpret_cast<float*>(dsmem + kRows * kRowBytes);  // [4 waves][128 rows][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const ShadeLayout L = shade_layout(a.feat_dim);
-    const int P = *a.n_points;
+    const int P = min(*a.n_points, a.max_points);
     const int ntiles = (P + kRows - 1) / kRows;
     const float* s1 = reinterpret_cast<const float*>(a.wpack + L.s1);
     const float* c4 = reinterpret_cast<const float*>(a.wpack + L.c4);
@@ -501,18 +504,16 @@ extern "C" int npcd_shade_points(const void* wpack, int feat_dim, int n_freqs, i
     a.feat_dim = feat_dim; a.k = k;
     a.nb_idx = nb_idx; a.pts = pts; a.kp_pos = kp_pos; a.kp_feat = kp_feat;
     a.n_points = n_points_dev;
+    a.max_points = max_points;
     a.G = static_cast<_Float16*>(workspace);
     a.sigma = sigma; a.rgb = rgb;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ldsA = kRows * kRowBytes + kRows * 4 + 32 * 4;   // activations, row weights, per-point packed-row ranges
     const int ldsB = kRows * kRowBytes + 4 * kRows * 4 * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
-        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(shade_pairs_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsA));
-        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(shade_pairs_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsA));
-        NPCD_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(shade_points_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsB));
-        attr_done = true;
-    }
+    static DynLds lds_a32, lds_a128, lds_b;
+    NPCD_HIP_CHECK(lds_a32.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<32>), ldsA));
+    NPCD_HIP_CHECK(lds_a128.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<128>), ldsA));
+    NPCD_HIP_CHECK(lds_b.ensure(reinterpret_cast<const void*>(shade_points_kernel), ldsB));
     // persistent-style grids: 2 workgroups per CU, tiles strided over the grid; the tile count is
     // read from device memory so that no host round trip is needed after the neighbour query
     const int tilesA = (max_points + 15) / 16, tilesB = (max_points + kRows - 1) / kRows;

@@ -25,6 +25,7 @@ def _fwd(q, k, v, scale):
 # When set to a dict {"fwd": [], "dq": [], "dkdv": []}, every launch is bracketed by HIP events recorded
 # on the launch stream (bench.py measures the kernels in situ with it).
 KERNEL_EVENTS = None
+KERNEL_TAGS = ("fwd", "dq", "dkdv")      # the kernels _timed() distinguishes (bench.py builds the dict from this)
 
 
 def _timed(tag, fn):

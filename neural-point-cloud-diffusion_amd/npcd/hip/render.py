@@ -188,7 +188,7 @@ def ray_march_compact(sigma, rgb, ray_bits, pts, ray_base, rays_o, rays_d, t1, M
     chan = torch.empty((Nr, 3), dtype=_f32, device=dev)
     ws = torch.empty(4, dtype=_f32, device=dev)
     check(lib().npcd_ray_march_compact(ptr(sigma), ptr(rgb), ptr(ray_bits), ptr(pts), ptr(ray_base), ptr(rays_o.contiguous()),
-                                       ptr(rays_d.contiguous()), ptr(t1.contiguous()), Nr, int(M), int(bool(white_back)), ptr(mask),
+                                       ptr(rays_d.contiguous()), ptr(t1.contiguous()), Nr, int(M), int(sigma.shape[0]), int(bool(white_back)), ptr(mask),
                                        ptr(depth), ptr(chan), ptr(ws), stream_ptr()), "npcd_ray_march_compact")
     return mask, depth, chan
 

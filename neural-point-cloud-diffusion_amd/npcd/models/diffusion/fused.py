@@ -112,7 +112,31 @@ class FusedBackboneEngine:
                 entry[key + "_g"] = flat.grad[off:off + p.numel()].view_as(p)   # fp32 gradient
             self.blocks.append(entry)
 
+        # The GEMMs read the bf16 SHADOW, which only the optimizer kernel (and load_trainer_state) refresh.  Any other in-place
+        # write to a parameter -- model.load_state_dict, copying EMA weights in to sample from them -- bumps the parameter's
+        # version counter (the optimizer kernel writes through raw pointers and does not): the stamp below notices that and the
+        # shadow is re-cast from the fp32 masters before the next forward instead of silently running stale Linear weights
+        # beside fresh LayerNorm ones.
+        self._flat, self._shadow = flat, shadow
+        self._stamped = [p for e in self.blocks for p in e["params"]]
+        self._stamp = self._versions()
+
+    def _versions(self):
+        return [p._version for p in self._stamped]
+
+    def sync_shadow(self, force=False):
+        """Re-cast fp32 masters -> bf16 shadow if a parameter was written outside the optimizer since the last check."""
+        v = self._versions()
+        if force or v != self._stamp:
+            for p, off in zip(self._flat.params, self._flat.offsets):
+                if p.data_ptr() != self._flat.flat.data_ptr() + off * self._flat.flat.element_size():
+                    raise RuntimeError("a parameter of the fused backbone was re-homed outside the trainer's flat buffer "
+                                       "(p.data replaced): build a new DiffusionTrainer for this model")
+            ew.cast_f32_bf16(self._flat.flat, self._shadow)
+            self._stamp = v
+
     def __call__(self, x):
+        self.sync_shadow()
         return _BackboneFn.apply(x, self)
 
 

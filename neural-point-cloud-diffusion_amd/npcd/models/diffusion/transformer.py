@@ -111,6 +111,7 @@ class Transformer(nn.Module):
                 # sampling / evaluation under bf16 autocast: fused forward-only kernels (fused.backbone_forward)
                 from . import fused
                 if eng is not None:
+                    eng.sync_shadow()
                     return fused.backbone_forward(x, eng.blocks, eng.heads)
                 if self._infer_weights is None:
                     self._infer_weights = fused.InferenceWeights(self)

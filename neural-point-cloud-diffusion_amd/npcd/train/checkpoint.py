@@ -41,8 +41,18 @@ def _moments(trainer):
 def trainer_state_dict(trainer, full_model: Optional[torch.nn.Module] = None, ema_prefix: str = "diffusion.") -> dict:
     """The reference's train-state dictionary for a DiffusionTrainer.  `full_model` (the NPCD module that owns
     trainer.model as `.diffusion`) makes the EMA entry cover the whole model like the reference's; without it the EMA entry
-    holds the diffusion model's keys only."""
-    trainer.gather_state()
+    holds the diffusion model's keys only.
+
+    COLLECTIVE when the optimizer is sharded over ranks: EVERY rank must call it (the moment / EMA shards are all-gathered);
+    a rank-0-only call would hang in the first gather, so a one-element all-reduce first turns that mistake into an error
+    on a timeout-free path: each rank contributes 1 and the sum must be the world size."""
+    red = trainer.reducer
+    if red.shard and red.world > 1:
+        import torch.distributed as dist
+        token = torch.ones(1, device=trainer.flat.flat.device)
+        dist.all_reduce(token, group=red.group)
+        assert int(token.item()) == red.world, "trainer_state_dict / save_train_state must be called on every rank"
+    trainer.gather_state()                              # Adam moments AND the EMA: gathered once, here
     model, flat = trainer.model, trainer.flat
     m, v = _moments(trainer)
     params = list(model.parameters())
@@ -62,7 +72,7 @@ def trainer_state_dict(trainer, full_model: Optional[torch.nn.Module] = None, em
             "scheduler_state_dict": sched.state_dict()}
     if trainer.ema is not None:
         name = ema_param_string(1.0, trainer.ema_decay, trainer.ema_decay, False)
-        ema_sd = trainer.ema_state_dict()
+        ema_sd = trainer.ema_state_dict(gathered=True)
         if full_model is not None:
             whole = {k: (val.clone() if torch.is_tensor(val) else val) for k, val in full_model.state_dict().items()}
             for k, val in ema_sd.items():
@@ -139,7 +149,8 @@ def list_checkpoints(base_path: str, base_name: str = "diffusion_training"):
 def save_train_state(trainer, base_path: str, base_name: str = "diffusion_training", max_to_keep: Optional[int] = None,
                      full_model: Optional[torch.nn.Module] = None) -> str:
     """Write `<base_name>-iter-<finished_iterations>.pt`; with max_to_keep the oldest files are removed (:226-234).
-    Every rank may call this (the optimizer shards are gathered collectively); rank 0 writes."""
+    EVERY rank MUST call this when the optimizer is sharded (the shards are gathered collectively, see
+    trainer_state_dict); rank 0 writes."""
     ckpt = trainer_state_dict(trainer, full_model)
     path = os.path.join(base_path, checkpoint_name(base_name, trainer.finished_iterations))
     if trainer.reducer.rank == 0:

@@ -223,9 +223,11 @@ class DiffusionTrainer:
             self.master.grad = self.flat.grad
             self.optimizer = torch.optim.AdamW([self.master], lr=lr, weight_decay=weight_decay, fused=self.flat.flat.is_cuda)
 
-    def ema_state_dict(self):
-        """state_dict of the EMA model: same keys as the running model (utils/ema.py:80), buffers copied."""
-        self.gather_ema()
+    def ema_state_dict(self, gathered: bool = False):
+        """state_dict of the EMA model: same keys as the running model (utils/ema.py:80), buffers copied.  Collective with a
+        sharded optimizer (all ranks call it) unless the caller has just gathered the EMA (`gathered=True`)."""
+        if not gathered:
+            self.gather_ema()
         sd = {k: v.clone() for k, v in self.model.state_dict().items()}
         names = {id(p): n for n, p in self.model.named_parameters()}
         for p, off in zip(self.flat.params, self.flat.offsets):

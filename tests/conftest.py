@@ -17,6 +17,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests are skipped (not failed) where no HIP device is visible, so that a plain `pytest` on a CPU-only box stays
+    green.  On a box WITH a GPU nothing is skipped: a missing libnpcd_hip.so then fails every GPU test loudly (the product
+    path has no fallback, npcd.hip.lib() raises)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    reason = "no HIP GPU visible"
+    skip = pytest.mark.skip(reason=reason)
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 def load_golden(name):
     """Load tests/golden/<name>.npz as a dict of numpy arrays."""
     with np.load(os.path.join(GOLDEN, name + ".npz")) as z:

@@ -141,6 +141,89 @@ def test_fused_backbone_matches_module_path():
     assert rel(ta.ema, tb.ema) < 1e-4
 
 
+@pytest.mark.parametrize("tag", ["f32_w64", "f128_w64"])
+def test_fused_engine_matches_reference_golden_directly(golden, tag):
+    """The BENCHMARKED code path (_BackboneFn: one autograd node, hand-written backward, flat buffers, bf16 shadow) against
+    the reference's own fp32 outputs and parameter gradients (fixtures denoiser_*.npz, generated by importing
+    /root/reference) -- no detour over this package's module path.  Bars as for the module path: eps rel-L2 <= 2e-2,
+    every parameter gradient rel-L2 <= 5e-2 (bf16 GEMM inputs against an fp32 reference)."""
+    from npcd.hip import elementwise as ew
+    from npcd.models.diffusion import NPCDTransformer
+    from npcd.models.diffusion.fused import FusedBackboneEngine
+    from npcd.train.engine import FlatBuffers
+    g = golden("denoiser_" + tag)
+    T = torch.from_numpy
+    F_ = g["feats"].shape[1]
+    net = NPCDTransformer(coords_dim=3, feats_dim=F_, width=64, layers=2 if tag == "f32_w64" else 1, heads=int(g["heads"]))
+    net.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith("w:")})
+    net = net.cuda()
+    flat = FlatBuffers(net)
+    shadow = torch.empty(flat.numel, dtype=torch.bfloat16, device="cuda")
+    ew.cast_f32_bf16(flat.flat, shadow)
+    net.backbone.fused_engine = FusedBackboneEngine(net.backbone, flat, shadow)
+    calls = []
+    import npcd.models.diffusion.fused as fused
+    orig = fused._BackboneFn.apply
+    fused._BackboneFn.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ec, ef = net(T(g["coords"]).cuda(), T(g["feats"]).cuda(), T(g["t"]).cuda())
+            loss = (ec.float() * T(g["gc"]).cuda()).sum() + (ef.float() * T(g["gf"]).cuda()).sum()
+        loss.backward()
+    finally:
+        fused._BackboneFn.apply = orig
+    assert calls, "the fused backbone node was not on the path"
+    assert rel(ec, T(g["eps_coords"]).cuda()) < 2e-2 and rel(ef, T(g["eps_feats"]).cuda()) < 2e-2
+    worst = ("", 0.0)
+    named = dict(net.named_parameters())
+    for k, v in g.items():
+        if k.startswith("g:") and np.abs(v).max() > 1e-3:
+            e = rel(named[k[2:]].grad, T(v).cuda())
+            if e > worst[1]:
+                worst = (k[2:], e)
+    assert worst[1] < 5e-2, worst
+
+
+def test_shadow_follows_parameter_writes_outside_the_optimizer():
+    """The fused paths read GEMM weights from the trainer's bf16 shadow; load_state_dict / EMA copies write the fp32 masters
+    behind its back.  The engine notices (parameter version stamps) and re-casts before the next forward: training forward
+    and no-grad sampling forward both see the new weights, LayerNorm and Linear consistently."""
+    from npcd.train import DiffusionTrainer
+    a, b = _models()
+    ta = DiffusionTrainer(a, fused=True)
+    g = torch.Generator().manual_seed(5)
+    B, N, F_ = 2, 48, 32
+    c0, f0 = torch.randn(B, 3, N, generator=g).cuda(), torch.randn(B, F_, N, generator=g).cuda()
+    t = torch.tensor([7, 700]).cuda()
+    with torch.no_grad():
+        for p in b.parameters():
+            p.add_(torch.randn_like(p) * 0.05)                     # a different set of weights
+    a.load_state_dict(b.state_dict())                              # written into the flat buffer, shadow now stale
+    tb = DiffusionTrainer(b, fused=True)                           # fresh shadow of the same weights
+    for mode in ("train", "sample"):
+        outs = []
+        for m in (a, b):
+            if mode == "train":
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    outs.append(m.denoiser(c0, f0, t)[1].float())
+            else:
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                    outs.append(m.denoiser(c0, f0, t)[1].float())
+        assert torch.equal(outs[0], outs[1]), mode
+    assert torch.equal(ta.shadow, tb.shadow)
+    # sampling from the EMA weights and switching back
+    keep = {k: v.clone() for k, v in a.state_dict().items()}
+    ta.step(c0, f0, t=t)
+    a.load_state_dict(ta.ema_state_dict())
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        e1 = a.denoiser(c0, f0, t)[1].float()
+    a.load_state_dict(keep)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        e2 = a.denoiser(c0, f0, t)[1].float()
+        e3 = b.denoiser(c0, f0, t)[1].float()
+    assert torch.equal(e2, e3) and not torch.equal(e1, e2)
+
+
 def test_forward_only_backbone_for_sampling():
     """no_grad + bf16 autocast (the sampler / evaluation): fused forward-only kernels vs the module path and vs fp32; the
     bf16 weight copies follow in-place parameter updates; with a trainer attached the trainer's shadow weights are used."""

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"libnpcd_hip.so does not export {name}"
     assert declared == set(hip.SIGNATURES), (declared ^ set(hip.SIGNATURES))
     assert L.npcd_missing == (), f"stale library, missing {L.npcd_missing}"
-    assert L.npcd_abi_version() == 1
+    assert L.npcd_abi_version() == 2
     assert L.npcd_error_string(-2).decode() == "unsupported shape or dtype"
 
 
