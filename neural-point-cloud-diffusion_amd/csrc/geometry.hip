@@ -622,13 +622,19 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
         if (cnt > 0) {
             if (lane == 0) base = atomicAdd(co.counter, cnt);
             base = __builtin_amdgcn_readfirstlane(base);
-            if (base + cnt > co.capacity) {
-                if (lane == 0) atomicOr(co.counter + 1, 1);
-            } else if (lane < nsel && ((valid_bits >> lane) & 1ull)) {
+            // Lists too small: raise the flag (the host retries with larger lists and discards this attempt).  Every row below
+            // the capacity must still hold DEFINED data, because the shading kernels run on rows 0 .. min(count, capacity) - 1
+            // before the host sees the flag: the one ray that straddles the end of the lists marks its rows as neighbour-less
+            // (-1) instead of leaving them uninitialised (a garbage index would be a wild gather).
+            const bool over = base + cnt > co.capacity;
+            if (over && lane == 0) atomicOr(co.counter + 1, 1);
+            if (lane < nsel && ((valid_bits >> lane) & 1ull)) {
                 const int row = base + __popcll(valid_bits & ((1ull << lane) - 1ull));
-                for (int t = 0; t < a.k; ++t) co.nb[(int64_t)row * a.k + t] = stage_idx[(wave * 64 + lane) * 8 + t];
+                if (row < co.capacity) {
+                    for (int t = 0; t < a.k; ++t) co.nb[(int64_t)row * a.k + t] = over ? -1 : stage_idx[(wave * 64 + lane) * 8 + t];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) co.pts[(int64_t)row * 3 + c] = stage_pos[(wave * 64 + lane) * 4 + c];
+                    for (int c = 0; c < 3; ++c) co.pts[(int64_t)row * 3 + c] = stage_pos[(wave * 64 + lane) * 4 + c];
+                }
             }
         }
         if (lane == 0) {
