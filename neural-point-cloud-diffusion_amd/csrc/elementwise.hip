@@ -13,6 +13,8 @@
 // reduction of column partials.  Roofline: HBM.
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace npcd {
@@ -290,20 +292,59 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
+// branch-free Phi(x) (same A&S 7.1.26 erf as gelu_grad_fast below, |error| <= 7.5e-8): gelu(x) = x Phi(x)
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float u = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, u, 1.f));
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);
+    float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 1.421413741f);
+    poly = __builtin_fmaf(poly, t, -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.254829592f);
+    const float erf_abs = __builtin_fmaf(-poly * t, e, 1.f);
+    return x * __builtin_fmaf(0.5f, copysignf(erf_abs, x), 0.5f);
+}
+
+template <int VARIANT>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16x8* __restrict__ h, bf16x8* __restrict__ g, int64_t n8) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
         const bf16x8 v = h[i];
         bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (__bf16)gelu_f((float)v[j]);
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)(VARIANT == 0 ? gelu_f((float)v[j]) : gelu_fast((float)v[j]));
         g[i] = o;
     }
 }
 
 // column-partial reductions: a thread owns 8 consecutive columns and walks kColRows rows
-static inline int col_rows(int T) { int r = T / 512; return r < 8 ? 8 : (r > 64 ? 64 : r); }
+static inline int col_rows(int T) {
+    static const int forced = [] { const char* e = getenv("NPCD_COL_ROWS"); return e ? atoi(e) : 0; }();     // A/B probes only
+    if (forced > 0) return forced;
+    int r = T / 512;
+    return r < 8 ? 8 : (r > 64 ? 64 : r);
+}
 
-template <bool GELU>
+// Branch-free gelu'(x) = Phi(x) + x phi(x) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, far below the
+// bf16 resolution of the result): ONE exponential e = exp(-x^2/2) serves both the erf tail and the density, one reciprocal,
+// a degree-5 Horner chain -- ~16 vector instructions per element.  libm's erff is a three-way branch per element (both sides
+// executed under the exec mask whenever a wave holds small and large |x|, i.e. always): ~59 instructions per element, which made
+// this kernel co-limited by vector-instruction issue (profiles/r2_elementwise_sq_pmc.json).
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    const float u = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, u, 1.f));
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);          // exp(-x^2 / 2)
+    float poly = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    poly = __builtin_fmaf(poly, t, 1.421413741f);
+    poly = __builtin_fmaf(poly, t, -0.284496736f);
+    poly = __builtin_fmaf(poly, t, 0.254829592f);
+    const float erf_abs = __builtin_fmaf(-poly * t, e, 1.f);                         // erf(|x| / sqrt 2)
+    const float phi_cdf = __builtin_fmaf(0.5f, copysignf(erf_abs, x), 0.5f);
+    return __builtin_fmaf(x * 0.3989422804014327f, e, phi_cdf);
+}
+
+// VARIANT (GELU only): 0 = libm erff; 1 = gelu_grad_fast; 2 = gelu_grad_fast, two rows per trip with all four loads issued first;
+// 3 = gelu_grad_fast with non-temporal loads of the two once-read inputs
+template <bool GELU, int VARIANT = 1>
 __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ hpre, __bf16* __restrict__ out,
                                                      float* __restrict__ part, int T, int N, int rows) {
     const int col = (blockIdx.x * 256 + threadIdx.x) * 8;
@@ -314,23 +355,47 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int rr = 0; rr < rows; ++rr) {
-        const int row = rr * gridDim.y + blockIdx.y;
-        if (row >= T) break;
-        const int64_t off = (int64_t)row * N + col;
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(a + off);
-        if (GELU) {
-            const bf16x8 hp = *reinterpret_cast<const bf16x8*>(hpre + off);
-            bf16x8 o;
+    auto one = [&](const bf16x8 v, const bf16x8 hp, int64_t off) {
+        bf16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                o[j] = (__bf16)((float)v[j] * gelu_grad_f((float)hp[j]));
-                acc[j] += (float)o[j];      // the bias gradient sums the SAME rounded values the GEMMs see
+        for (int j = 0; j < 8; ++j) {
+            const float gp = VARIANT == 0 ? gelu_grad_f((float)hp[j]) : gelu_grad_fast((float)hp[j]);
+            o[j] = (__bf16)((float)v[j] * gp);
+            acc[j] += (float)o[j];      // the bias gradient sums the SAME rounded values the GEMMs see
+        }
+        *reinterpret_cast<bf16x8*>(out + off) = o;
+    };
+    if (GELU && VARIANT == 2) {
+        int rr = 0;
+        for (; rr + 1 < rows; rr += 2) {
+            const int r0 = rr * gridDim.y + blockIdx.y, r1 = r0 + gridDim.y;
+            if (r1 >= T) break;
+            const int64_t o0 = (int64_t)r0 * N + col, o1 = (int64_t)r1 * N + col;
+            const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(a + o0), h0 = *reinterpret_cast<const bf16x8*>(hpre + o0);
+            const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(a + o1), h1 = *reinterpret_cast<const bf16x8*>(hpre + o1);
+            one(v0, h0, o0);
+            one(v1, h1, o1);
+        }
+        for (; rr < rows; ++rr) {
+            const int row = rr * gridDim.y + blockIdx.y;
+            if (row >= T) break;
+            const int64_t off = (int64_t)row * N + col;
+            one(*reinterpret_cast<const bf16x8*>(a + off), *reinterpret_cast<const bf16x8*>(hpre + off), off);
+        }
+    } else {
+        for (int rr = 0; rr < rows; ++rr) {
+            const int row = rr * gridDim.y + blockIdx.y;
+            if (row >= T) break;
+            const int64_t off = (int64_t)row * N + col;
+            const bf16x8 v = (GELU && VARIANT == 3) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(a + off))
+                                                    : *reinterpret_cast<const bf16x8*>(a + off);
+            if (GELU) {
+                one(v, VARIANT == 3 ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(hpre + off))
+                                    : *reinterpret_cast<const bf16x8*>(hpre + off), off);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
             }
-            *reinterpret_cast<bf16x8*>(out + off) = o;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
         }
     }
     float* p = part + (int64_t)blockIdx.y * N + col;
@@ -512,8 +577,13 @@ extern "C" int npcd_gelu_fwd(const void* h, void* g, int64_t numel, void* stream
     if (numel % 8 != 0 || !al16(h) || !al16(g)) return NPCD_ERR_UNSUPPORTED;
     const int64_t n8 = numel / 8;
     const int grid = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
-    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16x8*>(h),
-                       static_cast<bf16x8*>(g), n8);
+    static const int variant = [] { const char* e = getenv("NPCD_GELU_FWD_VARIANT"); return e ? atoi(e) : 1; }();   // A/B probes only
+    if (variant == 0)
+        hipLaunchKernelGGL(gelu_fwd_kernel<0>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16x8*>(h),
+                           static_cast<bf16x8*>(g), n8);
+    else
+        hipLaunchKernelGGL(gelu_fwd_kernel<1>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16x8*>(h),
+                           static_cast<bf16x8*>(g), n8);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }
@@ -525,8 +595,15 @@ extern "C" int npcd_gelu_bwd(const void* dg, const void* h, void* dh, float* par
     if (!dg || !h || !dh || !part || T <= 0 || N <= 0) return NPCD_ERR_ARG;
     if (N % 8 != 0 || !al16(dg) || !al16(h) || !al16(dh) || !al16(part)) return NPCD_ERR_UNSUPPORTED;
     dim3 grid((N / 8 + 255) / 256, npcd_colsum_blocks(T));
-    hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const __bf16*>(dg),
-                       static_cast<const __bf16*>(h), static_cast<__bf16*>(dh), part, T, N, col_rows(T));
+    static const int variant = [] { const char* e = getenv("NPCD_GELU_BWD_VARIANT"); return e ? atoi(e) : 1; }();   // A/B probes only
+#define NPCD_LAUNCH_GELU_BWD(V)                                                                                                       \
+    hipLaunchKernelGGL((colsum_kernel<true, V>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const __bf16*>(dg), \
+                       static_cast<const __bf16*>(h), static_cast<__bf16*>(dh), part, T, N, col_rows(T))
+    if (variant == 0) NPCD_LAUNCH_GELU_BWD(0);
+    else if (variant == 2) NPCD_LAUNCH_GELU_BWD(2);
+    else if (variant == 3) NPCD_LAUNCH_GELU_BWD(3);
+    else NPCD_LAUNCH_GELU_BWD(1);
+#undef NPCD_LAUNCH_GELU_BWD
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }
