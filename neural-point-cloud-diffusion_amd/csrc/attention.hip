@@ -397,6 +397,20 @@ __device__ __forceinline__ void fwd_stage(const FragAddr& fa, const typename TR:
     }
     tr_wait();
     f32x16 s0 = {0};
+#ifdef NPCD_DIAG_HALF_MFMA
+    // DIAGNOSTIC BUILD ONLY (tools/gpu_dev_fp8_bound.py): half of the matrix instructions of every stage are dropped (the
+    // operands they would have used are kept alive, all loads, all vector work and the whole control flow stay) -- wrong
+    // results, timing only: what a matrix pipe of TWICE the rate (block-scaled fp8, v_mfma_scale_f32_32x32x64_f8f6f4) could
+    // buy this kernel at best, before the cost of producing fp8 operands.
+#pragma unroll
+    for (int s = 0; s < 2; ++s) s0 = TR::mfma32(__builtin_bit_cast(V8, kr[s]), qf[s], s0);
+    asm volatile("" ::"v"(kr[2]), "v"(kr[3]));
+    if (ACC) {
+        o0 = TR::mfma32(tr_vec<TR>(vt[0][0]), __builtin_bit_cast(V8, pw[0]), o0);
+        o1 = TR::mfma32(tr_vec<TR>(vt[0][1]), __builtin_bit_cast(V8, pw[0]), o1);
+        asm volatile("" ::"v"(vt[1][0].lo), "v"(vt[1][0].hi), "v"(vt[1][1].lo), "v"(vt[1][1].hi), "v"(pw[1]));
+    }
+#else
 #pragma unroll
     for (int s = 0; s < 4; ++s) s0 = TR::mfma32(__builtin_bit_cast(V8, kr[s]), qf[s], s0);
     if (ACC) {
@@ -405,6 +419,7 @@ __device__ __forceinline__ void fwd_stage(const FragAddr& fa, const typename TR:
         o0 = TR::mfma32(tr_vec<TR>(vt[1][0]), __builtin_bit_cast(V8, pw[1]), o0);
         o1 = TR::mfma32(tr_vec<TR>(vt[1][1]), __builtin_bit_cast(V8, pw[1]), o1);
     }
+#endif
     u32x4 nw[2];
     fwd_softmax<TR>(s0, o0, o1, m, l, c, nw);
     pw[0] = nw[0];

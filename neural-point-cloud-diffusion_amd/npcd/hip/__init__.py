@@ -11,7 +11,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libnpcd_hip.so")
+# NPCD_HIP_LIB: development probes load a DIAGNOSTIC build of the library (tools/); never set in the product / tests / bench
+LIB_PATH = os.environ.get("NPCD_HIP_LIB") or os.path.join(_PKG_ROOT, "lib", "libnpcd_hip.so")
 
 NPCD_BF16, NPCD_F16, NPCD_F32 = 0, 1, 2
 _DTYPE_CODE = {torch.bfloat16: NPCD_BF16, torch.float16: NPCD_F16, torch.float32: NPCD_F32}
