@@ -260,6 +260,30 @@ int npcd_leaky_bwd_colsum(const void* dz, const void* z, void* dy, float* part, 
 int npcd_pair_aggregate(int backward, const float* src, const float* w, const int64_t* off, const int64_t* cnt, int channels,
                         int64_t n_points, float* dst, void* stream);
 
+/* ---- stage-1 training path: the per-pair aggregator MLP itself (aggregators/mlp.py:36-100; utils/model.py:22-36; pointnerf.py:
+ * 174-179: Linear(F+63,256) + 3 x Linear(256,256), LeakyReLU(0.01) after each) on the matrix cores, forward AND backward, bf16
+ * operands with fp32 accumulation (csrc/pairs_mlp.hip).  Pairs as above: row q of every [Q, .] array, ordered by point.
+ *   npcd_pair_mlp_pack : fp32 DEVICE weights W_l [256, in_l] (in_0 = F + 63) / biases b_l [256], l = 0..3  ->  wpack (device,
+ *                        npcd_pair_mlp_wpack_bytes()): bf16 fragment order of W_l (forward) and W_l^T (data gradient) + fp32 biases
+ *   npcd_pair_mlp_fwd  : nb_idx [P,k] int64 (-1 pad, valid first), pts [P,3], kp_pos [B*N,3], kp_feat [B*N,F] fp32, off [P] int64
+ *                        -> G [P,256] fp32 = inverse-distance weighted mean over a point's pairs of the 4th layer's output
+ *                        (aggregators/mlp.py:102-125; the network's 5th, linear layer is applied by the caller on points);
+ *                        saved for the backward: x0 [Q, F+64] bf16, acts [4][Q][256] bf16, wn [Q] fp32 (normalised weights)
+ *   npcd_pair_mlp_bwd  : dG [P,256] fp32, owner [Q] int64 -> dfeat [Q,F] fp32 (gradient w.r.t. the gathered feature rows, to be
+ *                        scattered with npcd_pair_input_bwd), dW[l] [256, in_l] fp32, db[l] [256] fp32 (overwritten; slabs summed
+ *                        in a fixed order: bitwise reproducible).  dact: 2 x [Q,256] bf16 scratch; part: fp32 scratch of
+ *                        npcd_pair_mlp_bwd_workspace_floats() elements.  F in {32, 128}. */
+int64_t npcd_pair_mlp_wpack_bytes(int feat_dim);
+int npcd_pair_mlp_pack(const float* const* weights_dev, const float* const* biases_dev, int feat_dim, void* wpack_dev, void* stream);
+int npcd_pair_mlp_fwd(const void* wpack, int feat_dim, const int64_t* nb_idx, const float* pts, const float* kp_pos,
+                      const float* kp_feat, const int64_t* off, int64_t n_points, int k, int64_t n_pairs, void* x0, void* acts,
+                      float* wn, float* G, void* stream);
+int npcd_pair_mlp_bwd_slabs(int64_t n_pairs);
+int64_t npcd_pair_mlp_bwd_workspace_floats(int feat_dim, int64_t n_pairs);
+int npcd_pair_mlp_bwd(const void* wpack, int feat_dim, const float* dG, const int64_t* owner, const float* wn, const void* x0,
+                      const void* acts, int64_t n_pairs, void* dact, float* dfeat, float* part, float* const* dW, float* const* db,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

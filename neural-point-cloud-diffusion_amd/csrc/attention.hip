@@ -931,8 +931,11 @@ __device__ __forceinline__ bool dkdv_step(unsigned char* smem, const FragAddr& f
     return true;
 }
 
+#ifndef NPCD_DKDV_WAVES
+#define NPCD_DKDV_WAVES 2
+#endif
 template <class TR>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, NPCD_DKDV_WAVES) void attn_bwd_dkdv_kernel(AttnParams p) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];

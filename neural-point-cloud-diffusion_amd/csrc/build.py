@@ -32,6 +32,7 @@ SOURCES = {
     "shade.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "elementwise.hip": [],
     "pairs.hip": ["-ffp-contract=off"],
+    "pairs_mlp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-fno-gpu-rdc", "-ffast-math" if False else "-fno-fast-math"]

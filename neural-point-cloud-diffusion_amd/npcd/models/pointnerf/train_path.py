@@ -14,6 +14,7 @@ renderers/math_utils.py:46-97.  The reference draws its random numbers inline; e
 dictionary: ray_perm, jitter, valid_perm) so that tests can replay the reference's numbers.
 """
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -122,6 +123,16 @@ def _mlp(seq, x, dtype):
     return x
 
 
+def fused_pair_mlp_ok(field, mlp_dtype) -> bool:
+    """The matrix-core pair MLP (csrc/pairs_mlp.hip) covers the published network (pointnerf.py:174-179: four LeakyReLU layers
+    of width 256 + a linear one, 10 frequency bands, feature width 32 or 128) in the bf16-operand mode of the trainer."""
+    agg = field.aggregator
+    lf = agg.local_field
+    return (mlp_dtype == torch.bfloat16 and not os.environ.get("NPCD_NO_FUSED_PAIR_MLP") and agg.in_dim in (32, 128) and agg.n_freqs == 10
+            and len(lf) == 9 and all(isinstance(lf[i], torch.nn.Linear) and lf[i].out_features == 256 for i in (0, 2, 4, 6, 8))
+            and all(isinstance(lf[i], torch.nn.LeakyReLU) and lf[i].negative_slope == 0.01 for i in (1, 3, 5, 7)))
+
+
 def shade_autograd(field, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch.Tensor, kp_feat: torch.Tensor):
     """Compact shading points -> sigma [P] (softplus(x - 1)), rgb [P, 3] (sigmoid), differentiable w.r.t. kp_feat and the
     field's parameters.  nb_idx [P, k] global point indices (-1 pad), pts [P, 3]; positions are constants (the point
@@ -133,13 +144,23 @@ def shade_autograd(field, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch
     flat = nb_idx[owner, col]
     cnt = valid.sum(dim=1)
     off = torch.cumsum(cnt, 0) - cnt                             # a point's pairs are rows off[p] .. off[p] + cnt[p]
-    # MLP input of every pair and its inverse-distance weight: one HIP kernel forward, one backward (csrc/pairs.hip)
-    x0, w = hr.pair_input(kp_feat.reshape(-1, kp_feat.shape[-1]), flat, owner, pts, kp_pos.detach().reshape(-1, 3), agg.n_freqs)
     # the reference trains stage 1 in fp32; `field.train_mlp_dtype = torch.bfloat16` (PointNeRFTrainer(mlp_dtype=...)) is an
     # opt-in that runs the Linear layers of the three MLPs under autocast (MFMA instead of fp32 matrix instructions)
     mlp_dtype = getattr(field, "train_mlp_dtype", None)
-    local = _mlp(agg.local_field, x0, mlp_dtype).float()
-    agg_feat = hr.pair_aggregate(local, w, off, cnt)             # weighted mean over each point's pairs (HIP fwd + bwd)
+    if fused_pair_mlp_ok(field, mlp_dtype):
+        # bf16 mode: the four non-linear per-pair layers and the weighted mean run as ONE forward launch and one backward launch
+        # per layer on the matrix cores (csrc/pairs_mlp.hip); the network's last, linear layer commutes with the mean (the
+        # normalised weights of a point sum to one and every compact point has a pair) and runs on the points
+        lf = agg.local_field
+        G = hr.pair_mlp(kp_feat.reshape(-1, kp_feat.shape[-1]), [(lf[i].weight, lf[i].bias) for i in (0, 2, 4, 6)], nb_idx, pts,
+                        kp_pos.detach().reshape(-1, 3), off, owner, flat)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            agg_feat = lf[8](G).float()
+    else:
+        # MLP input of every pair and its inverse-distance weight: one HIP kernel forward, one backward (csrc/pairs.hip)
+        x0, w = hr.pair_input(kp_feat.reshape(-1, kp_feat.shape[-1]), flat, owner, pts, kp_pos.detach().reshape(-1, 3), agg.n_freqs)
+        local = _mlp(agg.local_field, x0, mlp_dtype).float()
+        agg_feat = hr.pair_aggregate(local, w, off, cnt)         # weighted mean over each point's pairs (HIP fwd + bwd)
     shape, chan = _mlp(field.shape_net, agg_feat, mlp_dtype).float(), _mlp(field.channel_net, agg_feat, mlp_dtype).float()
     sigma = F.softplus(shape - 1.0)[:, 0]
     rgb = torch.sigmoid(chan)

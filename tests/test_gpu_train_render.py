@@ -329,3 +329,95 @@ def test_pair_input_and_aggregate_kernels_vs_torch():
     (aggr * ga).sum().backward()
     assert torch.allclose(agg, aggr, atol=1e-5) and torch.allclose(g2, local.grad, atol=1e-6)
     assert float(agg[7].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("F_", [32, 128])
+def test_fused_pair_mlp_forward_and_backward(F_):
+    """csrc/pairs_mlp.hip (bf16 operands, fp32 accumulation) against
+      (a) a step-by-step torch restatement with the SAME rounding points (inputs, weights, every layer's activations and every
+          layer's dZ / dA rounded to bf16, fp32 sums), layer by layer from the kernels' own stored activations: each layer's output
+          to 3e-3 (one bf16 rounding), every gradient to rel-L2 <= 2e-3 -- this is the kernel check;
+      (b) the fp32 formulation it replaces (npcd_pair_input -> four Linear + LeakyReLU(0.01) -> npcd_pair_aggregate under torch
+          autograd): forward <= 2e-2; gradients <= 1.5e-1 -- with a random upstream gradient the sums cancel heavily and the few
+          LeakyReLU units whose sign differs between the bf16 and the fp32 network (slope 1 vs 0.01) dominate the difference.
+    Ragged neighbour counts (1..8 per point), a tile with fewer pairs than one 32-row block, partial last tiles."""
+    import torch.nn.functional as F
+    from npcd.hip import render as hr
+    torch.manual_seed(F_)
+    P, k, Nt = 1237, 8, 300
+    cnt = torch.randint(1, k + 1, (P,))
+    cnt[16:32] = 1                                                   # a tile whose pairs fill less than one 32-row block
+    nb = torch.full((P, k), -1, dtype=torch.long)
+    for p in range(P):
+        nb[p, :cnt[p]] = torch.randperm(Nt)[:cnt[p]]
+    nb = nb.cuda()
+    pts = (torch.rand(P, 3) - 0.5).cuda()
+    pos = (torch.rand(Nt, 3) - 0.5).cuda()
+    feat = torch.randn(Nt, F_).cuda().requires_grad_(True)
+    dims = [F_ + 63, 256, 256, 256, 256]
+    lins = [torch.nn.Linear(dims[i], dims[i + 1]).cuda() for i in range(4)]
+    valid = nb >= 0
+    owner, col = torch.nonzero(valid, as_tuple=True)
+    flat = nb[owner, col]
+    c = valid.sum(dim=1)
+    off = torch.cumsum(c, 0) - c
+    gout = torch.randn(P, 256).cuda()
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    names = ["feat"] + [f"{n}{i}" for i in range(4) for n in ("W", "b")]
+
+    def grads():
+        out = [feat.grad.clone()] + [p_.grad.clone() for lin in lins for p_ in (lin.weight, lin.bias)]
+        feat.grad = None
+        for lin in lins:
+            lin.weight.grad = lin.bias.grad = None
+        return out
+
+    # ---- the kernels
+    G = hr.pair_mlp(feat, [(lin.weight, lin.bias) for lin in lins], nb, pts, pos, off, owner, flat)
+    (G * gout).sum().backward()
+    got = grads()
+    # ---- (b) fp32 formulation
+    x0, w = hr.pair_input(feat, flat, owner, pts, pos, 10)
+    h = x0
+    for lin in lins:
+        h = F.leaky_relu(lin(h), 0.01)
+    G_ref = hr.pair_aggregate(h, w, off, c)
+    (G_ref * gout).sum().backward()
+    ref32 = grads()
+    assert rel(G, G_ref.detach()) < 2e-2, rel(G, G_ref.detach())
+    errs32 = {n: rel(a, b) for n, a, b in zip(names, got, ref32)}
+    assert max(errs32.values()) < 1.5e-1, errs32
+    # ---- (a) same rounding points, step by step.  Forward: every layer from the PREVIOUS layer's stored activations; backward: from
+    # the stored activations too (a LeakyReLU unit whose tiny output rounds to the other sign would otherwise dominate the sums)
+    with torch.no_grad():
+        r16 = lambda t: t.bfloat16().float()
+        Q = flat.numel()
+        Gk, wpack, x0k, actk, wnk = hr.pair_mlp_forward_raw(feat, [l_.weight for l_ in lins], [l_.bias for l_ in lins], nb, pts, pos, off, Q)
+        assert torch.equal(Gk, G)
+        wsum = torch.zeros(P, device="cuda").index_add_(0, owner, w)
+        assert rel(wnk, w / wsum[owner]) < 1e-6
+        x0p = torch.cat((x0.detach(), torch.zeros(Q, 1, device="cuda")), dim=1)                  # the kernel pads the input to F + 64 columns
+        assert float((x0k.float() - r16(x0p)).abs().max()) < 1e-2 and rel(x0k.float(), r16(x0p)) < 2e-3   # v_sin / v_cos + bf16 rounding
+        layer_in = [x0k.float()[:, :F_ + 63]] + [actk[l].float() for l in range(3)]
+        for l, lin in enumerate(lins):
+            a_e = F.leaky_relu(layer_in[l] @ r16(lin.weight).t() + lin.bias, 0.01)
+            assert rel(actk[l].float(), a_e) < 3e-3, (l, rel(actk[l].float(), a_e))               # one bf16 rounding apart
+        G_e = torch.zeros(P, 256, device="cuda").index_add_(0, owner, wnk[:, None] * actk[3].float())
+        assert rel(G, G_e) < 1e-5
+        dA = wnk[:, None] * gout[owner]
+        emu = {}
+        for l in (3, 2, 1, 0):
+            dZ = r16(dA * torch.where(actk[l].float() > 0, 1.0, 0.01))
+            emu[f"b{l}"] = dZ.sum(0)
+            emu[f"W{l}"] = dZ.t() @ layer_in[l]
+            dA = dZ @ r16(lins[l].weight)
+            if l > 0:
+                dA = r16(dA)
+        emu["feat"] = torch.zeros(Nt, F_, device="cuda").index_add_(0, flat, dA[:, :F_])
+    errs = {n: rel(a, emu[n]) for n, a in zip(names, got)}
+    assert max(errs.values()) < 2e-3, errs
+    # ---- bitwise reproducible weight gradients (slabs summed in a fixed order; the feature scatter uses float atomics like the reference's)
+    G2 = hr.pair_mlp(feat, [(lin.weight, lin.bias) for lin in lins], nb, pts, pos, off, owner, flat)
+    (G2 * gout).sum().backward()
+    again = grads()
+    assert torch.equal(G, G2) and all(torch.equal(a, b) for a, b in zip(got[1:], again[1:]))
