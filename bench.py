@@ -140,7 +140,7 @@ def bench_stage1(device, n_iters=20, burn_in=3, mlp_dtype=None):
     per_it = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n_iters))
     return {"steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "ms_per_step_min_median_max": [per_it[0], per_it[n_iters // 2], per_it[-1]],
             "timed_iterations": n_iters, "objects": B, "views_per_object": T, "rays_per_view": net.pointnerf.renderer.ray_subsamples,
-            "loss": float(loss), "differentiable_part": getattr(tr, "describe", lambda: "HIP geometry / pair / ray-march kernels (fwd + bwd); MLP layers: see DESIGN.md")()}
+            "loss": float(loss), "differentiable_part": tr.describe()}
 
 
 def host_cpu_info():
@@ -463,9 +463,13 @@ def main():
             r["rays_per_s_all_gpus"] = float(tt)
         result["render"] = r
         try:
-            result["stage1_pointnerf_training"] = bench_stage1(device)
-            opt_in = bench_stage1(device, mlp_dtype=torch.bfloat16)
-            result["stage1_pointnerf_training"]["opt_in_bf16_mlp"] = {k: opt_in[k] for k in ("steps_per_s", "ms_per_step", "ms_per_step_min_median_max", "loss")}
+            # primary figure: bf16 operands / fp32 accumulation, per-pair MLP on the matrix cores (csrc/pairs_mlp.hip);
+            # the reference's numerics (all fp32, library GEMMs at the fp32 matrix rate) beside it
+            s1 = bench_stage1(device, mlp_dtype=torch.bfloat16)
+            s1["numerics"] = "bf16 operands, fp32 accumulation, fp32 weight gradients and optimizer (PointNeRFTrainer(mlp_dtype=torch.bfloat16))"
+            ref32 = bench_stage1(device)
+            s1["fp32_reference_numerics"] = {k: ref32[k] for k in ("steps_per_s", "ms_per_step", "ms_per_step_min_median_max", "loss")}
+            result["stage1_pointnerf_training"] = s1
         except Exception as e:                      # noqa: BLE001
             result["stage1_pointnerf_training"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:

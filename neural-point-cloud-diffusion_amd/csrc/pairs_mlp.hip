@@ -491,15 +491,30 @@ __global__ __launch_bounds__(512, 2) void pair_mlp_bwd_kernel(PairBwdArgs a) {
     }
 }
 
-// out[e] = sum over the slabs, in slab order (bitwise reproducible)
+// out[e] = sum over the slabs in a FIXED order (bitwise reproducible): a workgroup owns 64 consecutive elements, its four waves
+// each sum every fourth slab (independent chains: the loads of a chain are coalesced 256-byte rows), then one wave adds the four
+// partial sums.
 __global__ __launch_bounds__(256) void pair_slab_sum_kernel(const float* __restrict__ part, int nslabs, int64_t slab_elems, int64_t n_w,
                                                             float* __restrict__ dW, float* __restrict__ db) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= slab_elems) return;
-    float s = 0.f;
-    for (int g = 0; g < nslabs; ++g) s += part[(int64_t)g * slab_elems + e];
-    if (e < n_w) dW[e] = s;
-    else db[e - n_w] = s;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < slab_elems) {
+        int g = w;
+        for (; g + 4 < nslabs; g += 8) {
+            s0 += part[(int64_t)g * slab_elems + e];
+            s1 += part[(int64_t)(g + 4) * slab_elems + e];
+        }
+        if (g < nslabs) s0 += part[(int64_t)g * slab_elems + e];
+    }
+    red[w][lane] = s0 + s1;
+    __syncthreads();
+    if (w == 0 && e < slab_elems) {
+        const float s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        if (e < n_w) dW[e] = s;
+        else db[e - n_w] = s;
+    }
 }
 
 }  // namespace npcd
@@ -616,11 +631,11 @@ extern "C" int npcd_pair_mlp_bwd(const void* wpack, int feat_dim, const float* d
         const int KP = l > 0 ? kPH : feat_dim + kPEnc;
         const int64_t slab = (int64_t)kPH * KP + kPH;
         if (l > 0) {
-            hipLaunchKernelGGL(pair_slab_sum_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, part, grid, slab, (int64_t)kPH * KP, dW[l], db[l]);
+            hipLaunchKernelGGL(pair_slab_sum_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(256), 0, st, part, grid, slab, (int64_t)kPH * KP, dW[l], db[l]);
         } else {
             // layer 0: the slab rows are K0 = F + 64 wide, the weight gradient F + 63: sum into the head of the workspace, then copy rows
             float* tmp = part + (int64_t)grid * slab;
-            hipLaunchKernelGGL(pair_slab_sum_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, part, grid, slab, (int64_t)kPH * KP, tmp, db[0]);
+            hipLaunchKernelGGL(pair_slab_sum_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(256), 0, st, part, grid, slab, (int64_t)kPH * KP, tmp, db[0]);
             NPCD_HIP_CHECK(hipMemcpy2DAsync(dW[0], (size_t)in0 * 4, tmp, (size_t)KP * 4, (size_t)in0 * 4, kPH, hipMemcpyDeviceToDevice, st));
         }
         NPCD_HIP_CHECK(hipGetLastError());

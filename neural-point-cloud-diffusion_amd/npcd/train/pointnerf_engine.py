@@ -23,6 +23,18 @@ class PointNeRFTrainer:
         self.scheduler = torch.optim.lr_scheduler.StepLR(self.optimizer, step_size=1, gamma=1.0)       # constant (:105)
         self.iteration = 0
 
+    def describe(self) -> str:
+        """What runs where in this trainer's step (bench.py prints it next to the timing)."""
+        from ..models.pointnerf.train_path import fused_pair_mlp_ok
+        field = self.model.pointnerf.field
+        dt = getattr(field, "train_mlp_dtype", None)
+        base = ("HIP kernels with hand-written backward: ray generation, both neighbour queries, ray march; ")
+        if fused_pair_mlp_ok(field, dt):
+            return base + ("per-pair aggregator MLP (gather, positional encoding, 4 layers, weighted mean) forward + backward on the matrix "
+                           "cores (csrc/pairs_mlp.hip); point-level layers and losses: torch under bf16 autocast")
+        return base + ("pair inputs / aggregation (csrc/pairs.hip); Linear layers: library GEMMs (row-split weight gradients) in "
+                       + ("fp32" if dt is None else str(dt)) + " under torch autograd")
+
     def step(self, sample, rng=None):
         """sample: dict(images [B,T,3,H,W], intrinsics [B,T,3,3], extrinsics [B,T,4,4], obj_idx [B]) on the GPU."""
         self.model.pointnerf.train()

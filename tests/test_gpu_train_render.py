@@ -172,8 +172,10 @@ def test_losses_match_reference_golden_and_oracle(golden):
     assert isinstance(PointNeRFLoss(net), torch.nn.Module)
 
 
-def test_stage1_training_step_reduces_the_loss():
-    """PointNeRFTrainer on a synthetic target: images rendered from a 'teacher' feature table; the student starts from zeros"""
+@pytest.mark.parametrize("mlp_dtype", [None, torch.bfloat16])
+def test_stage1_training_step_reduces_the_loss(mlp_dtype):
+    """PointNeRFTrainer on a synthetic target: images rendered from a 'teacher' feature table; the student starts from zeros.
+    mlp_dtype None = the reference's fp32; torch.bfloat16 = the matrix-core pair MLP (csrc/pairs_mlp.hip), which must be engaged."""
     from npcd.train import PointNeRFTrainer
     B, Tn, N, F_, res = 2, 2, 512, 32, 32
     coords, feats = orr.synthetic_cloud(N, F_, B, seed=8)
@@ -196,7 +198,8 @@ def test_stage1_training_step_reduces_the_loss():
         images = target.transpose(-1, -2).reshape(B, Tn, 3, res, res).contiguous()
         pn.feats.get_emb().weight.view(B, N, 2 * F_)[..., F_:] = -6.0                                      # small variance
     coords_before = pn.get_all_coords().clone()
-    trainer = PointNeRFTrainer(net, lr=2e-3)
+    trainer = PointNeRFTrainer(net, lr=2e-3, mlp_dtype=mlp_dtype)
+    assert ("csrc/pairs_mlp.hip" in trainer.describe()) == (mlp_dtype is not None)
     sample = {"images": images, "intrinsics": intr, "extrinsics": extr, "obj_idx": torch.arange(B, device="cuda")}
     torch.manual_seed(0)
     losses = [float(trainer.step(sample)[0]) for _ in range(40)]
