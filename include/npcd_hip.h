@@ -232,6 +232,20 @@ int npcd_ddpm_reverse_step(const float* x_t, const void* eps, int eps_dtype, con
                            const float* tab_coef1, const float* tab_coef2, const float* tab_logvar, float clip_lo, float clip_hi,
                            int has_clip, void* stream);
 
+/* Forward process and training loss of the DDPM, fused (reference gaussian_diffusion.py:68-76 q_sample, :199-230 p_losses):
+ *   npcd_q_sample    : x_t = tab_sqrt_acp[t_b] * x_0 + tab_sqrt_1macp[t_b] * noise, fp32 [B, per_sample], t int64 [B]; the products
+ *                      and the sum are rounded separately like the reference's eager ops (bit-identical to them)
+ *   npcd_eps_mse_fwd : loss[0] = mean((noise - eps)^2 / 2) over numel elements (eps fp32 or bf16), optional pointwise output
+ *                      (fp32 [numel] or NULL); part: fp32 scratch of npcd_eps_mse_blocks() elements; fixed-order sums
+ *   npcd_eps_mse_bwd : grad = -(noise - eps) / numel * upstream_dev[0]   (grad has the dtype of eps) */
+int npcd_q_sample(const float* x0, const float* noise, const int64_t* t, const float* tab_sqrt_acp, const float* tab_sqrt_1macp,
+                  float* x_t, int B, int64_t per_sample, void* stream);
+int npcd_eps_mse_blocks(void);
+int npcd_eps_mse_fwd(const float* noise, const void* eps, int eps_dtype, int64_t numel, float* pointwise, float* part, float* loss,
+                     void* stream);
+int npcd_eps_mse_bwd(const float* noise, const void* eps, int eps_dtype, int64_t numel, const float* upstream_dev, void* grad,
+                     void* stream);
+
 /* ray march on the compact layout of npcd_grid_query_compact (same math as npcd_ray_march).  `capacity` = rows allocated in
  * sigma / rgb / pts: when the compact lists overflowed (counter[1] != 0) a ray whose rows lie past it is marched as empty --
  * the caller discards that result and retries with larger lists, nothing is read out of bounds meanwhile. */

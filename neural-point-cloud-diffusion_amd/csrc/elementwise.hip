@@ -658,6 +658,103 @@ extern "C" int npcd_ddpm_reverse_step(const float* x_t, const void* eps, int eps
     return NPCD_OK;
 }
 
+// ============================================================================================
+// forward process + training loss of the DDPM (gaussian_diffusion.py:68-76, 199-230)
+//   q_sample:  x_t = sqrt(acp[t_b]) x_0 + sqrt(1 - acp[t_b]) noise     (per-sample coefficients looked up on the device)
+//   eps-MSE :  loss = mean((noise - eps_hat)^2 / 2);   d loss / d eps_hat = -(noise - eps_hat) / numel * upstream
+// The reference runs them as ~12 elementwise / reduction launches per tensor; here one launch per tensor and direction, with a
+// fixed-order two-stage sum (bitwise reproducible loss).
+// ============================================================================================
+namespace npcd {
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const int64_t* __restrict__ t,
+                                                       const float* __restrict__ tab_a, const float* __restrict__ tab_s, float* __restrict__ xt,
+                                                       int64_t per_sample) {
+#pragma clang fp contract(off)      // mul, mul, add, each rounded, like the reference's eager ops: no fused multiply-add here
+    const int b = blockIdx.y;
+    const float ca = tab_a[t[b]], cs = tab_s[t[b]];
+    const int64_t base = (int64_t)b * per_sample;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * 256) {
+        const float p0 = ca * x0[base + i], p1 = cs * noise[base + i];
+        xt[base + i] = p0 + p1;
+    }
+}
+
+constexpr int kMseBlocks = 256;
+template <class T>
+__global__ __launch_bounds__(256) void eps_mse_fwd_kernel(const float* __restrict__ noise, const T* __restrict__ eps, float* __restrict__ pointwise,
+                                                          float* __restrict__ part, int64_t numel) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256) {
+        const float d = noise[i] - (float)eps[i];
+        const float pw = d * d * 0.5f;
+        if (pointwise) pointwise[i] = pw;
+        s += pw;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void eps_mse_finalize_kernel(const float* __restrict__ part, int nblocks, float inv_numel, float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 64) s += part[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) out[0] = s * inv_numel;
+}
+template <class T>
+__global__ __launch_bounds__(256) void eps_mse_bwd_kernel(const float* __restrict__ noise, const T* __restrict__ eps, const float* __restrict__ upstream,
+                                                          float inv_numel, T* __restrict__ grad, int64_t numel) {
+    const float g = upstream[0] * inv_numel;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < numel; i += (int64_t)gridDim.x * 256)
+        grad[i] = (T)(-(noise[i] - (float)eps[i]) * g);
+}
+}  // namespace npcd
+
+extern "C" int npcd_q_sample(const float* x0, const float* noise, const int64_t* t, const float* tab_sqrt_acp, const float* tab_sqrt_1macp,
+                             float* x_t, int B, int64_t per_sample, void* stream) {
+    if (!x0 || !noise || !t || !tab_sqrt_acp || !tab_sqrt_1macp || !x_t || B <= 0 || per_sample <= 0) return NPCD_ERR_ARG;
+    const int gx = (int)((per_sample + 255) / 256 < 256 ? (per_sample + 255) / 256 : 256);
+    hipLaunchKernelGGL(q_sample_kernel, dim3(gx, B), dim3(256), 0, static_cast<hipStream_t>(stream), x0, noise, t, tab_sqrt_acp, tab_sqrt_1macp, x_t,
+                       per_sample);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int npcd_eps_mse_blocks(void) { return kMseBlocks; }
+
+extern "C" int npcd_eps_mse_fwd(const float* noise, const void* eps, int eps_dtype, int64_t numel, float* pointwise, float* part, float* loss,
+                                void* stream) {
+    if (!noise || !eps || !part || !loss || numel <= 0) return NPCD_ERR_ARG;
+    if (eps_dtype != NPCD_F32 && eps_dtype != NPCD_BF16) return NPCD_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (eps_dtype == NPCD_F32)
+        hipLaunchKernelGGL(eps_mse_fwd_kernel<float>, dim3(kMseBlocks), dim3(256), 0, st, noise, static_cast<const float*>(eps), pointwise, part, numel);
+    else
+        hipLaunchKernelGGL(eps_mse_fwd_kernel<__bf16>, dim3(kMseBlocks), dim3(256), 0, st, noise, static_cast<const __bf16*>(eps), pointwise, part, numel);
+    hipLaunchKernelGGL(eps_mse_finalize_kernel, dim3(1), dim3(64), 0, st, part, kMseBlocks, 1.f / (float)numel, loss);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int npcd_eps_mse_bwd(const float* noise, const void* eps, int eps_dtype, int64_t numel, const float* upstream_dev, void* grad,
+                                void* stream) {
+    if (!noise || !eps || !upstream_dev || !grad || numel <= 0) return NPCD_ERR_ARG;
+    if (eps_dtype != NPCD_F32 && eps_dtype != NPCD_BF16) return NPCD_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int grid = (int)((numel + 255) / 256 < 2048 ? (numel + 255) / 256 : 2048);
+    if (eps_dtype == NPCD_F32)
+        hipLaunchKernelGGL(eps_mse_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, noise, static_cast<const float*>(eps), upstream_dev,
+                           1.f / (float)numel, static_cast<float*>(grad), numel);
+    else
+        hipLaunchKernelGGL(eps_mse_bwd_kernel<__bf16>, dim3(grid), dim3(256), 0, st, noise, static_cast<const __bf16*>(eps), upstream_dev,
+                           1.f / (float)numel, static_cast<__bf16*>(grad), numel);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
 extern "C" int npcd_cast_f32_bf16(const float* src, void* dst, int64_t numel, void* stream) {
     if (!src || !dst || numel <= 0) return NPCD_ERR_ARG;
     if (numel % 4 != 0 || !al16(src) || (reinterpret_cast<uintptr_t>(dst) & 7)) return NPCD_ERR_UNSUPPORTED;

@@ -150,3 +150,49 @@ def ddpm_reverse_step(x_t, eps, noise, t, tables, clip=None, want_x0=False):
     check(lib().npcd_ddpm_reverse_step(ptr(x_t), ptr(eps), code, ptr(noise), ptr(out), ptr(x0), ptr(t), B, x_t.numel() // B,
                                        *[ptr(tb) for tb in tables], lo, hi, int(clip is not None), stream_ptr()), "npcd_ddpm_reverse_step")
     return out, x0
+
+
+def q_sample(x0, noise, t, tab_sqrt_acp, tab_sqrt_1macp):
+    """x_t = sqrt(acp[t]) x_0 + sqrt(1 - acp[t]) noise in one launch (coefficients looked up on the device).  fp32 [B, ...]."""
+    require_gpu(x0, noise, t)
+    x0, noise = x0.contiguous(), noise.contiguous()
+    out = torch.empty_like(x0)
+    B = x0.shape[0]
+    check(lib().npcd_q_sample(ptr(x0), ptr(noise), ptr(t.contiguous()), ptr(tab_sqrt_acp), ptr(tab_sqrt_1macp), ptr(out), B, x0.numel() // B,
+                              stream_ptr()), "npcd_q_sample")
+    return out
+
+
+class _EpsMSE(torch.autograd.Function):
+    """mean((noise - eps)^2 / 2) with a one-launch forward (+ finalize) and a one-launch backward; eps fp32 or bf16."""
+
+    @staticmethod
+    def forward(ctx, eps, noise, want_pointwise):
+        from . import dtype_code
+        L = lib()
+        eps_c, noise_c = eps.contiguous(), noise.contiguous()
+        n = eps_c.numel()
+        pw = torch.empty(eps_c.shape, dtype=_f32, device=eps.device) if want_pointwise else None
+        part = torch.empty(L.npcd_eps_mse_blocks(), dtype=_f32, device=eps.device)
+        loss = torch.empty(1, dtype=_f32, device=eps.device)
+        check(L.npcd_eps_mse_fwd(ptr(noise_c), ptr(eps_c), dtype_code(eps_c), n, ptr(pw), ptr(part), ptr(loss), stream_ptr()), "npcd_eps_mse_fwd")
+        ctx.save_for_backward(eps_c, noise_c)
+        if pw is None:
+            pw = loss.new_empty(0)
+        ctx.mark_non_differentiable(pw)
+        return loss[0], pw
+
+    @staticmethod
+    def backward(ctx, g, _gpw):
+        from . import dtype_code
+        eps, noise = ctx.saved_tensors
+        grad = torch.empty_like(eps)
+        up = g.reshape(1).to(_f32).contiguous()
+        check(lib().npcd_eps_mse_bwd(ptr(noise), ptr(eps), dtype_code(eps), eps.numel(), ptr(up), ptr(grad), stream_ptr()), "npcd_eps_mse_bwd")
+        return grad, None, None
+
+
+def eps_mse(eps, noise, want_pointwise=True):
+    """-> (loss scalar, pointwise fp32 tensor or None)."""
+    loss, pw = _EpsMSE.apply(eps, noise, want_pointwise)
+    return loss, (pw if want_pointwise else None)

@@ -70,14 +70,14 @@ class DiffusionModel(nn.Module):
         self.coords_normalization = UnitGaussianNormalization(dim=coords_dim)
         self.feats_normalization = MinusOneToOneNormalization(dim=feats_dim)
 
-    def compute_loss(self, coords, feats, t=None, coords_noise=None, feats_noise=None):
+    def compute_loss(self, coords, feats, t=None, coords_noise=None, feats_noise=None, want_pointwise=True):
         """Reference :99-106.  t / noise may be injected (parity tests); by default they are drawn on
         the device like the reference does."""
         coords = self.coords_normalization(coords)
         feats = self.feats_normalization(feats)
         if t is None:
             t = torch.randint(0, self.diffusion_process.num_timesteps, size=(coords.shape[0],), device=coords.device)
-        return self.diffusion_process.p_losses(self.denoiser, coords, feats, t, coords_noise, feats_noise)
+        return self.diffusion_process.p_losses(self.denoiser, coords, feats, t, coords_noise, feats_noise, want_pointwise=want_pointwise)
 
     @torch.no_grad()
     def generate(self, num, batch_size=8, progress=True, dtype=None, use_graph=False):

@@ -52,10 +52,13 @@ class GaussianDiffusion(nn.Module):
         if noise is None:
             noise = torch.randn(data_start.shape, device=data_start.device)
         assert noise.shape == data_start.shape
+        if data_start.is_cuda and data_start.dtype == torch.float32 and noise.dtype == torch.float32 and self.sqrt_alphas_cumprod.is_cuda:
+            from ...hip import elementwise as ew            # one launch; bit-identical to the expression below (mul, mul, add)
+            return ew.q_sample(data_start, noise, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
         return (self._extract(self.sqrt_alphas_cumprod, t, data_start.shape) * data_start
                 + self._extract(self.sqrt_one_minus_alphas_cumprod, t, data_start.shape) * noise)
 
-    def p_losses(self, denoise_fn, coords_start, feats_start, t, coords_noise=None, feats_noise=None):
+    def p_losses(self, denoise_fn, coords_start, feats_start, t, coords_noise=None, feats_noise=None, want_pointwise=True):
         """Training loss (reference :199-230): 1/2 MSE(eps_c) + 1/2 MSE(eps_f), two separate means."""
         assert t.shape == (coords_start.shape[0],)
         if coords_noise is None:
@@ -65,11 +68,16 @@ class GaussianDiffusion(nn.Module):
         assert coords_noise.shape == coords_start.shape and feats_noise.shape == feats_start.shape
         eps_c, eps_f = denoise_fn(self.q_sample(coords_start, t, coords_noise),
                                   self.q_sample(feats_start, t, feats_noise), t)
-        pw_c = (coords_noise - eps_c) ** 2 / 2.0
-        pw_f = (feats_noise - eps_f) ** 2 / 2.0
-        lc, lf = pw_c.mean(), pw_f.mean()
-        return (lc + lf, {"00_coords_loss": lc, "01_feats_loss": lf},
-                {"pointwise_coords_loss": pw_c, "pointwise_feats_loss": pw_f})
+        if eps_c.is_cuda and eps_c.dtype in (torch.float32, torch.bfloat16) and eps_f.dtype == eps_c.dtype and coords_noise.dtype == torch.float32:
+            from ...hip import elementwise as ew            # fused squared error + mean (forward and backward one launch each)
+            lc, pw_c = ew.eps_mse(eps_c, coords_noise, want_pointwise)
+            lf, pw_f = ew.eps_mse(eps_f, feats_noise, want_pointwise)
+        else:
+            pw_c = (coords_noise - eps_c) ** 2 / 2.0
+            pw_f = (feats_noise - eps_f) ** 2 / 2.0
+            lc, lf = pw_c.mean(), pw_f.mean()
+        pointwise = {"pointwise_coords_loss": pw_c, "pointwise_feats_loss": pw_f} if want_pointwise else {}
+        return lc + lf, {"00_coords_loss": lc, "01_feats_loss": lf}, pointwise
 
     # ---- reverse process --------------------------------------------------------------------
     def _predict_xstart_from_eps(self, x_t, t, eps):

@@ -172,6 +172,11 @@ class DiffusionTrainer:
         parameters are all-gathered.  Same bytes on the wire as the all-reduce, optimizer pass divided by the number of ranks."""
         self.model = diffusion
         self.dtype = dtype
+        # the training loop never looks at the pointwise losses: this package's DiffusionModel can skip materialising them
+        # (a model with the reference's plain compute_loss signature is called as is)
+        import inspect
+        self._loss_kwargs = ({"want_pointwise": False}
+                             if "want_pointwise" in inspect.signature(diffusion.compute_loss).parameters else {})
         self.flat = FlatBuffers(diffusion)
         self.reducer = GradReducer(self.flat, group, bucket_bytes, always_reduce)
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, (0.9, 0.999), 1e-8
@@ -241,7 +246,7 @@ class DiffusionTrainer:
         self.finished_iterations += 1
         dev_type = "cuda" if coords.is_cuda else "cpu"
         with torch.autocast(dev_type, dtype=self.dtype, enabled=self.dtype is not None):
-            loss, sub, _ = self.model.compute_loss(coords, feats, t=t, coords_noise=coords_noise, feats_noise=feats_noise)
+            loss, sub, _ = self.model.compute_loss(coords, feats, t=t, coords_noise=coords_noise, feats_noise=feats_noise, **self._loss_kwargs)
         (loss if self.loss_scale is None else loss * self.loss_scale).backward()
         self.apply_gradients()
         return loss.detach(), sub

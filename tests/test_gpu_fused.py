@@ -317,3 +317,46 @@ def test_float16_training_with_dynamic_loss_scale():
     tr.step(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
     assert tr.skipped_steps == 1 and tr.loss_scale == 2.0 ** 39 and tr.iteration == 1
     assert torch.equal(tr.flat.flat, before) and float(tr.flat.grad.abs().max()) == 0.0
+
+
+def test_fused_q_sample_and_eps_mse_match_reference_golden(golden):
+    """npcd_q_sample / npcd_eps_mse_{fwd,bwd} against the reference's own q_sample and p_losses outputs (fixture diffusion.npz,
+    generated by importing the reference): x_t BIT-EXACT (the kernel rounds the two products and the sum separately, like the
+    reference's eager ops), loss terms to 1e-6 relative, pointwise losses to 1e-7 absolute; the backward against torch autograd
+    of the same expression, fp32 and bf16 predictions."""
+    from npcd.hip import elementwise as ew
+    from npcd.models.diffusion import GaussianDiffusion
+    g = golden("diffusion")
+    T = lambda k: torch.from_numpy(g[k]).cuda()
+    gd = GaussianDiffusion().cuda()
+    # the schedule tables are built on the HOST (float64 linspace / cumprod): their last bits depend on the host's numpy build
+    # (observed: this container's Xeon and the GPU box's EPYC differ in a few entries), exactly as the reference's would --
+    # the fixture's tables are loaded so that the comparison is about the kernel
+    gd.sqrt_alphas_cumprod.copy_(T("tab:sqrt_alphas_cumprod"))
+    gd.sqrt_one_minus_alphas_cumprod.copy_(T("tab:sqrt_one_minus_alphas_cumprod"))
+    t = T("t")
+    for x0, nz, xt in (("c0", "cn", "coords_t"), ("f0", "fn", "feats_t")):
+        out = gd.q_sample(T(x0), t, T(nz))
+        assert torch.equal(out, T(xt)), x0
+    # loss: the fixture's "denoiser" is a fixed function of (x_t, t) (make_golden.py: a channel-mixing matrix, + t / 1000 for the
+    # coordinates, tanh(.) - t / 1000 for the features), so eps_hat can be rebuilt here (on the CPU, in the fixture's own op order)
+    sft = (torch.from_numpy(g["t"]).float() / 1000.0).reshape(-1, 1, 1)
+    eps_of = {"coords_t": torch.einsum("ij,bjn->bin", torch.from_numpy(g["wc"]), torch.from_numpy(g["coords_t"])) + sft,
+              "feats_t": torch.tanh(torch.einsum("ij,bjn->bin", torch.from_numpy(g["wf"]), torch.from_numpy(g["feats_t"]))) - sft}
+    for nz, xt, wk, lk, pk in (("cn", "coords_t", "wc", "coords_loss", "pw_coords"), ("fn", "feats_t", "wf", "feats_loss", "pw_feats")):
+        eps = eps_of[xt].cuda().requires_grad_(True)
+        loss, pw = ew.eps_mse(eps, T(nz), want_pointwise=True)
+        assert abs(float(loss) - float(g[lk])) < 1e-6 * abs(float(g[lk]))
+        assert float((pw - T(pk)).abs().max()) < 1e-7 * max(1.0, float(T(pk).abs().max()))
+        (loss * 3.0).backward()
+        e2 = eps.detach().clone().requires_grad_(True)
+        (((T(nz) - e2) ** 2 / 2.0).mean() * 3.0).backward()
+        assert torch.allclose(eps.grad, e2.grad, rtol=1e-6, atol=1e-12)
+        eb = eps.detach().bfloat16().requires_grad_(True)
+        lb, none = ew.eps_mse(eb, T(nz), want_pointwise=False)
+        assert none is None
+        lb.backward()
+        e3 = eb.detach().clone().requires_grad_(True)
+        ((T(nz) - e3.float()) ** 2 / 2.0).mean().backward()
+        assert abs(float(lb) - float(((T(nz) - eb.detach().float()) ** 2 / 2).mean())) < 1e-6 * float(lb)
+        assert rel(eb.grad, e3.grad) < 4e-3 and eb.grad.dtype == torch.bfloat16
