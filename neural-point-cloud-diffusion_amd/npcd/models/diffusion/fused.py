@@ -117,6 +117,7 @@ class FusedBackboneEngine:
         # version counter (the optimizer kernel writes through raw pointers and does not): the stamp below notices that and the
         # shadow is re-cast from the fp32 masters before the next forward instead of silently running stale Linear weights
         # beside fresh LayerNorm ones.
+        self.block_ranges, self.wait_range = None, None      # set by a trainer with lazily gathered parameters (engine.py)
         self._flat, self._shadow = flat, shadow
         self._stamped = [p for e in self.blocks for p in e["params"]]
         self._stamp = self._versions()
@@ -128,6 +129,8 @@ class FusedBackboneEngine:
         """Re-cast fp32 masters -> bf16 shadow if a parameter was written outside the optimizer since the last check."""
         v = self._versions()
         if force or v != self._stamp:
+            if self.wait_range is not None:
+                self.wait_range()                                # every pending parameter gather first: the whole shadow is re-cast
             for p, off in zip(self._flat.params, self._flat.offsets):
                 if p.data_ptr() != self._flat.flat.data_ptr() + off * self._flat.flat.element_size():
                     raise RuntimeError("a parameter of the fused backbone was re-homed outside the trainer's flat buffer "
@@ -198,7 +201,9 @@ class _BackboneFn(torch.autograd.Function):
         with torch.autocast("cuda", enabled=False):
             xs = x.reshape(T, W).contiguous()
             delta = None
-            for e in eng.blocks:
+            for bi, e in enumerate(eng.blocks):
+                if eng.wait_range is not None:
+                    eng.wait_range(*eng.block_ranges[bi])        # this block's parameters (gathered lazily by the sharded optimizer)
                 x1, y1, mean1, rstd1 = ew.add_ln_fwd(xs, delta, e["ln_1_weight"], e["ln_1_bias"])
                 x_cur = xs if x1 is None else x1
                 qkv = _linear(e["attn_c_qkv_bias_16"], y1, e["attn_c_qkv_weight_16"])

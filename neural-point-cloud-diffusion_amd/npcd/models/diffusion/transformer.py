@@ -111,6 +111,8 @@ class Transformer(nn.Module):
                 # sampling / evaluation under bf16 autocast: fused forward-only kernels (fused.backbone_forward)
                 from . import fused
                 if eng is not None:
+                    if eng.wait_range is not None:
+                        eng.wait_range()
                     eng.sync_shadow()
                     return fused.backbone_forward(x, eng.blocks, eng.heads)
                 if self._infer_weights is None:

@@ -222,6 +222,19 @@ class DiffusionTrainer:
             want = shard_optimizer if shard_optimizer is not None else not os.environ.get("NPCD_NO_SHARD_OPTIMIZER")
             if want and self.reducer.active and max_grad_norm is None and self.loss_scale is None:
                 self.reducer.enable_sharding()
+            # Sharded optimizer: the updated parameters come back with one all-gather per bucket.  Those gathers are NOT awaited
+            # at the end of the step: a bucket is awaited (and its bf16 shadow refreshed) right before the next forward first
+            # reads a parameter of it -- the fused backbone asks block by block -- so that the 1.24 GB of parameter traffic runs
+            # under the next step's forward instead of after the optimizer.  Buckets are filled in reverse parameter order, so
+            # only the LAST bucket (block 0, ln_pre, time_embed) is needed immediately and stays exposed.
+            self._pending = {}                   # bucket index -> (work handle, send buffer, start, end)
+            self._bucket_of = {se: i for i, se in enumerate(self.reducer.buckets)}
+            self.lazy_gather = not os.environ.get("NPCD_EAGER_PARAM_GATHER")
+            eng = getattr(getattr(denoiser, "backbone", None), "fused_engine", None) if denoiser is not None else None
+            if eng is not None:
+                offs = {id(p): (o, o + p.numel()) for p, o in zip(self.flat.params, self.flat.offsets)}
+                eng.block_ranges = [(min(offs[id(p)][0] for p in e["params"]), max(offs[id(p)][1] for p in e["params"])) for e in eng.blocks]
+                eng.wait_range = self.wait_params
         else:
             # reference path (CPU tests / ablation): torch AdamW over ONE flat "parameter"
             self.master = nn.Parameter(self.flat.flat, requires_grad=True)
@@ -231,6 +244,7 @@ class DiffusionTrainer:
     def ema_state_dict(self, gathered: bool = False):
         """state_dict of the EMA model: same keys as the running model (utils/ema.py:80), buffers copied.  Collective with a
         sharded optimizer (all ranks call it) unless the caller has just gathered the EMA (`gathered=True`)."""
+        self.wait_params()
         if not gathered:
             self.gather_ema()
         sd = {k: v.clone() for k, v in self.model.state_dict().items()}
@@ -239,7 +253,23 @@ class DiffusionTrainer:
             sd[names[id(p)]] = self.ema[off:off + p.numel()].view_as(p).clone()
         return sd
 
+    def wait_params(self, lo: int = 0, hi: Optional[int] = None):
+        """Complete the parameter all-gathers of the previous step for the flat range [lo, hi) (default: everything): wait for
+        the collective of every still-pending bucket that overlaps the range and refresh its bf16 shadow.  Called lazily by
+        the forward; call it without arguments before reading `flat.flat` / `shadow` directly."""
+        pend = getattr(self, "_pending", None)
+        if not pend:
+            return
+        hi = self.flat.numel if hi is None else hi
+        for b in [b for b, (_, _, s0, e0) in pend.items() if s0 < hi and e0 > lo]:
+            h, _, s0, e0 = pend.pop(b)
+            h.wait()
+            self._ew.cast_f32_bf16(self.flat.flat[s0:e0], self.shadow[s0:e0])
+
     def step(self, coords, feats, t=None, coords_noise=None, feats_noise=None):
+        if getattr(self, "_pending", None):
+            for off, n in self._accum_ranges:         # parameters the forward reads through ordinary modules (time_embed, ln_pre,
+                self.wait_params(off, off + n)        # ln_post, input / output projection): must be current before it starts
         if not self.native or self.iteration == 0:
             self.flat.zero_grad()                 # afterwards the fused optimizer kernel leaves the gradients zeroed
         self.reducer.start_step()
@@ -256,7 +286,6 @@ class DiffusionTrainer:
         (diffusion_training.py:169-174).  step() calls this after backward."""
         self.iteration += 1
         if self.native and self.reducer.shard:
-            self._gathers = []
             if self.reducer.finish(self._adamw_shard):
                 self._finish_shards()
                 return
@@ -318,6 +347,7 @@ class DiffusionTrainer:
     def _adamw_shard(self, s0, e0):
         """called when bucket [s0, e0)'s reduce-scatter is done: update this rank's shard, start the parameter all-gather"""
         red = self.reducer
+        self.wait_params(s0, e0)                      # (a no-op unless a step ran without any forward in between)
         a, b = red.shard_range(s0, e0)
         g = red.gshard[s0 // red.world:e0 // red.world]
         ema = None if self.ema is None else self.ema[a:b]
@@ -325,13 +355,11 @@ class DiffusionTrainer:
                            self.betas[1], self.eps, self.weight_decay, self.iteration, self.ema_decay, zero_grad=False)
         mine = self.flat.flat[a:b].clone()            # out-of-place gather: the output range contains the input range
         h = dist.all_gather_into_tensor(self.flat.flat[s0:e0], mine, group=red.group, async_op=True)
-        self._gathers.append((h, mine, s0, e0))
+        self._pending[self._bucket_of[(s0, e0)]] = (h, mine, s0, e0)
 
     def _finish_shards(self):
-        for h, _, s0, e0 in self._gathers:            # parameters of the other ranks' shards have arrived: refresh the bf16 shadow
-            h.wait()
-            self._ew.cast_f32_bf16(self.flat.flat[s0:e0], self.shadow[s0:e0])
-        self._gathers = []
+        if not self.lazy_gather:
+            self.wait_params()                        # parameters of the other ranks' shards have arrived: refresh the bf16 shadow
         self._zero_accumulating()
 
     def _gather(self, bufs):
@@ -350,6 +378,7 @@ class DiffusionTrainer:
 
     def gather_state(self):
         """EMA and Adam-moment shards -> full vectors on every rank (before writing a checkpoint; collective)."""
+        self.wait_params()
         if self.native:
             self._gather([self.exp_avg, self.exp_avg_sq] + ([self.ema] if self.ema is not None else []))
 
@@ -359,6 +388,7 @@ class DiffusionTrainer:
         return trainer_state_dict(self, full_model)
 
     def load_state_dict(self, ckpt):
+        self.wait_params()
         from .checkpoint import load_trainer_state
         load_trainer_state(self, ckpt)
 

@@ -51,6 +51,9 @@ def _worker(rank, world, port, out):
             assert tr.reducer.world == 2 and len(tr.reducer.buckets) > 2 and tr.reducer.shard == shard
             for _ in range(2):
                 loss, _ = tr.step(c0[sl], f0[sl], t=t[sl], coords_noise=cn[sl], feats_noise=fn[sl])
+            if shard:                                  # the parameter all-gathers of the last step are awaited lazily (by the next forward)
+                assert tr._pending, "expected pending parameter gathers after a sharded step"
+                tr.wait_params()
             torch.cuda.synchronize()
             tr.gather_ema()
             res[shard] = (tr.flat.flat.cpu(), tr.ema.cpu(), float(loss), tr.shadow.float().cpu())
@@ -97,6 +100,7 @@ def _nccl_worker(rank, world, port, out):
         for _ in range(2):
             loss, _ = tr.step(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
         assert len(tr.reducer.launched) == len(tr.reducer.buckets)
+        tr.wait_params()
         torch.cuda.synchronize()
         out[0] = (tr.flat.flat.cpu(), tr.ema.cpu(), float(loss))
     finally:
