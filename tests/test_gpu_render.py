@@ -387,3 +387,29 @@ def test_pointnerf_forward_surface():
     assert net.pointnerf.field.aggregator.max_shading_pts == 50
     assert net.pointnerf.get_all_coords().shape == (5, 512, 3) and net.pointnerf.get_all_feats().shape == (5, 512, 32)
     # sample_rays=True (training mode) is covered by tests/test_gpu_train_render.py
+
+
+def test_evaluation_protocol_counterpart():
+    """npcd.eval.evaluate_pointnerf (reference pointnerf_evaluation.py:152-257): per-view renders with the burn-in rule, PSNR against
+    images rendered by the CPU oracle from the same weights (>= 50 dB: the HIP path IS the model, up to f16 shading), timing records
+    only after the burn-in objects."""
+    from npcd.eval import evaluate_pointnerf
+    from npcd.models import NPCD
+    res = 16
+    coords, feats, extr, intr = _scene(res, 2, 512, 32, seed=3, B=1)
+    net = NPCD(n_obj=5, coords_dim=3, feats_dim=32, num_points=512, use_view_dir=False, width=64, layers=1, heads=1, pointnerf_only=True).cuda().eval()
+    net.pointnerf.opt.sizes.default_resolution = res
+    net.pointnerf.set_all_coords(coords.expand(5, -1, -1).contiguous().cuda())
+    with torch.no_grad():
+        net.pointnerf.feats.get_emb().weight.view(5, 512, 64)[:, :, :32] = feats.cuda()
+        for name, p_ in net.pointnerf.field.named_parameters():
+            if "shape_net.2" in name:
+                p_.mul_(8).add_(1.0)
+    fp = {k: v.cpu() for k, v in net.pointnerf.field.state_dict().items()}
+    ref = orr.render(fp, coords, feats, extr, intr, res=res)
+    images = orr.unflatten_image(ref["channels"])                                  # [1, V, 3, res, res]
+    samples = [{"obj_idx": torch.tensor([i]), "intrinsics": intr, "extrinsics": extr, "images": images} for i in range(5)]
+    out = evaluate_pointnerf(net.pointnerf, samples, eval_batch_size=1, burn_in_samples=3)
+    assert len(out["views"]) == 10 and out["psnr"] > 50.0
+    timed = [r for r in out["views"] if r["runtime_model_in_msec"] == r["runtime_model_in_msec"]]
+    assert len(timed) == 4 and all(r["sample"] >= 3 for r in timed) and out["runtime_model_in_msec"] > 0
