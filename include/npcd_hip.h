@@ -81,6 +81,20 @@ int npcd_attn_bwd_pass(int pass, const void* q, const void* k, const void* v, co
                        int64_t g_sb, int64_t g_sn, int64_t g_sh,
                        float scale, int dtype, void* stream);
 
+/* Single-pass backward (csrc/attention.hip, attn_bwd_fused_kernel): the same gradients as npcd_attn_bwd from FIVE matrix products per
+ * (query, key) tile instead of seven -- S and dP are formed once, dV / dK are accumulated from them with the keys on the lanes,
+ * dS crosses LDS once and dQ is summed over the keys inside the matrix instruction; one workgroup per (batch, head), 256 keys per
+ * pass.  dq_slab: fp32 scratch of npcd_attn_bwd_fused_slab_floats(B, n, H) elements (0 for n <= 256: may be NULL), the running
+ * dQ between passes.  delta as above (written by the kernel's prologue).  Bitwise reproducible. */
+int64_t npcd_attn_bwd_fused_slab_floats(int B, int n, int H);
+int npcd_attn_bwd_fused(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                        const float* lse, void* dq, void* dk, void* dv, float* delta, float* dq_slab,
+                        int B, int n, int H, int d,
+                        int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh,
+                        int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                        int64_t g_sb, int64_t g_sn, int64_t g_sh,
+                        float scale, int dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Voxel grid (torch_knnquery.VoxelGrid).  The grid description is passed by value.
  * ------------------------------------------------------------------------------------------ */

@@ -23,6 +23,8 @@
 // and the measurements.
 #include <math.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace npcd {
@@ -1063,6 +1065,425 @@ __global__ __launch_bounds__(256, NPCD_DKDV_WAVES) void attn_bwd_dkdv_kernel(Att
 }
 
 // ============================================================================================
+// backward, ONE pass over the scores (5 products: S, dP, dV, dK, dQ) -- attn_bwd_fused_kernel
+// ============================================================================================
+// One workgroup = one (batch, head), eight waves, 32 keys per wave: a PASS covers 256 keys and streams every query sub-block
+// (32 rows) through the ring of the dK/dV kernel above; sequences longer than 256 keys take several passes, one after the
+// other in the same workgroup.  Per sub-block and wave, with the keys on the lanes exactly as in the dK/dV kernel:
+// S = Q K^T, dP = dO V^T (row constants as initial accumulators), P, dS, dV^T += dO^T P, dK^T += Q^T dS.  New here: dS is
+// written once to LDS as a [key][query] image (8 bytes per lane and 4-row group, 8-byte chunks XOR-swizzled with the key) and
+// after the workgroup's barrier every wave computes ONE 16 x 16 tile of dQ^T[64 d][32 q] over ALL 256 keys of the pass with
+// v_mfma_f32_16x16x32 (A = K^T from a [key][d] image of the pass's keys, B = dS^T, both by transposed LDS reads): the sum
+// over keys is the K dimension of the matrix instruction, no cross-wave fp32 reduction and no atomics.  dQ of a sub-block is
+// therefore complete for the pass's keys; across passes it is accumulated in a private fp32 slab of the (batch, head) in global
+// memory (same lanes, same addresses in every pass: plain read-modify-write), the last pass scales, rounds and stores it.
+// The per-row constants (-lse/scale, -rowsum(dO * O)) are computed by the workgroup itself in a prologue.
+// Deterministic: fixed summation orders everywhere.
+constexpr int kFWaves = 8;
+constexpr int kFStage = kFWaves * 2048;                          // dS^T exchange buffer: [wave][32 keys][32 q] 16-bit
+constexpr int kFKimg = kFWaves * 4096;                           // K image: [wave][32 keys][64 d] 16-bit, tile_off swizzle
+constexpr int kFLds = 3 * kDkdvSlot + 2 * kFStage + kFKimg;      // 116,224 B: one workgroup per CU
+
+template <class E>
+struct FusedStream {
+    const E* base;        // q (waves 0..3) or dout (waves 4..7) of this (batch, head), advanced to the wave's first row of a tile
+    const E* q;
+    const E* dout;
+    const float* stat;
+    int64_t stride, qstride, dostride;
+    DmaLane dl;
+    int dst, stat_dst, w4;
+    bool second;
+};
+// tile t of the Q / dO stream into ring slot `slot`: eight waves, two 1 KiB pieces each
+template <class E>
+__device__ __forceinline__ void fused_prefetch(unsigned char* slot, const FusedStream<E>& qs, int t, int n, int lane) {
+    const int row0 = t * 64;
+    const uint32_t sl = lds_addr(slot);
+    if (row0 + 64 <= n) {
+        const char* sbase = reinterpret_cast<const char*>(qs.base + (int64_t)row0 * qs.stride);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            dma16_issue(sbase + (int64_t)i * 8 * qs.stride * (int64_t)sizeof(E), qs.dl.off[i & 1],
+                        __builtin_amdgcn_readfirstlane(sl + qs.dst + i * 1024));
+    } else {
+        const E* base = qs.second ? qs.dout : qs.q;
+        const int64_t stride = qs.second ? qs.dostride : qs.qstride;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int prow = (qs.w4 * 2 + i) * 8 + (lane >> 3);
+            const int grow = min(row0 + prow, n - 1);
+            const uint32_t voff = (uint32_t)((grow * stride + (((lane & 7) ^ tile_swz(prow)) << 3)) * (int64_t)sizeof(E));
+            dma16_issue(base, voff, __builtin_amdgcn_readfirstlane(sl + qs.dst + i * 1024));
+        }
+    }
+    dma4_issue(qs.stat, (uint32_t)(row0 + lane) * 4u, __builtin_amdgcn_readfirstlane(sl + qs.stat_dst));
+}
+
+struct FusedCtx {
+    uint32_t stg;          // LDS byte address of the two dS^T exchange buffers
+    uint32_t kimg;         // LDS byte address of the K image
+    uint32_t wr_off;       // this lane's write offset inside its wave's 2 KiB of an exchange buffer (chunk 0)
+    uint32_t a_tr[2];      // transposed-read lane offsets into a 4 KiB K block   (rows 8g + q, 8g + 4 + q; 16 d columns of this wave's tile)
+    uint32_t b_tr[2];      // transposed-read lane offsets into a 2 KiB dS^T block (rows 8g + q, 8g + 4 + q; 16 q columns of this wave's tile)
+    float* slab;           // fp32 dQ accumulator of this (batch, head): [npad][64]
+    void* dq;              // output rows of this (batch, head)
+    int64_t gsn;
+    int n, nkb, wave, dt, qt;
+    bool first_pass, last_pass, key_ok;
+    float scale;
+};
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+// slab address of this lane's 4 consecutive d of query row q0 + 16 qt + (lane & 15); nullptr past the end of the sequence
+__device__ __forceinline__ float* fused_slab_ptr(const FusedCtx& fc, int q0, int lane) {
+    const int q = q0 + 16 * fc.qt + (lane & 15);
+    return q < fc.n ? fc.slab + (int64_t)q * 64 + 16 * fc.dt + 4 * (lane >> 4) : nullptr;
+}
+// dQ^T tile of the sub-block that starts at query row q0 (its dS^T sits in exchange buffer PAR): one MFMA per key block of the
+// pass, operands fetched two blocks at a time (8 transposed reads, one wait); `prev` = the tile's running sum from the
+// earlier passes (loaded by the caller a stage ago; ignored in the first pass)
+template <class TR, int PAR>
+__device__ __forceinline__ void fused_dq(const FusedCtx& fc, int q0, f32x4v prev, int lane) {
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < fc.nkb; j0 += 2) {
+        u32x2 a0[2], a1[2], b0[2], b1[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = min(j0 + jj, fc.nkb - 1);                          // (a block past the end re-reads the last one; its product is dropped)
+            const uint32_t ka = fc.kimg + j * 4096, sb = fc.stg + PAR * kFStage + j * 2048;
+            a0[jj] = tr_issue_one(ka + fc.a_tr[0]); a1[jj] = tr_issue_one(ka + fc.a_tr[1]);
+            b0[jj] = tr_issue_one(sb + fc.b_tr[0]); b1[jj] = tr_issue_one(sb + fc.b_tr[1]);
+        }
+        tr_wait();
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            if (j0 + jj < fc.nkb) {
+                const u32x4 av = {a0[jj][0], a0[jj][1], a1[jj][0], a1[jj][1]}, bv = {b0[jj][0], b0[jj][1], b1[jj][0], b1[jj][1]};
+                if constexpr (std::is_same<typename TR::elem, __bf16>::value)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc, 0, 0, 0);
+                else
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av), __builtin_bit_cast(f16x8, bv), acc, 0, 0, 0);
+            }
+        }
+    }
+    const int q = q0 + 16 * fc.qt + (lane & 15), dcol = 16 * fc.dt + 4 * (lane >> 4);
+    if (q < fc.n) {
+        if (!fc.first_pass) acc += prev;
+        if (fc.last_pass) {
+            u32x2 o;
+            o[0] = pack2<TR>(acc[0] * fc.scale, acc[1] * fc.scale);
+            o[1] = pack2<TR>(acc[2] * fc.scale, acc[3] * fc.scale);
+            *reinterpret_cast<u32x2*>(static_cast<typename TR::elem*>(fc.dq) + (int64_t)q * fc.gsn + dcol) = o;
+        } else {
+            *reinterpret_cast<f32x4v*>(fc.slab + (int64_t)q * 64 + dcol) = acc;
+        }
+    }
+}
+
+// One stage = one 32-row query sub-block (SLOT, SUB), cf. dkdv_stage; additionally the dQ tile of the PREVIOUS sub-block
+// (its dS^T was published by every wave at the end of the previous stage and the caller has passed a barrier since) and, at
+// the end, this sub-block's dS^T into exchange buffer PAR.
+template <class TR, int SLOT, int SUB, int PSLOT, int PSUB, bool ACC, int PAR, class PF>
+__device__ __forceinline__ void fused_stage(const FragAddr& fa, uint32_t st_addr, const typename TR::vec8 (&kf)[4],
+                                            const typename TR::vec8 (&vf)[4], float c, DkdvState& a, typename TR::vec8 (&pf)[2],
+                                            typename TR::vec8 (&df)[2], const FusedCtx& fc, int prev_q0, int cur_q0, f32x4v& slab_val,
+                                            bool compute, int lane, PF&& prefetch) {
+    using V8 = typename TR::vec8;
+    constexpr int QT = SLOT * kDkdvSlot + SUB * 4096, DT = QT + 8192, ST = SLOT * kDkdvSlot + 16384 + SUB * 128;
+    constexpr int PQ = PSLOT * kDkdvSlot, PD = PQ + 8192;
+#if !defined(NPCD_FUSED_ABL) || NPCD_FUSED_ABL < 1
+    if (ACC) fused_dq<TR, PAR ^ 1>(fc, prev_q0, slab_val, lane);
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    // the Q / dO tile two ahead is requested only now: the running dQ sums above are ordinary loads, and an ordinary load's
+    // wait (vmcnt(0), the compiler cannot count past hand-issued LDS-DMA) must not fall behind a freshly issued DMA
+    prefetch();
+#if !defined(NPCD_FUSED_ABL) || NPCD_FUSED_ABL < 1
+    if (!fc.first_pass) {                                        // this sub-block's running sum, consumed by the next stage
+#else
+    if (false) {
+#endif
+        const float* sp = fused_slab_ptr(fc, cur_q0, lane);
+        slab_val = sp ? *reinterpret_cast<const f32x4v*>(sp) : f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
+    if (!compute) return;                                       // wave without keys in this pass (wave-uniform)
+    u32x4 si[4], di[4], qr[4], dr[4];
+    si[0] = lds_b128_issue<ST>(st_addr);       si[1] = lds_b128_issue<ST + 32>(st_addr);
+    si[2] = lds_b128_issue<ST + 64>(st_addr);  si[3] = lds_b128_issue<ST + 96>(st_addr);
+    qr[0] = lds_b128_issue<QT>(fa.row[0]);     qr[1] = lds_b128_issue<QT>(fa.row[1]);
+    qr[2] = lds_b128_issue<QT>(fa.row[2]);     qr[3] = lds_b128_issue<QT>(fa.row[3]);
+    di[0] = lds_b128_issue<ST + 256>(st_addr); di[1] = lds_b128_issue<ST + 288>(st_addr);
+    di[2] = lds_b128_issue<ST + 320>(st_addr); di[3] = lds_b128_issue<ST + 352>(st_addr);
+    dr[0] = lds_b128_issue<DT>(fa.row[0]);     dr[1] = lds_b128_issue<DT>(fa.row[1]);
+    dr[2] = lds_b128_issue<DT>(fa.row[2]);     dr[3] = lds_b128_issue<DT>(fa.row[3]);
+    tr_wait();
+    f32x16 s, d;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) {
+            s[4 * g + bq] = __uint_as_float(si[g][bq]);
+            d[4 * g + bq] = __uint_as_float(di[g][bq]);
+        }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        s = TR::mfma32(__builtin_bit_cast(V8, qr[ks]), kf[ks], s);
+        d = TR::mfma32(__builtin_bit_cast(V8, dr[ks]), vf[ks], d);
+    }
+    TrPair to[2][2], tq[2][2];
+    if (ACC) {
+        __builtin_amdgcn_sched_barrier(0);
+        to[0][0] = tr_issue_at<PD, 2 * PSUB>(fa, 0);     to[0][1] = tr_issue_at<PD, 2 * PSUB>(fa, 1);
+        to[1][0] = tr_issue_at<PD, 2 * PSUB + 1>(fa, 0); to[1][1] = tr_issue_at<PD, 2 * PSUB + 1>(fa, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int ks = 2; ks < 4; ++ks) {
+        s = TR::mfma32(__builtin_bit_cast(V8, qr[ks]), kf[ks], s);
+        d = TR::mfma32(__builtin_bit_cast(V8, dr[ks]), vf[ks], d);
+    }
+    u32x4 pw[2], dw[2];
+    auto softmax_half = [&](int h2) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * h2 + jj;
+            const float p0 = __builtin_amdgcn_exp2f(s[2 * j] * c), p1 = __builtin_amdgcn_exp2f(s[2 * j + 1] * c);
+            pw[h2][jj] = pack2<TR>(p0, p1);
+            dw[h2][jj] = pack2<TR>(p0 * d[2 * j], p1 * d[2 * j + 1]);
+        }
+    };
+    if (ACC) {
+        tr_wait();
+        a.dv0 = TR::mfma32(tr_vec<TR>(to[0][0]), pf[0], a.dv0);
+        a.dv1 = TR::mfma32(tr_vec<TR>(to[0][1]), pf[0], a.dv1);
+        a.dv0 = TR::mfma32(tr_vec<TR>(to[1][0]), pf[1], a.dv0);
+        a.dv1 = TR::mfma32(tr_vec<TR>(to[1][1]), pf[1], a.dv1);
+        __builtin_amdgcn_sched_barrier(0);
+        tq[0][0] = tr_issue_at<PQ, 2 * PSUB>(fa, 0);     tq[0][1] = tr_issue_at<PQ, 2 * PSUB>(fa, 1);
+        tq[1][0] = tr_issue_at<PQ, 2 * PSUB + 1>(fa, 0); tq[1][1] = tr_issue_at<PQ, 2 * PSUB + 1>(fa, 1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    softmax_half(0);
+    if (ACC) {
+        tr_wait();
+        a.dk0 = TR::mfma32(tr_vec<TR>(tq[0][0]), df[0], a.dk0);
+        a.dk1 = TR::mfma32(tr_vec<TR>(tq[0][1]), df[0], a.dk1);
+        a.dk0 = TR::mfma32(tr_vec<TR>(tq[1][0]), df[1], a.dk0);
+        a.dk1 = TR::mfma32(tr_vec<TR>(tq[1][1]), df[1], a.dk1);
+    }
+    softmax_half(1);
+    pf[0] = __builtin_bit_cast(V8, pw[0]);
+    pf[1] = __builtin_bit_cast(V8, pw[1]);
+    df[0] = __builtin_bit_cast(V8, dw[0]);
+    df[1] = __builtin_bit_cast(V8, dw[1]);
+    // publish dS^T of this sub-block: lane = key, registers 4g..4g+3 = four consecutive query rows 8g + 4hh .. -> 8 bytes at
+    // [key][q = 8g + 4hh], 8-byte chunk index XOR (key & 7); keys past the end of the sequence publish zeros (their P is not
+    // zero -- harmless for dK / dV, whose rows are never stored, but it would leak into every query's dQ)
+#if !defined(NPCD_FUSED_ABL) || NPCD_FUSED_ABL < 2
+    {
+#else
+    if (false) {
+#endif
+        const uint32_t base = fc.stg + PAR * kFStage + fc.wave * 2048 + fc.wr_off;
+        const int key = lane & 31, hh = lane >> 5;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2 v = {dw[g >> 1][2 * (g & 1)], dw[g >> 1][2 * (g & 1) + 1]};
+            if (!fc.key_ok) v = u32x2{0u, 0u};
+            const uint32_t addr = base + ((((2 * g + hh) ^ (key & 7)) & 7) << 3);
+            asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+        }
+    }
+}
+
+template <class TR>
+__global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnParams p, float* dq_slab) {
+    using E = typename TR::elem;
+    using V8 = typename TR::vec8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+    unsigned char* stg = dsmem + 3 * kDkdvSlot;
+    unsigned char* kimg = stg + 2 * kFStage;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = p.n, nt = (n + 63) >> 6, npad = nt * 64;
+    const int bh = blockIdx.x, h = bh % p.H, b = bh / p.H;
+    const E* qb = static_cast<const E*>(p.q) + b * p.sb + h * p.sh;
+    const E* kb = static_cast<const E*>(p.k) + b * p.sb + h * p.sh;
+    const E* vb = static_cast<const E*>(p.v) + b * p.sb + h * p.sh;
+    const E* ob = static_cast<const E*>(p.out) + b * p.osb + h * p.osh;
+    const E* dob = static_cast<const E*>(p.dout) + b * p.osb + h * p.osh;
+    float* plane0 = p.delta + (int64_t)bh * npad;
+    float* plane1 = p.delta + ((int64_t)p.B * p.H + bh) * npad;
+
+    // ---- prologue: the per-row constants of every query of this (batch, head): eight lanes per row, 16 bytes each
+    for (int row0 = wave * 8; row0 < npad; row0 += 8 * kFWaves) {
+        const int row = row0 + (lane >> 3), chunk = lane & 7;
+        float part = 0.f;
+        if (row < n) {
+            const V8 dv = *reinterpret_cast<const V8*>(dob + (int64_t)row * p.osn + chunk * 8);
+            const V8 ov = *reinterpret_cast<const V8*>(ob + (int64_t)row * p.osn + chunk * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += (float)dv[j] * (float)ov[j];
+        }
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        if (chunk == 0) {
+            plane0[row] = row < n ? -p.lse[(int64_t)bh * n + row] / p.scale : -INFINITY;
+            plane1[row] = row < n ? -part : 0.f;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    FusedStream<E> qs;
+    {
+        qs.second = wave >= 4;
+        qs.w4 = wave & 3;
+        qs.q = qb; qs.dout = dob; qs.qstride = p.sn; qs.dostride = p.osn;
+        qs.stride = qs.second ? p.osn : p.sn;
+        qs.base = (qs.second ? dob : qb) + (int64_t)(qs.w4 * 16) * qs.stride;
+        qs.dl = dma_lane<E>(qs.stride, lane);
+        qs.dst = (qs.second ? 8192 : 0) + qs.w4 * 2048;
+        qs.stat = (wave & 1) ? plane1 : plane0;
+        qs.stat_dst = 16384 + (wave & 1) * 256;
+    }
+    const FragAddr fa = frag_addr(dsmem, lane);
+    const uint32_t st_addr = lds_addr(dsmem) + hh * 16;
+    FusedCtx fc;
+    fc.stg = lds_addr(stg);
+    fc.kimg = lds_addr(kimg);
+    fc.wave = wave;
+    fc.dt = wave & 3;
+    fc.qt = wave >> 2;
+    fc.n = n;
+    fc.scale = p.scale;
+    fc.slab = dq_slab + (int64_t)bh * npad * 64;
+    fc.dq = static_cast<E*>(p.dq) + b * p.gsb + h * p.gsh;
+    fc.gsn = p.gsn;
+    fc.wr_off = (uint32_t)((lane & 31) * 64);
+    {   // transposed reads (ds_read_b64_tr_b16): 16-lane group g = lane >> 4 supplies rows 8g + (0..3) [second read: + 4], lane 4q' + pp
+        // of a group the address of row q', columns 4pp .. 4pp + 3 of the group's 16 columns
+        const int g = lane >> 4, li = lane & 15, q4 = li >> 2, pp = li & 3;
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+            const int krow = 8 * g + 4 * hi + q4;                                   // key inside a 32-key block
+            const int dcol = 16 * fc.dt + 4 * pp;                                   // K image: [key][64 d], tile_off swizzle of 16-byte chunks
+            fc.a_tr[hi] = (uint32_t)(tile_off(krow, dcol >> 3) + (dcol & 7) * 2);
+            const int qc8 = (16 * fc.qt + 4 * pp) >> 2;                             // dS^T image: [key][32 q], 8-byte chunk XOR (key & 7)
+            fc.b_tr[hi] = (uint32_t)(krow * 64 + (((qc8 ^ (krow & 7)) & 7) << 3));
+        }
+    }
+    const float c = p.scale_log2;
+    const int npass = (n + 255) >> 8;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int key0 = pass * 256 + wave * 32;
+        const bool wave_active = key0 < n;
+        const int key = key0 + r;
+        const bool key_ok = key < n;
+        fc.key_ok = key_ok;
+        fc.nkb = min(kFWaves, (n - pass * 256 + 31) >> 5);
+        fc.first_pass = pass == 0;
+        fc.last_pass = pass == npass - 1;
+        V8 kf[4], vf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const u32x4 z = {0, 0, 0, 0};
+            kf[s] = __builtin_bit_cast(V8, key_ok ? *reinterpret_cast<const u32x4*>(kb + (int64_t)key * p.sn + 16 * s + 8 * hh) : z);
+            vf[s] = __builtin_bit_cast(V8, key_ok ? *reinterpret_cast<const u32x4*>(vb + (int64_t)key * p.sn + 16 * s + 8 * hh) : z);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(kf[s]), "+v"(vf[s]));
+        __builtin_amdgcn_s_barrier();                             // previous pass (ring, images, exchange buffers) is finished everywhere
+        asm volatile("" ::: "memory");
+        if (wave < fc.nkb) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) *reinterpret_cast<V8*>(kimg + wave * 4096 + tile_off(r, 2 * s + hh)) = kf[s];
+        }
+        fused_prefetch(dsmem, qs, 0, n, lane);
+        if (nt > 1) fused_prefetch(dsmem + kDkdvSlot, qs, 1, n, lane);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        DkdvState a;
+        a.dk0 = f32x16{0}; a.dk1 = f32x16{0}; a.dv0 = f32x16{0}; a.dv1 = f32x16{0};
+        V8 pf[2], df[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) { pf[g] = V8{0}; df[g] = V8{0}; }
+        // stage sequence: sub-block i = 2t + sub lives in ring slot t % 3, its dS^T in exchange buffer i & 1
+        bool both = true;
+#define NPCD_F_STAGE(SLOT, SUB, PSLOT, PSUB, ACCV, PARV, PQ0, CQ0, PREF) \
+    fused_stage<TR, SLOT, SUB, PSLOT, PSUB, ACCV, PARV>(fa, st_addr, kf, vf, c, a, pf, df, fc, PQ0, CQ0, slab_val, wave_active, lane, PREF)
+        f32x4v slab_val = {0.f, 0.f, 0.f, 0.f};
+        auto nopf = [] {};
+        {
+            NPCD_F_STAGE(0, 0, 2, 1, false, 0, 0, 0, nopf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's dS^T writes have reached the LDS
+            NPCD_DMA_WAIT_BARRIER(0);                             // tile 1 landed; dS^T of sub-block 0 published
+            if (32 < n) NPCD_F_STAGE(0, 1, 0, 0, true, 1, 0, 32, [&] { if (2 < nt) fused_prefetch(dsmem + 2 * kDkdvSlot, qs, 2, n, lane); });
+            else both = false;
+        }
+        auto step = [&](auto slot_c, int t) {
+            constexpr int SLOT = decltype(slot_c)::value, PREV = (SLOT + 2) % 3;
+#if !defined(NPCD_FUSED_ABL) || NPCD_FUSED_ABL < 3
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                         // dS^T of the previous tile's second sub-block published
+            asm volatile("" ::: "memory");
+#endif
+            NPCD_F_STAGE(SLOT, 0, PREV, 1, true, 0, (t - 1) * 64 + 32, t * 64, nopf);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            NPCD_DMA_WAIT_BARRIER(0);                             // tile t+1 landed; every wave done with tile t-1; dS^T published
+            if (t * 64 + 32 >= n) {
+                if (t + 2 < nt) fused_prefetch(dsmem + PREV * kDkdvSlot, qs, t + 2, n, lane);
+                return false;
+            }
+            NPCD_F_STAGE(SLOT, 1, SLOT, 0, true, 1, t * 64, t * 64 + 32, [&] { if (t + 2 < nt) fused_prefetch(dsmem + PREV * kDkdvSlot, qs, t + 2, n, lane); });
+            return true;
+        };
+        for (int t = 1; t < nt; t += 3) {
+            both = step(std::integral_constant<int, 1>{}, t);
+            if (t + 1 < nt) both = step(std::integral_constant<int, 2>{}, t + 1);
+            if (t + 2 < nt) both = step(std::integral_constant<int, 0>{}, t + 2);
+        }
+#undef NPCD_F_STAGE
+        // ---- flush: the last sub-block's dV / dK products and its dQ tile
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {
+            const int last = (nt - 1) % 3;
+            const int lq0 = (nt - 1) * 64 + (both ? 32 : 0);
+            if (both) fused_dq<TR, 1>(fc, lq0, slab_val, lane);
+            else fused_dq<TR, 0>(fc, lq0, slab_val, lane);
+            if (wave_active) {
+                if (both) {
+                    if (last == 0) dkdv_flush<TR, 0, 1>(fa, a, pf, df);
+                    else if (last == 1) dkdv_flush<TR, 1, 1>(fa, a, pf, df);
+                    else dkdv_flush<TR, 2, 1>(fa, a, pf, df);
+                } else {
+                    if (last == 0) dkdv_flush<TR, 0, 0>(fa, a, pf, df);
+                    else if (last == 1) dkdv_flush<TR, 1, 0>(fa, a, pf, df);
+                    else dkdv_flush<TR, 2, 0>(fa, a, pf, df);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                             // every wave has left the images: the K image stages the gradient rows
+        asm volatile("" ::: "memory");
+        if (wave_active) {
+            unsigned char* stage = kimg + wave * 4096;
+            E* gk = static_cast<E*>(p.dk) + b * p.gsb + (int64_t)key0 * p.gsn + h * p.gsh;
+            E* gv = static_cast<E*>(p.dv) + b * p.gsb + (int64_t)key0 * p.gsn + h * p.gsh;
+            store_rows_staged<TR>(stage, gk, p.gsn, n - key0, a.dk0, a.dk1, p.scale, lane);
+            store_rows_staged<TR>(stage, gv, p.gsn, n - key0, a.dv0, a.dv1, 1.f, lane);
+        }
+    }
+}
+
+// ============================================================================================
 // fp32 forward (sampling / fp32 inference path: the reference runs DiffusionModel.generate in fp32 with
 // the einsum attention, diffusion_model.py:108-133, npcd.py:8 use_flash_attn=False).  Exact fp32 math on
 // the vector ALU: no 16-bit rounding anywhere.  One wave = 4 query rows, workgroup = 16 rows; 64-key K/V
@@ -1232,6 +1653,43 @@ static int attn_bwd_launch(int passes, const void* q, const void* k, const void*
         if (passes & 1) hipLaunchKernelGGL(attn_bwd_dq_kernel<F16>, dim3(grid), dim3(256), 0, st, p);
         if (passes & 2) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<F16>, dim3(grid), dim3(256), dyn, st, p);
     }
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int64_t npcd_attn_bwd_fused_slab_floats(int B, int n, int H) {
+    if (B <= 0 || n <= 0 || H <= 0) return -1;
+    return n <= 256 ? 0 : (int64_t)B * H * ((n + 63) / 64 * 64) * 64;
+}
+
+// The single-pass backward (attn_bwd_fused_kernel): same arguments as npcd_attn_bwd + dq_slab, an fp32 scratch of
+// npcd_attn_bwd_fused_slab_floats(B, n, H) elements (may be NULL when that is 0).
+extern "C" int npcd_attn_bwd_fused(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                                   void* dq, void* dk, void* dv, float* delta, float* dq_slab, int B, int n, int H, int d,
+                                   int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                                   int64_t g_sb, int64_t g_sn, int64_t g_sh, float scale, int dtype, void* stream) {
+    int rc = check_common(B, n, H, d, dtype);
+    if (rc != NPCD_OK) return rc;
+    if (!q || !k || !v || !out || !dout || !lse || !delta || !dq || !dk || !dv) return NPCD_ERR_ARG;
+    if (n > 256 && !dq_slab) return NPCD_ERR_ARG;
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(dq) || !aligned16(dk) ||
+        !aligned16(dv) || (dq_slab && !aligned16(dq_slab)))
+        return NPCD_ERR_ARG;
+    if (!strides_ok(qkv_sb, qkv_sn, qkv_sh) || !strides_ok(out_sb, out_sn, out_sh) || !strides_ok(g_sb, g_sn, g_sh)) return NPCD_ERR_ARG;
+    AttnParams p{};
+    p.q = q; p.k = k; p.v = v; p.out = out; p.dout = dout; p.lse = const_cast<float*>(lse); p.delta = delta;
+    p.dq = dq; p.dk = dk; p.dv = dv;
+    p.B = B; p.n = n; p.H = H;
+    p.sb = qkv_sb; p.sn = qkv_sn; p.sh = qkv_sh;
+    p.osb = out_sb; p.osn = out_sn; p.osh = out_sh;
+    p.gsb = g_sb; p.gsn = g_sn; p.gsh = g_sh;
+    p.scale = scale; p.scale_log2 = scale * kLog2e;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static DynLds lds_bf16, lds_f16;
+    NPCD_HIP_CHECK(lds_bf16.ensure(reinterpret_cast<const void*>(attn_bwd_fused_kernel<BF16>), kFLds));
+    NPCD_HIP_CHECK(lds_f16.ensure(reinterpret_cast<const void*>(attn_bwd_fused_kernel<F16>), kFLds));
+    if (dtype == NPCD_BF16) hipLaunchKernelGGL(attn_bwd_fused_kernel<BF16>, dim3(B * H), dim3(512), kFLds, st, p, dq_slab);
+    else hipLaunchKernelGGL(attn_bwd_fused_kernel<F16>, dim3(B * H), dim3(512), kFLds, st, p, dq_slab);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }

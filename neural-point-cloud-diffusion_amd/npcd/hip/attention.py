@@ -25,7 +25,7 @@ def _fwd(q, k, v, scale):
 # When set to a dict {"fwd": [], "dq": [], "dkdv": []}, every launch is bracketed by HIP events recorded
 # on the launch stream (bench.py measures the kernels in situ with it).
 KERNEL_EVENTS = None
-KERNEL_TAGS = ("fwd", "dq", "dkdv")      # the kernels _timed() distinguishes (bench.py builds the dict from this)
+KERNEL_TAGS = ("fwd", "dq", "dkdv", "bwd")      # the kernels _timed() distinguishes (bench.py builds the dict from this)
 
 
 def _timed(tag, fn):
@@ -39,10 +39,24 @@ def _timed(tag, fn):
     return rc
 
 
+import os
+
+# "fused": the single-pass backward (attn_bwd_fused_kernel, 5 products); "twopass": dq pass + dk/dv pass (7 products)
+BWD_MODE = os.environ.get("NPCD_ATTN_BWD", "twopass")
+
+
 def _bwd(q, k, v, out, dout, lse, dq, dk, dv, scale):
     B, n, H, d = q.shape
     delta = torch.empty((2, B, H, (n + 63) // 64 * 64), dtype=torch.float32, device=q.device)   # row constants handed from pass 1 to pass 2
     assert dq.stride() == dk.stride() == dv.stride() and dout.stride() == out.stride()
+    if BWD_MODE == "fused":
+        nslab = lib().npcd_attn_bwd_fused_slab_floats(B, n, H)
+        slab = torch.empty(nslab, dtype=torch.float32, device=q.device) if nslab > 0 else None
+        check(_timed("bwd", lambda: lib().npcd_attn_bwd_fused(
+            ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(dq), ptr(dk), ptr(dv), ptr(delta), ptr(slab), B, n, H, d,
+            q.stride(0), q.stride(1), q.stride(2), out.stride(0), out.stride(1), out.stride(2), dq.stride(0), dq.stride(1), dq.stride(2),
+            scale, dtype_code(q), stream_ptr())), "npcd_attn_bwd_fused")
+        return
     args = (ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(dq), ptr(dk), ptr(dv),
             ptr(delta), B, n, H, d, q.stride(0), q.stride(1), q.stride(2),
             out.stride(0), out.stride(1), out.stride(2), dq.stride(0), dq.stride(1), dq.stride(2),

@@ -276,3 +276,29 @@ def test_attention_is_bitwise_reproducible():
         out.backward(gout)
         res.append((out.detach().clone(), x.grad.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("n", [1, 33, 64, 130, 256, 257, 448, 513, 576, 1025, 2049])
+def test_single_pass_backward_matches_oracle_and_two_pass(n, monkeypatch):
+    """The opt-in single-pass backward (NPCD_ATTN_BWD=fused, attn_bwd_fused_kernel: five matrix products, dS through LDS, dQ summed
+    inside the matrix instruction over 256-key passes with an fp32 running sum between passes) against the fp32 oracle with the bars
+    of the default two-pass kernels, and against those kernels themselves (different summation orders: <= 1.5e-2 apart); bitwise
+    reproducible."""
+    from npcd.hip import attention as hattn
+    gen = torch.Generator().manual_seed(1000 + n)
+    B, H = 2, 3
+    qkv = (torch.randn(B, n, 3 * H * 64, generator=gen) * 1.5).bfloat16()
+    gout = torch.randn(B, n, H * 64, generator=gen).bfloat16()
+
+    def grads(mode):
+        monkeypatch.setattr(hattn, "BWD_MODE", mode)
+        x = qkv.cuda().requires_grad_(True)
+        out = hattn.attention_qkvpacked(x, H)
+        out.backward(gout.cuda())
+        return x.grad.clone()
+
+    g_two, g_one, g_again = grads("twopass"), grads("fused"), grads("fused")
+    assert torch.equal(g_one, g_again)
+    assert rel_l2(g_one, g_two.float().cpu()) < 1.5e-2
+    monkeypatch.setattr(hattn, "BWD_MODE", "fused")
+    check(qkv, H, gout, f"fused n={n}")

@@ -26,13 +26,15 @@ ref = torch.softmax(qq @ kk.transpose(-1, -2) * scale, -1) @ vv
 ref.backward(dout[:2].float().permute(0, 2, 1, 3))
 rel = lambda a, b: ((a.float() - b).norm() / b.norm()).item()
 print(f"rel-L2 out {rel(out[:2], ref.permute(0, 2, 1, 3)):.2e}  dqkv {rel(g[:2], qs.grad):.2e}", flush=True)
-A.KERNEL_EVENTS = {"fwd": [], "dq": [], "dkdv": []}
+A.KERNEL_EVENTS = {k: [] for k in A.KERNEL_TAGS}
 for _ in range(reps):
     out, lse = A._fwd(q, k, v, scale)
     A._bwd(q, k, v, out, dout, lse, g[..., :d], g[..., d:2 * d], g[..., 2 * d:], scale)
 torch.cuda.synchronize()
 fl = 4 * B * H * n * n * d
-for tag, mult in (("fwd", 1.0), ("dq", 1.5), ("dkdv", 2.0)):
+for tag, mult in (("fwd", 1.0), ("dq", 1.5), ("dkdv", 2.0), ("bwd", 2.5)):      # executed products: 2 / 3 / 4 / 5 (fused) x (2 B H n^2 d)
+    if not A.KERNEL_EVENTS[tag]:
+        continue
     ts = sorted(a.elapsed_time(b) for a, b in A.KERNEL_EVENTS[tag][3:])
     med = ts[len(ts) // 2]
     print(f"{tag}: median {med * 1e3:.1f} us  min {ts[0] * 1e3:.1f} us  {fl * mult / med / 1e9:.0f} TFLOP/s", flush=True)
