@@ -1,4 +1,4 @@
-"""Dev probe: hipBLASLt time of the step's forward / dgrad GEMM shapes at M = 32832 (64 x 513 tokens) vs M = 32768."""
+"""Dev probe: hipBLASLt time of the step's forward / dgrad GEMM shapes at M = 32832 (64 x 513 tokens) vs M = 32768 (MS=33024,32768 for another list; TUNE=1 lets TunableOp pick the solution)."""
 import sys, os
 import torch
 if os.environ.get("TUNE"):
@@ -15,7 +15,8 @@ def timeit(fn, reps=30):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
-for M in ((32832, 32768) if os.environ.get("TUNE") else (32832, 32768, 64)):
+MS = [int(m) for m in os.environ["MS"].split(",")] if os.environ.get("MS") else ((32832, 32768) if os.environ.get("TUNE") else (32832, 32768, 64))
+for M in MS:
     tot = 0.0
     for name, K, N in shapes:
         x = torch.randn(M, K, device=dev).bfloat16(); w = torch.randn(N, K, device=dev).bfloat16(); b = torch.randn(N, device=dev).bfloat16()
