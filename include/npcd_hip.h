@@ -59,9 +59,12 @@ int npcd_attn_fwd(const void* q, const void* k, const void* v, void* out, float*
                   float scale, int dtype, void* stream);
 
 /* Backward of the above.  dq/dk/dv share (g_sb, g_sn, g_sh); out/dout share the out strides.
- * delta [2, B, H, npad] fp32 (npad = n rounded up to a multiple of 64) is scratch, written by the call: the per-row
- * constants the dK/dV pass starts its accumulators from, plane 0 = -lse / scale, plane 1 = -rowsum(dout * out);
- * the pad rows hold -inf / 0. */
+ * delta: fp32 scratch of npcd_attn_bwd_workspace_floats(B, n, H) elements, written by the call.  First [2, B, H, npad]
+ * (npad = n rounded up to a multiple of 64): the per-row constants the dK/dV pass starts its accumulators from, plane 0 =
+ * -lse / scale, plane 1 = -rowsum(dout * out), pad rows -inf / 0.  Behind them, for sequences of 128 j + 1 tokens (the
+ * denoiser's 512 points + timestep token): 192 floats per (batch, head, 32-row block), the partial sums of the last token's
+ * dK / dV / dQ rows (that token gets no workgroup of its own; csrc/attention.hip, 'the edge token').  Bitwise reproducible. */
+int64_t npcd_attn_bwd_workspace_floats(int B, int n, int H);
 int npcd_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                   const float* lse, void* dq, void* dk, void* dv, float* delta,
                   int B, int n, int H, int d,
@@ -85,7 +88,7 @@ int npcd_attn_bwd_pass(int pass, const void* q, const void* k, const void* v, co
  * (query, key) tile instead of seven -- S and dP are formed once, dV / dK are accumulated from them with the keys on the lanes,
  * dS crosses LDS once and dQ is summed over the keys inside the matrix instruction; one workgroup per (batch, head), 256 keys per
  * pass.  dq_slab: fp32 scratch of npcd_attn_bwd_fused_slab_floats(B, n, H) elements (0 for n <= 256: may be NULL), the running
- * dQ between passes.  delta as above (written by the kernel's prologue).  Bitwise reproducible. */
+ * dQ between passes.  delta: the [2, B, H, npad] planes above (written by the kernel's prologue).  Bitwise reproducible. */
 int64_t npcd_attn_bwd_fused_slab_floats(int B, int n, int H);
 int npcd_attn_bwd_fused(const void* q, const void* k, const void* v, const void* out, const void* dout,
                         const float* lse, void* dq, void* dk, void* dv, float* delta, float* dq_slab,

@@ -268,6 +268,156 @@ __device__ __forceinline__ float half_sum(float x) {
 // for the retry loop spilled 51 VGPRs and the kernel ran 2x slower.)
 constexpr float kDeferLog2 = 8.f;
 
+// ---- the single key behind the last full tile (sequence length 64 j + 1) -----------------------------------------------
+// Lane (r, hh) of a wave owns, of its row r, the head dimensions 16 s + 8 hh + j of the four MFMA k-steps (the operand
+// fragments qf / dof / kf ...), and of a transposed accumulator pair (o0, o1) the dimensions 8 g + 4 hh + j and 32 + 8 g + 4 hh + j
+// (store_rows_staged).
+#ifndef NPCD_SEED_TAIL
+#define NPCD_SEED_TAIL 1
+#endif
+// All three seeds run on the matrix pipe, which has room (the kernels are bound by vector-instruction issue):
+//   row_bcast_issue: the row as an MFMA operand in which EVERY row (column) of the 32-wide block is that row -- four 16-byte
+//               loads from one address per lane-half; mfma_dot(that, f) is then x . (row of each lane) in all 16 accumulators;
+//   outer_seed: acc[d][lane's row] += x[d] * w(lane's row), one matrix instruction per 32 dimensions with a single non-zero
+//               k-index (A = x[d] at k = 0, B = w at k = 0; w passes through the 16-bit type like every P / dS).
+template <class TR>
+__device__ __forceinline__ float mfma_dot(const typename TR::vec8 (&a)[4], const typename TR::vec8 (&b)[4]) {
+    f32x16 acc = {0};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc = TR::mfma32(a[s], b[s], acc);
+    return acc[0];
+}
+template <class TR>
+__device__ __forceinline__ void outer_seed(uint32_t x0_bits, uint32_t x1_bits, float w, int lane, f32x16& a0, f32x16& a1) {
+    using V8 = typename TR::vec8;
+    using E = typename TR::elem;
+    const bool lo = lane < 32;
+    V8 bw = V8{0}, x0 = V8{0}, x1 = V8{0};
+    bw[0] = lo ? (E)w : (E)0.f;
+    x0[0] = lo ? __builtin_bit_cast(E, (uint16_t)x0_bits) : (E)0.f;
+    x1[0] = lo ? __builtin_bit_cast(E, (uint16_t)x1_bits) : (E)0.f;
+    a0 = TR::mfma32(x0, bw, a0);
+    a1 = TR::mfma32(x1, bw, a1);
+}
+
+// ---- prologue loads that do not wait for the LDS-DMA --------------------------------------------------------------------
+// vmcnt retires in order and the compiler's own wait insertion does not see the hand-issued LDS-DMA: an ordinary load issued
+// after the first tiles' DMA makes its first use wait for those tiles, and whatever is computed from it (delta, the seeds) then
+// runs AFTER the tiles have landed instead of under their flight.  The per-row operands and the seed rows are therefore loaded
+// by hand-issued instructions BEFORE the DMA and awaited with a counted vmcnt that leaves exactly the DMA outstanding
+// (cdna_hip_programming.md: "=v" loads, a wait-only statement, counted waits only).  NPCD_ARRIVED ties a value to the wait.
+__device__ __forceinline__ u32x4 gload16(const void* ptr) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ uint32_t gload_u16(const void* ptr) {
+    uint32_t v;
+    asm volatile("global_load_ushort %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+__device__ __forceinline__ float gload_f32(const void* ptr) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+#define NPCD_ARRIVED(x) asm volatile("" : "+v"(x))
+template <class V8>
+__device__ __forceinline__ void arrived4(u32x4 (&raw)[4], V8 (&f)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        NPCD_ARRIVED(raw[s]);
+        f[s] = __builtin_bit_cast(V8, raw[s]);
+    }
+}
+// the row as an MFMA operand in which every row (column) of the 32-wide block is that row: four 16-byte loads per lane-half
+template <class E>
+__device__ __forceinline__ void row_bcast_issue(const E* row, int hh, u32x4 (&raw)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) raw[s] = gload16(row + 16 * s + 8 * hh);
+}
+
+// ---- the edge token of a sequence of 128 j + 1 tokens in the BACKWARD ---------------------------------------------------------
+// With the last key / query seeded as above, the only work left for a fifth workgroup per (batch, head) would be ONE row: dQ of
+// the last query in the dQ pass, dK / dV of the last key in the dK/dV pass.  Those workgroups are not launched (NPCD_EDGE_TOKEN):
+//   * every dQ-pass row already holds P and dS against the last key (the seed); the workgroup's 128 rows are summed into partial
+//     dV_E = sum_i P_i dO_i and dK_E = sum_i dS_i q_i,
+//   * every dK/dV-pass key already holds dS of the last query against it; the workgroup's 128 keys give partial dQ_E = sum_j dS_j k_j,
+// each WAVE on its own 32 rows: four matrix instructions per sum over a wave-private row-major LDS image of the register-resident
+// operand rows (edge_reduce; no barrier), and attn_bwd_edge_kernel adds the partials of a (batch, head) in (workgroup, wave) order
+// and writes the three rows.  Scratch: kEdgeFloats floats per (batch, head, 32-row block) behind the row-constant planes of
+// `delta` (npcd_attn_bwd_workspace_floats).
+#ifndef NPCD_EDGE_TOKEN
+#define NPCD_EDGE_TOKEN 1
+#endif
+// DIAGNOSTIC builds only (wrong results, timing): what the seeds / the edge reductions cost
+#ifndef NPCD_DIAG_NO_SEED
+#define NPCD_DIAG_NO_SEED 0
+#endif
+#ifndef NPCD_DIAG_NO_EDGE_REDUCE
+#define NPCD_DIAG_NO_EDGE_REDUCE 0
+#endif
+#ifndef NPCD_DIAG_EDGE_LEVEL
+#define NPCD_DIAG_EDGE_LEVEL 3
+#endif
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int kEdgeFloats = 192;       // [dK_E | dV_E | dQ_E] x 64
+__host__ __device__ inline bool edge_mode(int n) { return NPCD_SEED_TAIL && NPCD_EDGE_TOKEN && (n & 127) == 1 && n > 128; }
+
+// this wave's 32 operand rows as a row-major 32 x 64 image at LDS byte offset img_off (wave-private: no barrier)
+template <class V8>
+__device__ __forceinline__ void edge_put_rows(const FragAddr& fa, uint32_t img_off, const V8 (&f)[4]) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        asm volatile("ds_write_b128 %0, %1" ::"v"(fa.row[s] + img_off), "v"(__builtin_bit_cast(u32x4, f[s])) : "memory");
+}
+// The weights sit in LDS in the 16-bit type, permuted so that the eight a lane-half needs for one 16-row k-step are contiguous:
+// the transposed fragment's k order is the accumulator-row order, rows 16 g + 4 hh + (0..3) and 16 g + 8 + 4 hh + (0..3).
+__device__ __forceinline__ int edge_w_slot(int i) { return (i & ~15) | ((i & 4) << 1) | ((i & 8) >> 1) | (i & 3); }
+// lo[m] / hi[m] = sum over the wave's 32 rows i of w[i] * image[i][m] / image[i][32 + m]: four matrix instructions in two
+// independent chains; every lane returns the 16 sums of the rows m = acc_row(i, hh) (all 32 columns of the product are equal).
+// w_addr: LDS byte address of the wave's 32 permuted 16-bit weights.
+template <class TR>
+__device__ __forceinline__ void edge_reduce(const FragAddr& fa, uint32_t img_off, uint32_t w_addr, int hh, f32x16& lo, f32x16& hi) {
+    using V8 = typename TR::vec8;
+    TrPair t[2][2];
+    u32x4 wv[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        t[db][0].lo = tr_issue_one(fa.tr[db][0] + img_off);
+        t[db][0].hi = tr_issue_one(fa.tr[db][1] + img_off);
+        t[db][1].lo = tr_issue_one(fa.tr[db][0] + img_off + 2048);
+        t[db][1].hi = tr_issue_one(fa.tr[db][1] + img_off + 2048);
+    }
+    wv[0] = lds_b128_issue<0>(w_addr + hh * 16);
+    wv[1] = lds_b128_issue<32>(w_addr + hh * 16);
+    tr_wait();
+    lo = TR::mfma32(tr_vec<TR>(t[0][0]), __builtin_bit_cast(V8, wv[0]), f32x16{0});
+    hi = TR::mfma32(tr_vec<TR>(t[1][0]), __builtin_bit_cast(V8, wv[0]), f32x16{0});
+    lo = TR::mfma32(tr_vec<TR>(t[0][1]), __builtin_bit_cast(V8, wv[1]), lo);
+    hi = TR::mfma32(tr_vec<TR>(t[1][1]), __builtin_bit_cast(V8, wv[1]), hi);
+}
+// Lanes 0 and 32 hold a whole 32-dim block between them; the sums go through a wave-private LDS scratch (256 B per 64 sums) so
+// that the wave writes them as ONE coalesced store of whole cache lines (stored as 16-byte pieces from two lanes they cost
+// 7 us per launch: 16 K waves x 16 partial-line stores).
+__device__ __forceinline__ void edge_stage(unsigned char* scratch64, int lane, const f32x16& lo, const f32x16& hi) {
+    if ((lane & 31) == 0) {
+        const int hh = lane >> 5;
+        float* dst64 = reinterpret_cast<float*>(scratch64);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4v x = {lo[4 * g], lo[4 * g + 1], lo[4 * g + 2], lo[4 * g + 3]};
+            const f32x4v y = {hi[4 * g], hi[4 * g + 1], hi[4 * g + 2], hi[4 * g + 3]};
+            *reinterpret_cast<f32x4v*>(dst64 + 8 * g + 4 * hh) = x;
+            *reinterpret_cast<f32x4v*>(dst64 + 32 + 8 * g + 4 * hh) = y;
+        }
+    }
+}
+
 // One 32-key half tile: S^T (4 MFMAs) -> online softmax on 16 scores per lane -> O^T += V^T P^T (4 MFMAs).
 // Working in 32-key halves keeps the live register set small enough for 3 waves per SIMD.  The kernel is bound
 // by vector-instruction ISSUE (MI355X_MICROARCH.md, per-instruction cycle constants): every address in here
@@ -467,7 +617,12 @@ __global__ __launch_bounds__(256, NPCD_FWD_WAVES) void attn_fwd_kernel(AttnParam
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 16384];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = p.n, nt = (n + 63) >> 6, nfull = n >> 6;
+    // A sequence of 64 j + 1 tokens (the denoiser's: 512 points + the timestep token) would end in a key tile with ONE key.
+    // That key never enters the ring: its score and its value row SEED the online softmax (m = s, l = 1, O = v) from a few
+    // direct loads and six matrix instructions while the first tiles are still in flight (row_bcast / outer_seed), and the stream
+    // below covers nk = n - 1 keys, all in full tiles.
+    const bool seeded = NPCD_SEED_TAIL && (p.n & 63) == 1 && p.n > 64;          // kernel-uniform
+    const int n = p.n, nk = seeded ? n - 1 : n, nt = (nk + 63) >> 6, nfull = nk >> 6;
     const int nqt = (n + 127) >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = bid % nqt, bh = bid / nqt, h = bh % p.H, b = bh / p.H;
@@ -480,26 +635,41 @@ __global__ __launch_bounds__(256, NPCD_FWD_WAVES) void attn_fwd_kernel(AttnParam
     const float c = p.scale_log2;
     const DmaLane dl = dma_lane<E>(p.sn, lane);
 
-    // 3-deep LDS ring filled by LDS-DMA
-    dma_tile_pair(smem, kb, p.sn, vb, p.sn, 0, n, wave, lane);
-    if (nt > 1) dma_tile_pair(smem + 16384, kb, p.sn, vb, p.sn, 64, n, wave, lane);
-
     // Q fragments stay unscaled (scores are scaled in fp32 after the MFMA, identically in fwd and bwd, so
     // that P recomputed in the backward matches the forward's LSE even for very large logits)
+    u32x4 qraw[4], keraw[4] = {};
+    uint32_t vx0 = 0, vx1 = 0;
+    row_bcast_issue(qb + (int64_t)min(qrow, n - 1) * p.sn, hh, qraw);            // (one row per lane here, not a broadcast)
+    const bool seed = seeded && !NPCD_DIAG_NO_SEED;
+    if (seed) {
+        row_bcast_issue(kb + (int64_t)(n - 1) * p.sn, hh, keraw);
+        vx0 = gload_u16(vb + (int64_t)(n - 1) * p.sn + r);
+        vx1 = gload_u16(vb + (int64_t)(n - 1) * p.sn + 32 + r);
+    }
+    // 3-deep LDS ring filled by LDS-DMA (4 wave-instructions per tile pair and wave)
+    if (nt > 0) dma_tile_pair(smem, kb, p.sn, vb, p.sn, 0, nk, wave, lane);
+    if (nt > 1) dma_tile_pair(smem + 16384, kb, p.sn, vb, p.sn, 64, nk, wave, lane);
+    if (nt > 1) vm_wait<8>();
+    else if (nt > 0) vm_wait<4>();
+    else vm_wait<0>();
     V8 qf[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-        qf[s] = *reinterpret_cast<const V8*>(qb + (int64_t)min(qrow, n - 1) * p.sn + 16 * s + 8 * hh);
+    arrived4(qraw, qf);
     f32x16 o0 = {0}, o1 = {0};
     float m = -INFINITY, l = 0.f;
-    // the row operands have arrived: tell the compiler's wait-count tracking here, not inside the loop
+    if (seed) {
+        V8 ke[4];
+        arrived4(keraw, ke);
+        NPCD_ARRIVED(vx0);
+        NPCD_ARRIVED(vx1);
+        m = mfma_dot<TR>(ke, qf) * c;                 // the exp2 domain, like every later maximum
+        l = 0.5f;                                     // P = 1; the two half-wave partial sums are added at the end
+        outer_seed<TR>(vx0, vx1, 1.f, lane, o0, o1);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]));
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (!wave_active) {                                          // wave-uniform
-        kv_idle_loop<E>(smem, kb, vb, p.sn, nfull, nt, n, wave, lane, dl);
+        kv_idle_loop<E>(smem, kb, vb, p.sn, nfull, nt, nk, wave, lane, dl);
         return;
     }
     const FragAddr fa = frag_addr(smem, lane);
@@ -507,12 +677,12 @@ __global__ __launch_bounds__(256, NPCD_FWD_WAVES) void attn_fwd_kernel(AttnParam
     if (nfull > 0) {
         // tile 0 (slot 0) is peeled: its first stage has no predecessor
         fwd_stage<TR, 0, 0, 2, 1, false>(fa, qf, o0, o1, m, l, c, pw);
-        kv_mid<E, 0>(smem, kb, vb, p.sn, 0, nt, n, wave, lane, dl);
+        kv_mid<E, 0>(smem, kb, vb, p.sn, 0, nt, nk, wave, lane, dl);
         fwd_stage<TR, 0, 1, 0, 0, true>(fa, qf, o0, o1, m, l, c, pw);
         for (int t = 1; t < nfull; t += 3) {
-            fwd_step<TR, 1>(smem, fa, dl, kb, vb, p.sn, t, nt, n, wave, lane, qf, o0, o1, m, l, c, pw);
-            if (t + 1 < nfull) fwd_step<TR, 2>(smem, fa, dl, kb, vb, p.sn, t + 1, nt, n, wave, lane, qf, o0, o1, m, l, c, pw);
-            if (t + 2 < nfull) fwd_step<TR, 0>(smem, fa, dl, kb, vb, p.sn, t + 2, nt, n, wave, lane, qf, o0, o1, m, l, c, pw);
+            fwd_step<TR, 1>(smem, fa, dl, kb, vb, p.sn, t, nt, nk, wave, lane, qf, o0, o1, m, l, c, pw);
+            if (t + 1 < nfull) fwd_step<TR, 2>(smem, fa, dl, kb, vb, p.sn, t + 1, nt, nk, wave, lane, qf, o0, o1, m, l, c, pw);
+            if (t + 2 < nfull) fwd_step<TR, 0>(smem, fa, dl, kb, vb, p.sn, t + 2, nt, nk, wave, lane, qf, o0, o1, m, l, c, pw);
         }
         const int last = (nfull - 1) % 3;
         if (last == 0) fwd_flush<TR, 0, 1>(fa, o0, o1, pw);
@@ -523,9 +693,9 @@ __global__ __launch_bounds__(256, NPCD_FWD_WAVES) void attn_fwd_kernel(AttnParam
     }
     if (nfull < nt) {        // ragged last tile: landed at the mid-point of tile nfull-1 (or in the prologue)
         const int slot = nfull % 3;
-        if (slot == 0) fwd_tail<TR, 0>(fa, qf, o0, o1, m, l, c, nfull * 64, n, hh);
-        else if (slot == 1) fwd_tail<TR, 1>(fa, qf, o0, o1, m, l, c, nfull * 64, n, hh);
-        else fwd_tail<TR, 2>(fa, qf, o0, o1, m, l, c, nfull * 64, n, hh);
+        if (slot == 0) fwd_tail<TR, 0>(fa, qf, o0, o1, m, l, c, nfull * 64, nk, hh);
+        else if (slot == 1) fwd_tail<TR, 1>(fa, qf, o0, o1, m, l, c, nfull * 64, nk, hh);
+        else fwd_tail<TR, 2>(fa, qf, o0, o1, m, l, c, nfull * 64, nk, hh);
     }
     l = half_sum(l);
     __builtin_amdgcn_s_barrier();     // every wave has left the ring: 4 KiB of it per wave stage the output rows
@@ -653,11 +823,13 @@ template <class TR>
 __global__ __launch_bounds__(256, NPCD_DQ_WAVES) void attn_bwd_dq_kernel(AttnParams p) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 16384];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 16384 + 512];       // ring + [dS_E | P_E] of the 128 rows (edge token), 16-bit
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = p.n, nt = (n + 63) >> 6, nfull = n >> 6;
-    const int nqt = (n + 127) >> 7;
+    const bool seeded = NPCD_SEED_TAIL && (p.n & 63) == 1 && p.n > 64;          // the single last key is folded into the initial dQ (see attn_fwd_kernel)
+    const int n = p.n, nk = seeded ? n - 1 : n, nt = (nk + 63) >> 6, nfull = nk >> 6;
+    const bool edge = edge_mode(p.n);          // the last row has no workgroup of its own: its dQ comes from the dK/dV pass
+    const int nqt = edge ? n >> 7 : (n + 127) >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = bid % nqt, bh = bid / nqt, h = bh % p.H, b = bh / p.H;
     const E* qb = static_cast<const E*>(p.q) + b * p.sb + h * p.sh;
@@ -672,26 +844,41 @@ __global__ __launch_bounds__(256, NPCD_DQ_WAVES) void attn_bwd_dq_kernel(AttnPar
     const float c = p.scale_log2;
     const DmaLane dl = dma_lane<E>(p.sn, lane);
 
-    // start the K/V stream first, then fetch the per-row operands while it is in flight
-    dma_tile_pair(smem, kb, p.sn, vb, p.sn, 0, n, wave, lane);
-    if (nt > 1) dma_tile_pair(smem + 16384, kb, p.sn, vb, p.sn, 64, n, wave, lane);
-
-    V8 qf[4], dof[4];
-    float delta = 0.f;
+    // the per-row operands (and the seed rows) first, then the K/V stream; delta and the seeds are computed under its flight
     const int qclamp = min(qrow, n - 1);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        qf[s] = *reinterpret_cast<const V8*>(qb + (int64_t)qclamp * p.sn + 16 * s + 8 * hh);
-        dof[s] = *reinterpret_cast<const V8*>(dob + (int64_t)qclamp * p.osn + 16 * s + 8 * hh);
-        const V8 of = *reinterpret_cast<const V8*>(ob + (int64_t)qclamp * p.osn + 16 * s + 8 * hh);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) delta += (float)dof[s][j] * (float)of[j];
+    const bool seed = seeded && !NPCD_DIAG_NO_SEED;
+    u32x4 qraw[4], doraw[4], oraw[4], keraw[4] = {}, veraw[4] = {};
+    uint32_t kx0 = 0, kx1 = 0;
+    row_bcast_issue(qb + (int64_t)qclamp * p.sn, hh, qraw);
+    row_bcast_issue(dob + (int64_t)qclamp * p.osn, hh, doraw);
+    row_bcast_issue(ob + (int64_t)qclamp * p.osn, hh, oraw);
+    float lse_row = gload_f32(p.lse + (int64_t)(b * p.H + h) * n + qclamp);   // rows past the end duplicate the last row; never stored
+    if (seed) {
+        row_bcast_issue(kb + (int64_t)(n - 1) * p.sn, hh, keraw);
+        row_bcast_issue(vb + (int64_t)(n - 1) * p.sn, hh, veraw);
+        kx0 = gload_u16(kb + (int64_t)(n - 1) * p.sn + r);
+        kx1 = gload_u16(kb + (int64_t)(n - 1) * p.sn + 32 + r);
     }
+    if (nt > 0) dma_tile_pair(smem, kb, p.sn, vb, p.sn, 0, nk, wave, lane);
+    if (nt > 1) dma_tile_pair(smem + 16384, kb, p.sn, vb, p.sn, 64, nk, wave, lane);
+    if (nt > 1) vm_wait<8>();
+    else if (nt > 0) vm_wait<4>();
+    else vm_wait<0>();
+
+    V8 qf[4], dof[4], of[4];
+    arrived4(qraw, qf);
+    arrived4(doraw, dof);
+    arrived4(oraw, of);
+    NPCD_ARRIVED(lse_row);
+    float delta = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) delta += (float)dof[s][j] * (float)of[s][j];
     delta = half_sum(delta);
-    const float lse_row = p.lse[(int64_t)(b * p.H + h) * n + qclamp];   // rows past the end duplicate the last row; never stored
     {   // row constants of the dK/dV pass (its initial accumulators), planes [2][B][H][npad]; the pad rows of the last
         // 64-row tile get -inf / 0 so that their P and dS vanish there without masking
-        const int npad = nt << 6;
+        const int npad = ((n + 63) >> 6) << 6;
         if (hh == 0 && qrow < npad) {
             const int64_t at = (int64_t)(b * p.H + h) * npad + qrow;
             p.delta[at] = row_ok ? -lse_row / p.scale : -INFINITY;
@@ -700,14 +887,26 @@ __global__ __launch_bounds__(256, NPCD_DQ_WAVES) void attn_bwd_dq_kernel(AttnPar
     }
     const float lse2 = lse_row * kLog2e;
     f32x16 dq0 = {0}, dq1 = {0};
-    // the row operands have arrived: tell the compiler's wait-count tracking here, not inside the loop
+    if (seed) {       // dQ of the last key: dS = P (dP - delta), dQ = dS k
+        V8 ke[4], ve[4];
+        arrived4(keraw, ke);
+        arrived4(veraw, ve);
+        NPCD_ARRIVED(kx0);
+        NPCD_ARRIVED(kx1);
+        const float s1 = mfma_dot<TR>(ke, qf), dp1 = mfma_dot<TR>(ve, dof);
+        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s1, c, -lse2)), ds1 = pe * (dp1 - delta);
+        if (edge && hh == 0) {
+            E* we = reinterpret_cast<E*>(smem + 3 * 16384) + wave * 64;
+            we[edge_w_slot(r)] = (E)ds1;
+            we[32 + edge_w_slot(r)] = (E)pe;
+        }
+        outer_seed<TR>(kx0, kx1, ds1, lane, dq0, dq1);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(qf[s]), "+v"(dof[s]));
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (!wave_active) {      // wave-uniform: no query rows (ragged last query tile): keep the stream and the barriers going
-        kv_idle_loop<E>(smem, kb, vb, p.sn, nfull, nt, n, wave, lane, dl);
+        kv_idle_loop<E>(smem, kb, vb, p.sn, nfull, nt, nk, wave, lane, dl);
         return;
     }
     const FragAddr fa = frag_addr(smem, lane);
@@ -715,12 +914,12 @@ __global__ __launch_bounds__(256, NPCD_DQ_WAVES) void attn_bwd_dq_kernel(AttnPar
     if (nfull > 0) {
         // tile 0 (slot 0) is peeled: its first stage has no predecessor
         dq_stage<TR, 0, 0, 2, 1, false>(fa, qf, dof, dq0, dq1, c, lse2, delta, dw);
-        kv_mid<E, 0>(smem, kb, vb, p.sn, 0, nt, n, wave, lane, dl);
+        kv_mid<E, 0>(smem, kb, vb, p.sn, 0, nt, nk, wave, lane, dl);
         dq_stage<TR, 0, 1, 0, 0, true>(fa, qf, dof, dq0, dq1, c, lse2, delta, dw);
         for (int t = 1; t < nfull; t += 3) {
-            dq_step<TR, 1>(smem, fa, dl, kb, vb, p.sn, t, nt, n, wave, lane, qf, dof, dq0, dq1, c, lse2, delta, dw);
-            if (t + 1 < nfull) dq_step<TR, 2>(smem, fa, dl, kb, vb, p.sn, t + 1, nt, n, wave, lane, qf, dof, dq0, dq1, c, lse2, delta, dw);
-            if (t + 2 < nfull) dq_step<TR, 0>(smem, fa, dl, kb, vb, p.sn, t + 2, nt, n, wave, lane, qf, dof, dq0, dq1, c, lse2, delta, dw);
+            dq_step<TR, 1>(smem, fa, dl, kb, vb, p.sn, t, nt, nk, wave, lane, qf, dof, dq0, dq1, c, lse2, delta, dw);
+            if (t + 1 < nfull) dq_step<TR, 2>(smem, fa, dl, kb, vb, p.sn, t + 1, nt, nk, wave, lane, qf, dof, dq0, dq1, c, lse2, delta, dw);
+            if (t + 2 < nfull) dq_step<TR, 0>(smem, fa, dl, kb, vb, p.sn, t + 2, nt, nk, wave, lane, qf, dof, dq0, dq1, c, lse2, delta, dw);
         }
         const int last = (nfull - 1) % 3;
         if (last == 0) dq_flush<TR, 0, 1>(fa, dq0, dq1, dw);
@@ -731,13 +930,38 @@ __global__ __launch_bounds__(256, NPCD_DQ_WAVES) void attn_bwd_dq_kernel(AttnPar
     }
     if (nfull < nt) {        // ragged last tile: landed at the mid-point of tile nfull-1 (or just above)
         const int slot = nfull % 3;
-        if (slot == 0) dq_tail<TR, 0>(fa, qf, dof, dq0, dq1, c, lse2, delta, nfull * 64, n, hh);
-        else if (slot == 1) dq_tail<TR, 1>(fa, qf, dof, dq0, dq1, c, lse2, delta, nfull * 64, n, hh);
-        else dq_tail<TR, 2>(fa, qf, dof, dq0, dq1, c, lse2, delta, nfull * 64, n, hh);
+        if (slot == 0) dq_tail<TR, 0>(fa, qf, dof, dq0, dq1, c, lse2, delta, nfull * 64, nk, hh);
+        else if (slot == 1) dq_tail<TR, 1>(fa, qf, dof, dq0, dq1, c, lse2, delta, nfull * 64, nk, hh);
+        else dq_tail<TR, 2>(fa, qf, dof, dq0, dq1, c, lse2, delta, nfull * 64, nk, hh);
     }
     __builtin_amdgcn_s_barrier();     // every wave has left the ring: 4 KiB of it per wave stage the gradient rows
+    f32x16 k0 = {0}, k1 = {0}, v0 = {0}, v1 = {0};
+    if (edge && !NPCD_DIAG_NO_EDGE_REDUCE) {       // partial dK_E (Q rows weighted by dS_E) and dV_E (dO rows weighted by P_E) of this wave's 32 rows
+        const uint32_t img = 16384 + wave * 8192, wa = lds_addr(smem) + 3 * 16384 + wave * 128;
+        edge_put_rows(fa, img, qf);
+        edge_put_rows(fa, img + 4096, dof);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if NPCD_DIAG_EDGE_LEVEL >= 2
+        edge_reduce<TR>(fa, img, wa, hh, k0, k1);
+        edge_reduce<TR>(fa, img + 4096, wa + 64, hh, v0, v1);
+#endif
+    }
     E* grow0 = static_cast<E*>(p.dq) + b * p.gsb + (int64_t)q0 * p.gsn + h * p.gsh;
     store_rows_staged<TR>(smem + wave * 4096, grow0, p.gsn, n - q0, dq0, dq1, p.scale, lane);
+    if (edge && !NPCD_DIAG_NO_EDGE_REDUCE) {
+        float* part = p.delta + 2 * (int64_t)p.B * p.H * (((n + 63) >> 6) << 6) + (((int64_t)bh * nqt + qt) * 4 + wave) * kEdgeFloats;
+        unsigned char* scratch = smem + 16384 + wave * 8192;        // the wave's own image, read out by edge_reduce
+#if NPCD_DIAG_EDGE_LEVEL >= 3
+        edge_stage(scratch, lane, k0, k1);
+        edge_stage(scratch + 256, lane, v0, v1);
+#else
+        asm volatile("" ::"v"(k0), "v"(k1), "v"(v0), "v"(v1));
+#endif
+#ifndef NPCD_DIAG_NO_EDGE_STORE
+        typedef float f32x2v __attribute__((ext_vector_type(2)));
+        reinterpret_cast<f32x2v*>(part)[lane] = reinterpret_cast<const f32x2v*>(scratch)[lane];
+#endif
+    }
 }
 
 // ============================================================================================
@@ -943,8 +1167,13 @@ __global__ __launch_bounds__(256, NPCD_DKDV_WAVES) void attn_bwd_dkdv_kernel(Att
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = p.n, nt = (n + 63) >> 6;
-    const int nkt = (n + 127) >> 7;
+    // A sequence of 64 j + 1 tokens: the single last QUERY row never enters the ring, its dK / dV contributions are the
+    // initial accumulators (from direct loads and a few matrix instructions while the first tiles are in flight; cf. attn_fwd_kernel),
+    // and the stream below covers nq = n - 1 query rows in full tiles.
+    const bool seeded = NPCD_SEED_TAIL && (p.n & 63) == 1 && p.n > 64;          // kernel-uniform
+    const int n = p.n, nq = seeded ? n - 1 : n, nt = (nq + 63) >> 6;
+    const bool edge = edge_mode(p.n);          // the last key has no workgroup of its own: its dK / dV come from the dQ pass
+    const int nkt = edge ? n >> 7 : (n + 127) >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int kt = bid % nkt, bh = bid / nkt, h = bh % p.H, b = bh / p.H;
     const E* qb = static_cast<const E*>(p.q) + b * p.sb + h * p.sh;
@@ -971,36 +1200,74 @@ __global__ __launch_bounds__(256, NPCD_DKDV_WAVES) void attn_bwd_dkdv_kernel(Att
         qs.base = (second ? dob : qb) + (int64_t)(w2 * 32) * qs.stride;
         qs.dl = dma_lane<E>(qs.stride, lane);
         qs.dst = (second ? 8192 : 0) + w2 * 4096;
-        const int npad = nt * 64;                    // row constants: planes [2][B][H][npad], pad rows hold -inf / 0
+        const int npad = ((n + 63) >> 6) << 6;       // row constants: planes [2][B][H][npad], pad rows hold -inf / 0
         qs.stat = p.delta + ((int64_t)w2 * p.B * p.H + (b * p.H + h)) * npad;
         qs.stat_dst = 16384 + w2 * 256;
     }
-    qdo_prefetch(dsmem, qs, 0, n, wave, lane);
-    if (nt > 1) qdo_prefetch(dsmem + kDkdvSlot, qs, 1, n, wave, lane);
-
     if (!wave_active) {      // wave-uniform: no keys in this wave (ragged last key block): keep the stream and the barriers going
+        qdo_prefetch(dsmem, qs, 0, nq, wave, lane);
+        if (nt > 1) qdo_prefetch(dsmem + kDkdvSlot, qs, 1, nq, wave, lane);
         if (nt > 1) NPCD_DMA_WAIT_BARRIER(5);
         else NPCD_DMA_WAIT_BARRIER(0);
         for (int t = 0; t < nt; ++t) {
             NPCD_DMA_WAIT_BARRIER(0);
-            if (t + 2 < nt) qdo_prefetch(dsmem + ((t + 2) % 3) * kDkdvSlot, qs, t + 2, n, wave, lane);
+            if (t + 2 < nt) qdo_prefetch(dsmem + ((t + 2) % 3) * kDkdvSlot, qs, t + 2, nq, wave, lane);
         }
         return;
     }
 
+    // this lane's K / V row (and the seed rows) first, then the Q / dO stream (5 wave-instructions per tile and wave): the
+    // seeds are computed under its flight (see gload16)
+    const bool seed = seeded && !NPCD_DIAG_NO_SEED;
+    const int kclamp = min(key, n - 1);
+    u32x4 kraw[4], vraw[4], qeraw[4] = {}, doeraw[4] = {}, oeraw[4] = {};
+    uint32_t qx0 = 0, qx1 = 0, dx0 = 0, dx1 = 0;
+    float lse_e = 0.f;
+    row_bcast_issue(kb + (int64_t)kclamp * p.sn, hh, kraw);
+    row_bcast_issue(vb + (int64_t)kclamp * p.sn, hh, vraw);
+    if (seed) {
+        const E* qrow = qb + (int64_t)(n - 1) * p.sn;
+        const E* dorow = dob + (int64_t)(n - 1) * p.osn;
+        row_bcast_issue(qrow, hh, qeraw);
+        row_bcast_issue(dorow, hh, doeraw);
+        row_bcast_issue(static_cast<const E*>(p.out) + b * p.osb + h * p.osh + (int64_t)(n - 1) * p.osn, hh, oeraw);
+        lse_e = gload_f32(p.lse + (int64_t)(b * p.H + h) * n + (n - 1));
+        qx0 = gload_u16(qrow + r);   qx1 = gload_u16(qrow + 32 + r);
+        dx0 = gload_u16(dorow + r);  dx1 = gload_u16(dorow + 32 + r);
+    }
+    qdo_prefetch(dsmem, qs, 0, nq, wave, lane);
+    if (nt > 1) qdo_prefetch(dsmem + kDkdvSlot, qs, 1, nq, wave, lane);
+    if (nt > 1) vm_wait<10>();
+    else vm_wait<5>();
+
     V8 kf[4], vf[4];
+    arrived4(kraw, kf);
+    arrived4(vraw, vf);
+    if (!key_ok) {          // keys past the end: zero operands (their rows are never stored)
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const u32x4 z = {0, 0, 0, 0};
-        kf[s] = __builtin_bit_cast(V8, key_ok ? *reinterpret_cast<const u32x4*>(kb + key * p.sn + 16 * s + 8 * hh) : z);
-        vf[s] = __builtin_bit_cast(V8, key_ok ? *reinterpret_cast<const u32x4*>(vb + key * p.sn + 16 * s + 8 * hh) : z);
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = V8{0};
+            vf[s] = V8{0};
+        }
     }
     DkdvState a;
     a.dk0 = f32x16{0}; a.dk1 = f32x16{0}; a.dv0 = f32x16{0}; a.dv1 = f32x16{0};
-#ifdef NPCD_TIMELINE
-    a.tl = tl;
-    a.tl_on = tl_on;
-#endif
+    float ds_edge = 0.f;
+    if (seed) {       // the last query row against this lane's key: P = exp2(c (k.q - lse/scale)), dS = P (v.dO - delta)
+        V8 qe[4], doe[4], oe[4];
+        arrived4(qeraw, qe);
+        arrived4(doeraw, doe);
+        arrived4(oeraw, oe);
+        NPCD_ARRIVED(lse_e);
+        NPCD_ARRIVED(qx0); NPCD_ARRIVED(qx1); NPCD_ARRIVED(dx0); NPCD_ARRIVED(dx1);
+        // the row constants of the last query (the dQ pass, in edge mode, has no workgroup that would have written them)
+        const float c0 = -lse_e / p.scale, c1 = -mfma_dot<TR>(doe, oe);
+        const float p1 = __builtin_amdgcn_exp2f((mfma_dot<TR>(qe, kf) + c0) * p.scale_log2);
+        const float ds1 = p1 * (mfma_dot<TR>(doe, vf) + c1);
+        ds_edge = ds1;
+        outer_seed<TR>(dx0, dx1, p1, lane, a.dv0, a.dv1);
+        outer_seed<TR>(qx0, qx1, ds1, lane, a.dk0, a.dk1);
+    }
     V8 pf[2], df[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -1011,11 +1278,7 @@ __global__ __launch_bounds__(256, NPCD_DKDV_WAVES) void attn_bwd_dkdv_kernel(Att
     const FragAddr fa = frag_addr(dsmem, lane);
     const uint32_t st_addr = lds_addr(dsmem) + hh * 16;
     NPCD_TS(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // K/V fragments (and tile 0/1) have arrived
-    // make the arrival visible to the compiler's wait-count tracking HERE: otherwise it re-waits with vmcnt(0) at the
-    // fragments' first use inside the loop, which also drains the LDS-DMA prefetch
-#pragma unroll
-    for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(kf[s]), "+v"(vf[s]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // tiles 0 / 1 have arrived
     NPCD_TS(2);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -1026,15 +1289,15 @@ __global__ __launch_bounds__(256, NPCD_DKDV_WAVES) void attn_bwd_dkdv_kernel(Att
         const int t = 0;
         dkdv_stage<TR, 0, 0, 2, 1, false>(fa, st_addr, kf, vf, c, a, pf, df);
         NPCD_DKDV_MID();
-        if (2 < nt) qdo_prefetch(dsmem + 2 * kDkdvSlot, qs, 2, n, wave, lane);
-        if (32 < n) dkdv_stage<TR, 0, 1, 0, 0, true>(fa, st_addr, kf, vf, c, a, pf, df);
+        if (2 < nt) qdo_prefetch(dsmem + 2 * kDkdvSlot, qs, 2, nq, wave, lane);
+        if (32 < nq) dkdv_stage<TR, 0, 1, 0, 0, true>(fa, st_addr, kf, vf, c, a, pf, df);
         else both = false;
         (void)t;
     }
     for (int t = 1; t < nt; t += 3) {
-        both = dkdv_step<TR, 1>(dsmem, fa, st_addr, qs, t, nt, n, wave, lane, kf, vf, c, a, pf, df);
-        if (t + 1 < nt) both = dkdv_step<TR, 2>(dsmem, fa, st_addr, qs, t + 1, nt, n, wave, lane, kf, vf, c, a, pf, df);
-        if (t + 2 < nt) both = dkdv_step<TR, 0>(dsmem, fa, st_addr, qs, t + 2, nt, n, wave, lane, kf, vf, c, a, pf, df);
+        both = dkdv_step<TR, 1>(dsmem, fa, st_addr, qs, t, nt, nq, wave, lane, kf, vf, c, a, pf, df);
+        if (t + 1 < nt) both = dkdv_step<TR, 2>(dsmem, fa, st_addr, qs, t + 1, nt, nq, wave, lane, kf, vf, c, a, pf, df);
+        if (t + 2 < nt) both = dkdv_step<TR, 0>(dsmem, fa, st_addr, qs, t + 2, nt, nq, wave, lane, kf, vf, c, a, pf, df);
     }
     NPCD_TS(20);
     {
@@ -1049,12 +1312,29 @@ __global__ __launch_bounds__(256, NPCD_DKDV_WAVES) void attn_bwd_dkdv_kernel(Att
             else dkdv_flush<TR, 2, 0>(fa, a, pf, df);
         }
     }
+    f32x16 eq0 = {0}, eq1 = {0};
+    if (edge && !NPCD_DIAG_NO_EDGE_REDUCE) {   // partial dQ_E of this wave's 32 keys (K rows weighted by dS_E), in the slot before the last
+        // tile's -- released, like the staging slot below, at the last mid-tile barrier
+        const uint32_t img = ((nt + 1) % 3) * kDkdvSlot + wave * 4096, wa = lds_addr(dsmem) + ((nt + 1) % 3) * kDkdvSlot + 16384 + wave * 64;
+        edge_put_rows(fa, img, kf);
+        if (hh == 0) reinterpret_cast<E*>(dsmem + ((nt + 1) % 3) * kDkdvSlot + 16384 + wave * 64)[edge_w_slot(r)] = (E)ds_edge;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        edge_reduce<TR>(fa, img, wa, hh, eq0, eq1);
+    }
     {   // the slot after the last tile's was released at the last mid-tile barrier: 4 KiB of it per wave stage the rows
         unsigned char* stage = dsmem + (nt % 3) * kDkdvSlot + wave * 4096;
         E* gk = static_cast<E*>(p.dk) + b * p.gsb + (int64_t)key0 * p.gsn + h * p.gsh;
         E* gv = static_cast<E*>(p.dv) + b * p.gsb + (int64_t)key0 * p.gsn + h * p.gsh;
         store_rows_staged<TR>(stage, gk, p.gsn, n - key0, a.dk0, a.dk1, p.scale, lane);
         store_rows_staged<TR>(stage, gv, p.gsn, n - key0, a.dv0, a.dv1, 1.f, lane);
+    }
+    if (edge && !NPCD_DIAG_NO_EDGE_REDUCE) {
+        float* part = p.delta + 2 * (int64_t)p.B * p.H * (((n + 63) >> 6) << 6) + (((int64_t)bh * nkt + kt) * 4 + wave) * kEdgeFloats;
+        unsigned char* scratch = dsmem + ((nt + 1) % 3) * kDkdvSlot + wave * 4096;      // the wave's own image, read out by edge_reduce
+        edge_stage(scratch, lane, eq0, eq1);
+#ifndef NPCD_DIAG_NO_EDGE_STORE
+        part[128 + lane] = reinterpret_cast<const float*>(scratch)[lane];
+#endif
     }
 #ifdef NPCD_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1134,7 +1414,6 @@ struct FusedCtx {
     float scale;
 };
 
-typedef float f32x4v __attribute__((ext_vector_type(4)));
 // slab address of this lane's 4 consecutive d of query row q0 + 16 qt + (lane & 15); nullptr past the end of the sequence
 __device__ __forceinline__ float* fused_slab_ptr(const FusedCtx& fc, int q0, int lane) {
     const int q = q0 + 16 * fc.qt + (lane & 15);
@@ -1619,6 +1898,51 @@ extern "C" int npcd_attn_fwd(const void* q, const void* k, const void* v, void* 
     return NPCD_OK;
 }
 
+// The three gradient rows of the edge token E = n - 1: partials of the waves of the (n - 1) / 128 workgroups of each pass, added in
+// (workgroup, wave) order, plus the one pair neither pass has seen: query E against key E (fp32 from the rows themselves).  One wave per row.
+template <class E>
+__global__ __launch_bounds__(192) void attn_bwd_edge_kernel(AttnParams p) {
+    const int bh = blockIdx.x, h = bh % p.H, b = bh / p.H, mat = threadIdx.x >> 6, d = threadIdx.x & 63;
+    const int nb = (p.n >> 7) * 4, last = p.n - 1;          // one partial per wave of the (n - 1) / 128 workgroups
+    const float* part = p.delta + 2 * (int64_t)p.B * p.H * (((p.n + 63) >> 6) << 6) + (int64_t)bh * nb * kEdgeFloats + mat * 64 + d;
+    float acc = 0.f;
+    int j = 0;
+    for (; j + 16 <= nb; j += 16) {         // loads first (independent), then the adds in index order
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = part[(int64_t)(j + u) * kEdgeFloats];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc += v[u];
+    }
+    for (; j < nb; j += 4) {                // nb is a multiple of 4
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = part[(int64_t)(j + u) * kEdgeFloats];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += v[u];
+    }
+    const int64_t qkv_at = b * p.sb + (int64_t)last * p.sn + h * p.sh + d, o_at = b * p.osb + (int64_t)last * p.osn + h * p.osh + d;
+    const float qe = (float)static_cast<const E*>(p.q)[qkv_at], ke = (float)static_cast<const E*>(p.k)[qkv_at];
+    const float ve = (float)static_cast<const E*>(p.v)[qkv_at];
+    const float oe = (float)static_cast<const E*>(p.out)[o_at], doe = (float)static_cast<const E*>(p.dout)[o_at];
+    float s = qe * ke, dp = doe * ve, dl = doe * oe;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s += __shfl_xor(s, m);
+        dp += __shfl_xor(dp, m);
+        dl += __shfl_xor(dl, m);
+    }
+    const float pe = __builtin_amdgcn_exp2f(s * p.scale_log2 - p.lse[(int64_t)bh * p.n + last] * kLog2e), ds = pe * (dp - dl);
+    acc += mat == 0 ? ds * qe : mat == 1 ? pe * doe : ds * ke;
+    E* dst = static_cast<E*>(mat == 0 ? p.dk : mat == 1 ? p.dv : p.dq) + b * p.gsb + (int64_t)last * p.gsn + h * p.gsh + d;
+    *dst = (E)(mat == 1 ? acc : acc * p.scale);
+}
+
+extern "C" int64_t npcd_attn_bwd_workspace_floats(int B, int n, int H) {
+    if (B <= 0 || n <= 0 || H <= 0) return -1;
+    return 2 * (int64_t)B * H * ((n + 63) / 64 * 64) + (edge_mode(n) ? (int64_t)B * H * (n >> 7) * 4 * kEdgeFloats : 0);
+}
+
 static int attn_bwd_launch(int passes, const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
                            void* dq, void* dk, void* dv, float* delta, int B, int n, int H, int d,
                            int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
@@ -1640,7 +1964,8 @@ static int attn_bwd_launch(int passes, const void* q, const void* k, const void*
     p.osb = out_sb; p.osn = out_sn; p.osh = out_sh;
     p.gsb = g_sb; p.gsn = g_sn; p.gsh = g_sh;
     p.scale = scale; p.scale_log2 = scale * kLog2e;
-    const int grid = B * H * ceil_div(n, 128);
+    const bool edge = edge_mode(n);
+    const int grid = B * H * (edge ? n >> 7 : ceil_div(n, 128));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int dyn = 3 * kDkdvSlot;
     static DynLds lds_bf16, lds_f16;
@@ -1649,9 +1974,11 @@ static int attn_bwd_launch(int passes, const void* q, const void* k, const void*
     if (dtype == NPCD_BF16) {
         if (passes & 1) hipLaunchKernelGGL(attn_bwd_dq_kernel<BF16>, dim3(grid), dim3(256), 0, st, p);
         if (passes & 2) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<BF16>, dim3(grid), dim3(256), dyn, st, p);
+        if ((passes & 2) && edge) hipLaunchKernelGGL(attn_bwd_edge_kernel<BF16::elem>, dim3(B * H), dim3(192), 0, st, p);
     } else {
         if (passes & 1) hipLaunchKernelGGL(attn_bwd_dq_kernel<F16>, dim3(grid), dim3(256), 0, st, p);
         if (passes & 2) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<F16>, dim3(grid), dim3(256), dyn, st, p);
+        if ((passes & 2) && edge) hipLaunchKernelGGL(attn_bwd_edge_kernel<F16::elem>, dim3(B * H), dim3(192), 0, st, p);
     }
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;

@@ -47,7 +47,8 @@ BWD_MODE = os.environ.get("NPCD_ATTN_BWD", "twopass")
 
 def _bwd(q, k, v, out, dout, lse, dq, dk, dv, scale):
     B, n, H, d = q.shape
-    delta = torch.empty((2, B, H, (n + 63) // 64 * 64), dtype=torch.float32, device=q.device)   # row constants handed from pass 1 to pass 2
+    # row constants handed from pass 1 to pass 2 (+ the partial sums of the edge token's three gradient rows when n = 128 j + 1)
+    delta = torch.empty(lib().npcd_attn_bwd_workspace_floats(B, n, H), dtype=torch.float32, device=q.device)
     assert dq.stride() == dk.stride() == dv.stride() and dout.stride() == out.stride()
     if BWD_MODE == "fused":
         nslab = lib().npcd_attn_bwd_fused_slab_floats(B, n, H)

@@ -95,6 +95,25 @@ def test_attention_forced_rescale():
     check(qkv.bfloat16(), H, torch.randn(1, n, 64, generator=gen).bfloat16(), "spike")
 
 
+@pytest.mark.parametrize("n", [129, 513])
+def test_attention_edge_token_extremes(n):
+    """Sequences of 128 j + 1 tokens: the last token never enters the key / query stream -- it seeds the online softmax and the
+    gradient accumulators, and its own three gradient rows are summed from per-wave partials (csrc/attention.hip, 'the edge
+    token').  Here it DOMINATES: as a key it wins every row's softmax, as a query it is peaked on one early key; the gradients must
+    also be bitwise reproducible (fixed summation order)."""
+    gen = torch.Generator().manual_seed(100 + n)
+    H = 2
+    qkv = torch.randn(2, n, 3 * H * 64, generator=gen)
+    q, k = qkv.view(2, n, H, 3, 64)[:, :, :, 0], qkv.view(2, n, H, 3, 64)[:, :, :, 1]
+    k[:, -1] = 0.35 * q.mean(dim=1) + 0.9          # the last key: scores well above the rest for most rows
+    q[:, -1, 0] = 4.0 * k[:, 7, 0]                 # the last query, head 0: peaked on key 7
+    gout = torch.randn(2, n, H * 64, generator=gen).bfloat16()
+    check(qkv.bfloat16(), H, gout, f"edge-dominant n={n}")
+    a = run_hip(qkv.bfloat16(), H, gout)[1]
+    b = run_hip(qkv.bfloat16(), H, gout)[1]
+    assert torch.equal(a, b), "attention backward is not bitwise reproducible"
+
+
 def test_flash_attn_func_dropin_strided():
     """The reference's call pattern: q,k,v = split(view(B,n,H,3d)) -> flash_attn_func (transformer.py:71-75)."""
     from flash_attn import flash_attn_func

@@ -22,8 +22,20 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"libnpcd_hip.so does not export {name}"
     assert declared == set(hip.SIGNATURES), (declared ^ set(hip.SIGNATURES))
     assert L.npcd_missing == (), f"stale library, missing {L.npcd_missing}"
-    assert L.npcd_abi_version() == 2
+    assert L.npcd_abi_version() == 3
     assert L.npcd_error_string(-2).decode() == "unsupported shape or dtype"
+
+
+def test_attention_backward_workspace_size():
+    """Host-side sizing of the backward's scratch (include/npcd_hip.h): two row-constant planes over n padded to 64, plus 192
+    floats per (batch, head, 32-row block) when the sequence is 128 j + 1 tokens long (the edge token's partial sums)."""
+    from npcd import hip
+    f = hip.lib().npcd_attn_bwd_workspace_floats
+    assert f(2, 512, 3) == 2 * 2 * 3 * 512
+    assert f(2, 513, 3) == 2 * 2 * 3 * 576 + 2 * 3 * 4 * 4 * 192
+    assert f(2, 129, 3) == 2 * 2 * 3 * 192 + 2 * 3 * 1 * 4 * 192
+    assert f(2, 65, 3) == 2 * 2 * 3 * 128 and f(2, 1, 3) == 2 * 2 * 3 * 64          # seeded / too short: no edge scratch
+    assert f(0, 513, 3) == -1
 
 
 def test_no_cpu_fallback():
