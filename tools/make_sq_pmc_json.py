@@ -18,6 +18,8 @@ for r in csv.DictReader(open(f)):
     if not any(w in k for w in want):
         continue
     k = k.split("<")[0].split("(")[0].split("::")[-1].replace("void ", "")
+    if k.startswith("_Z") and "attn_bwd_edge_kernel" in k:          # (rocprofv3 leaves the __bf16 instantiation mangled)
+        k = "attn_bwd_edge_kernel"
     acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and "Start_Timestamp" in r:
         dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))

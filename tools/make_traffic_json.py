@@ -10,6 +10,11 @@ if kind == "attn":
     alg = {"attn_fwd_kernel": 4 * B * n * H * d * 2 + B * H * n * 4,
            "attn_bwd_dq_kernel": 6 * B * n * H * d * 2 + 4 * B * H * n * 4,       # q,k,v,out,dout read + dq written; lse read, 2 row-constant planes written
            "attn_bwd_dkdv_kernel": 6 * B * n * H * d * 2 + 2 * B * H * n * 4}     # q,k,v,dout read + dk,dv written; 2 row-constant planes read
+    edge = B * H * (n >> 7) * 4 * 192 * 4 if (n & 127) == 1 and n > 128 else 0      # per-wave partial sums of the edge token's three gradient rows
+    alg["attn_bwd_dq_kernel"] += edge * 2 // 3
+    alg["attn_bwd_dkdv_kernel"] += edge // 3
+    if edge:
+        alg["attn_bwd_edge_kernel"] = edge + 3 * B * H * d * 2 + 5 * B * H * d * 2  # partials read, 3 rows written, 5 rows read
     note = "per launch, B=64 H=16 n=513 d=64 bf16 (tools/gpu_dev_attn_time.py)"
 else:
     alg = {"add_ln_fwd_kernel": T * W * (4 + 2 + 4 + 2), "ln_bwd_kernel": T * W * (2 + 4 + 4 + 4 + 2), "gelu_fwd_kernel": T * 4 * W * 4,
@@ -18,7 +23,7 @@ else:
 def mean_counter(path, name):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != name or "npcd" not in r["Kernel_Name"]:
+        if r["Counter_Name"] != name or ("npcd" not in r["Kernel_Name"] and "attn_bwd_edge" not in r["Kernel_Name"]):
             continue
         k = r["Kernel_Name"]                      # demangled ("void npcd::colsum_kernel<true>(...)") or mangled ("_ZN4npcd13colsum_kernelILb1E...")
         def hit(a):
