@@ -58,6 +58,18 @@ int npcd_attn_fwd(const void* q, const void* k, const void* v, void* out, float*
                   int64_t out_sb, int64_t out_sn, int64_t out_sh,
                   float scale, int dtype, void* stream);
 
+/* The same forward with fp8 (e4m3) operands on the block-scaled matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4; BASELINE
+ * configs[4] names fp8 attention; opt-in, csrc/attention.hip attn_fwd_fp8_kernel): k is quantised to e4m3 and v to e4m3
+ * transposed by a packing pass into `workspace`, q and P (with a 2^-8 block scale) inside the kernel (npcd_attn_fwd_fp8_workspace_bytes(B, n, H)
+ * bytes; 0 = this length is not covered, use npcd_attn_fwd: n or n - 1 must be a multiple of 64).  bf16 only; out / lse as above;
+ * the backward is npcd_attn_bwd on the bf16 operands.  Measured slower than the bf16 kernel at head_dim 64. */
+int64_t npcd_attn_fwd_fp8_workspace_bytes(int B, int n, int H);
+int npcd_attn_fwd_fp8(const void* q, const void* k, const void* v, void* out, float* lse, void* workspace,
+                      int B, int n, int H, int d,
+                      int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh,
+                      int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                      float scale, int dtype, void* stream);
+
 /* Backward of the above.  dq/dk/dv share (g_sb, g_sn, g_sh); out/dout share the out strides.
  * delta: fp32 scratch of npcd_attn_bwd_workspace_floats(B, n, H) elements, written by the call.  First [2, B, H, npad]
  * (npad = n rounded up to a multiple of 64): the per-row constants the dK/dV pass starts its accumulators from, plane 0 =

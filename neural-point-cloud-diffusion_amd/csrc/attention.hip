@@ -1846,6 +1846,202 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 // ============================================================================================
 // host entry points
 // ============================================================================================
+// ============================================================================================
+// forward with fp8 (e4m3) operands on the block-scaled matrix instruction  -- opt-in, BASELINE configs[4] names it
+// ============================================================================================
+// v_mfma_scale_f32_32x32x64_f8f6f4 contracts 64 elements per instruction at twice the bf16 rate: one instruction per 32 x 32
+// score block (head_dim 64) and one per 32 output dimensions and 64 keys.  Operand lane map (tools/probes/mfma_scale_fp8_map.hip,
+// exact integer data): lane (i = l & 31, g = l >> 5) holds elements k = 32 g .. 32 g + 31 of row / column i in its eight
+// registers; C/D as for every 32 x 32 form; block scales are E8M0 bytes (127 = 1).
+//   * attn_fp8_pack_kernel: k -> e4m3 rows [B, H, nk, 64]; v -> e4m3 TRANSPOSED [B, H, 64, nk] so that the second product's
+//     A operand (V^T: 32 consecutive keys of one dimension) is a plain row read, with the keys of each 64-key tile permuted
+//     into the order in which a lane holds the scores of the first product: lane half g owns keys acc_row(j, g) of the tile's first
+//     32-key block (slots j = 0..15) and 32 + acc_row(j - 16, g) (slots 16..31) -- P goes from the accumulators into the B operand
+//     without leaving the lane.  (The queries are converted by the forward kernel itself: each row is used by one wave only.)
+//   * attn_fwd_fp8_kernel: same decomposition as attn_fwd_kernel (4 waves x 32 queries, 64-key tiles through a 3-slot LDS ring by
+//     LDS-DMA, 8 KiB per slot), 4 matrix instructions per tile instead of 16.  P is stored as e4m3(256 P) with the block scale
+//     2^-8 (e4m3 has 3 mantissa bits and a smallest normal of 2^-6: the scale moves the softmax tail into range); the running
+//     maximum is not deferred (256 P must stay below 448).  A single last key (n = 64 j + 1) seeds the state exactly as in the
+//     bf16 kernel, from the bf16 rows.  Output, LSE and the whole backward stay as they are (the backward recomputes P from the
+//     bf16 operands against this LSE, like FlashAttention-3's fp8 forward).
+// Needs nk = n or n - 1 to be a multiple of 64; other lengths: NPCD_ERR_UNSUPPORTED (the caller uses the bf16 kernel).
+typedef int v8i32 __attribute__((ext_vector_type(8)));
+constexpr int kF8Slot = 8192;          // K tile 64 x 64 B, then V^T tile 64 x 64 B
+__device__ __forceinline__ int f8_swz(int row) { return (row >> 2) & 3; }      // 16-byte chunk XOR of a 64-byte row: conflict-free b128 row reads
+__device__ __forceinline__ int f8_key_of_slot(int p) {                        // position p of a permuted 64-key tile -> key inside the tile
+    const int g = p >> 5, j = p & 31;
+    return (j < 16 ? 0 : 32) + acc_row(j & 15, g);
+}
+__device__ __forceinline__ uint32_t f8_pack4(float a, float b, float c, float d) {
+    int x = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    x = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, x, true);
+    return (uint32_t)x;
+}
+
+// one workgroup per (batch, head, 64-key tile; nk is a multiple of 64): the tile's k rows, and its v rows transposed + permuted
+__global__ __launch_bounds__(256) void attn_fp8_pack_kernel(AttnParams p, unsigned char* k8, unsigned char* v8t, int nk) {
+    __shared__ __attribute__((aligned(16))) unsigned char vt[64 * 80];      // [key][64 B + pad]
+    const int ntile = nk >> 6;
+    const int tile = blockIdx.x % ntile, bh = blockIdx.x / ntile, h = bh % p.H, b = bh / p.H, tid = threadIdx.x;
+    const __bf16* kb = static_cast<const __bf16*>(p.k) + b * p.sb + h * p.sh;
+    const __bf16* vb = static_cast<const __bf16*>(p.v) + b * p.sb + h * p.sh;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = tid + 256 * it, row = c >> 3, ch = c & 7, tok = tile * 64 + row;     // 8 elements of one token
+        {
+            const bf16x8 x = *reinterpret_cast<const bf16x8*>(kb + (int64_t)tok * p.sn + 8 * ch);
+            u32x2 o = {f8_pack4((float)x[0], (float)x[1], (float)x[2], (float)x[3]), f8_pack4((float)x[4], (float)x[5], (float)x[6], (float)x[7])};
+            *reinterpret_cast<u32x2*>(k8 + ((int64_t)bh * nk + tok) * 64 + 8 * ch) = o;
+            const bf16x8 y = *reinterpret_cast<const bf16x8*>(vb + (int64_t)tok * p.sn + 8 * ch);
+            u32x2 w = {f8_pack4((float)y[0], (float)y[1], (float)y[2], (float)y[3]), f8_pack4((float)y[4], (float)y[5], (float)y[6], (float)y[7])};
+            *reinterpret_cast<u32x2*>(vt + row * 80 + 8 * ch) = w;
+        }
+    }
+    __syncthreads();
+    {
+        const int d = tid >> 2, pq = tid & 3;
+        uint32_t o[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int by = 0; by < 4; ++by) x |= (uint32_t)vt[f8_key_of_slot(16 * pq + 4 * w + by) * 80 + d] << (8 * by);
+            o[w] = x;
+        }
+        *reinterpret_cast<u32x4*>(v8t + ((int64_t)bh * 64 + d) * nk + tile * 64 + 16 * pq) = u32x4{o[0], o[1], o[2], o[3]};
+    }
+}
+
+// LDS-DMA of tile t into ring slot `slot`: 8 pieces of 16 rows x 64 B (K: 0..3, V^T: 4..7), two per wave
+__device__ __forceinline__ void f8_dma_tile(unsigned char* smem, int slot, const unsigned char* k8, const unsigned char* v8t, int nk, int t,
+                                            int wave, int lane) {
+    const uint32_t dst = lds_addr(smem) + slot * kF8Slot;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int piece = 2 * wave + j, pr = (piece & 3) * 16 + (lane >> 2);                    // row inside the K or V^T tile
+        const uint32_t lchunk = (uint32_t)((lane & 3) ^ f8_swz(pr));
+        if (piece < 4) dma16_issue(k8 + (int64_t)t * 4096, (uint32_t)(pr * 64) + lchunk * 16, __builtin_amdgcn_readfirstlane(dst + piece * 1024));
+        else dma16_issue(v8t + (int64_t)t * 64, (uint32_t)pr * (uint32_t)nk + lchunk * 16, __builtin_amdgcn_readfirstlane(dst + piece * 1024));
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_fp8_kernel(AttnParams p, const unsigned char* k8, const unsigned char* v8t, int nk) {
+    using E = __bf16;
+    using V8 = bf16x8;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * kF8Slot + 4 * 4096];      // ring + the four output staging areas
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, g = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = p.n, nt = nk >> 6;
+    const bool seeded = nk < n;
+    const int nqt = (n + 127) >> 7;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = bid % nqt, bh = bid / nqt, h = bh % p.H, b = bh / p.H;
+    const int q0 = qt * 128 + wave * 32, qrow = q0 + r, qclamp = min(qrow, n - 1);
+    const float c = p.scale_log2;
+    const unsigned char* k8b = k8 + (int64_t)bh * nk * 64;
+    const unsigned char* v8b = v8t + (int64_t)bh * 64 * nk;
+    // prologue loads ahead of the DMA (see gload16): this lane half's 32 dimensions of the query row (e4m3 operand: elements
+    // 32 g .. 32 g + 31), and for the seed the row in the bf16 operand order + the last k / v rows
+    const E* qb = static_cast<const E*>(p.q) + b * p.sb + h * p.sh;
+    u32x4 q32[4], qraw[4] = {}, keraw[4] = {};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) q32[s] = gload16(qb + (int64_t)qclamp * p.sn + 32 * g + 8 * s);
+    uint32_t vx0 = 0, vx1 = 0;
+    if (seeded) {
+        const E* kb = static_cast<const E*>(p.k) + b * p.sb + h * p.sh;
+        const E* vb = static_cast<const E*>(p.v) + b * p.sb + h * p.sh;
+        row_bcast_issue(qb + (int64_t)qclamp * p.sn, g, qraw);
+        row_bcast_issue(kb + (int64_t)(n - 1) * p.sn, g, keraw);
+        vx0 = gload_u16(vb + (int64_t)(n - 1) * p.sn + r);
+        vx1 = gload_u16(vb + (int64_t)(n - 1) * p.sn + 32 + r);
+    }
+    f8_dma_tile(smem, 0, k8b, v8b, nk, 0, wave, lane);
+    if (nt > 1) f8_dma_tile(smem, 1, k8b, v8b, nk, 1, wave, lane);
+    if (nt > 1) vm_wait<4>();
+    else vm_wait<2>();
+    v8i32 qf8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        NPCD_ARRIVED(q32[s]);
+        const V8 x = __builtin_bit_cast(V8, q32[s]);
+        qf8[2 * s] = (int)f8_pack4((float)x[0], (float)x[1], (float)x[2], (float)x[3]);
+        qf8[2 * s + 1] = (int)f8_pack4((float)x[4], (float)x[5], (float)x[6], (float)x[7]);
+    }
+    f32x16 o0 = {0}, o1 = {0};
+    float m = -INFINITY, l = 0.f;           // l is kept times 256 (the scale of the stored P)
+    if (seeded) {
+        V8 qf[4], ke[4];
+        arrived4(qraw, qf);
+        arrived4(keraw, ke);
+        NPCD_ARRIVED(vx0);
+        NPCD_ARRIVED(vx1);
+        m = mfma_dot<BF16>(ke, qf) * c;
+        l = 0.5f * 256.f;
+        outer_seed<BF16>(vx0, vx1, 1.f, lane, o0, o1);
+    }
+    // per-lane LDS addresses inside a slot: row r, this lane half's two 16-byte chunks
+    const uint32_t base = lds_addr(smem) + r * 64;
+    const uint32_t ad0 = base + (((2 * g) ^ f8_swz(r)) << 4), ad1 = base + (((2 * g + 1) ^ f8_swz(r)) << 4);
+    const int unit = 0x7f7f7f7f, pscale = 0x77777777;            // E8M0: 2^0, 2^-8
+    for (int t = 0; t < nt; ++t) {
+        const int slot = t % 3;
+        // tile t has landed (at most tile t + 1 is still in flight); every wave is done with tile t - 1: its slot takes tile t + 2
+        if (t + 1 < nt) NPCD_DMA_WAIT_BARRIER(2);
+        else NPCD_DMA_WAIT_BARRIER(0);
+        if (t + 2 < nt) f8_dma_tile(smem, (t + 2) % 3, k8b, v8b, nk, t + 2, wave, lane);
+        const uint32_t so = slot * kF8Slot;
+        u32x4 ka[4], va[4];
+        ka[0] = lds_b128_issue<0>(ad0 + so);       ka[1] = lds_b128_issue<0>(ad1 + so);
+        ka[2] = lds_b128_issue<2048>(ad0 + so);    ka[3] = lds_b128_issue<2048>(ad1 + so);
+        va[0] = lds_b128_issue<4096>(ad0 + so);    va[1] = lds_b128_issue<4096>(ad1 + so);
+        va[2] = lds_b128_issue<6144>(ad0 + so);    va[3] = lds_b128_issue<6144>(ad1 + so);
+        tr_wait();
+        const v8i32 k0 = {(int)ka[0][0], (int)ka[0][1], (int)ka[0][2], (int)ka[0][3], (int)ka[1][0], (int)ka[1][1], (int)ka[1][2], (int)ka[1][3]};
+        const v8i32 k1 = {(int)ka[2][0], (int)ka[2][1], (int)ka[2][2], (int)ka[2][3], (int)ka[3][0], (int)ka[3][1], (int)ka[3][2], (int)ka[3][3]};
+        const f32x16 z = {0};
+        const f32x16 s0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k0, qf8, z, 0, 0, 0, unit, 0, unit);
+        const f32x16 s1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k1, qf8, z, 0, 0, 0, unit, 0, unit);
+        float mx = fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s1[0], s1[1]));
+#pragma unroll
+        for (int i = 2; i < 16; i += 2) mx = fmaxf(fmaxf(fmaxf(mx, s0[i]), s0[i + 1]), fmaxf(s1[i], s1[i + 1]));
+        mx = half_max(mx) * c;
+        if (__any(mx > m)) {
+            const float mn = fmaxf(mx, m), alpha = __builtin_amdgcn_exp2f(m - mn);
+            m = mn;
+            l *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                o0[i] *= alpha;
+                o1[i] *= alpha;
+            }
+        }
+        const float off = 8.f - m;
+        float rs = 0.f;
+        v8i32 pf;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[4 * w], c, off)), a1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[4 * w + 1], c, off));
+            const float a2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[4 * w + 2], c, off)), a3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[4 * w + 3], c, off));
+            const float b0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[4 * w], c, off)), b1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[4 * w + 1], c, off));
+            const float b2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[4 * w + 2], c, off)), b3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[4 * w + 3], c, off));
+            rs += (a0 + a1) + (a2 + a3) + (b0 + b1) + (b2 + b3);
+            pf[w] = (int)f8_pack4(a0, a1, a2, a3);
+            pf[4 + w] = (int)f8_pack4(b0, b1, b2, b3);
+        }
+        l += rs;
+        const v8i32 v0 = {(int)va[0][0], (int)va[0][1], (int)va[0][2], (int)va[0][3], (int)va[1][0], (int)va[1][1], (int)va[1][2], (int)va[1][3]};
+        const v8i32 v1 = {(int)va[2][0], (int)va[2][1], (int)va[2][2], (int)va[2][3], (int)va[3][0], (int)va[3][1], (int)va[3][2], (int)va[3][3]};
+        o0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v0, pf, o0, 0, 0, 0, unit, 0, pscale);
+        o1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(v1, pf, o1, 0, 0, 0, unit, 0, pscale);
+    }
+    l = half_sum(l) * (1.f / 256.f);
+    if (q0 < n) {
+        E* orow0 = static_cast<E*>(p.o_w) + b * p.osb + (int64_t)q0 * p.osn + h * p.osh;
+        store_rows_staged<BF16>(smem + 3 * kF8Slot + wave * 4096, orow0, p.osn, n - q0, o0, o1, 1.f / l, lane);
+        if (qrow < n && g == 0) p.lse[(int64_t)(b * p.H + h) * n + qrow] = m * kLn2 + logf(l);
+    }
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static int check_common(int B, int n, int H, int d, int dtype) {
@@ -1894,6 +2090,40 @@ extern "C" int npcd_attn_fwd(const void* q, const void* k, const void* v, void* 
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == NPCD_BF16) hipLaunchKernelGGL(attn_fwd_kernel<BF16>, dim3(grid), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(attn_fwd_kernel<F16>, dim3(grid), dim3(256), 0, st, p);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+// fp8 forward (opt-in): workspace = the e4m3 copies of k and v^T
+static int fp8_nk(int n) { return (n & 63) == 1 && n > 64 ? n - 1 : n; }
+extern "C" int64_t npcd_attn_fwd_fp8_workspace_bytes(int B, int n, int H) {
+    if (B <= 0 || n <= 0 || H <= 0) return -1;
+    const int nk = fp8_nk(n);
+    if (nk % 64 != 0) return 0;              // length not covered: use npcd_attn_fwd
+    return (int64_t)B * H * 64 * 2 * (int64_t)nk;
+}
+extern "C" int npcd_attn_fwd_fp8(const void* q, const void* k, const void* v, void* out, float* lse, void* workspace, int B, int n, int H,
+                                 int d, int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                                 float scale, int dtype, void* stream) {
+    int rc = npcd::check_common(B, n, H, d, dtype);
+    if (rc != NPCD_OK) return rc;
+    if (dtype != NPCD_BF16) return NPCD_ERR_UNSUPPORTED;
+    const int nk = fp8_nk(n);
+    if (nk % 64 != 0) return NPCD_ERR_UNSUPPORTED;
+    if (!q || !k || !v || !out || !lse || !workspace) return NPCD_ERR_ARG;
+    if (!npcd::aligned16(q) || !npcd::aligned16(k) || !npcd::aligned16(v) || !npcd::aligned16(out) || !npcd::aligned16(workspace)) return NPCD_ERR_ARG;
+    if (!npcd::strides_ok(qkv_sb, qkv_sn, qkv_sh) || !npcd::strides_ok(out_sb, out_sn, out_sh)) return NPCD_ERR_ARG;
+    npcd::AttnParams p{};
+    p.q = q; p.k = k; p.v = v; p.o_w = out; p.lse = lse;
+    p.B = B; p.n = n; p.H = H;
+    p.sb = qkv_sb; p.sn = qkv_sn; p.sh = qkv_sh;
+    p.osb = out_sb; p.osn = out_sn; p.osh = out_sh;
+    p.scale = scale; p.scale_log2 = scale * npcd::kLog2e;
+    unsigned char* k8 = static_cast<unsigned char*>(workspace);
+    unsigned char* v8t = k8 + (int64_t)B * H * nk * 64;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(npcd::attn_fp8_pack_kernel, dim3(B * H * (nk / 64)), dim3(256), 0, st, p, k8, v8t, nk);
+    hipLaunchKernelGGL(npcd::attn_fwd_fp8_kernel, dim3(B * H * npcd::ceil_div(n, 128)), dim3(256), 0, st, p, k8, v8t, nk);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }

@@ -16,6 +16,16 @@ def _fwd(q, k, v, scale):
     out = torch.empty((B, n, H, d), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, H, n), dtype=torch.float32, device=q.device)
     assert q.stride() == k.stride() == v.stride() and q.stride(3) == 1
+    if FWD_FP8 and q.dtype == torch.bfloat16:
+        # opt-in: e4m3 operands on the block-scaled matrix instruction (csrc/attention.hip, attn_fwd_fp8_kernel); lengths it does not
+        # cover (0 bytes of workspace) fall through to the bf16 kernel
+        nbytes = lib().npcd_attn_fwd_fp8_workspace_bytes(B, n, H)
+        if nbytes > 0:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+            check(_timed("fwd", lambda: lib().npcd_attn_fwd_fp8(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(ws), B, n, H, d,
+                                                                q.stride(0), q.stride(1), q.stride(2), out.stride(0), out.stride(1),
+                                                                out.stride(2), scale, dtype_code(q), stream_ptr())), "npcd_attn_fwd_fp8")
+            return out, lse
     check(_timed("fwd", lambda: lib().npcd_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), B, n, H, d,
                                                     q.stride(0), q.stride(1), q.stride(2), out.stride(0), out.stride(1),
                                                     out.stride(2), scale, dtype_code(q), stream_ptr())), "npcd_attn_fwd")
@@ -43,6 +53,8 @@ import os
 
 # "fused": the single-pass backward (attn_bwd_fused_kernel, 5 products); "twopass": dq pass + dk/dv pass (7 products)
 BWD_MODE = os.environ.get("NPCD_ATTN_BWD", "twopass")
+# "1": the forward with fp8 (e4m3) operands (BASELINE configs[4] names fp8 attention); the backward stays on the bf16 kernels
+FWD_FP8 = os.environ.get("NPCD_ATTN_FP8", "") == "1"
 
 
 def _bwd(q, k, v, out, dout, lse, dq, dk, dv, scale):

@@ -36,6 +36,8 @@ def test_attention_backward_workspace_size():
     assert f(2, 129, 3) == 2 * 2 * 3 * 192 + 2 * 3 * 1 * 4 * 192
     assert f(2, 65, 3) == 2 * 2 * 3 * 128 and f(2, 1, 3) == 2 * 2 * 3 * 64          # seeded / too short: no edge scratch
     assert f(0, 513, 3) == -1
+    g = hip.lib().npcd_attn_fwd_fp8_workspace_bytes            # e4m3 k and v^T of the opt-in fp8 forward; 0 = length not covered
+    assert g(2, 513, 3) == 2 * 3 * 64 * 2 * 512 and g(2, 512, 3) == 2 * 3 * 64 * 2 * 512 and g(2, 100, 3) == 0 and g(2, 1, 3) == 0
 
 
 def test_no_cpu_fallback():
