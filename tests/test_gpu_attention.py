@@ -114,6 +114,21 @@ def test_attention_edge_token_extremes(n):
     assert torch.equal(a, b), "attention backward is not bitwise reproducible"
 
 
+@pytest.mark.parametrize("n", [129, 200, 513])
+def test_backward_passes_launched_separately_match_the_single_call(n, monkeypatch):
+    """npcd_attn_bwd_pass(1) then (2) -- what bench.py times -- against npcd_attn_bwd: the same kernels, bitwise equal gradients
+    (for 128 j + 1 tokens pass 2 also launches the kernel that finishes the last token's three rows from both passes' partials)."""
+    from npcd.hip import attention as A
+    gen = torch.Generator().manual_seed(n)
+    qkv = torch.randn(2, n, 3 * 2 * 64, generator=gen).bfloat16()
+    gout = torch.randn(2, n, 2 * 64, generator=gen).bfloat16()
+    one = run_hip(qkv, 2, gout)[1]
+    monkeypatch.setattr(A, "KERNEL_EVENTS", {t: [] for t in A.KERNEL_TAGS})
+    two = run_hip(qkv, 2, gout)[1]
+    assert len(A.KERNEL_EVENTS["dq"]) == 1 and len(A.KERNEL_EVENTS["dkdv"]) == 1
+    assert torch.equal(one, two)
+
+
 @pytest.mark.parametrize("n,B", [(128, 2), (513, 2), (2049, 1)])
 def test_attention_fp8_forward(n, B, monkeypatch):
     """Opt-in forward with e4m3 operands on the block-scaled matrix instruction (BASELINE configs[4]: 'fp8 MFMA attention';
