@@ -99,8 +99,23 @@ def bench_render(device, n_iters=100, burn_in=5):
             out = net.render(c, f, extr, intr, 128)
             P, Q = int(out["num_shading_points"]), int(out["num_pairs"])
             flops = Q * 2 * (95 * 256 + 3 * 256 * 256) + P * 2 * (256 * 256 * 6 + 256 + 3 * 256)   # as executed (last agg layer on points)
+            # the renderer's dominant kernels (shade_pairs_kernel + shade_points_kernel, f16 MFMA) on their own: HIP events on the
+            # launch stream around the one C call that enqueues both, 20 renders, against the dense f16 MFMA peak
+            from npcd.hip import render as hrender
+            hrender.SHADE_EVENTS = []
+            net.renderer.count_pairs = False
+            for _ in range(22):
+                net.render(c, f, extr, intr, 128)
+            torch.cuda.synchronize()
+            ev, hrender.SHADE_EVENTS = hrender.SHADE_EVENTS[2:], None
+            shade_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
             per_s[S] = {"rays_per_s": 128 * 128 / dt, "rays_per_s_8_views_per_call": 8 * 128 * 128 / dt8, "ms_per_view": dt * 1e3,
-                        "shading_points": P, "pairs": Q, "mlp_tflops_whole_view": flops / dt / 1e12}
+                        "shading_points": P, "pairs": Q, "mlp_tflops_whole_view": flops / dt / 1e12,
+                        "roofline_shading": {"kernel": "shade_pairs_kernel + shade_points_kernel (csrc/shade.hip)", "bound": "mfma",
+                                             "achieved": flops / (shade_ms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                             "frac": flops / (shade_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "avg_ms": shade_ms,
+                                             "algorithmic_flops_per_view": flops, "launches": len(ev),
+                                             "note": "f16 operands, fp32 accumulation (same dense peak as bf16); FLOPs as executed: the linear last aggregator layer on points, not pairs"}}
     r = dict(per_s[128])
     r.update({"timed_renders": n_iters, "resolution": 128, "depth_samples": 128, "k": 8,
               "depth_samples_64": per_s[64],

@@ -157,6 +157,11 @@ def pack_field_weights(state: dict, feat_dim: int, device, n_freqs: int = 10, hi
     return host.to(device)
 
 
+# When set to a list, the two shading kernels of every shade_points() call (shade_pairs_kernel + shade_points_kernel, one C call)
+# are bracketed by HIP events recorded on the launch stream (bench.py: per-kernel roofline of the renderer's dominant kernels).
+SHADE_EVENTS = None
+
+
 def shade_points(wpack: torch.Tensor, feat_dim: int, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch.Tensor,
                  kp_feat: torch.Tensor, n_points: Optional[torch.Tensor] = None, n_freqs: int = 10, hidden: int = 256):
     """nb_idx [P,k] int32 (global indices, -1 pad), pts [P,3], kp_pos [B*N,3], kp_feat [B*N,F] -> sigma [P], rgb [P,3]."""
@@ -174,8 +179,15 @@ def shade_points(wpack: torch.Tensor, feat_dim: int, nb_idx: torch.Tensor, pts: 
     L = lib()
     wsb = L.npcd_shade_workspace_bytes(P, hidden)
     work = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    ev = None
+    if SHADE_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     check(L.npcd_shade_points(ptr(wpack), feat_dim, n_freqs, hidden, ptr(nb_idx), ptr(pts), ptr(kp_pos), ptr(kp_feat),
                               ptr(n_points), P, k, ptr(sigma), ptr(rgb), ptr(work), stream_ptr()), "npcd_shade_points")
+    if ev is not None:
+        ev[1].record()
+        SHADE_EVENTS.append(ev)
     return sigma, rgb
 
 
