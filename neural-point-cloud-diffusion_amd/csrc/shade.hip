@@ -65,10 +65,13 @@ __host__ __device__ inline ShadeLayout shade_layout(int feat_dim) {
 // (the kernel is bound by vector-instruction issue, not by the matrix pipe).
 __device__ __forceinline__ int act_off(int row, int chunk) { return row * kRowBytes + (chunk << 4); }
 
-// One layer:  acc[oi][cb] (+)= W[(2*wave+oi)*32.., :] . H^T[:, cb*32..]   for oi in {0,1}, cb in 0..3
-template <int KSTEPS, int UNROLL = 4>
+// One layer:  acc[oi][cb] (+)= W[(2*wave+oi)*32.., :] . H^T[:, cb*32..]   for oi in {0,1}, cb in 0..NB-1.
+// NB (the number of 32-row blocks that hold packed rows) is a COMPILE-TIME parameter: as a run-time bound inside the k-loop it
+// split the loop body into one basic block per row block -- LDS read, wait, two matrix instructions, branch -- so that no read
+// was ever in flight behind a matrix instruction (round 2: the kernel ran at the latency of its LDS reads).
+template <int KSTEPS, int UNROLL = 4, int NB = 4>
 __device__ __forceinline__ void layer_mfma(const unsigned char* H, const unsigned char* wfrag, const float* bias, int wave, int lane,
-                                           f32x16 (&acc)[2][4], int nblk = 4) {
+                                           f32x16 (&acc)[2][4]) {
     const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int oi = 0; oi < 2; ++oi) {
@@ -81,7 +84,7 @@ __device__ __forceinline__ void layer_mfma(const unsigned char* H, const unsigne
             for (int b = 0; b < 4; ++b) init[4 * g + b] = b4[b];
         }
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[oi][cb] = init;
+        for (int cb = 0; cb < NB; ++cb) acc[oi][cb] = init;
     }
     const f16x8* w0 = reinterpret_cast<const f16x8*>(wfrag + (int64_t)(2 * wave) * KSTEPS * kFragBytes) + lane;
     const f16x8* w1 = reinterpret_cast<const f16x8*>(wfrag + (int64_t)(2 * wave + 1) * KSTEPS * kFragBytes) + lane;
@@ -90,17 +93,19 @@ __device__ __forceinline__ void layer_mfma(const unsigned char* H, const unsigne
 #pragma unroll UNROLL
     for (int s = 0; s < KSTEPS; ++s) {
         f16x8 n0 = a0, n1 = a1;
+#ifndef NPCD_DIAG_NO_WLOAD          // DIAGNOSTIC builds only (wrong results, timing): the layer loops without their weight loads
         if (s + 1 < KSTEPS) {
             n0 = w0[(s + 1) * 64];
             n1 = w1[(s + 1) * 64];
         }
+#endif
+        f16x8 b[NB];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-            if (cb < nblk) {                         // wave-uniform: 32-row blocks past the tile's packed rows are skipped
-                const f16x8 b = *reinterpret_cast<const f16x8*>(hb + cb * 32 * kRowBytes + s * 32);
-                acc[0][cb] = F16::mfma32(a0, b, acc[0][cb]);
-                acc[1][cb] = F16::mfma32(a1, b, acc[1][cb]);
-            }
+        for (int cb = 0; cb < NB; ++cb) b[cb] = *reinterpret_cast<const f16x8*>(hb + cb * 32 * kRowBytes + s * 32);
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {            // 32-row blocks past the tile's packed rows are skipped (NB < 4)
+            acc[0][cb] = F16::mfma32(a0, b[cb], acc[0][cb]);
+            acc[1][cb] = F16::mfma32(a1, b[cb], acc[1][cb]);
         }
         a0 = n0;
         a1 = n1;
@@ -108,8 +113,8 @@ __device__ __forceinline__ void layer_mfma(const unsigned char* H, const unsigne
 }
 
 // epilogue: optional LeakyReLU, convert to fp16, write back in place (4 consecutive channels = 8 bytes)
-template <bool ACT>
-__device__ __forceinline__ void layer_store(unsigned char* H, int wave, int lane, const f32x16 (&acc)[2][4], int nblk = 4) {
+template <bool ACT, int NB = 4>
+__device__ __forceinline__ void layer_store(unsigned char* H, int wave, int lane, const f32x16 (&acc)[2][4]) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     const int r = lane & 31, hh = lane >> 5;
@@ -117,10 +122,9 @@ __device__ __forceinline__ void layer_store(unsigned char* H, int wave, int lane
 #pragma unroll
     for (int oi = 0; oi < 2; ++oi)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < NB; ++cb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                if (cb >= nblk) continue;
                 u32x2 v;
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
@@ -167,9 +171,26 @@ __device__ long long g_shade_tl[64];
 #else
 #define NPCD_STS(i) do { } while (0)
 #endif
+// the four non-linear aggregator layers of one tile, activations in place in LDS (two barriers per layer)
+template <int FEAT, int NB>
+__device__ __forceinline__ void pair_layers(unsigned char* H, const ShadeArgs& a, const ShadeLayout& L, int wave, int lane) {
+    constexpr int K0 = FEAT + kEncBlock;
+    f32x16 acc[2][4];
+    layer_mfma<K0 / 16, K0 / 16, NB>(H, a.wpack + L.w[0], reinterpret_cast<const float*>(a.wpack + L.bias[0]), wave, lane, acc);
+    __syncthreads();
+    layer_store<true, NB>(H, wave, lane, acc);
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 1; l < 4; ++l) {
+        layer_mfma<kHidden / 16, kHidden / 16, NB>(H, a.wpack + L.w[l], reinterpret_cast<const float*>(a.wpack + L.bias[l]), wave, lane, acc);
+        __syncthreads();
+        layer_store<true, NB>(H, wave, lane, acc);
+        __syncthreads();
+    }
+}
+
 template <int FEAT>
 __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
-    constexpr int K0 = FEAT + kEncBlock;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
     unsigned char* H = dsmem;
     float* wrow = reinterpret_cast<float*>(dsmem + kRows * kRowBytes);  // [128] inverse distances of the packed rows
@@ -254,26 +275,13 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
         NPCD_STS(1);
         __syncthreads();
         NPCD_STS(2);
-        // ---- four non-linear layers ---------------------------------------------------------
-        f32x16 acc[2][4];
-        layer_mfma<K0 / 16, K0 / 16>(H, a.wpack + L.w[0], reinterpret_cast<const float*>(a.wpack + L.bias[0]), wave, lane, acc, nblk);
-        NPCD_STS(3);
-        __syncthreads();
-        NPCD_STS(4);
-        layer_store<true>(H, wave, lane, acc, nblk);
-        NPCD_STS(5);
-        __syncthreads();
-        NPCD_STS(6);
-#pragma unroll 1
-        for (int l = 1; l < 4; ++l) {
-            layer_mfma<kHidden / 16, kHidden / 16>(H, a.wpack + L.w[l], reinterpret_cast<const float*>(a.wpack + L.bias[l]), wave, lane, acc, nblk);
-            if (l == 1) NPCD_STS(7);
-            __syncthreads();
-            if (l == 1) NPCD_STS(8);
-            layer_store<true>(H, wave, lane, acc, nblk);
-            if (l == 1) NPCD_STS(9);
-            __syncthreads();
-            if (l == 1) NPCD_STS(10);
+        // ---- four non-linear layers (one instantiation per number of occupied 32-row blocks; nblk is workgroup-uniform) ----
+        switch (nblk) {
+            case 4: pair_layers<FEAT, 4>(H, a, L, wave, lane); break;
+            case 3: pair_layers<FEAT, 3>(H, a, L, wave, lane); break;
+            case 2: pair_layers<FEAT, 2>(H, a, L, wave, lane); break;
+            case 1: pair_layers<FEAT, 1>(H, a, L, wave, lane); break;
+            default: break;                                    // no valid pair in the tile
         }
         NPCD_STS(11);
         // ---- inverse-distance aggregation over the 8 neighbour slots ------------------------
