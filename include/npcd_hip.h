@@ -250,6 +250,11 @@ int npcd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* sha
                    float ema_decay, int zero_grad, void* stream);
 int npcd_cast_f32_bf16(const float* src, void* dst, int64_t numel, void* stream);
 
+/* out[i] = part[0 * numel + i] + ... + part[(S - 1) * numel + i], fp32, added in slice order (S = 2, 4 or 8; numel % 4 == 0;
+ * 16-byte aligned): the sum of the row-split weight-gradient partials of the fused backbone (replaces torch.sum(part, dim=0)
+ * there; the reference's nn.Linear weight gradient, summed over token slices). */
+int npcd_sum_slices(const float* part, float* out, int S, int64_t numel, void* stream);
+
 /* One DDPM reverse step of the sampler, fused (reference gaussian_diffusion.py:100-146: _predict_xstart_from_eps :127-129,
  * clamp :111-113, posterior mean :88-98, noise add :138-144):
  *   x0 = recip[t] x_t - recipm1[t] eps (clamped to [clip_lo, clip_hi] if has_clip); x_prev = coef1[t] x0 + coef2[t] x_t

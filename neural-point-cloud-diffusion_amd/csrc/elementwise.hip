@@ -464,6 +464,22 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const f32x4* __restrict_
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) dst[i] = f32_to_bf16x4(src[i]);
 }
 
+// out[i] = part[0][i] + part[1][i] + ... + part[S - 1][i] (fp32, added in slice order): the row-split weight-gradient GEMMs of the
+// fused backbone produce S partial [N, K] matrices.  All S loads of an element are issued before the first add; one 16-byte piece
+// per thread and iteration.  HBM-bound: (S + 1) x 4 bytes per element.
+template <int S>
+__global__ __launch_bounds__(256) void sum_slices_kernel(const f32x4* __restrict__ part, f32x4* __restrict__ out, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 v[S];
+#pragma unroll
+        for (int s2 = 0; s2 < S; ++s2) v[s2] = __builtin_nontemporal_load(part + s2 * n4 + i);
+        f32x4 acc = v[0];
+#pragma unroll
+        for (int s2 = 1; s2 < S; ++s2) acc += v[s2];
+        out[i] = acc;
+    }
+}
+
 // DDPM reverse step (gaussian_diffusion.py:100-146 of the reference): x0 = a x_t - b eps (clamped), mean = c1 x0 + c2 x_t,
 // x_{t-1} = mean + [t > 0] exp(logvar / 2) noise; the five per-sample coefficients are looked up from the 1000-entry tables.
 struct DdpmTables {
@@ -751,6 +767,21 @@ extern "C" int npcd_eps_mse_bwd(const float* noise, const void* eps, int eps_dty
     else
         hipLaunchKernelGGL(eps_mse_bwd_kernel<__bf16>, dim3(grid), dim3(256), 0, st, noise, static_cast<const __bf16*>(eps), upstream_dev,
                            1.f / (float)numel, static_cast<__bf16*>(grad), numel);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int npcd_sum_slices(const float* part, float* out, int S, int64_t numel, void* stream) {
+    if (!part || !out || numel <= 0) return NPCD_ERR_ARG;
+    if ((S != 2 && S != 4 && S != 8) || numel % 4 != 0 || !al16(part) || !al16(out)) return NPCD_ERR_UNSUPPORTED;
+    const int64_t n4 = numel / 4;
+    const int grid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(part);
+    f32x4* o4 = reinterpret_cast<f32x4*>(out);
+    if (S == 2) hipLaunchKernelGGL(sum_slices_kernel<2>, dim3(grid), dim3(256), 0, st, p4, o4, n4);
+    else if (S == 4) hipLaunchKernelGGL(sum_slices_kernel<4>, dim3(grid), dim3(256), 0, st, p4, o4, n4);
+    else hipLaunchKernelGGL(sum_slices_kernel<8>, dim3(grid), dim3(256), 0, st, p4, o4, n4);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }

@@ -131,6 +131,15 @@ def adamw_ema(p, g, m, v, ema, shadow, lr, beta1, beta2, eps, weight_decay, step
                                int(bool(zero_grad)), stream_ptr()), "npcd_adamw_ema")
 
 
+def sum_slices(part, out):
+    """out = part.sum(dim=0) for fp32 part [S, ...] (S in 2, 4, 8), slices added in order; False if the shape is not covered."""
+    S, n = part.shape[0], out.numel()
+    if S not in (2, 4, 8) or n % 4 or not part.is_contiguous() or not out.is_contiguous() or part.dtype != _f32 or out.dtype != _f32:
+        return False
+    check(lib().npcd_sum_slices(ptr(part), ptr(out), S, n, stream_ptr()), "npcd_sum_slices")
+    return True
+
+
 def cast_f32_bf16(src, dst):
     check(lib().npcd_cast_f32_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr()), "npcd_cast_f32_bf16")
     return dst

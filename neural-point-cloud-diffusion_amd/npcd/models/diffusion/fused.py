@@ -37,6 +37,7 @@ import os
 
 _SPLIT = 0 if os.environ.get("NPCD_NO_GEMM_SPLIT") else 256       # (the env switches exist for A/B measurements)
 _SPLIT_MIN = int(os.environ.get("NPCD_GEMM_SPLIT_MIN", "16000"))
+_SUM_KERNEL = not os.environ.get("NPCD_NO_SUM_KERNEL")          # the weight-gradient partials summed by csrc/elementwise.hip (A/B switch)
 
 
 def _split_gemm(fn, T):
@@ -88,7 +89,8 @@ def _wgrad(dy, x, out):
         torch.mm(dy.t(), x, out_dtype=_f32, out=out)
         return
     part = torch.bmm(dy.view(S, T // S, -1).transpose(1, 2), x.view(S, T // S, -1), out_dtype=_f32)
-    torch.sum(part, dim=0, out=out)
+    if not (_SUM_KERNEL and ew.sum_slices(part, out)):
+        torch.sum(part, dim=0, out=out)
 
 
 class FusedBackboneEngine:

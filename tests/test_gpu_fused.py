@@ -360,3 +360,18 @@ def test_fused_q_sample_and_eps_mse_match_reference_golden(golden):
         ((T(nz) - e3.float()) ** 2 / 2.0).mean().backward()
         assert abs(float(lb) - float(((T(nz) - eb.detach().float()) ** 2 / 2).mean())) < 1e-6 * float(lb)
         assert rel(eb.grad, e3.grad) < 4e-3 and eb.grad.dtype == torch.bfloat16
+
+
+@pytest.mark.parametrize("S", [2, 4, 8])
+def test_sum_slices_is_the_ordered_sum(S):
+    """csrc/elementwise.hip sum_slices_kernel (the weight-gradient partials of the row-split GEMMs): slices added in order, bitwise."""
+    from npcd.hip import elementwise as ew
+    g = torch.Generator().manual_seed(S)
+    part = torch.randn(S, 1024, 772, generator=g).cuda()
+    out = torch.empty(1024, 772, device="cuda")
+    assert ew.sum_slices(part, out)
+    ref = part[0].clone()
+    for s in range(1, S):
+        ref = ref + part[s]
+    assert torch.equal(out, ref)
+    assert not ew.sum_slices(part[:, :3, :5].contiguous(), torch.empty(3, 5, device="cuda"))             # numel % 4 != 0: declined
