@@ -6,6 +6,7 @@ load unchanged.  The attention operator is the gfx950 HIP ker
 (npcd.hip.attention); the Linear GEMMs run on hipBLASLt through torch.
 """
 import math
+import os
 from typing import Tuple
 
 import torch
@@ -13,6 +14,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ...hip.attention import attention_qkvpacked
+
+_NO_FAST_GLUE = bool(os.environ.get("NPCD_NO_FAST_GLUE"))       # A/B switch: the reference's expressions around the backbone as they are
 
 
 def timestep_embedding(t: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
@@ -123,6 +126,57 @@ class Transformer(nn.Module):
         return x
 
 
+class _TimeTokenCat(torch.autograd.Function):
+    """h = cat(temb[:, None], tokens) for bf16 tokens [B, N, W] = input_proj(x) on the GPU, carrying the BIAS GRADIENT of the
+    input projection: the Linear is called with its bias detached (same forward values: the library GEMM adds the bias to the fp32
+    accumulator), and this function returns the bias gradient from the fused backbone's column-sum kernel over the whole contiguous
+    dh minus the B time-token rows (25 us) -- torch reduces the [B, N, W] bf16 slice with a 360 us column reduction
+    (reference expression: transformer.py:246-248)."""
+
+    @staticmethod
+    def forward(ctx, temb, tokens, bias):
+        B, N, W = tokens.shape
+        h = torch.empty((B, N + 1, W), dtype=tokens.dtype, device=tokens.device)
+        h[:, 0] = temb
+        h[:, 1:] = tokens
+        ctx.bias_dtype = bias.dtype
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        from ...hip import elementwise as ew
+        dh = dh.contiguous()
+        B, n, W = dh.shape
+        db = torch.empty(W, dtype=torch.float32, device=dh.device)
+        ew.colsum_bf16(dh.view(B * n, W), db)
+        db -= dh[:, 0].float().sum(dim=0)
+        return dh[:, 0], dh[:, 1:], db.to(ctx.bias_dtype)
+
+
+class _LayerNormToBF16(torch.autograd.Function):
+    """ln_post on the fused backbone's LayerNorm kernels (csrc/elementwise.hip): fp32 statistics and normalisation like the
+    reference's fp32 nn.LayerNorm under autocast (transformer.py:249), the result rounded to bf16 once -- exactly what the
+    following Linear's autocast does to the fp32 output -- and a backward of 92 us instead of torch's 190 us pair of kernels."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        from ...hip import elementwise as ew
+        B, n, W = x.shape
+        x2 = x.reshape(B * n, W).contiguous()
+        _, y, mean, rstd = ew.add_ln_fwd(x2, None, gamma, beta, eps=eps)
+        ctx.save_for_backward(x2, mean, rstd, gamma)
+        return y.view(B, n, W)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ...hip import elementwise as ew
+        x2, mean, rstd, gamma = ctx.saved_tensors
+        B, n, W = dy.shape
+        dgamma, dbeta = torch.empty(W, dtype=torch.float32, device=dy.device), torch.empty(W, dtype=torch.float32, device=dy.device)
+        dx, _ = ew.ln_bwd(dy.reshape(B * n, W).contiguous(), x2, mean, rstd, gamma, None, dgamma, dbeta, want_bf16=False)
+        return dx.view(B, n, W), dgamma.to(gamma.dtype), dbeta.to(gamma.dtype), None
+
+
 class NPCDTransformer(nn.Module):
     """eps-prediction network: (coords [B,3,N], feats [B,F,N], t [B]) -> (eps_coords, eps_feats)."""
 
@@ -142,9 +196,21 @@ class NPCDTransformer(nn.Module):
         nn.init.zeros_(self.output_proj.bias)
 
     def forward(self, coords: torch.Tensor, feats: torch.Tensor, t: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-        tokens = self.input_proj(torch.cat((coords, feats), dim=1).transpose(1, 2))      # [B,N,W]
+        x = torch.cat((coords, feats), dim=1).transpose(1, 2)
         temb = self.time_embed(timestep_embedding(t, self.backbone.width))               # [B,W]
-        h = torch.cat((temb.unsqueeze(1).to(tokens.dtype), tokens), dim=1)               # time token first
-        h = self.ln_post(self.backbone(self.ln_pre(h)))
+        if (x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
+                and not _NO_FAST_GLUE):
+            tokens = F.linear(x, self.input_proj.weight, self.input_proj.bias.detach())  # [B,N,W] bf16; the bias gradient comes from _TimeTokenCat
+            h = _TimeTokenCat.apply(temb.to(tokens.dtype), tokens, self.input_proj.bias)
+        else:
+            tokens = self.input_proj(x)                                                  # [B,N,W]
+            h = torch.cat((temb.unsqueeze(1).to(tokens.dtype), tokens), dim=1)           # time token first
+        h = self.backbone(self.ln_pre(h))
+        W = h.shape[-1]
+        if (h.is_cuda and h.dtype == torch.float32 and torch.is_grad_enabled() and torch.is_autocast_enabled() and W % 4 == 0 and W <= 2048
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and self.ln_post.weight.dtype == torch.float32 and not _NO_FAST_GLUE):
+            h = _LayerNormToBF16.apply(h, self.ln_post.weight, self.ln_post.bias, self.ln_post.eps)
+        else:
+            h = self.ln_post(h)
         eps = self.output_proj(h[:, 1:]).transpose(1, 2)                                 # [B,C,N]
         return eps[:, :self.coords_dim], eps[:, self.coords_dim:]
