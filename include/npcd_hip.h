@@ -85,6 +85,20 @@ int npcd_attn_bwd(const void* q, const void* k, const void* v, const void* out, 
                   int64_t g_sb, int64_t g_sn, int64_t g_sh,
                   float scale, int dtype, void* stream);
 
+/* The backward with the COLUMN SUMS of the packed gradient as a by-product (the bias gradient of c_qkv; replaces the separate
+ * npcd_colsum_bf16 pass over dqkv in the fused backbone; reference: nn.Linear bias gradient of c_qkv, transformer.py:67-72).
+ * Only for the packed layout (dk = dq + 64 elements, dv = dq + 128, g_sh = 192).  passes: 1 = dq pass, 2 = dk/dv pass, 3 = both.
+ * colsum_part: fp32 [npcd_attn_bwd_colsum_rows(B, n, H) + npcd_colsum_scratch_rows(), 3 H 64]; every wave writes the sums of the
+ * ROUNDED rows it stores (fixed order); finish with npcd_colsum_finalize(colsum_part, rows, 3 H 64, out, ...).  Bitwise reproducible. */
+int npcd_attn_bwd_colsum_rows(int B, int n, int H);
+int npcd_attn_bwd_colsum(int passes, const void* q, const void* k, const void* v, const void* out, const void* dout,
+                         const float* lse, void* dq, void* dk, void* dv, float* delta, float* colsum_part,
+                         int B, int n, int H, int d,
+                         int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh,
+                         int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                         int64_t g_sb, int64_t g_sn, int64_t g_sh,
+                         float scale, int dtype, void* stream);
+
 /* One pass of the backward on its own: pass 1 = dq (also writes delta), pass 2 = dk/dv (reads delta,
  * so pass 1 must have run).  Same arguments as npcd_attn_bwd.  Lets a caller time / schedule the two
  * kernels separately. */

@@ -50,6 +50,9 @@ struct AttnParams {
     int64_t osb, osn, osh;  // out / dout strides
     int64_t gsb, gsn, gsh;  // dq/dk/dv strides
     float scale, scale_log2;
+    // optional by-product of the backward (npcd_attn_bwd_colsum): per-wave column sums of the stored dq / dk / dv rows, one fp32 row of
+    // 3 H 64 columns (the packed c_qkv order: h, {q, k, v}, d) per (batch, 128-row block, wave) [+ one per batch for the edge token]
+    float* colsum;
 };
 
 // Rows past the end of a sequence are CLAMPED to the last valid row instead of being predicated (the duplicated rows are
@@ -225,9 +228,10 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
 // instructions per matrix instead of 8, and whole cache lines (cdna_hip_programming.md, attention forward: 'O staged
 // through LDS and stored as whole rows').  `stage` must not be in use by any other wave; rows >= rows_valid are
 // not written.  The 16-byte chunk index is XOR-ed with the row so that the 8-byte writes spread over the banks.
+__device__ __forceinline__ float half_sum(float x);
 template <class TR>
 __device__ __forceinline__ void store_rows_staged(unsigned char* stage, typename TR::elem* row0_ptr, int64_t row_stride, int rows_valid,
-                                                  const f32x16& a0, const f32x16& a1, float mul, int lane) {
+                                                  const f32x16& a0, const f32x16& a1, float mul, int lane, float* colsum64 = nullptr) {
     const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -239,11 +243,33 @@ __device__ __forceinline__ void store_rows_staged(unsigned char* stage, typename
         *reinterpret_cast<u32x2*>(stage + r * 128 + (((g) ^ (r & 7)) << 4) + hh * 8) = x;        // elements 8g + 4hh ..
         *reinterpret_cast<u32x2*>(stage + r * 128 + (((4 + g) ^ (r & 7)) << 4) + hh * 8) = y;    // elements 32 + 8g + 4hh ..
     }
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = i * 8 + (lane >> 3);
         const u32x4 v = *reinterpret_cast<const u32x4*>(stage + row * 128 + (((lane & 7) ^ (row & 7)) << 4));
-        if (row < rows_valid) *reinterpret_cast<u32x4*>(row0_ptr + row * row_stride + (lane & 7) * 8) = v;
+        if (row < rows_valid) {
+            *reinterpret_cast<u32x4*>(row0_ptr + row * row_stride + (lane & 7) * 8) = v;
+            if (colsum64) {         // (wave-uniform pointer) the ROUNDED values, as a later column sum of the stored matrix would see them
+                const typename TR::vec8 e = __builtin_bit_cast(typename TR::vec8, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cs[j] += (float)e[j];
+            }
+        }
+    }
+    if (colsum64) {
+        // lanes with the same lane & 7 hold the same 8 columns for different rows: add over lane bits 3, 4, 5 (fixed order)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = cs[j];
+            x += __shfl_xor(x, 8);
+            x += __shfl_xor(x, 16);
+            cs[j] = half_sum(x);
+        }
+        if (lane < 8) {
+            *reinterpret_cast<f32x4*>(colsum64 + 8 * lane) = f32x4{cs[0], cs[1], cs[2], cs[3]};
+            *reinterpret_cast<f32x4*>(colsum64 + 8 * lane + 4) = f32x4{cs[4], cs[5], cs[6], cs[7]};
+        }
     }
 }
 
@@ -339,6 +365,14 @@ template <class E>
 __device__ __forceinline__ void row_bcast_issue(const E* row, int hh, u32x4 (&raw)[4]) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) raw[s] = gload16(row + 16 * s + 8 * hh);
+}
+
+// column-sum by-product (AttnParams::colsum): this wave's 64-float segment for matrix `which` (0 q, 1 k, 2 v) of head h
+__device__ __forceinline__ float* colsum_seg(const AttnParams& p, int64_t row_id, int h, int which) {
+    return p.colsum ? p.colsum + row_id * (3 * 64 * (int64_t)p.H) + h * 192 + which * 64 : nullptr;
+}
+__device__ __forceinline__ void colsum_zero(float* seg, int lane) {      // a wave without rows contributes zeros
+    if (seg && lane < 16) *reinterpret_cast<f32x4*>(seg + 4 * lane) = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // ---- the edge token of a sequence of 128 j + 1 tokens in the BACKWARD ---------------------------------------------------------
@@ -906,6 +940,7 @@ __global__ __launch_bounds__(256, NPCD_DQ_WAVES) void attn_bwd_dq_kernel(AttnPar
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (!wave_active) {      // wave-uniform: no query rows (ragged last query tile): keep the stream and the barriers going
+        colsum_zero(colsum_seg(p, ((int64_t)b * nqt + qt) * 4 + wave, h, 0), lane);
         kv_idle_loop<E>(smem, kb, vb, p.sn, nfull, nt, nk, wave, lane, dl);
         return;
     }
@@ -947,7 +982,7 @@ __global__ __launch_bounds__(256, NPCD_DQ_WAVES) void attn_bwd_dq_kernel(AttnPar
 #endif
     }
     E* grow0 = static_cast<E*>(p.dq) + b * p.gsb + (int64_t)q0 * p.gsn + h * p.gsh;
-    store_rows_staged<TR>(smem + wave * 4096, grow0, p.gsn, n - q0, dq0, dq1, p.scale, lane);
+    store_rows_staged<TR>(smem + wave * 4096, grow0, p.gsn, n - q0, dq0, dq1, p.scale, lane, colsum_seg(p, ((int64_t)b * nqt + qt) * 4 + wave, h, 0));
     if (edge && !NPCD_DIAG_NO_EDGE_REDUCE) {
         float* part = p.delta + 2 * (int64_t)p.B * p.H * (((n + 63) >> 6) << 6) + (((int64_t)bh * nqt + qt) * 4 + wave) * kEdgeFloats;
         unsigned char* scratch = smem + 16384 + wave * 8192;        // the wave's own image, read out by edge_reduce
@@ -1205,6 +1240,8 @@ __global__ __launch_bounds__(256, NPCD_DKDV_WAVES) void attn_bwd_dkdv_kernel(Att
         qs.stat_dst = 16384 + w2 * 256;
     }
     if (!wave_active) {      // wave-uniform: no keys in this wave (ragged last key block): keep the stream and the barriers going
+        colsum_zero(colsum_seg(p, ((int64_t)b * nkt + kt) * 4 + wave, h, 1), lane);
+        colsum_zero(colsum_seg(p, ((int64_t)b * nkt + kt) * 4 + wave, h, 2), lane);
         qdo_prefetch(dsmem, qs, 0, nq, wave, lane);
         if (nt > 1) qdo_prefetch(dsmem + kDkdvSlot, qs, 1, nq, wave, lane);
         if (nt > 1) NPCD_DMA_WAIT_BARRIER(5);
@@ -1325,8 +1362,8 @@ __global__ __launch_bounds__(256, NPCD_DKDV_WAVES) void attn_bwd_dkdv_kernel(Att
         unsigned char* stage = dsmem + (nt % 3) * kDkdvSlot + wave * 4096;
         E* gk = static_cast<E*>(p.dk) + b * p.gsb + (int64_t)key0 * p.gsn + h * p.gsh;
         E* gv = static_cast<E*>(p.dv) + b * p.gsb + (int64_t)key0 * p.gsn + h * p.gsh;
-        store_rows_staged<TR>(stage, gk, p.gsn, n - key0, a.dk0, a.dk1, p.scale, lane);
-        store_rows_staged<TR>(stage, gv, p.gsn, n - key0, a.dv0, a.dv1, 1.f, lane);
+        store_rows_staged<TR>(stage, gk, p.gsn, n - key0, a.dk0, a.dk1, p.scale, lane, colsum_seg(p, ((int64_t)b * nkt + kt) * 4 + wave, h, 1));
+        store_rows_staged<TR>(stage, gv, p.gsn, n - key0, a.dv0, a.dv1, 1.f, lane, colsum_seg(p, ((int64_t)b * nkt + kt) * 4 + wave, h, 2));
     }
     if (edge && !NPCD_DIAG_NO_EDGE_REDUCE) {
         float* part = p.delta + 2 * (int64_t)p.B * p.H * (((n + 63) >> 6) << 6) + (((int64_t)bh * nkt + kt) * 4 + wave) * kEdgeFloats;
@@ -2165,7 +2202,12 @@ __global__ __launch_bounds__(192) void attn_bwd_edge_kernel(AttnParams p) {
     const float pe = __builtin_amdgcn_exp2f(s * p.scale_log2 - p.lse[(int64_t)bh * p.n + last] * kLog2e), ds = pe * (dp - dl);
     acc += mat == 0 ? ds * qe : mat == 1 ? pe * doe : ds * ke;
     E* dst = static_cast<E*>(mat == 0 ? p.dk : mat == 1 ? p.dv : p.dq) + b * p.gsb + (int64_t)last * p.gsn + h * p.gsh + d;
-    *dst = (E)(mat == 1 ? acc : acc * p.scale);
+    const E r = (E)(mat == 1 ? acc : acc * p.scale);
+    *dst = r;
+    if (p.colsum) {      // the three rows as one more partial row per batch element (behind the per-wave rows)
+        const int which = mat == 0 ? 1 : mat == 1 ? 2 : 0;
+        p.colsum[((int64_t)p.B * (p.n >> 7) * 4 + b) * (3 * 64 * (int64_t)p.H) + h * 192 + which * 64 + d] = (float)r;
+    }
 }
 
 extern "C" int64_t npcd_attn_bwd_workspace_floats(int B, int n, int H) {
@@ -2173,10 +2215,15 @@ extern "C" int64_t npcd_attn_bwd_workspace_floats(int B, int n, int H) {
     return 2 * (int64_t)B * H * ((n + 63) / 64 * 64) + (edge_mode(n) ? (int64_t)B * H * (n >> 7) * 4 * kEdgeFloats : 0);
 }
 
+extern "C" int npcd_attn_bwd_colsum_rows(int B, int n, int H) {
+    if (B <= 0 || n <= 0 || H <= 0) return -1;
+    return npcd::edge_mode(n) ? B * ((n >> 7) * 4 + 1) : B * npcd::ceil_div(n, 128) * 4;
+}
+
 static int attn_bwd_launch(int passes, const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
                            void* dq, void* dk, void* dv, float* delta, int B, int n, int H, int d,
                            int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
-                           int64_t g_sb, int64_t g_sn, int64_t g_sh, float scale, int dtype, void* stream) {
+                           int64_t g_sb, int64_t g_sn, int64_t g_sh, float scale, int dtype, void* stream, float* colsum = nullptr) {
     int rc = check_common(B, n, H, d, dtype);
     if (rc != NPCD_OK) return rc;
     if (!q || !k || !v || !out || !dout || !lse || !delta) return NPCD_ERR_ARG;
@@ -2194,6 +2241,13 @@ static int attn_bwd_launch(int passes, const void* q, const void* k, const void*
     p.osb = out_sb; p.osn = out_sn; p.osh = out_sh;
     p.gsb = g_sb; p.gsn = g_sn; p.gsh = g_sh;
     p.scale = scale; p.scale_log2 = scale * kLog2e;
+    if (colsum) {       // only for the packed c_qkv gradient: [.., H, (dq | dk | dv) x 64]
+        const size_t es = 2;
+        if (g_sh != 192 || (dk && reinterpret_cast<const char*>(dk) != reinterpret_cast<const char*>(dq) + 64 * es) ||
+            (dv && reinterpret_cast<const char*>(dv) != reinterpret_cast<const char*>(dq) + 128 * es) || !aligned16(colsum))
+            return NPCD_ERR_ARG;
+        p.colsum = colsum;
+    }
     const bool edge = edge_mode(n);
     const int grid = B * H * (edge ? n >> 7 : ceil_div(n, 128));
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2257,6 +2311,17 @@ extern "C" int npcd_attn_bwd(const void* q, const void* k, const void* v, const 
                              int64_t g_sb, int64_t g_sn, int64_t g_sh, float scale, int dtype, void* stream) {
     return attn_bwd_launch(3, q, k, v, out, dout, lse, dq, dk, dv, delta, B, n, H, d, qkv_sb, qkv_sn, qkv_sh, out_sb, out_sn, out_sh,
                            g_sb, g_sn, g_sh, scale, dtype, stream);
+}
+
+// npcd_attn_bwd / npcd_attn_bwd_pass with the column sums of the packed gradient as a by-product: colsum_part [rows + scratch, 3 H 64]
+// fp32, rows = npcd_attn_bwd_colsum_rows(B, n, H) -- finished by npcd_colsum_finalize(colsum_part, rows, 3 H 64, bias_grad, ...).
+extern "C" int npcd_attn_bwd_colsum(int passes, const void* q, const void* k, const void* v, const void* out, const void* dout,
+                                    const float* lse, void* dq, void* dk, void* dv, float* delta, float* colsum_part, int B, int n, int H, int d,
+                                    int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                                    int64_t g_sb, int64_t g_sn, int64_t g_sh, float scale, int dtype, void* stream) {
+    if (passes < 1 || passes > 3 || !colsum_part || !dq) return NPCD_ERR_ARG;
+    return attn_bwd_launch(passes, q, k, v, out, dout, lse, dq, dk, dv, delta, B, n, H, d, qkv_sb, qkv_sn, qkv_sh, out_sb, out_sn, out_sh,
+                           g_sb, g_sn, g_sh, scale, dtype, stream, colsum_part);
 }
 
 extern "C" int npcd_attn_bwd_pass(int pass, const void* q, const void* k, const void* v, const void* out, const void* dout,

@@ -40,6 +40,8 @@ SIGNATURES = {
     "npcd_pair_aggregate": (c_int, [c_int, _P, _P, _P, _P, c_int, c_int64, _P, _P]),
     "npcd_attn_bwd": (c_int, [_P] * 10 + [c_int] * 4 + [c_int64] * 9 + [c_float, c_int, _P]),
     "npcd_attn_bwd_workspace_floats": (c_int64, [c_int, c_int, c_int]),
+    "npcd_attn_bwd_colsum_rows": (c_int, [c_int, c_int, c_int]),
+    "npcd_attn_bwd_colsum": (c_int, [c_int] + [_P] * 11 + [c_int] * 4 + [c_int64] * 9 + [c_float, c_int, _P]),
     "npcd_attn_fwd_fp8_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "npcd_attn_fwd_fp8": (c_int, [_P] * 6 + [c_int] * 4 + [c_int64] * 6 + [c_float, c_int, _P]),
     "npcd_attn_bwd_fused_slab_floats": (c_int64, [c_int, c_int, c_int]),

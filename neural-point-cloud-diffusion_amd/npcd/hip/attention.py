@@ -57,7 +57,17 @@ BWD_MODE = os.environ.get("NPCD_ATTN_BWD", "twopass")
 FWD_FP8 = os.environ.get("NPCD_ATTN_FP8", "") == "1"
 
 
-def _bwd(q, k, v, out, dout, lse, dq, dk, dv, scale):
+def colsum_part_for(dq):
+    """Partial buffer for the column-sum by-product of _bwd (dq: the [B, n, H, 64] view of a packed [B, n, H, 192] gradient):
+    (part [rows + scratch, 3 H 64] fp32, rows).  None in the single-pass mode."""
+    if BWD_MODE == "fused":
+        return None
+    B, n, H, d = dq.shape
+    rows = lib().npcd_attn_bwd_colsum_rows(B, n, H)
+    return torch.empty((rows + lib().npcd_colsum_scratch_rows(), 3 * H * d), dtype=torch.float32, device=dq.device), rows
+
+
+def _bwd(q, k, v, out, dout, lse, dq, dk, dv, scale, colsum_part=None):
     B, n, H, d = q.shape
     # row constants handed from pass 1 to pass 2 (+ the partial sums of the edge token's three gradient rows when n = 128 j + 1)
     delta = torch.empty(lib().npcd_attn_bwd_workspace_floats(B, n, H), dtype=torch.float32, device=q.device)
@@ -74,7 +84,14 @@ def _bwd(q, k, v, out, dout, lse, dq, dk, dv, scale):
             ptr(delta), B, n, H, d, q.stride(0), q.stride(1), q.stride(2),
             out.stride(0), out.stride(1), out.stride(2), dq.stride(0), dq.stride(1), dq.stride(2),
             scale, dtype_code(q), stream_ptr())
-    if KERNEL_EVENTS is None:
+    if colsum_part is not None:       # column sums of the packed gradient as a by-product (csrc/attention.hip, AttnParams::colsum)
+        cargs = args[:10] + (ptr(colsum_part),) + args[10:]
+        if KERNEL_EVENTS is None:
+            check(lib().npcd_attn_bwd_colsum(3, *cargs), "npcd_attn_bwd_colsum")
+        else:
+            check(_timed("dq", lambda: lib().npcd_attn_bwd_colsum(1, *cargs)), "npcd_attn_bwd_colsum(dq)")
+            check(_timed("dkdv", lambda: lib().npcd_attn_bwd_colsum(2, *cargs)), "npcd_attn_bwd_colsum(dkdv)")
+    elif KERNEL_EVENTS is None:
         check(lib().npcd_attn_bwd(*args), "npcd_attn_bwd")
     else:
         check(_timed("dq", lambda: lib().npcd_attn_bwd_pass(1, *args)), "npcd_attn_bwd_pass(dq)")

@@ -37,6 +37,7 @@ import os
 
 _SPLIT = 0 if os.environ.get("NPCD_NO_GEMM_SPLIT") else 256       # (the env switches exist for A/B measurements)
 _SPLIT_MIN = int(os.environ.get("NPCD_GEMM_SPLIT_MIN", "16000"))
+_ATTN_COLSUM = not os.environ.get("NPCD_NO_ATTN_COLSUM")      # c_qkv bias gradient from the attention backward itself (A/B switch)
 _SUM_KERNEL = not os.environ.get("NPCD_NO_SUM_KERNEL")          # the weight-gradient partials summed by csrc/elementwise.hip (A/B switch)
 
 
@@ -253,10 +254,15 @@ class _BackboneFn(torch.autograd.Function):
                 _wgrad(dx2b, a, e["attn_c_proj_weight_g"])
                 dqkv = torch.empty_like(qkv)
                 q4, g4 = qkv.view(B, n, H, 3 * d), dqkv.view(B, n, H, 3 * d)
+                # the c_qkv bias gradient (column sums of dqkv) is a by-product of the attention backward's row stores
+                cpart = hattn.colsum_part_for(g4[..., :d]) if _ATTN_COLSUM else None
                 hattn._bwd(q4[..., :d], q4[..., d:2 * d], q4[..., 2 * d:], a.view(B, n, H, d), da.view(B, n, H, d), lse,
-                           g4[..., :d], g4[..., d:2 * d], g4[..., 2 * d:], scale)
+                           g4[..., :d], g4[..., d:2 * d], g4[..., 2 * d:], scale, colsum_part=cpart[0] if cpart else None)
                 del da, a, qkv, dx2b
-                ew.colsum_bf16(dqkv, e["attn_c_qkv_bias_g"], batch=sums)
+                if cpart:
+                    sums.add(cpart[0], cpart[1], 3 * W, e["attn_c_qkv_bias_g"])
+                else:
+                    ew.colsum_bf16(dqkv, e["attn_c_qkv_bias_g"], batch=sums)
                 dy1 = _dgrad(dqkv, e["attn_c_qkv_weight_16"])
                 _wgrad(dqkv, y1, e["attn_c_qkv_weight_g"])
                 del dqkv, y1

@@ -129,6 +129,33 @@ def test_backward_passes_launched_separately_match_the_single_call(n, monkeypatc
     assert torch.equal(one, two)
 
 
+@pytest.mark.parametrize("n", [40, 129, 200, 513])
+def test_backward_column_sums_by_product(n):
+    """npcd_attn_bwd_colsum: the column sums of the packed dqkv (the c_qkv bias gradient) from the backward's own row stores --
+    against the sum of the stored bf16 gradient (fp32 accumulation; order differs: 1e-5 of the column's absolute sum) and with
+    gradients bitwise equal to the plain call; ragged blocks (waves without rows) and the edge token's rows included."""
+    from npcd.hip import attention as A
+    from npcd.hip import elementwise as ew
+    B, H, d = 3, 2, 64
+    gen = torch.Generator().manual_seed(n)
+    qkv = torch.randn(B, n, H, 3 * d, generator=gen).bfloat16().cuda()
+    dout = torch.randn(B, n, H, d, generator=gen).bfloat16().cuda()
+    q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    out, lse = A._fwd(q, k, v, 0.125)
+    g0, g1 = torch.zeros_like(qkv), torch.zeros_like(qkv)
+    A._bwd(q, k, v, out, dout, lse, g0[..., :d], g0[..., d:2 * d], g0[..., 2 * d:], 0.125)
+    part, rows = A.colsum_part_for(g1[..., :d])
+    part.fill_(float("nan"))                         # every partial row must be written
+    A._bwd(q, k, v, out, dout, lse, g1[..., :d], g1[..., d:2 * d], g1[..., 2 * d:], 0.125, colsum_part=part)
+    assert torch.equal(g0, g1)
+    got = torch.empty(3 * H * d, device="cuda")
+    ew._finish(None, part, rows, 3 * H * d, got)
+    flat = g1.float().view(B * n, 3 * H * d)
+    want, scale_ = flat.sum(0), flat.abs().sum(0)
+    assert torch.isfinite(got).all()
+    assert float(((got - want).abs() / scale_.clamp_min(1e-6)).max()) < 1e-5
+
+
 @pytest.mark.parametrize("n,B", [(128, 2), (513, 2), (2049, 1)])
 def test_attention_fp8_forward(n, B, monkeypatch):
     """Opt-in forward with e4m3 operands on the block-scaled matrix instruction (BASELINE configs[4]: 'fp8 MFMA attention';
