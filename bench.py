@@ -415,7 +415,7 @@ def main():
         "bound": "mfma", "achieved": bwd_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": bwd_tf / PEAK_BF16_TFLOPS,
         "traffic": traffic, "traffic_source": f"profiles/{tname} (rocprofv3 --pmc, bytes per launch, summed over the kernels)" if traffic else None,
         "basis": "ALGORITHMIC FLOPs, SURVEY 8(d): backward = 5 products = 5 U, U = 2 B H n^2 d; recomputed products are not credited; "
-                 "the timed kernels also produce the c_qkv bias gradient (column sums of dq / dk / dv from their row stores, ~11 us of avg_ms, "
+                 "the timed kernels also produce the c_qkv bias gradient (column sums of dq / dk / dv from their row stores, ~6 us of avg_ms, "
                  "instead of a separate 46 us pass over dqkv)",
         "algorithmic_flops_per_launch": 5 * U, "avg_ms": bwd_ms, "launches": len(events[bwd_tags[0]]),
         "executed_flops_per_launch": sum(executed[k] for k in bwd_tags),

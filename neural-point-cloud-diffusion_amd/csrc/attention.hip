@@ -259,11 +259,13 @@ __device__ __forceinline__ void store_rows_staged(unsigned char* stage, typename
     }
     if (colsum64) {
         // lanes with the same lane & 7 hold the same 8 columns for different rows: add over lane bits 3, 4, 5 (fixed order)
+        // on the vector ALU, no LDS crossbar: DPP row rotation by 8, v_permlane16_swap, v_permlane32_swap
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float x = cs[j];
-            x += __shfl_xor(x, 8);
-            x += __shfl_xor(x, 16);
+            x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+            const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+            x = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
             cs[j] = half_sum(x);
         }
         if (lane < 8) {
