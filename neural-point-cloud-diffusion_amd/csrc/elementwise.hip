@@ -21,10 +21,23 @@ namespace npcd {
 
 constexpr int kMaxChunks = 8;  // a wave covers 256 columns per chunk -> width <= 2048
 
+// sum over the 64 lanes, on every lane, entirely on the vector ALU: four DPP row rotations (16-lane rows), v_permlane16_swap,
+// v_permlane32_swap -- no ds_bpermute (LDS crossbar) round trips.  Fixed order: bitwise reproducible.
 __device__ __forceinline__ float wave_sum(float x) {
+#ifdef NPCD_WAVE_SUM_BPERMUTE       // the previous form (A/B builds)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
     return x;
+#else
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122 /* row_ror:2 */, 0xf, 0xf, false));
+    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+#endif
 }
 __device__ __forceinline__ f32x4 bf16x4_to_f32(bf16x4 v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
 __device__ __forceinline__ bf16x4 f32_to_bf16x4(f32x4 v) { return bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; }
