@@ -397,9 +397,6 @@ __device__ __forceinline__ void colsum_zero(float* seg, int lane) {      // a wa
 #ifndef NPCD_DIAG_NO_EDGE_REDUCE
 #define NPCD_DIAG_NO_EDGE_REDUCE 0
 #endif
-#ifndef NPCD_DIAG_EDGE_LEVEL
-#define NPCD_DIAG_EDGE_LEVEL 3
-#endif
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 constexpr int kEdgeFloats = 192;       // [dK_E | dV_E | dQ_E] x 64
 __host__ __device__ inline bool edge_mode(int n) { return NPCD_SEED_TAIL && NPCD_EDGE_TOKEN && (n & 127) == 1 && n > 128; }
@@ -978,26 +975,18 @@ __global__ __launch_bounds__(256, NPCD_DQ_WAVES) void attn_bwd_dq_kernel(AttnPar
         edge_put_rows(fa, img, qf);
         edge_put_rows(fa, img + 4096, dof);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if NPCD_DIAG_EDGE_LEVEL >= 2
         edge_reduce<TR>(fa, img, wa, hh, k0, k1);
         edge_reduce<TR>(fa, img + 4096, wa + 64, hh, v0, v1);
-#endif
     }
     E* grow0 = static_cast<E*>(p.dq) + b * p.gsb + (int64_t)q0 * p.gsn + h * p.gsh;
     store_rows_staged<TR>(smem + wave * 4096, grow0, p.gsn, n - q0, dq0, dq1, p.scale, lane, colsum_seg(p, ((int64_t)b * nqt + qt) * 4 + wave, h, 0));
     if (edge && !NPCD_DIAG_NO_EDGE_REDUCE) {
         float* part = p.delta + 2 * (int64_t)p.B * p.H * (((n + 63) >> 6) << 6) + (((int64_t)bh * nqt + qt) * 4 + wave) * kEdgeFloats;
         unsigned char* scratch = smem + 16384 + wave * 8192;        // the wave's own image, read out by edge_reduce
-#if NPCD_DIAG_EDGE_LEVEL >= 3
         edge_stage(scratch, lane, k0, k1);
         edge_stage(scratch + 256, lane, v0, v1);
-#else
-        asm volatile("" ::"v"(k0), "v"(k1), "v"(v0), "v"(v1));
-#endif
-#ifndef NPCD_DIAG_NO_EDGE_STORE
         typedef float f32x2v __attribute__((ext_vector_type(2)));
         reinterpret_cast<f32x2v*>(part)[lane] = reinterpret_cast<const f32x2v*>(scratch)[lane];
-#endif
     }
 }
 
@@ -1371,9 +1360,7 @@ __global__ __launch_bounds__(256, NPCD_DKDV_WAVES) void attn_bwd_dkdv_kernel(Att
         float* part = p.delta + 2 * (int64_t)p.B * p.H * (((n + 63) >> 6) << 6) + (((int64_t)bh * nkt + kt) * 4 + wave) * kEdgeFloats;
         unsigned char* scratch = dsmem + ((nt + 1) % 3) * kDkdvSlot + wave * 4096;      // the wave's own image, read out by edge_reduce
         edge_stage(scratch, lane, eq0, eq1);
-#ifndef NPCD_DIAG_NO_EDGE_STORE
         part[128 + lane] = reinterpret_cast<const float*>(scratch)[lane];
-#endif
     }
 #ifdef NPCD_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
