@@ -82,8 +82,11 @@ def _wgrad(dy, x, out):
     kernels of the critical path -- 84.39 -> 84.14 ms per step on the same box, i.e. nothing: the GEMM's workgroups hold
     every CU and the other stream's kernels are dispatched as they drain.)"""
     T = dy.shape[0]
-    S = 8 if out.numel() <= (1 << 20) else 4
-    S = min(S, max(1, T // 4096))          # keep >= 4096 rows per slice: short reductions need no split
+    small = out.numel() <= (1 << 20)
+    S = 8 if small else 4
+    # keep >= 4096 rows per slice (2048 for the 1024 x 1024 output, 16 tiles: tools/gpu_dev_wgrad_split.py at T = 4104 / 8208): short
+    # reductions need no split
+    S = min(S, max(1, T // (2048 if small else 4096)))
     while S > 1 and T % S:
         S //= 2
     if S == 1:
