@@ -65,9 +65,19 @@ class HipVoxelGrid:
         self.vsize_tup = tuple(float(v) for v in voxel_size)
         self.points: Optional[torch.Tensor] = None
         self.workspace: Optional[torch.Tensor] = None
+        self._built_from = None          # (tensor sharing the storage the grid was built from, its version, geometry)
 
     def set_pointset(self, points: torch.Tensor, counts: Optional[torch.Tensor] = None):
+        """Build the grid's device-side state for a batch of clouds.  Rendering many views of the same cloud (the evaluation
+        protocol: 251 views per object) calls this once per view with the same, unmodified tensor: the build (16 us, 4 % of a 128^2
+        view) is skipped when the storage, its version counter and the view geometry are the ones of the last build and every
+        cloud is complete (counts None).  The cache holds a reference to that storage, so its address cannot be reused."""
         require_gpu(points)
+        key = (points._version, points.storage_offset(), tuple(points.shape), tuple(points.stride()), points.dtype, points.device)
+        if (counts is None and self._built_from is not None and self._built_from[1] == key
+                and self._built_from[0].untyped_storage().data_ptr() == points.untyped_storage().data_ptr()):
+            return
+        self._built_from = None
         pts = points.detach().to(_f32).contiguous()
         B, N, _ = pts.shape
         nbytes = lib().npcd_grid_workspace_bytes(ctypes.byref(self.params), B, N)
@@ -79,6 +89,8 @@ class HipVoxelGrid:
         check(lib().npcd_grid_build(ctypes.byref(self.params), ptr(pts), ptr(cnt), B, N, ptr(self.workspace), stream_ptr()),
               "npcd_grid_build")
         self.points = pts
+        if counts is None:
+            self._built_from = (points.detach(), key)
 
     def query_dense(self, k: int, r: float, M: int, *, x: Optional[torch.Tensor] = None, rays=None, S: Optional[int] = None,
                     mode: int = 0, points: Optional[torch.Tensor] = None):

@@ -69,9 +69,13 @@ class PointNeRF(nn.Module):
         return w.reshape(w.shape[0], self.opt.model.kp.num, F_)
 
     def _set_pointset(self, coords):
-        B = coords.shape[0]
-        counts = torch.full((B,), self.opt.model.kp.num, device=coords.device, dtype=torch.int)
-        self.voxel_grid.set_pointset(coords.detach(), counts)
+        # every cloud holds all of its kp.num points (the reference passes that count per example, pointnerf.py:67): the HIP grid
+        # takes "no counts" as exactly that, and can then recognise an unchanged cloud from one view to the next
+        if coords.shape[1] != self.opt.model.kp.num:
+            counts = torch.full((coords.shape[0],), self.opt.model.kp.num, device=coords.device, dtype=torch.int)
+            self.voxel_grid.set_pointset(coords.detach(), counts)
+        else:
+            self.voxel_grid.set_pointset(coords.detach())
 
     def forward(self, obj_idx, intrinsics, extrinsics, sample_rays: bool, rng=None):
         """reference pointnerf.py:56-105 -> (pred AttrDict, aux dict).  `rng` (tests) replays given random draws:

@@ -413,3 +413,44 @@ def test_evaluation_protocol_counterpart():
     assert len(out["views"]) == 10 and out["psnr"] > 50.0
     timed = [r for r in out["views"] if r["runtime_model_in_msec"] == r["runtime_model_in_msec"]]
     assert len(timed) == 4 and all(r["sample"] >= 3 for r in timed) and out["runtime_model_in_msec"] > 0
+
+
+def test_grid_build_is_skipped_for_an_unchanged_cloud_and_redone_after_a_write():
+    """HipVoxelGrid.set_pointset recognises the cloud of the previous call (same storage, same version counter, same geometry) and
+    does not rebuild; an in-place write bumps the version counter and the grid follows.  Results are those of a fresh grid."""
+    from npcd.hip import render as hrender
+    coords, feats, extr, intr = _scene(32, 1, 512, 32, seed=3)
+    p = orr.init_field_params(32, seed=0)
+    for kname in p:
+        if "shape_net.2" in kname:
+            p[kname] = p[kname] * 8 + 1.0
+    m = _model(32, 512, p)
+    c, f, e, k = coords.cuda(), feats.cuda(), extr.cuda(), intr.cuda()
+    builds = []
+
+    class CountingLib:                                         # the library with npcd_grid_build counted
+        def __init__(self, L):
+            self._L = L
+
+        def __getattr__(self, name):
+            fn = getattr(self._L, name)
+            if name != "npcd_grid_build":
+                return fn
+            return lambda *args: (builds.append(1), fn(*args))[1]
+
+    orig, proxy = hrender.lib, CountingLib(hrender.lib())
+    hrender.lib = lambda: proxy
+    try:
+        with torch.no_grad():
+            a = m.render(c, f, e, k, 32)
+            b = m.render(c, f, e, k, 32)                      # same cloud: no second build
+            assert len(builds) == 1 and torch.equal(a["channels"], b["channels"])
+            c.mul_(0.9)                                        # in-place write -> version bump -> rebuild
+            d = m.render(c, f, e, k, 32)
+            assert len(builds) == 2
+    finally:
+        hrender.lib = orig
+    m2 = _model(32, 512, p)                                    # a fresh grid on the modified cloud
+    with torch.no_grad():
+        d2 = m2.render(c.clone(), f, e, k, 32)
+    assert torch.equal(d["channels"], d2["channels"]) and not torch.equal(a["channels"], d["channels"])
