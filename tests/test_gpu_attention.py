@@ -129,7 +129,7 @@ def test_backward_passes_launched_separately_match_the_single_call(n, monkeypatc
     assert torch.equal(one, two)
 
 
-@pytest.mark.parametrize("n", [40, 129, 200, 513])
+@pytest.mark.parametrize("n", [40, 65, 129, 193, 200, 513])
 def test_backward_column_sums_by_product(n):
     """npcd_attn_bwd_colsum: the column sums of the packed dqkv (the c_qkv bias gradient) from the backward's own row stores --
     against the sum of the stored bf16 gradient (fp32 accumulation; order differs: 1e-5 of the column's absolute sum) and with
