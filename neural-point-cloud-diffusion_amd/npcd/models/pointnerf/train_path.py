@@ -42,6 +42,9 @@ def positional_encoding(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
     return torch.cat((x, torch.cat((spec.sin(), spec.cos()), dim=-1).flatten(start_dim=-2)), dim=-1)
 
 
+_ROWSPLIT_MIN = int(os.environ.get("NPCD_ROWSPLIT_MIN", "32768"))      # rows from which a Linear layer takes the row-split weight gradient
+
+
 class _RowSplitLinear(torch.autograd.Function):
     """y = x W^T + b for x of ~10^6 rows and a few hundred columns.  The forward and the data gradient are plain library GEMMs;
     the WEIGHT gradient dW = dy^T x reduces over the ~10^6 rows into a 256 x 256 output, which the library runs on 16 tiles
@@ -82,7 +85,12 @@ class _RowSplitLinear(torch.autograd.Function):
         S = rows // c
         f32 = torch.float32
         mixed = xx.dtype != f32
-        if S >= 2:
+        if dy.shape[1] < 16 and mixed:
+            # the heads' last layers (256 -> 1, 256 -> 3): the library's fp32-output GEMM with a handful of output rows spends
+            # 10-400 ms per call on the HOST (tools/gpu_dev_stage1_hosttrace.py); bf16 output (fp32 accumulation inside), which
+            # is what the reference's autocast computes for every weight gradient
+            dw = torch.mm(dy.t(), xx).float()
+        elif S >= 2:
             head, tail = S * c, rows > S * c
             part = torch.empty((S + int(tail), dy.shape[1], xx.shape[1]), dtype=f32, device=dy.device)
             a, b = dy[:head].view(S, c, -1).transpose(1, 2), xx[:head].view(S, c, -1)
@@ -104,10 +112,12 @@ class _RowSplitLinear(torch.autograd.Function):
 
 
 def _mlp(seq, x, dtype):
-    """nn.Sequential of Linear / LeakyReLU (utils/model.py:22-36).  With several hundred thousand rows (the per-pair network) the
-    Linear layers run as _RowSplitLinear; below that the plain modules (under autocast for the bf16 opt-in) -- the step is
-    bound by launch count on the host, and the split costs three more launches per layer."""
-    if x.shape[0] < 262144:          # (measured: lower thresholds gain nothing in fp32 and cost 10 ms per step in the bf16 mode)
+    """nn.Sequential of Linear / LeakyReLU (utils/model.py:22-36).  From a few ten thousand rows on (the per-pair network, and the
+    point-level layers of a training batch: ~2 x 10^5 shading points) the Linear layers run as _RowSplitLinear; below that the
+    plain modules (under autocast for the bf16 opt-in).  (Round 1 had the threshold at 262,144 rows because lower values cost
+    10 ms per step in the bf16 mode: that was the library's fp32-output GEMM for the heads' 1- and 3-row weight gradients, see
+    _RowSplitLinear.backward; with those on the bf16-output path the point-level layers gain 1.1 ms of a 9.7 ms step.)"""
+    if x.shape[0] < _ROWSPLIT_MIN:
         with torch.autocast("cuda", dtype=dtype or torch.bfloat16, enabled=dtype is not None):
             return seq(x)
     mods, i = list(seq), 0
