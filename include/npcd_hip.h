@@ -257,6 +257,12 @@ int npcd_gelu_fwd(const void* h, void* g, int64_t numel, void* stream);
 int npcd_colsum_blocks(int T);
 int npcd_gelu_bwd(const void* dg, const void* h, void* dh, float* part, int T, int N, void* stream);
 int npcd_colsum_bf16(const void* a, float* part, int T, int N, void* stream);
+/* Weight gradient of a Linear layer with J <= 4 outputs (the PointNeRF field's heads: fields/mlp.py:38-72, last layers 256 -> 1 and
+ * 256 -> 3) over T rows: part [npcd_small_wgrad_blocks(T) + npcd_colsum_scratch_rows(), J * K] fp32 partial sums of
+ * dW[j][k] = sum_p dy[p][j] x[p][k] (dy [T, J], x [T, K] bf16 row-major, K a power of two in 64..2048); finish with
+ * npcd_colsum_finalize(part, blocks, J * K, dW, ...).  Replaces the library GEMM (350 us for one workgroup's worth of work). */
+int npcd_small_wgrad_blocks(int T);
+int npcd_small_wgrad(const void* dy, const void* x, float* part, int T, int J, int K, void* stream);
 /* AdamW (torch semantics) + EMA lerp + bf16 shadow copy + optional gradient zeroing, one pass.
  * ema and shadow_bf16 may be NULL; step is the 1-based step count (bias correction). */
 int npcd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* shadow_bf16, int64_t numel,

@@ -416,6 +416,45 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
 }
 
+// Weight gradient of a Linear layer with a HANDFUL of outputs (the heads' last layers of the PointNeRF field: 256 -> 1, 256 -> 3):
+// dW[j][k] = sum_p dy[p][j] x[p][k], J <= 4 rows.  As a GEMM this is 1-3 output rows for ~2 x 10^5 reduction steps and the
+// library spends 350 us on one workgroup; it is one pass over x: 256 threads = (rows of a band) x (16-byte column chunks), fp32
+// sums per thread, the row lanes added through LDS, one partial row of J K sums per workgroup, finished by the column-sum
+// finalisation (fixed order).  bf16 operands, fp32 accumulation and output.
+template <int J>
+__global__ __launch_bounds__(256) void small_wgrad_kernel(const __bf16* __restrict__ dy, const __bf16* __restrict__ x, float* __restrict__ part,
+                                                          int T, int K, int rows_per_block) {
+    extern __shared__ float swg_red[];                      // [row lanes][J][K]
+    const int chunks = K >> 3, lanes = 256 / chunks;
+    const int cc = threadIdx.x % chunks, rl = threadIdx.x / chunks;
+    const int row0 = blockIdx.x * rows_per_block, row1 = min(T, row0 + rows_per_block);
+    float acc[J][8];
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+    for (int row = row0 + rl; row < row1; row += lanes) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + (int64_t)row * K + 8 * cc);
+        float w[J];
+#pragma unroll
+        for (int j = 0; j < J; ++j) w[j] = (float)dy[(int64_t)row * J + j];
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[j][i] = __builtin_fmaf(w[j], (float)v[i], acc[j][i]);
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) swg_red[(rl * J + j) * K + 8 * cc + i] = acc[j][i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < J * K; e += 256) {
+        float sum = 0.f;
+        for (int r2 = 0; r2 < lanes; ++r2) sum += swg_red[r2 * J * K + e];       // row lanes in order
+        part[(int64_t)blockIdx.x * J * K + e] = sum;
+    }
+}
+
 // ============================================================================================
 // AdamW (torch.optim.AdamW semantics, amsgrad=False, maximize=False) + EMA + bf16 shadow + grad zeroing
 //   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
@@ -643,6 +682,26 @@ extern "C" int npcd_colsum_bf16(const void* a, float* part, int T, int N, void* 
     dim3 grid((N / 8 + 255) / 256, npcd_colsum_blocks(T));
     hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const __bf16*>(a),
                        static_cast<const __bf16*>(nullptr), static_cast<__bf16*>(nullptr), part, T, N, col_rows(T));
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int npcd_small_wgrad_blocks(int T) { return T <= 0 ? -1 : (T + 255) / 256 < 1024 ? (T + 255) / 256 : 1024; }
+
+extern "C" int npcd_small_wgrad(const void* dy, const void* x, float* part, int T, int J, int K, void* stream) {
+    if (!dy || !x || !part || T <= 0) return NPCD_ERR_ARG;
+    if (J < 1 || J > 4 || K < 64 || K > 2048 || (K & (K - 1)) || !al16(x) || !al16(part)) return NPCD_ERR_UNSUPPORTED;
+    const int nblk = npcd_small_wgrad_blocks(T), rpb = (T + nblk - 1) / nblk;
+    const size_t lds = (size_t)(256 / (K / 8)) * J * K * sizeof(float);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const __bf16* d = static_cast<const __bf16*>(dy);
+    const __bf16* xx = static_cast<const __bf16*>(x);
+    switch (J) {
+        case 1: hipLaunchKernelGGL(small_wgrad_kernel<1>, dim3(nblk), dim3(256), lds, st, d, xx, part, T, K, rpb); break;
+        case 2: hipLaunchKernelGGL(small_wgrad_kernel<2>, dim3(nblk), dim3(256), lds, st, d, xx, part, T, K, rpb); break;
+        case 3: hipLaunchKernelGGL(small_wgrad_kernel<3>, dim3(nblk), dim3(256), lds, st, d, xx, part, T, K, rpb); break;
+        default: hipLaunchKernelGGL(small_wgrad_kernel<4>, dim3(nblk), dim3(256), lds, st, d, xx, part, T, K, rpb); break;
+    }
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }

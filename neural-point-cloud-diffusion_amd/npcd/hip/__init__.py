@@ -73,6 +73,8 @@ SIGNATURES = {
     "npcd_adamw_ema": (c_int, [_P] * 6 + [c_int64] + [c_float] * 5 + [c_int, c_float, c_int, _P]),
     "npcd_cast_f32_bf16": (c_int, [_P, _P, c_int64, _P]),
     "npcd_sum_slices": (c_int, [_P, _P, c_int, c_int64, _P]),
+    "npcd_small_wgrad_blocks": (c_int, [c_int]),
+    "npcd_small_wgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "npcd_q_sample": (c_int, [_P] * 6 + [c_int, c_int64, _P]),
     "npcd_eps_mse_blocks": (c_int, []),
     "npcd_eps_mse_fwd": (c_int, [_P, _P, c_int, c_int64, _P, _P, _P, _P]),

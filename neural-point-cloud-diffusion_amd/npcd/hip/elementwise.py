@@ -131,6 +131,22 @@ def adamw_ema(p, g, m, v, ema, shadow, lr, beta1, beta2, eps, weight_decay, step
                                int(bool(zero_grad)), stream_ptr()), "npcd_adamw_ema")
 
 
+def small_wgrad(dy, x):
+    """dW [J, K] fp32 = dy^T @ x for bf16 dy [T, J <= 4], x [T, K] (K a power of two in 64..2048); None if the shape is not covered."""
+    T, J = dy.shape
+    K = x.shape[1]
+    if not (1 <= J <= 4 and 64 <= K <= 2048 and K & (K - 1) == 0 and dy.dtype == _bf16 and x.dtype == _bf16 and dy.is_contiguous()
+            and x.is_contiguous() and T > 0):
+        return None
+    L = lib()
+    nblk = L.npcd_small_wgrad_blocks(T)
+    part = torch.empty((nblk + L.npcd_colsum_scratch_rows(), J * K), dtype=_f32, device=x.device)
+    out = torch.empty((J, K), dtype=_f32, device=x.device)
+    check(L.npcd_small_wgrad(ptr(dy), ptr(x), ptr(part), T, J, K, stream_ptr()), "npcd_small_wgrad")
+    check(L.npcd_colsum_finalize(ptr(part), nblk, J * K, ptr(out), 0, stream_ptr()), "npcd_colsum_finalize")
+    return out
+
+
 def sum_slices(part, out):
     """out = part.sum(dim=0) for fp32 part [S, ...] (S in 2, 4, 8), slices added in order; False if the shape is not covered."""
     S, n = part.shape[0], out.numel()

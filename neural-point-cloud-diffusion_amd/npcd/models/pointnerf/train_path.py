@@ -20,6 +20,7 @@ from typing import Dict, Optional
 import torch
 import torch.nn.functional as F
 
+from ...hip import elementwise as ew
 from ...hip import render as hr
 from ...utils import AttrDict
 
@@ -42,6 +43,7 @@ def positional_encoding(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
     return torch.cat((x, torch.cat((spec.sin(), spec.cos()), dim=-1).flatten(start_dim=-2)), dim=-1)
 
 
+_SMALL_WGRAD = os.environ.get("NPCD_NO_SMALL_WGRAD", "") != "1"     # A/B switch: the library GEMM for the heads' weight gradients
 _ROWSPLIT_MIN = int(os.environ.get("NPCD_ROWSPLIT_MIN", "32768"))      # rows from which a Linear layer takes the row-split weight gradient
 
 
@@ -89,7 +91,9 @@ class _RowSplitLinear(torch.autograd.Function):
             # the heads' last layers (256 -> 1, 256 -> 3): the library's fp32-output GEMM with a handful of output rows spends
             # 10-400 ms per call on the HOST (tools/gpu_dev_stage1_hosttrace.py); bf16 output (fp32 accumulation inside), which
             # is what the reference's autocast computes for every weight gradient
-            dw = torch.mm(dy.t(), xx).float()
+            dw = ew.small_wgrad(dy, xx) if dy.is_cuda and _SMALL_WGRAD else None            # one pass over x (csrc/elementwise.hip small_wgrad_kernel)
+            if dw is None:
+                dw = torch.mm(dy.t(), xx).float()
         elif S >= 2:
             head, tail = S * c, rows > S * c
             part = torch.empty((S + int(tail), dy.shape[1], xx.shape[1]), dtype=f32, device=dy.device)

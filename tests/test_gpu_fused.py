@@ -375,3 +375,21 @@ def test_sum_slices_is_the_ordered_sum(S):
         ref = ref + part[s]
     assert torch.equal(out, ref)
     assert not ew.sum_slices(part[:, :3, :5].contiguous(), torch.empty(3, 5, device="cuda"))             # numel % 4 != 0: declined
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T,J,K", [(1, 1, 256), (257, 3, 256), (70001, 1, 256), (200003, 3, 256), (5000, 4, 64), (3000, 2, 2048)])
+def test_small_wgrad_matches_the_fp32_product(T, J, K):
+    """csrc/elementwise.hip small_wgrad_kernel (weight gradient of the field heads' last layers, fields/mlp.py:38-72): dy^T x with
+    fp32 accumulation of the bf16 operands; tolerance 1e-5 relative to the column's sum of magnitudes (fp32 summation order only)."""
+    from npcd.hip import elementwise as ew
+    g = torch.Generator(device="cuda").manual_seed(T + J)
+    dy = torch.randn(T, J, device="cuda", generator=g).bfloat16()
+    x = torch.randn(T, K, device="cuda", generator=g).bfloat16()
+    out = ew.small_wgrad(dy, x)
+    assert out is not None and out.shape == (J, K) and out.dtype == torch.float32
+    ref = dy.double().t() @ x.double()
+    mag = dy.double().abs().t() @ x.double().abs()
+    assert ((out.double() - ref).abs() <= 1e-5 * mag + 1e-30).all()
+    assert torch.equal(out, ew.small_wgrad(dy, x))                                      # fixed summation order
+    assert ew.small_wgrad(dy.float(), x) is None and ew.small_wgrad(dy, x[:, :48].contiguous()) is None   # declined, caller falls back
