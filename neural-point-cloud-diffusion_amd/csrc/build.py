@@ -30,6 +30,9 @@ SOURCES = {
     "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-fno-slp-vectorize"],
     "geometry.hip": ["-ffp-contract=off"],
     "shade.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
+    # the rows kernel runs one wave per SIMD on the whole register file: accumulators (which the epilogues read) in VGPRs, the
+    # activation fragments (matrix-instruction operands only) in AGPRs
+    "shade_rows.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "elementwise.hip": [],
     "pairs.hip": ["-ffp-contract=off"],
     "pairs_mlp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],

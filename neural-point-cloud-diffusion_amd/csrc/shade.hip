@@ -22,42 +22,13 @@
 // point's neighbours: kernel A runs the four non-linear layers on the (point, neighbour) pairs and
 // aggregates; kernel B applies that last linear layer and both heads on POINTS (6.3x fewer rows).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
+#include "shade_common.h"
 
 namespace npcd {
-
-constexpr int kHidden = 256;
-constexpr int kNFreqs = 10;
-constexpr int kEncBlock = 64;          // 3 + 60 positional-encoding columns + 1 zero pad
-constexpr int kRows = 128;             // rows per tile
-constexpr int kRowBytes = kHidden * 2 + 16; // 528: rows padded by one 16-byte chunk instead of an XOR swizzle (below)
-constexpr int kFragBytes = 1024;       // one 32(out) x 16(in) fp16 weight fragment
-constexpr float kLeaky = 0.01f;
-
-struct ShadeLayout {
-    int k0;          // padded input width of layer 0
-    int64_t w[10];   // byte offsets of the packed matrices: A0..A3, A4, S0, C0..C3
-    int64_t bias[10];
-    int64_t s1, c4;  // fp32 vectors: s1 = [256 w | 1 b | pad], c4 = [3*256 w | 3 b | pad]
-    int64_t total;
-};
-__host__ __device__ inline ShadeLayout shade_layout(int feat_dim) {
-    ShadeLayout L;
-    L.k0 = feat_dim + kEncBlock;
-    int64_t off = 0;
-    for (int i = 0; i < 10; ++i) {
-        L.w[i] = off;
-        const int ksteps = (i == 0 ? L.k0 : kHidden) / 16;
-        off += (int64_t)8 * ksteps * kFragBytes;
-    }
-    for (int i = 0; i < 10; ++i) { L.bias[i] = off; off += kHidden * 4; }
-    L.s1 = off; off += 264 * 4;
-    L.c4 = off; off += 776 * 4;
-    L.total = off;
-    return L;
-}
 
 // LDS byte offset of 16-byte chunk `chunk` (0..31) of activation row `row`.  The row pitch is 512 + 16 bytes: consecutive rows
 // start 4 banks apart, so the 16 rows a ds_read_b128 lane group touches (same chunk) cover all 64 banks -- conflict-free like
@@ -140,28 +111,6 @@ __device__ __forceinline__ void layer_store(unsigned char* H, int wave, int lane
             }
 }
 
-struct ShadeArgs {
-    const unsigned char* wpack;
-    int feat_dim, k;
-    const int32_t* nb_idx;
-    const float *pts, *kp_pos, *kp_feat;
-    const int32_t* n_points;
-    int max_points;  // rows allocated in nb_idx / pts / G / sigma / rgb: the device-side count is clamped to it
-    _Float16* G;  // [max_points][256] aggregated hidden features (workspace)
-    float *sigma, *rgb;
-};
-
-// ---- positional-encoding column q (0..63) of the [x_rel(3) | per coord: sin f0..9, cos f0..9 | 0] block
-__device__ __forceinline__ float enc_value(int q, const float rel[3]) {
-    if (q < 3) return rel[q];
-    if (q >= 63) return 0.f;
-    const int c = (q - 3) / 20, rem = (q - 3) % 20, i = rem % 10;
-    // sin(x * 2^i * pi) = sin(2 pi u), u = x * 2^(i-1) (exact scaling); v_sin/v_cos take revolutions
-    const float u = rel[c] * (0.5f * (float)(1 << i));
-    const float f = __builtin_amdgcn_fractf(u);
-    return rem < 10 ? __builtin_amdgcn_sinf(f) : __builtin_amdgcn_cosf(f);
-}
-
 // ============================================================================================
 // kernel A: (point, neighbour) pairs.  tile = 16 points x 8 neighbour slots = 128 rows
 // ============================================================================================
@@ -172,20 +121,37 @@ __device__ long long g_shade_tl[64];
 #define NPCD_STS(i) do { } while (0)
 #endif
 // the four non-linear aggregator layers of one tile, activations in place in LDS (two barriers per layer)
+#ifdef NPCD_SHADE_TL
+#define NPCD_TL_PARAMS , long long* tl, bool tl_hit
+#define NPCD_TL_ARGS , tl, tl_on && tile == tl_tile
+#define NPCD_STL(i) do { if (tl_hit) tl[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NPCD_TL_PARAMS
+#define NPCD_TL_ARGS
+#define NPCD_STL(i) do { } while (0)
+#endif
 template <int FEAT, int NB>
-__device__ __forceinline__ void pair_layers(unsigned char* H, const ShadeArgs& a, const ShadeLayout& L, int wave, int lane) {
+__device__ __forceinline__ void pair_layers(unsigned char* H, const ShadeArgs& a, const ShadeLayout& L, int wave, int lane NPCD_TL_PARAMS) {
     constexpr int K0 = FEAT + kEncBlock;
     f32x16 acc[2][4];
     layer_mfma<K0 / 16, K0 / 16, NB>(H, a.wpack + L.w[0], reinterpret_cast<const float*>(a.wpack + L.bias[0]), wave, lane, acc);
+    NPCD_STL(3);
     __syncthreads();
+    NPCD_STL(4);
     layer_store<true, NB>(H, wave, lane, acc);
+    NPCD_STL(5);
     __syncthreads();
+    NPCD_STL(6);
 #pragma unroll 1
     for (int l = 1; l < 4; ++l) {
         layer_mfma<kHidden / 16, kHidden / 16, NB>(H, a.wpack + L.w[l], reinterpret_cast<const float*>(a.wpack + L.bias[l]), wave, lane, acc);
+        if (l == 1) NPCD_STL(7);
         __syncthreads();
+        if (l == 1) NPCD_STL(8);
         layer_store<true, NB>(H, wave, lane, acc);
+        if (l == 1) NPCD_STL(9);
         __syncthreads();
+        if (l == 1) NPCD_STL(10);
     }
 }
 
@@ -277,10 +243,10 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
         NPCD_STS(2);
         // ---- four non-linear layers (one instantiation per number of occupied 32-row blocks; nblk is workgroup-uniform) ----
         switch (nblk) {
-            case 4: pair_layers<FEAT, 4>(H, a, L, wave, lane); break;
-            case 3: pair_layers<FEAT, 3>(H, a, L, wave, lane); break;
-            case 2: pair_layers<FEAT, 2>(H, a, L, wave, lane); break;
-            case 1: pair_layers<FEAT, 1>(H, a, L, wave, lane); break;
+            case 4: pair_layers<FEAT, 4>(H, a, L, wave, lane NPCD_TL_ARGS); break;
+            case 3: pair_layers<FEAT, 3>(H, a, L, wave, lane NPCD_TL_ARGS); break;
+            case 2: pair_layers<FEAT, 2>(H, a, L, wave, lane NPCD_TL_ARGS); break;
+            case 1: pair_layers<FEAT, 1>(H, a, L, wave, lane NPCD_TL_ARGS); break;
             default: break;                                    // no valid pair in the tile
         }
         NPCD_STS(11);
@@ -323,9 +289,11 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
 }
 #ifdef NPCD_SHADE_TL
 }
+namespace npcd { int rows_debug_read(long long* out, int count); }
 extern "C" int npcd_shade_debug_read(long long* out, int count) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(npcd::g_shade_tl), sizeof(long long) * count);
 }
+extern "C" int npcd_shade_rows_debug_read(long long* out, int count) { return npcd::rows_debug_read(out, count); }
 namespace npcd {
 #endif
 
@@ -454,7 +422,7 @@ extern "C" int64_t npcd_shade_wpack_bytes(int feat_dim, int n_freqs, int hidden)
 
 extern "C" int64_t npcd_shade_workspace_bytes(int max_points, int hidden) {
     if (hidden != kHidden || max_points < 0) return -1;
-    return (int64_t)(max_points + kRows) * kHidden * 2;
+    return (int64_t)(max_points + kRows) * kHidden * 2 + shade_rows_workspace_bytes(max_points);
 }
 
 // fragment order: [out block ob][k-step s][lane][8]  with  element = W[ob*32 + (lane&31)][16 s + 8 (lane>>5) + j]
@@ -469,6 +437,38 @@ static void pack_matrix(const float* W, int out_dim, int in_dim, int k_padded, u
                     const float v = c < in_dim ? W[(int64_t)o * in_dim + c] : 0.f;
                     d[(((int64_t)ob * ksteps + s) * 64 + lane) * 8 + j] = (_Float16)v;
                 }
+}
+
+// The slab stream of the rows kernel (shade_rows.hip): layers A0..A3, each as 4 quarters (output blocks 2 q, 2 q + 1) x steps of
+// two k-steps; a slab = fragments (k-step, block) = (0,0) (0,1) (1,0) (1,1).  Input column of k-slot (s, g = lane >> 5, e):
+//   hidden layers: 32 (s/2) + 8 (2 (s%2) + e/4) + 4 g + e%4   (an accumulator tile's values 8 jp .. 8 jp + 7 ARE fragment 2 mb + jp)
+//   layer 0: the feature channels in order, then per pair t = 8 s2 + e < 30 of (coordinate, frequency) the sine on g = 0 and the
+//   cosine on g = 1, then x, y (g = 0) and z, zero (g = 1)
+static void pack_rows_stream(const float* const* W, int feat_dim, int k0, unsigned char* dst) {
+    _Float16* d = reinterpret_cast<_Float16*>(dst);
+    const int in0 = feat_dim + 3 + 6 * kNFreqs;
+    int64_t frag = 0;
+    for (int l = 0; l < 4; ++l) {
+        const int ks = (l == 0 ? k0 : kHidden) / 16, in_dim = l == 0 ? in0 : kHidden;
+        for (int q = 0; q < 4; ++q)
+            for (int i = 0; i < ks / 2; ++i)
+                for (int sl = 0; sl < 2; ++sl)
+                    for (int m = 0; m < 2; ++m, ++frag)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int o = 32 * (2 * q + m) + (lane & 31), g = lane >> 5, s = 2 * i + sl;
+                                int c;
+                                if (l > 0) c = 32 * (s / 2) + 8 * (2 * (s % 2) + e / 4) + 4 * g + e % 4;
+                                else if (s < feat_dim / 16) c = 16 * s + 8 * g + e;
+                                else {
+                                    const int t = 8 * (s - feat_dim / 16) + e;
+                                    const int qq = t < 30 ? 3 + 20 * (t / 10) + (g ? 10 : 0) + t % 10 : (t == 30 ? (g ? 2 : 0) : (g ? 63 : 1));
+                                    c = feat_dim + qq;
+                                }
+                                const float v = c < in_dim ? W[l][(int64_t)o * in_dim + c] : 0.f;
+                                d[(frag * 64 + lane) * 8 + e] = (_Float16)v;
+                            }
+    }
 }
 
 // weights_host / biases_host: 12 pointers in the order
@@ -490,6 +490,7 @@ extern "C" int npcd_shade_pack_weights(const float* const* weights_host, const f
         pack_matrix(weights_host[src[i]], kHidden, i == 0 ? in0 : kHidden, i == 0 ? L.k0 : kHidden, out + L.w[i]);
         memcpy(out + L.bias[i], biases_host[src[i]], kHidden * 4);
     }
+    pack_rows_stream(weights_host, feat_dim, L.k0, out + L.rows);
     float* s1 = reinterpret_cast<float*>(out + L.s1);
     memcpy(s1, weights_host[6], kHidden * 4);
     s1[kHidden] = biases_host[6][0];
@@ -526,7 +527,14 @@ extern "C" int npcd_shade_points(const void* wpack, int feat_dim, int n_freqs, i
     // read from device memory so that no host round trip is needed after the neighbour query
     const int tilesA = (max_points + 15) / 16, tilesB = (max_points + kRows - 1) / kRows;
     const int gridA = tilesA < 512 ? tilesA : 512, gridB = tilesB < 512 ? tilesB : 512;
-    if (feat_dim == 32) hipLaunchKernelGGL(shade_pairs_kernel<32>, dim3(gridA), dim3(256), ldsA, st, a);
+    // kernel A: LDS tiles of 16 points (below), or with NPCD_SHADE_ROWS=1 the rows form (shade_rows.hip: activations in registers;
+    // opt-in: as fast, but its matrix-product aggregation adds a point's rows in an order that depends on where the point sits in
+    // the compact lists, so two renders agree to fp16 rounding instead of bit for bit -- DESIGN.md 5.3).  Read per call.
+    const char* rows_env = getenv("NPCD_SHADE_ROWS");
+    if (rows_env && rows_env[0] == '1') {
+        rc = shade_rows_launch(a, static_cast<unsigned char*>(workspace) + (int64_t)(max_points + kRows) * kHidden * 2, st);
+        if (rc != NPCD_OK) return rc;
+    } else if (feat_dim == 32) hipLaunchKernelGGL(shade_pairs_kernel<32>, dim3(gridA), dim3(256), ldsA, st, a);
     else hipLaunchKernelGGL(shade_pairs_kernel<128>, dim3(gridA), dim3(256), ldsA, st, a);
     hipLaunchKernelGGL(shade_points_kernel, dim3(gridB), dim3(256), ldsB, st, a);
     NPCD_HIP_CHECK(hipGetLastError());

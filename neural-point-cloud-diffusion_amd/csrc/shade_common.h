@@ -1,0 +1,73 @@
+// Definitions shared by the shading kernels (shade.hip: tiles of 16 points in LDS, the point-level heads; shade_rows.hip: the
+// per-pair layers with the activations in registers).
+#pragma once
+#include "common.h"
+
+namespace npcd {
+
+constexpr int kHidden = 256;
+constexpr int kNFreqs = 10;
+constexpr int kEncBlock = 64;          // 3 + 60 positional-encoding columns + 1 zero pad
+constexpr int kRows = 128;             // rows per tile
+constexpr int kRowBytes = kHidden * 2 + 16; // 528: rows padded by one 16-byte chunk instead of an XOR swizzle (below)
+constexpr int kFragBytes = 1024;       // one 32(out) x 16(in) fp16 weight fragment
+constexpr float kLeaky = 0.01f;
+
+struct ShadeLayout {
+    int k0;          // padded input width of layer 0
+    int64_t w[10];   // byte offsets of the packed matrices: A0..A3, A4, S0, C0..C3
+    int64_t bias[10];
+    int64_t s1, c4;  // fp32 vectors: s1 = [256 w | 1 b | pad], c4 = [3*256 w | 3 b | pad]
+    int64_t rows;    // A0..A3 once more, as the slab stream of the rows kernel (shade_rows.hip)
+    int rows_slabs;  // its length in 4-KiB slabs: 4 quarters x (k0 / 32 + 3 * 8)
+    int64_t total;
+};
+__host__ __device__ inline ShadeLayout shade_layout(int feat_dim) {
+    ShadeLayout L;
+    L.k0 = feat_dim + kEncBlock;
+    int64_t off = 0;
+    for (int i = 0; i < 10; ++i) {
+        L.w[i] = off;
+        const int ksteps = (i == 0 ? L.k0 : kHidden) / 16;
+        off += (int64_t)8 * ksteps * kFragBytes;
+    }
+    for (int i = 0; i < 10; ++i) { L.bias[i] = off; off += kHidden * 4; }
+    L.s1 = off; off += 264 * 4;
+    L.c4 = off; off += 776 * 4;
+    off = (off + 4095) / 4096 * 4096;
+    L.rows = off;
+    L.rows_slabs = 4 * (L.k0 / 32 + 3 * (kHidden / 32));
+    off += (int64_t)L.rows_slabs * 4096;
+    L.total = off;
+    return L;
+}
+
+struct ShadeArgs {
+    const unsigned char* wpack;
+    int feat_dim, k;
+    const int32_t* nb_idx;
+    const float *pts, *kp_pos, *kp_feat;
+    const int32_t* n_points;
+    int max_points;  // rows allocated in nb_idx / pts / G / sigma / rgb: the device-side count is clamped to it
+    _Float16* G;  // [max_points][256] aggregated hidden features (workspace)
+    float *sigma, *rgb;
+};
+
+// ---- positional-encoding column q (0..63) of the [x_rel(3) | per coord: sin f0..9, cos f0..9 | 0] block
+__device__ __forceinline__ float enc_value(int q, const float rel[3]) {
+    if (q < 3) return rel[q];
+    if (q >= 63) return 0.f;
+    const int c = (q - 3) / 20, rem = (q - 3) % 20, i = rem % 10;
+    // sin(x * 2^i * pi) = sin(2 pi u), u = x * 2^(i-1) (exact scaling); v_sin/v_cos take revolutions
+    const float u = rel[c] * (0.5f * (float)(1 << i));
+    const float f = __builtin_amdgcn_fractf(u);
+    return rem < 10 ? __builtin_amdgcn_sinf(f) : __builtin_amdgcn_cosf(f);
+}
+
+
+// shade_rows.hip: the per-pair layers + aggregation (kernel A) with register-resident activations; `rows_ws` is the part of the
+// workspace behind the aggregated features (npcd_shade_workspace_bytes)
+int64_t shade_rows_workspace_bytes(int max_points);
+int shade_rows_launch(const ShadeArgs& a, void* rows_ws, hipStream_t st);
+
+}  // namespace npcd

@@ -140,7 +140,18 @@ def test_grid_capacity_limits_and_batches():
         hg.query_dense(9, 2.0, 5, x=T(x).cuda())
 
 
-def test_shading_matches_reference_golden(golden):
+@pytest.fixture(params=["tiles", "rows"])
+def shade_form(request, monkeypatch):
+    """Both forms of the per-pair shading kernel: LDS tiles of 16 points (default) and NPCD_SHADE_ROWS=1 (csrc/shade_rows.hip:
+    activations in registers, aggregation as a matrix product); the library reads the switch at every call."""
+    if request.param == "rows":
+        monkeypatch.setenv("NPCD_SHADE_ROWS", "1")
+    else:
+        monkeypatch.delenv("NPCD_SHADE_ROWS", raising=False)
+    return request.param
+
+
+def test_shading_matches_reference_golden(golden, shade_form):
     """The reference's own neighbour lists (brute-force branch) and its own sigma / rgb."""
     g = golden("render_brute")
     p = orr.init_field_params(32, seed=int(g["field_seed"]))
@@ -151,7 +162,7 @@ def test_shading_matches_reference_golden(golden):
 
 
 @pytest.mark.parametrize("F_", [32, 128])
-def test_shading_large_weights(F_):
+def test_shading_large_weights(F_, shade_form):
     """Scaled-up weights (activations ~ O(10)) so that fp16 rounding is actually exercised."""
     p = orr.init_field_params(F_, seed=5)
     for kname in p:
@@ -174,6 +185,40 @@ def test_shading_large_weights(F_):
     es = ((sig.cpu() - sig_ref[:, 0]).abs() / sig_ref[:, 0].clamp_min(1.0)).max()
     er = (rgb.cpu() - rgb_ref).abs().max()
     assert float(es) < 5e-3 and float(er) < 5e-3, (float(es), float(er))
+
+
+def test_rows_form_of_the_shading_kernel(monkeypatch):
+    """csrc/shade_rows.hip against the tile form on neighbour lists with everything the C interface allows: points without any
+    neighbour (their sigma / rgb come from the biases alone), -1 entries before valid ones, 1..8 neighbours, a point count that is
+    not a multiple of anything, a device-side count above the allocation.  The two forms round differently (LeakyReLU on the
+    packed fp16 pair, fp16 aggregation weights): 3e-3 of max(1, |value|).  Same input order -> same windows -> bitwise repeatable."""
+    from npcd.hip import render as hr
+    torch.manual_seed(1)
+    Np, k, F_, Ntab = 3001, 8, 32, 512
+    p = orr.init_field_params(F_, seed=0)
+    for kname in p:
+        if kname.endswith("weight"):
+            p[kname] = p[kname] * 1.5
+    wp = hr.pack_field_weights(p, F_, "cuda")
+    nb = torch.randint(0, Ntab, (Np, k), dtype=torch.int32, device="cuda")
+    nb[torch.rand(Np, k, device="cuda") < 0.35] = -1                              # holes anywhere in a row
+    nb[5:40] = -1                                                                 # a run of points without neighbours
+    nb[torch.rand(Np, device="cuda") < 0.05] = -1
+    pts = torch.rand(Np, 3, device="cuda") - 0.5
+    kp = torch.rand(Ntab, 3, device="cuda") - 0.5
+    kf = torch.randn(Ntab, F_, device="cuda")
+    monkeypatch.delenv("NPCD_SHADE_ROWS", raising=False)
+    s_t, c_t = hr.shade_points(wp, F_, nb, pts, kp, kf)
+    monkeypatch.setenv("NPCD_SHADE_ROWS", "1")
+    s_r, c_r = hr.shade_points(wp, F_, nb, pts, kp, kf)
+    s_r2, c_r2 = hr.shade_points(wp, F_, nb, pts, kp, kf, n_points=torch.full((1,), 7 * Np, dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()
+    assert torch.isfinite(s_r).all() and torch.isfinite(c_r).all()
+    assert float(((s_r - s_t).abs() / s_t.abs().clamp_min(1.0)).max()) < 3e-3
+    assert float((c_r - c_t).abs().max()) < 3e-3
+    assert torch.equal(s_r, s_r2) and torch.equal(c_r, c_r2)
+    empty = (nb < 0).all(dim=1)
+    assert int(empty.sum()) > 35 and torch.equal(s_r[empty], s_t[empty]) and torch.equal(c_r[empty], c_t[empty])   # zero features in both
 
 
 def test_ray_march_golden(golden):
@@ -209,7 +254,7 @@ def test_render_matches_reference_golden_brute(golden):
 
 
 @pytest.mark.parametrize("res,B,views", [(32, 2, 2), (128, 1, 1)])
-def test_render_vs_oracle_grid(res, B, views):
+def test_render_vs_oracle_grid(res, B, views, shade_form):
     """Full pipeline (incl. BASELINE cfg 3: 128x128, k=8) vs the oracle with voxel-grid semantics."""
     coords, feats, extr, intr = _scene(res, views, 512, 32, seed=1, B=B)
     if B > 1:

@@ -15,6 +15,7 @@ wait
 /opt/rocm/bin/hipcc $COMMON "$@" -c $C/elementwise.hip -o $O/elementwise.o &
 /opt/rocm/bin/hipcc $COMMON -ffp-contract=off "$@" -c $C/pairs.hip -o $O/pairs.o &
 /opt/rocm/bin/hipcc $COMMON -mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans "$@" -c $C/pairs_mlp.hip -o $O/pairs_mlp.o &
+/opt/rocm/bin/hipcc $COMMON -mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans "$@" -c $C/shade_rows.hip -o $O/shade_rows.o &
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/neural-point-cloud-diffusion_amd/lib/diag/libnpcd_hip_$tag.so $O/*.o
 echo built $R/neural-point-cloud-diffusion_amd/lib/diag/libnpcd_hip_$tag.so

@@ -19,3 +19,12 @@ names = ["tile start", "prologue done", "barrier", "L0 mfma", "barrier", "L0 sto
 t = list(buf); prev = t[0]
 for i, x in enumerate(t[:14]):
     print(f"{i:2d} {names[i]:16s} +{x - prev:7d}  (={x - t[0]})"); prev = x
+if hasattr(L, "npcd_shade_rows_debug_read") and not os.environ.get("NPCD_SHADE_TILES"):
+    L.npcd_shade_rows_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.npcd_shade_rows_debug_read(ctypes.cast(buf, ctypes.c_void_p), 16)
+    names = ["tile start", "window tables", "layer-0 operand", "layer 0", "layer 1", "layer 2", "layer 3", "last epilogue", "aggregation"]
+    t = list(buf); prev = t[0]
+    print("rows kernel:")
+    for i, x in enumerate(t[:9]):
+        print(f"{i:2d} {names[i]:16s} +{x - prev:7d}  (={x - t[0]})"); prev = x
+    print(f"   aggregation: weights operand +{t[9] - t[7]}, products + staging +{t[10] - t[9]}, row stores +{t[8] - t[10]}")
