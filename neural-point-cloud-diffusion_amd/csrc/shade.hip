@@ -100,12 +100,24 @@ __device__ __forceinline__ void layer_store(unsigned char* H, int wave, int lane
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     float x0 = acc[oi][cb][4 * g + 2 * b], x1 = acc[oi][cb][4 * g + 2 * b + 1];
+#ifdef NPCD_SHADE_LEAKY_F32
                     if (ACT) {                       // LeakyReLU(0.01): max(x, 0.01 x)
                         x0 = fmaxf(x0, kLeaky * x0);
                         x1 = fmaxf(x1, kLeaky * x1);
                     }
                     const f32x2 f = {x0, x1};
                     v[b] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2));
+#else
+                    // LeakyReLU on the converted pair: max(h, 0.01 h) in packed fp16 -- 1.5 vector instructions per value instead of
+                    // 2.5 (the negative side is rounded twice: to fp16, and after the scaling)
+                    const f32x2 f = {x0, x1};
+                    f16x2 h = __builtin_convertvector(f, f16x2);
+                    if (ACT) {
+                        const f16x2 sc = {(_Float16)kLeaky, (_Float16)kLeaky};
+                        h = __builtin_elementwise_max(h, h * sc);
+                    }
+                    v[b] = __builtin_bit_cast(uint32_t, h);
+#endif
                 }
                 *reinterpret_cast<u32x2*>(sb + cb * 32 * kRowBytes + (oi * 4 + g) * 16) = v;
             }
