@@ -260,8 +260,9 @@ def parity_full_width(device, ref):
     named = dict(model.denoiser.named_parameters())
     gn = {k: float(named[k].grad.norm()) for k in PARITY_PARAMS}
     rel = {k: abs(gn[k] - ref["grad_norm"][k]) / max(ref["grad_norm"][k], 1e-30) for k in PARITY_PARAMS}
-    loss_rel = abs(float(loss) - ref["loss"]) / abs(ref["loss"])
-    return {"loss_gpu": float(loss), "loss_oracle": ref["loss"], "loss_rel_diff": loss_rel,
+    loss_gpu = float(loss.detach())
+    loss_rel = abs(loss_gpu - ref["loss"]) / abs(ref["loss"])
+    return {"loss_gpu": loss_gpu, "loss_oracle": ref["loss"], "loss_rel_diff": loss_rel,
             "grad_norm_gpu": gn, "grad_norm_oracle": ref["grad_norm"], "grad_norm_rel_diff": rel,
             "bars": {"loss_rel": 2e-2, "grad_norm_rel": 5e-2},
             "ok": bool(loss_rel < 2e-2 and max(rel.values()) < 5e-2),
