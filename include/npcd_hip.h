@@ -208,8 +208,11 @@ int npcd_shade_points(const void* wpack, int feat_dim, int n_freqs, int hidden,
  * Ray marching (renderer.py:96-110,120-185, volume_renderer.py:23-39) on the dense slot layout:
  * sigma/rgb are COMPACT per valid slot (row-major over [ray, slot]); slot_valid [Nr,M] uint8,
  * slot_loc [Nr,M,3], point_base [Nr] int32 = index of the ray's first compact point.
- * -> mask [Nr], depth [Nr], channels [Nr,3].  depth_ws: 2 floats scratch (global min/max).
+ * -> mask [Nr], depth [Nr], channels [Nr,3].  depth_ws: npcd_ray_march_ws_floats(Nr) floats of scratch, uninitialised: the
+ * call leaves the global depth limits in its first two words (npcd_ray_march_bwd reads them), the rest holds the per-workgroup
+ * limits of the march (one wave per ray for M <= 64; combined without atomics by the clamp kernel).
  * ------------------------------------------------------------------------------------------ */
+int64_t npcd_ray_march_ws_floats(int Nr);
 int npcd_ray_march(const float* sigma, const float* rgb, const uint8_t* slot_valid, const float* slot_loc,
                    const int32_t* point_base, const float* rays_o, const float* rays_d, const float* t1,
                    int Nr, int M, int white_back, float* mask, float* depth, float* channels,

@@ -13,6 +13,8 @@
 //   depth / ray march   renderers/renderer.py:96-110,120-185, volume_renderer.py:23-39
 #include <math.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace npcd {
@@ -734,6 +736,117 @@ __global__ __launch_bounds__(256) void ray_march_kernel(const float* __restrict_
     }
 }
 
+// The same march with one WAVE per ray (lane = slot, M <= 64).  The thread-per-ray form above walks its <= 64 slots one after the
+// other behind dependent loads on 64 workgroups for a 128^2 view; here the running depth maximum is a wave prefix maximum, the
+// transmittance an exclusive prefix product, the outputs wave sums -- all on the vector ALU by DPP (row shifts inside the 16-lane
+// rows, row_bcast 15 / 31 across them, wave_shr 1 for "the previous slot"): a scan is 6 instructions, where the ds_bpermute form
+// (__shfl_up) costs an LDS round trip per step (measured: 28.6 us, no better than the loop).  Sums and products are taken in scan
+// / tree order instead of slot order: same values to a few fp32 ulps.  The depth limits leave the kernel as one (min, max) pair per
+// workgroup behind the two result words of `ws`; depth_clamp_kernel combines them (atomics on the two global words made that cache
+// line the bottleneck of the kernel: 104 us with a pair per ray, 47 / 30 / 20 us with a conditional pair per 4 / 8 / 16 rays).
+#define NPCD_DPP_F(IDENT, X, CTRL, ROWMASK) \
+    __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(IDENT), __float_as_int(X), CTRL, ROWMASK, 0xf, false))
+template <class Op>
+__device__ __forceinline__ float wave_scan_incl(float x, float ident, Op op) {
+    x = op(x, NPCD_DPP_F(ident, x, 0x111 /* row_shr:1 */, 0xf));
+    x = op(x, NPCD_DPP_F(ident, x, 0x112 /* row_shr:2 */, 0xf));
+    x = op(x, NPCD_DPP_F(ident, x, 0x114 /* row_shr:4 */, 0xf));
+    x = op(x, NPCD_DPP_F(ident, x, 0x118 /* row_shr:8 */, 0xf));
+    x = op(x, NPCD_DPP_F(ident, x, 0x142 /* row_bcast:15 */, 0xa));     // rows 1 and 3 take the total of the row before them
+    x = op(x, NPCD_DPP_F(ident, x, 0x143 /* row_bcast:31 */, 0xc));     // rows 2 and 3 take the total of rows 0-1
+    return x;
+}
+__device__ __forceinline__ float wave_prev(float x, float first) {     // lane j gets lane j - 1's value, lane 0 gets `first`
+    return NPCD_DPP_F(first, x, 0x138 /* wave_shr:1 */, 0xf);
+}
+__device__ __forceinline__ float wave_total(float x) {                  // sum over the wave, on every lane (as csrc/elementwise.hip)
+    x += NPCD_DPP_F(0.f, x, 0x128 /* row_ror:8 */, 0xf);
+    x += NPCD_DPP_F(0.f, x, 0x124, 0xf);
+    x += NPCD_DPP_F(0.f, x, 0x122, 0xf);
+    x += NPCD_DPP_F(0.f, x, 0x121, 0xf);
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+#ifndef NPCD_MARCH_RAYS
+#define NPCD_MARCH_RAYS 1
+#endif
+constexpr int kMarchRays = NPCD_MARCH_RAYS;
+template <bool COMPACT>
+__global__ __launch_bounds__(256) void ray_march_wave_kernel(const float* __restrict__ sigma, const float* __restrict__ rgb,
+                                                             const uint8_t* __restrict__ slot_valid, const float* __restrict__ slot_loc,
+                                                             const int32_t* __restrict__ point_base, const float* __restrict__ rays_o,
+                                                             const float* __restrict__ rays_d, const float* __restrict__ t1, int Nr, int M,
+                                                             int capacity, int white_back, float* __restrict__ mask, float* __restrict__ depth,
+                                                             float* __restrict__ channels, uint32_t* ws) {
+    __shared__ uint32_t wg_min[4], wg_max[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool in = lane < M;
+    float dmin = INFINITY, dmax = -INFINITY;           // this lane's slot depths over the wave's rays
+    bool any = false;
+#pragma unroll 1
+    for (int it = 0; it < kMarchRays; ++it) {
+        const int ray = (blockIdx.x * 4 + wave) * kMarchRays + it;      // wave-uniform
+        if (ray >= Nr) break;
+        const float o[3] = {rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2]};
+        const float d[3] = {rays_d[ray * 3], rays_d[ray * 3 + 1], rays_d[ray * 3 + 2]};
+        const float ray_end = t1[ray];
+        unsigned long long bits;
+        if (COMPACT) bits = reinterpret_cast<const unsigned long long*>(slot_valid)[ray];
+        else bits = __ballot(in && slot_valid[(int64_t)ray * M + lane] != 0);
+        const int cp0 = point_base[ray];
+        if (COMPACT && cp0 + __popcll(bits) > capacity) bits = 0ull;      // overflowed lists: the ray is marched as empty (see above)
+        const bool valid = in && ((bits >> lane) & 1ull) != 0;
+        const int cp = cp0 + __popcll(bits & ((1ull << lane) - 1ull));
+        float dep = -INFINITY, sg = 0.f, r_ = 0.f, g_ = 0.f, b_ = 0.f;
+        if (valid) {
+            const float* pp = COMPACT ? slot_loc + (int64_t)cp * 3 : slot_loc + ((int64_t)ray * M + lane) * 3;
+            float acc = 0.f;
+            int cnt = 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float q = (pp[c] - o[c]) / d[c];
+                if (q == q) { acc += q; ++cnt; }
+            }
+            const float dv = acc / (float)cnt;       // cnt == 0 -> NaN, which the running maximum ignores (fmaxf)
+            dep = dv == dv ? dv : -INFINITY;
+            sg = sigma[cp]; r_ = rgb[cp * 3]; g_ = rgb[cp * 3 + 1]; b_ = rgb[cp * 3 + 2];
+        }
+        const float run = wave_scan_incl(dep, -INFINITY, [](float a, float b2) { return fmaxf(a, b2); });
+        const float dj = (run == -INFINITY) ? ray_end : run;
+        const float pd = wave_prev(dj, 0.f), ps = wave_prev(sg, 0.f), pr = wave_prev(r_, 0.f), pg = wave_prev(g_, 0.f), pb = wave_prev(b_, 0.f);
+        const bool pv = wave_prev(valid ? 1.f : 0.f, 0.f) != 0.f;
+        const bool step = in && lane >= 1;            // slot j >= 1 closes the interval that slot j - 1 opened
+        const float alpha = step ? 1.f - expf(-(ps * (dj - pd))) : 0.f;
+        const float prod = wave_scan_incl(step ? (1.f - alpha + 1e-10f) : 1.f, 1.f, [](float a, float b2) { return a * b2; });
+        const float w = alpha * wave_prev(prod, 1.f);
+        const float total = wave_total(w), wd = wave_total(w * pd);
+        const float cr = wave_total(pv ? w * pr : 0.f), cg = wave_total(pv ? w * pg : 0.f), cb = wave_total(pv ? w * pb : 0.f);
+        if (in) { dmin = fminf(dmin, dj); dmax = fmaxf(dmax, dj); any = true; }
+        if (lane == 0) {
+            mask[ray] = total;
+            depth[ray] = wd / total;                  // NaN when total == 0; fixed up by depth_clamp_kernel
+            const float bg = white_back ? 1.f - total : 0.f;
+            channels[ray * 3 + 0] = cr + bg;
+            channels[ray * 3 + 1] = cg + bg;
+            channels[ray * 3 + 2] = cb + bg;
+        }
+    }
+    uint32_t kmin = any ? fkey(dmin) : 0xffffffffu, kmax = any ? fkey(dmax) : 0u;      // fkey is monotone
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+    }
+    if (lane == 0) { wg_min[wave] = kmin; wg_max[wave] = kmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {           // this workgroup's depth limits: depth_clamp_kernel combines them (no atomics, no initialisation)
+        ws[2 + 2 * blockIdx.x] = min(min(wg_min[0], wg_min[1]), min(wg_min[2], wg_min[3]));
+        ws[3 + 2 * blockIdx.x] = max(max(wg_max[0], wg_max[1]), max(wg_max[2], wg_max[3]));
+    }
+}
+
 // Backward of the ray march w.r.t. the compact densities and colours (stage-1 training; slot positions, ray geometry and hence
 // all depths are constants there).  One thread per ray, three passes over its <= 64 slots: slot depths; alpha_i, T_i, w_i
 // (kept in thread-private arrays); then in reverse, with G_i = dL/dw_i and the suffix sum S_i = sum_{j>i} G_j w_j,
@@ -816,8 +929,33 @@ __global__ __launch_bounds__(64) void ray_march_bwd_kernel(const float* __restri
 }
 
 // nan -> +inf -> clamp to the global [min, max] of the per-slot depths (renderer.py:151-156)
-__global__ __launch_bounds__(256) void depth_clamp_kernel(int Nr, float* __restrict__ depth, const uint32_t* ws) {
+// nparts > 0: ws[2 + 2 i], ws[3 + 2 i] hold the limits of march workgroup i; every workgroup here combines them (a few thousand
+// words from L2) and workgroup 0 leaves the result in ws[0], ws[1] for the backward
+__global__ __launch_bounds__(256) void depth_clamp_kernel(int Nr, float* __restrict__ depth, uint32_t* ws, int nparts) {
+    __shared__ uint32_t red_lo[4], red_hi[4];
     const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nparts > 0) {
+        uint32_t kmin = 0xffffffffu, kmax = 0u;
+        for (int i = threadIdx.x; i < nparts; i += 256) {
+            kmin = min(kmin, ws[2 + 2 * i]);
+            kmax = max(kmax, ws[3 + 2 * i]);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+            kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) { red_lo[threadIdx.x >> 6] = kmin; red_hi[threadIdx.x >> 6] = kmax; }
+        __syncthreads();
+        kmin = min(min(red_lo[0], red_lo[1]), min(red_lo[2], red_lo[3]));
+        kmax = max(max(red_hi[0], red_hi[1]), max(red_hi[2], red_hi[3]));
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ws[0] = kmin; ws[1] = kmax; }
+        if (ray >= Nr) return;
+        float x = depth[ray];
+        if (x != x) x = INFINITY;
+        depth[ray] = fminf(fmaxf(x, fkey_inv(kmin)), fkey_inv(kmax));
+        return;
+    }
     if (ray >= Nr) return;
     const float lo = fkey_inv(ws[0]), hi = fkey_inv(ws[1]);
     float x = depth[ray];
@@ -948,6 +1086,9 @@ extern "C" int npcd_grid_query(const npcd_grid_params* g, const void* workspace,
     return NPCD_OK;
 }
 
+static int march_parts(int Nr) { return (Nr + 4 * kMarchRays - 1) / (4 * kMarchRays); }
+extern "C" int64_t npcd_ray_march_ws_floats(int Nr) { return Nr <= 0 ? -1 : 2 + 2 * (int64_t)march_parts(Nr); }
+
 extern "C" int npcd_ray_march(const float* sigma, const float* rgb, const uint8_t* slot_valid, const float* slot_loc,
                               const int32_t* point_base, const float* rays_o, const float* rays_d, const float* t1, int Nr, int M,
                               int white_back, float* mask, float* depth, float* channels, float* depth_ws, void* stream) {
@@ -957,10 +1098,17 @@ extern "C" int npcd_ray_march(const float* sigma, const float* rgb, const uint8_
     hipStream_t st = static_cast<hipStream_t>(stream);
     uint32_t* ws = reinterpret_cast<uint32_t*>(depth_ws);
     const int grid = (Nr + 255) / 256;
-    hipLaunchKernelGGL(march_init_kernel, dim3(1), dim3(1), 0, st, ws);
-    hipLaunchKernelGGL(ray_march_kernel<false>, dim3(grid), dim3(256), 0, st, sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1,
-                       Nr, M, 0, white_back, mask, depth, channels, ws);
-    hipLaunchKernelGGL(depth_clamp_kernel, dim3(grid), dim3(256), 0, st, Nr, depth, ws);
+    int nparts = 0;
+    if (M <= 64 && !getenv("NPCD_MARCH_PER_THREAD")) {        // (A/B switch: the thread-per-ray form)
+        nparts = march_parts(Nr);
+        hipLaunchKernelGGL(ray_march_wave_kernel<false>, dim3(nparts), dim3(256), 0, st, sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d,
+                           t1, Nr, M, 0, white_back, mask, depth, channels, ws);
+    } else {
+        hipLaunchKernelGGL(march_init_kernel, dim3(1), dim3(1), 0, st, ws);
+        hipLaunchKernelGGL(ray_march_kernel<false>, dim3(grid), dim3(256), 0, st, sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1,
+                           Nr, M, 0, white_back, mask, depth, channels, ws);
+    }
+    hipLaunchKernelGGL(depth_clamp_kernel, dim3(grid), dim3(256), 0, st, Nr, depth, ws, nparts);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }
@@ -1032,10 +1180,17 @@ extern "C" int npcd_ray_march_compact(const float* sigma, const float* rgb, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     uint32_t* ws = reinterpret_cast<uint32_t*>(depth_ws);
     const int grid = (Nr + 255) / 256;
-    hipLaunchKernelGGL(march_init_kernel, dim3(1), dim3(1), 0, st, ws);
-    hipLaunchKernelGGL(ray_march_kernel<true>, dim3(grid), dim3(256), 0, st, sigma, rgb, reinterpret_cast<const uint8_t*>(ray_bits), pts, ray_base,
-                       rays_o, rays_d, t1, Nr, M, capacity, white_back, mask, depth, channels, ws);
-    hipLaunchKernelGGL(depth_clamp_kernel, dim3(grid), dim3(256), 0, st, Nr, depth, ws);
+    int nparts = 0;
+    if (!getenv("NPCD_MARCH_PER_THREAD")) {
+        nparts = march_parts(Nr);
+        hipLaunchKernelGGL(ray_march_wave_kernel<true>, dim3(nparts), dim3(256), 0, st, sigma, rgb, reinterpret_cast<const uint8_t*>(ray_bits), pts,
+                           ray_base, rays_o, rays_d, t1, Nr, M, capacity, white_back, mask, depth, channels, ws);
+    } else {
+        hipLaunchKernelGGL(march_init_kernel, dim3(1), dim3(1), 0, st, ws);
+        hipLaunchKernelGGL(ray_march_kernel<true>, dim3(grid), dim3(256), 0, st, sigma, rgb, reinterpret_cast<const uint8_t*>(ray_bits), pts, ray_base,
+                           rays_o, rays_d, t1, Nr, M, capacity, white_back, mask, depth, channels, ws);
+    }
+    hipLaunchKernelGGL(depth_clamp_kernel, dim3(grid), dim3(256), 0, st, Nr, depth, ws, nparts);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }

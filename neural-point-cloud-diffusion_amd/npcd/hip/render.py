@@ -210,7 +210,7 @@ def ray_march_compact(sigma, rgb, ray_bits, pts, ray_base, rays_o, rays_d, t1, M
     mask = torch.empty(Nr, dtype=_f32, device=dev)
     depth = torch.empty(Nr, dtype=_f32, device=dev)
     chan = torch.empty((Nr, 3), dtype=_f32, device=dev)
-    ws = torch.empty(4, dtype=_f32, device=dev)
+    ws = torch.empty(lib().npcd_ray_march_ws_floats(Nr), dtype=_f32, device=dev)
     check(lib().npcd_ray_march_compact(ptr(sigma), ptr(rgb), ptr(ray_bits), ptr(pts), ptr(ray_base), ptr(rays_o.contiguous()),
                                        ptr(rays_d.contiguous()), ptr(t1.contiguous()), Nr, int(M), int(sigma.shape[0]), int(bool(white_back)), ptr(mask),
                                        ptr(depth), ptr(chan), ptr(ws), stream_ptr()), "npcd_ray_march_compact")
@@ -227,7 +227,7 @@ def ray_march(sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1, 
     mask = torch.empty(Nr, dtype=_f32, device=dev)
     depth = torch.empty(Nr, dtype=_f32, device=dev)
     chan = torch.empty((Nr, 3), dtype=_f32, device=dev)
-    ws = torch.empty(4, dtype=_f32, device=dev)
+    ws = torch.empty(lib().npcd_ray_march_ws_floats(Nr), dtype=_f32, device=dev)
     if sigma.numel() == 0:                      # keep the pointers valid
         sigma = torch.zeros(1, dtype=_f32, device=dev)
         rgb = torch.zeros((1, 3), dtype=_f32, device=dev)
@@ -305,7 +305,7 @@ class _RayMarch(torch.autograd.Function):
         mask = torch.empty(Nr, dtype=_f32, device=dev)
         depth = torch.empty(Nr, dtype=_f32, device=dev)
         chan = torch.empty((Nr, 3), dtype=_f32, device=dev)
-        ws = torch.empty(4, dtype=_f32, device=dev)
+        ws = torch.empty(lib().npcd_ray_march_ws_floats(Nr), dtype=_f32, device=dev)
         check(lib().npcd_ray_march(ptr(sigma), ptr(rgb), ptr(sv), ptr(slot_loc), ptr(base), ptr(o), ptr(d), ptr(t1), Nr, M,
                                    int(bool(white_back)), ptr(mask), ptr(depth), ptr(chan), ptr(ws), stream_ptr()), "npcd_ray_march")
         ctx.save_for_backward(sigma, rgb, sv, slot_loc, base, o, d, t1, ws)
