@@ -176,8 +176,11 @@ int npcd_grid_query_compact(const npcd_grid_params* g, const void* workspace, co
 /* ------------------------------------------------------------------------------------------
  * Ray generation + box limits (ray_sampler.py:10-49, math_utils.py:46-97, renderer.py:36-47).
  * extr [V,4,4] world2cam fp32, intr [V,3,3] fp32 -> rays_o/rays_d [V,res*res,3], t0/t1 [V,res*res].
- * limits_ws: 4 floats of device scratch (global min start / max end, hit flag).
+ * limits_ws: npcd_ray_gen_ws_floats(V, res, n_ids) floats of device scratch (n_ids = 0 for all res^2 pixels), uninitialised: the
+ * call leaves the global min start / max end / hit flag in its first words, behind them the per-workgroup limits (combined without
+ * atomics by the fix-up kernel).
  * ------------------------------------------------------------------------------------------ */
+int64_t npcd_ray_gen_ws_floats(int V, int res, int n_ids);
 int npcd_ray_gen(const float* extr, const float* intr, int V, int res, float box,
                  float* rays_o, float* rays_d, float* t0, float* t1, float* limits_ws, void* stream);
 /* Same for a subset of the pixels: pixel_ids [n_ids] int32 row-major pixel numbers (i * res + j), the same for every view

@@ -31,12 +31,6 @@ __device__ __forceinline__ float fkey_inv(uint32_t k) {
 // ============================================================================================
 // rays
 // ============================================================================================
-__global__ void limits_init_kernel(uint32_t* ws) {
-    ws[0] = 0xffffffffu;  // min start key
-    ws[1] = 0u;           // max end key
-    ws[2] = 0u;           // any ray hit the box
-    ws[3] = 0u;
-}
 
 // pixel_ids (may be NULL): the n_ids pixels (row-major ids, the same for every view) to generate rays for -- the training
 // path renders ~100 random pixels per view; without it all res^2 pixels of every view are generated
@@ -100,19 +94,41 @@ __global__ __launch_bounds__(256) void ray_gen_kernel(const float* __restrict__ 
         kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
         kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
     }
-    if ((threadIdx.x & 63) == 0 && kmax != 0u) {
-        atomicMin(&ws[0], kmin);
-        atomicMax(&ws[1], kmax);
-        atomicOr(&ws[2], 1u);
+    // one (min, max) pair per workgroup behind the four result words; ray_limits_fix_kernel combines them (no atomics on one
+    // cache line, no initialisation launch)
+    __shared__ uint32_t wg_lo[4], wg_hi[4];
+    if ((threadIdx.x & 63) == 0) { wg_lo[threadIdx.x >> 6] = kmin; wg_hi[threadIdx.x >> 6] = kmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ws[4 + 2 * blockIdx.x] = min(min(wg_lo[0], wg_lo[1]), min(wg_lo[2], wg_lo[3]));
+        ws[5 + 2 * blockIdx.x] = max(max(wg_hi[0], wg_hi[1]), max(wg_hi[2], wg_hi[3]));
     }
 }
 
-__global__ __launch_bounds__(256) void ray_limits_fix_kernel(int64_t n, float* __restrict__ t0, float* __restrict__ t1, const uint32_t* ws) {
+// every workgroup combines the per-workgroup limits ray_gen_kernel left in ws[4 ..] (gridDim.x pairs: the two kernels share their
+// grid); workgroup 0 leaves min / max / "any ray hit" in ws[0 .. 2]
+__global__ __launch_bounds__(256) void ray_limits_fix_kernel(int64_t n, float* __restrict__ t0, float* __restrict__ t1, uint32_t* ws) {
+    __shared__ uint32_t red_lo[4], red_hi[4];
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= n || ws[2] == 0u) return;
+    uint32_t kmin = 0xffffffffu, kmax = 0u;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) {
+        kmin = min(kmin, ws[4 + 2 * i]);
+        kmax = max(kmax, ws[5 + 2 * i]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+        kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { red_lo[threadIdx.x >> 6] = kmin; red_hi[threadIdx.x >> 6] = kmax; }
+    __syncthreads();
+    kmin = min(min(red_lo[0], red_lo[1]), min(red_lo[2], red_lo[3]));
+    kmax = max(max(red_hi[0], red_hi[1]), max(red_hi[2], red_hi[3]));
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ws[0] = kmin; ws[1] = kmax; ws[2] = kmax != 0u ? 1u : 0u; ws[3] = 0u; }
+    if (gid >= n || kmax == 0u) return;
     if (!(t1[gid] > t0[gid])) {
-        t0[gid] = fkey_inv(ws[0]);
-        t1[gid] = fkey_inv(ws[1]);
+        t0[gid] = fkey_inv(kmin);
+        t1[gid] = fkey_inv(kmax);
     }
 }
 
@@ -976,11 +992,16 @@ static int ray_gen_launch(const float* extr, const float* intr, int V, int res, 
     const int64_t n = (int64_t)V * (pixel_ids ? (int64_t)n_ids : (int64_t)res * res);
     const int grid = (int)((n + 255) / 256);
     uint32_t* ws = reinterpret_cast<uint32_t*>(limits_ws);
-    hipLaunchKernelGGL(limits_init_kernel, dim3(1), dim3(1), 0, st, ws);
     hipLaunchKernelGGL(ray_gen_kernel, dim3(grid), dim3(256), 0, st, extr, intr, V, res, box, pixel_ids, n_ids, rays_o, rays_d, t0, t1, ws);
     hipLaunchKernelGGL(ray_limits_fix_kernel, dim3(grid), dim3(256), 0, st, n, t0, t1, ws);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
+}
+
+extern "C" int64_t npcd_ray_gen_ws_floats(int V, int res, int n_ids) {
+    if (V <= 0 || res <= 0 || n_ids < 0) return -1;
+    const int64_t n = (int64_t)V * (n_ids ? (int64_t)n_ids : (int64_t)res * res);
+    return 4 + 2 * ((n + 255) / 256);
 }
 
 extern "C" int npcd_ray_gen(const float* extr, const float* intr, int V, int res, float box, float* rays_o, float* rays_d,

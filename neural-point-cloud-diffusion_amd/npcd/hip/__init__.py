@@ -59,6 +59,7 @@ SIGNATURES = {
     "npcd_shade_pack_weights": (c_int, [POINTER(_P), POINTER(_P), c_int, c_int, c_int, _P]),
     "npcd_shade_points": (c_int, [_P, c_int, c_int, c_int] + [_P] * 5 + [c_int, c_int] + [_P] * 3 + [_P]),
     "npcd_ray_march_ws_floats": (c_int64, [c_int]),
+    "npcd_ray_gen_ws_floats": (c_int64, [c_int, c_int, c_int]),
     "npcd_ray_march": (c_int, [_P] * 8 + [c_int, c_int, c_int] + [_P] * 4 + [_P]),
     "npcd_add_ln_fwd": (c_int, [_P] * 8 + [c_int, c_int, c_float, _P]),
     "npcd_ln_bwd_blocks": (c_int, [c_int]),

@@ -40,7 +40,7 @@ def ray_gen(extr: torch.Tensor, intr: torch.Tensor, res: int, box: float = 1.0, 
         d = torch.empty((V, R, 3), dtype=_f32, device=dev)
         t0 = torch.empty((V, R), dtype=_f32, device=dev)
         t1 = torch.empty((V, R), dtype=_f32, device=dev)
-        ws = torch.empty(4, dtype=_f32, device=dev)
+        ws = torch.empty(lib().npcd_ray_gen_ws_floats(V, res, R), dtype=_f32, device=dev)
         check(lib().npcd_ray_gen_subset(ptr(extr), ptr(intr), V, res, float(box), ptr(ids), R, ptr(o), ptr(d), ptr(t0), ptr(t1), ptr(ws),
                                         stream_ptr()), "npcd_ray_gen_subset")
         return o, d, t0, t1
@@ -49,7 +49,7 @@ def ray_gen(extr: torch.Tensor, intr: torch.Tensor, res: int, box: float = 1.0, 
     d = torch.empty((V, R, 3), dtype=_f32, device=dev)
     t0 = torch.empty((V, R), dtype=_f32, device=dev)
     t1 = torch.empty((V, R), dtype=_f32, device=dev)
-    ws = torch.empty(4, dtype=_f32, device=dev)
+    ws = torch.empty(lib().npcd_ray_gen_ws_floats(V, res, 0), dtype=_f32, device=dev)
     check(lib().npcd_ray_gen(ptr(extr), ptr(intr), V, res, float(box), ptr(o), ptr(d), ptr(t0), ptr(t1), ptr(ws), stream_ptr()),
           "npcd_ray_gen")
     return o, d, t0, t1
