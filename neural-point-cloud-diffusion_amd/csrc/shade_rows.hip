@@ -14,7 +14,7 @@
 //     for one feature, which is the k-layout of one more matrix product, G^T[feature][point] = H^T[feature][row] . A[row][point]
 //     with A = the normalised inverse-distance weights of the window's <= 64 points: the aggregation is 32 MFMAs;
 //   * the weights (432 KB per tile of 256 rows for 32 feature channels) stream through a 64-KB LDS ring as 4-KB slabs (two k-steps
-//     of two output blocks) by LDS-DMA, 12 slabs ahead, one counted vmcnt wait + one barrier per slab; all four waves of the
+//     of two output blocks) by LDS-DMA, 12 slabs ahead, one counted vmcnt wait + one barrier per four slabs; all four waves of the
 //     workgroup read every slab (ds_read_b128 of contiguous 1-KB fragments: conflict-free), each fragment feeds two MFMAs;
 //   * one wave per SIMD (the register file of a SIMD belongs to one wave: 128 + 128 activation registers, 64 + 64 accumulators):
 //     the epilogue of a quarter layer (two output blocks) is spread over the k-steps of the next quarter so that its ~2.5 vector
@@ -31,6 +31,10 @@ namespace {
 
 constexpr int kSlab = 4096;                     // 2 k-steps x 2 output blocks x 1 KiB
 constexpr int kRingSlabs = 16;
+#ifndef NPCD_ROWS_SYNC_STEPS
+#define NPCD_ROWS_SYNC_STEPS 4
+#endif
+constexpr int kSyncSteps = NPCD_ROWS_SYNC_STEPS;   // steps (slabs) per counted wait + barrier: 2 or 4 (every layer is a multiple of 4 steps long)
 constexpr int kAhead = 12;                      // slabs in flight ahead of the one being read; <= kRingSlabs - 3
 constexpr int kRingBytes = kRingSlabs * kSlab;
 constexpr int kBiasBytes = 4 * kHidden * 4;
@@ -277,17 +281,17 @@ __global__ __launch_bounds__(256, 1) void shade_rows_kernel(ShadeArgs a, RowsWs 
     auto land0 = [&](f16x8 (&A)[4]) __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0]), "+v"(A[1]), "+v"(A[2]), "+v"(A[3])::"memory");
     };
-    // one step of the stream.  Even steps: the next two slabs have landed for every wave (counted wait on this wave's own DMA +
-    // barrier) and nobody reads the two slabs that are overwritten; odd steps only read.
-    auto advance = [&](f16x8 (&An)[4], f16x8 (&Cur)[4], bool even) __attribute__((always_inline)) {
-        if (even) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAhead - 2) : "memory");
+    // one step of the stream.  Every kSyncSteps-th step: the next kSyncSteps slabs have landed for every wave (counted wait on this
+    // wave's own DMA + barrier) and nobody reads the slabs that are overwritten; the other steps only read.
+    auto advance = [&](f16x8 (&An)[4], f16x8 (&Cur)[4], bool sync) __attribute__((always_inline)) {
+        if (sync) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kAhead - kSyncSteps) : "memory");
 #ifndef NPCD_DIAG_NO_BARRIER         // DIAGNOSTIC builds only (races)
             __builtin_amdgcn_s_barrier();
 #endif
             asm volatile("" ::: "memory");
-            issue_slab();
-            issue_slab();
+#pragma unroll
+            for (int u = 0; u < kSyncSteps; ++u) issue_slab();
         }
         read_slab2(An, Cur);
     };
@@ -439,11 +443,11 @@ __global__ __launch_bounds__(256, 1) void shade_rows_kernel(ShadeArgs a, RowsWs 
                     acc[m][0] = init;
                     acc[m][1] = init;
                 }
-                static_assert(KS % 4 == 0 || KS == 6, "a layer starts on an even step of the slab stream");
+                static_assert((4 * (KS / 2)) % kSyncSteps == 0, "a layer is a whole number of synchronisation periods of the slab stream");
 #pragma unroll
                 for (int i = 0; i < NST; ++i) {
                     f16x8 An[4];
-                    advance(An, Ac, ((q * NST + i) & 1) == 0);
+                    advance(An, Ac, ((q * NST + i) % kSyncSteps) == 0);
                     // a single wave feeds the SIMD: vector instructions hide behind a matrix instruction only if they sit in its
                     // own 32-cycle slot (<= 5 of them).  The step is therefore written as 8 x (1 matrix instruction, its share of
                     // the pending epilogue: pairs of values -> convert, scale, max), with nothing allowed across the slots.
