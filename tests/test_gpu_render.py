@@ -237,6 +237,40 @@ def test_ray_march_golden(golden):
     np.testing.assert_allclose(ch.cpu().numpy(), g["out_channels"].reshape(Nr, 3), atol=2e-6)
 
 
+def test_ray_march_wave_form_against_the_slot_loop(monkeypatch):
+    """csrc/geometry.hip ray_march_wave_kernel (one wave per ray: prefix maximum / prefix product / sums by DPP, depth limits as
+    per-workgroup pairs combined by the clamp kernel) against the thread-per-ray loop over the slots (NPCD_MARCH_PER_THREAD=1): same
+    mask / depth / colour to a few fp32 ulps (scan order instead of slot order), on rays with 0 .. M valid slots, M < 64, a ray
+    count that is not a multiple of the workgroup's four rays; the global depth limits (first two scratch words, which the backward
+    reads) are identical, and rays without any weight get the clamped depth in both forms."""
+    from npcd.hip import render as hr
+    g = torch.Generator().manual_seed(3)
+    Nr, M = 1003, 48
+    valid = torch.rand(Nr, M, generator=g) < 0.3
+    valid[:17] = False                                    # empty rays
+    valid[17:25] = True                                   # full rays
+    o = torch.randn(Nr, 3, generator=g) * 0.1 + torch.tensor([0.0, 0.0, -2.0])
+    d = torch.nn.functional.normalize(torch.randn(Nr, 3, generator=g) * 0.2 + torch.tensor([0.0, 0.0, 1.0]), dim=1)
+    tt = torch.sort(torch.rand(Nr, M, generator=g) * 2.0 + 1.0, dim=1).values
+    loc = o[:, None, :] + tt[..., None] * d[:, None, :]
+    per_ray = valid.sum(1).int()
+    base = (torch.cumsum(per_ray, 0) - per_ray).int()
+    P = int(per_ray.sum())
+    sigma = torch.rand(P, generator=g) * 5.0
+    rgb = torch.rand(P, 3, generator=g)
+    t1 = torch.full((Nr,), 3.5)
+    args = [x.cuda() for x in (sigma, rgb, valid, loc, base, o, d, t1)]
+    monkeypatch.setenv("NPCD_MARCH_PER_THREAD", "1")
+    m0, d0, c0 = hr.ray_march(*args, True)
+    monkeypatch.delenv("NPCD_MARCH_PER_THREAD")
+    m1, d1, c1 = hr.ray_march(*args, True)
+    torch.cuda.synchronize()
+    assert float(m0.max()) > 0.9 and float(m0[:17].abs().max()) == 0.0
+    assert float((m1 - m0).abs().max()) < 2e-6 and float((c1 - c0).abs().max()) < 2e-6
+    assert float((d1 - d0).abs().max()) < 2e-5
+    assert torch.equal(d1[:17], d0[:17])                  # no weight: the depth is the clamp limit, identical in both forms
+
+
 def test_render_matches_reference_golden_brute(golden):
     """End to end against the reference's own rendering (its voxel_grid=None branch)."""
     g = golden("render_brute")
