@@ -156,7 +156,10 @@ __device__ __forceinline__ void pair_layers(unsigned char* H, const ShadeArgs& a
     NPCD_STL(6);
 #pragma unroll 1
     for (int l = 1; l < 4; ++l) {
-        layer_mfma<kHidden / 16, kHidden / 16, NB>(H, a.wpack + L.w[l], reinterpret_cast<const float*>(a.wpack + L.bias[l]), wave, lane, acc);
+        // (offsets in closed form: indexing L.w[l] / L.bias[l] with the loop counter put the whole layout struct into scratch
+        // memory and a scratch load in front of every layer's first weight and bias loads)
+        const int64_t w_off = L.w[1] + (int64_t)(l - 1) * (8 * (kHidden / 16) * kFragBytes), b_off = L.bias[0] + (int64_t)l * (kHidden * 4);
+        layer_mfma<kHidden / 16, kHidden / 16, NB>(H, a.wpack + w_off, reinterpret_cast<const float*>(a.wpack + b_off), wave, lane, acc);
         if (l == 1) NPCD_STL(7);
         __syncthreads();
         if (l == 1) NPCD_STL(8);
@@ -367,7 +370,9 @@ __global__ __launch_bounds__(256, 2) void shade_points_kernel(ShadeArgs a) {
         // ---- colour head: 4 x [Linear(256,256) + LeakyReLU] + Linear(256,3), sigmoid ----------
 #pragma unroll 1
         for (int l = 0; l < 4; ++l) {
-            layer_mfma<16>(H, a.wpack + L.w[6 + l], reinterpret_cast<const float*>(a.wpack + L.bias[6 + l]), wave, lane, acc);
+            // (closed form instead of L.w[6 + l] / L.bias[6 + l]: see pair_layers)
+            const int64_t w_off = L.w[6] + (int64_t)l * (8 * (kHidden / 16) * kFragBytes), b_off = L.bias[6] + (int64_t)l * (kHidden * 4);
+            layer_mfma<16>(H, a.wpack + w_off, reinterpret_cast<const float*>(a.wpack + b_off), wave, lane, acc);
             if (l < 3) {
                 __syncthreads();
                 layer_store<true>(H, wave, lane, acc);
