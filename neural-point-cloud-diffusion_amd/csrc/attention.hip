@@ -583,7 +583,7 @@ __device__ __forceinline__ void fwd_stage(const FragAddr& fa, const typename TR:
     tr_wait();
     f32x16 s0 = {0};
 #ifdef NPCD_DIAG_HALF_MFMA
-    // DIAGNOSTIC BUILD ONLY (tools/gpu_dev_fp8_bound.py): half of the matrix instructions of every stage are dropped (the
+    // DIAGNOSTIC BUILD ONLY (tools/probes/gpu_dev_fp8_bound.py): half of the matrix instructions of every stage are dropped (the
     // operands they would have used are kept alive, all loads, all vector work and the whole control flow stay) -- wrong
     // results, timing only: what a matrix pipe of TWICE the rate (block-scaled fp8, v_mfma_scale_f32_32x32x64_f8f6f4) could
     // buy this kernel at best, before the cost of producing fp8 operands.

@@ -26,7 +26,7 @@ _BLOCK_PARAMS = ("ln_1.weight", "ln_1.bias", "attn.c_qkv.weight", "attn.c_qkv.bi
 
 # ---- token-dimension split of the forward / data-gradient GEMMs ---------------------------------------------------------------
 # The token count of a step is B x (N + 1): the time token makes it 64 x 513 = 32,832 = 128.25 tiles of 256 rows, and hipBLASLt
-# loses 12 % on that quarter tile (tools/gpu_dev_gemm_m.py: 1683 -> 1475 us per block for the eight GEMMs).  A GEMM does not
+# loses 12 % on that quarter tile (tools/probes/gpu_dev_gemm_m.py: 1683 -> 1475 us per block for the eight GEMMs).  A GEMM does not
 # care which rows it gets, so every [T, K] x [K, N] product is issued as one call on the last T % 256 rows and one on the rest.
 # Measured in situ (same box, tuned solutions for both): 10.78 -> 11.13 steps/s.  (Tried: the small call on a second stream --
 # its workgroups queue behind the large GEMM's and the join waits for them: no gain at either stream priority.  Tried: a
@@ -84,7 +84,7 @@ def _wgrad(dy, x, out):
     T = dy.shape[0]
     small = out.numel() <= (1 << 20)
     S = 8 if small else 4
-    # keep >= 4096 rows per slice (2048 for the 1024 x 1024 output, 16 tiles: tools/gpu_dev_wgrad_split.py at T = 4104 / 8208): short
+    # keep >= 4096 rows per slice (2048 for the 1024 x 1024 output, 16 tiles: tools/probes/gpu_dev_wgrad_split.py at T = 4104 / 8208): short
     # reductions need no split
     S = min(S, max(1, T // (2048 if small else 4096)))
     while S > 1 and T % S:

@@ -52,7 +52,11 @@ class GaussianDiffusion(nn.Module):
         if noise is None:
             noise = torch.randn(data_start.shape, device=data_start.device)
         assert noise.shape == data_start.shape
-        if data_start.is_cuda and data_start.dtype == torch.float32 and noise.dtype == torch.float32 and self.sqrt_alphas_cumprod.is_cuda:
+        # fused launch only where it is the expression below exactly: fp32 operands, int64 device timesteps (the kernel indexes the
+        # tables with them unchecked) and no gradient to carry (a raw-pointer launch is invisible to autograd)
+        if (data_start.is_cuda and data_start.dtype == torch.float32 and noise.dtype == torch.float32 and self.sqrt_alphas_cumprod.is_cuda
+                and t.is_cuda and t.dtype == torch.int64
+                and not (torch.is_grad_enabled() and (data_start.requires_grad or noise.requires_grad))):
             from ...hip import elementwise as ew            # one launch; bit-identical to the expression below (mul, mul, add)
             return ew.q_sample(data_start, noise, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
         return (self._extract(self.sqrt_alphas_cumprod, t, data_start.shape) * data_start

@@ -121,6 +121,8 @@ class Transformer(nn.Module):
                 if self._infer_weights is None:
                     self._infer_weights = fused.InferenceWeights(self)
                 return fused.backbone_forward(x, self._infer_weights.current(), self._infer_weights.heads)
+        if eng is not None and eng.wait_range is not None:
+            eng.wait_range()            # module path while a trainer's parameter gathers may still be in flight (engine.py)
         for blk in self.resblocks:
             x = blk(x)
         return x
@@ -147,10 +149,13 @@ class _TimeTokenCat(torch.autograd.Function):
         from ...hip import elementwise as ew
         dh = dh.contiguous()
         B, n, W = dh.shape
-        db = torch.empty(W, dtype=torch.float32, device=dh.device)
-        ew.colsum_bf16(dh.view(B * n, W), db)
-        db -= dh[:, 0].float().sum(dim=0)
-        return dh[:, 0], dh[:, 1:], db.to(ctx.bias_dtype)
+        db = None
+        if ctx.needs_input_grad[2]:
+            db = torch.empty(W, dtype=torch.float32, device=dh.device)
+            ew.colsum_bf16(dh.view(B * n, W), db)
+            db -= dh[:, 0].float().sum(dim=0)
+            db = db.to(ctx.bias_dtype)
+        return dh[:, 0], dh[:, 1:], db
 
 
 class _LayerNormToBF16(torch.autograd.Function):
@@ -198,8 +203,9 @@ class NPCDTransformer(nn.Module):
     def forward(self, coords: torch.Tensor, feats: torch.Tensor, t: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         x = torch.cat((coords, feats), dim=1).transpose(1, 2)
         temb = self.time_embed(timestep_embedding(t, self.backbone.width))               # [B,W]
+        # (the column-sum kernel behind _TimeTokenCat's backward takes bf16 rows of a multiple of 8 columns)
         if (x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
-                and not _NO_FAST_GLUE):
+                and self.backbone.width % 8 == 0 and not _NO_FAST_GLUE):
             tokens = F.linear(x, self.input_proj.weight, self.input_proj.bias.detach())  # [B,N,W] bf16; the bias gradient comes from _TimeTokenCat
             h = _TimeTokenCat.apply(temb.to(tokens.dtype), tokens, self.input_proj.bias)
         else:

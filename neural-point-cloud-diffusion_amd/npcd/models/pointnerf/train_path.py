@@ -88,12 +88,13 @@ class _RowSplitLinear(torch.autograd.Function):
         f32 = torch.float32
         mixed = xx.dtype != f32
         if dy.shape[1] < 16 and mixed:
-            # the heads' last layers (256 -> 1, 256 -> 3): the library's fp32-output GEMM with a handful of output rows spends
-            # 10-400 ms per call on the HOST (tools/gpu_dev_stage1_hosttrace.py); bf16 output (fp32 accumulation inside), which
-            # is what the reference's autocast computes for every weight gradient
-            dw = ew.small_wgrad(dy, xx) if dy.is_cuda and _SMALL_WGRAD else None            # one pass over x (csrc/elementwise.hip small_wgrad_kernel)
+            # the heads' last layers (256 -> 1, 256 -> 3): one pass over x with fp32 sums (csrc/elementwise.hip small_wgrad_kernel).
+            # Shapes it does not cover (fp16 operands, K not a power of two, NPCD_NO_SMALL_WGRAD=1) keep fp32 accumulation AND
+            # fp32 output through the library GEMM -- slow on the host for a handful of output rows
+            # (tools/probes/gpu_dev_stage1_hosttrace.py: 10-400 ms per call), but the same numerics as every other weight gradient here
+            dw = ew.small_wgrad(dy, xx) if dy.is_cuda and _SMALL_WGRAD else None
             if dw is None:
-                dw = torch.mm(dy.t(), xx).float()
+                dw = torch.mm(dy.t(), xx, out_dtype=f32)
         elif S >= 2:
             head, tail = S * c, rows > S * c
             part = torch.empty((S + int(tail), dy.shape[1], xx.shape[1]), dtype=f32, device=dy.device)

@@ -43,15 +43,8 @@ def trainer_state_dict(trainer, full_model: Optional[torch.nn.Module] = None, em
     trainer.model as `.diffusion`) makes the EMA entry cover the whole model like the reference's; without it the EMA entry
     holds the diffusion model's keys only.
 
-    COLLECTIVE when the optimizer is sharded over ranks: EVERY rank must call it (the moment / EMA shards are all-gathered);
-    a rank-0-only call would hang in the first gather, so a one-element all-reduce first turns that mistake into an error
-    on a timeout-free path: each rank contributes 1 and the sum must be the world size."""
-    red = trainer.reducer
-    if red.shard and red.world > 1:
-        import torch.distributed as dist
-        token = torch.ones(1, device=trainer.flat.flat.device)
-        dist.all_reduce(token, group=red.group)
-        assert int(token.item()) == red.world, "trainer_state_dict / save_train_state must be called on every rank"
+    COLLECTIVE when the optimizer is sharded over ranks: EVERY rank must call it (the moment / EMA shards are all-gathered;
+    a rank-0-only call blocks in the first gather like any unmatched collective -- nothing in here can detect that)."""
     trainer.gather_state()                              # Adam moments AND the EMA: gathered once, here
     model, flat = trainer.model, trainer.flat
     m, v = _moments(trainer)

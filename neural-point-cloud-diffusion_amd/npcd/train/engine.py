@@ -235,6 +235,13 @@ class DiffusionTrainer:
                 offs = {id(p): (o, o + p.numel()) for p, o in zip(self.flat.params, self.flat.offsets)}
                 eng.block_ranges = [(min(offs[id(p)][0] for p in e["params"]), max(offs[id(p)][1] for p in e["params"])) for e in eng.blocks]
                 eng.wait_range = self.wait_params
+            # The waits live in the MODEL, not in step(): whoever runs a forward (step(), a custom compute_loss + apply_gradients
+            # loop, generate() in any precision) or reads the weights through state_dict() first completes the gathers it depends
+            # on.  In-place writes into parameters (copying EMA weights in) cannot be intercepted: call wait_params() first.
+            self._fused_engine = eng
+            if denoiser is not None:
+                denoiser.register_forward_pre_hook(self._await_params_for_forward)
+            diffusion.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self.wait_params())
         else:
             # reference path (CPU tests / ablation): torch AdamW over ONE flat "parameter"
             self.master = nn.Parameter(self.flat.flat, requires_grad=True)
@@ -266,10 +273,22 @@ class DiffusionTrainer:
             h.wait()
             self._ew.cast_f32_bf16(self.flat.flat[s0:e0], self.shadow[s0:e0])
 
+    def _await_params_for_forward(self, module, args):
+        """forward-pre-hook of the denoiser.  The fused training forward asks for its blocks one by one (so that the gathers of
+        the later blocks stay under the earlier blocks' compute): only the parameters read through ordinary modules (time_embed,
+        ln_pre, ln_post, input / output projection) must be current before it starts.  Every other forward (module path in fp32 /
+        f16, sampling) gets everything."""
+        if not getattr(self, "_pending", None):
+            return
+        fused_training = (self._fused_engine is not None and torch.is_grad_enabled() and torch.is_autocast_enabled()
+                          and torch.get_autocast_dtype("cuda") == torch.bfloat16 and args and args[0].is_cuda)
+        if not fused_training:
+            self.wait_params()
+            return
+        for off, n in self._accum_ranges:
+            self.wait_params(off, off + n)
+
     def step(self, coords, feats, t=None, coords_noise=None, feats_noise=None):
-        if getattr(self, "_pending", None):
-            for off, n in self._accum_ranges:         # parameters the forward reads through ordinary modules (time_embed, ln_pre,
-                self.wait_params(off, off + n)        # ln_post, input / output projection): must be current before it starts
         if not self.native or self.iteration == 0:
             self.flat.zero_grad()                 # afterwards the fused optimizer kernel leaves the gradients zeroed
         self.reducer.start_step()

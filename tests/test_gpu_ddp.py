@@ -57,6 +57,31 @@ def _worker(rank, world, port, out):
             torch.cuda.synchronize()
             tr.gather_ema()
             res[shard] = (tr.flat.flat.cpu(), tr.ema.cpu(), float(loss), tr.shadow.float().cpu())
+        # the waits for the lazily gathered parameters live in the model (round-2 advisor finding): a custom loop of
+        # compute_loss + apply_gradients, an fp32 forward through the module path and state_dict() must all see current weights
+        tr = DiffusionTrainer(_build(), bucket_bytes=256 << 10, shard_optimizer=True)
+        for _ in range(2):
+            tr.reducer.start_step()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss2, _, _ = tr.model.compute_loss(c0[sl], f0[sl], t=t[sl], coords_noise=cn[sl], feats_noise=fn[sl])
+            loss2.backward()
+            tr.apply_gradients()
+        assert tr._pending
+        with torch.no_grad():                                     # module path (fp32, no autocast): everything is awaited first
+            e_lazy = tr.model.denoiser(c0[sl], f0[sl], t[sl])[0].clone()
+        assert not tr._pending
+        tr.step(c0[sl], f0[sl], t=t[sl], coords_noise=cn[sl], feats_noise=fn[sl])
+        assert tr._pending
+        sd = tr.model.state_dict()                                # state_dict pre-hook
+        assert not tr._pending
+        torch.cuda.synchronize()
+        assert float(loss2) == res[True][2], "custom compute_loss + apply_gradients loop differs from step()"
+        tr2 = DiffusionTrainer(_build(), bucket_bytes=256 << 10, shard_optimizer=False)
+        for _ in range(2):
+            tr2.step(c0[sl], f0[sl], t=t[sl], coords_noise=cn[sl], feats_noise=fn[sl])
+        with torch.no_grad():
+            e_ref = tr2.model.denoiser(c0[sl], f0[sl], t[sl])[0]
+        assert torch.equal(e_lazy, e_ref), "forward after a sharded step read parameters of a gather still in flight"
         assert torch.equal(res[True][0], res[False][0]), "sharded optimizer diverged from the all-reduce path (parameters)"
         assert torch.equal(res[True][1], res[False][1]), "sharded optimizer diverged from the all-reduce path (EMA)"
         assert torch.equal(res[True][3], res[False][3]), "bf16 shadow of the parameters differs"

@@ -1,4 +1,4 @@
-"""Build profiles/*_attention_sq_pmc.json from a rocprofv3 --pmc + --kernel-trace csv pass over tools/gpu_dev_attn_only.py.
+"""Build profiles/*_attention_sq_pmc.json from a rocprofv3 --pmc + --kernel-trace csv pass over tools/probes/gpu_dev_attn_only.py.
 Counters (one pass: 8 SQ slots + 1 GRBM): SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY
 SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE.
 Derived per kernel (means over the launches after the first two):

@@ -1,5 +1,5 @@
 """Build profiles/*_hbm_traffic_pmc.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only)
-of tools/gpu_dev_attn_time.py (attention kernels) or tools/gpu_dev_ew_time.py (elementwise kernels).  FETCH_SIZE / WRITE_SIZE are
+of tools/probes/gpu_dev_attn_time.py (attention kernels) or tools/probes/gpu_dev_ew_time.py (elementwise kernels).  FETCH_SIZE / WRITE_SIZE are
 reported in KiB; FETCH_SIZE is doubled on gfx950 (MI355X_MICROARCH.md, HBM: 128-B requests are tallied at 64 B).
 usage: make_traffic_json.py attn|ew fetch.csv write.csv out.json"""
 import csv, collections, json, sys
@@ -15,11 +15,11 @@ if kind == "attn":
     alg["attn_bwd_dkdv_kernel"] += edge // 3
     if edge:
         alg["attn_bwd_edge_kernel"] = edge + 3 * B * H * d * 2 + 5 * B * H * d * 2  # partials read, 3 rows written, 5 rows read
-    note = "per launch, B=64 H=16 n=513 d=64 bf16 (tools/gpu_dev_attn_time.py)"
+    note = "per launch, B=64 H=16 n=513 d=64 bf16 (tools/probes/gpu_dev_attn_time.py)"
 else:
     alg = {"add_ln_fwd_kernel": T * W * (4 + 2 + 4 + 2), "ln_bwd_kernel": T * W * (2 + 4 + 4 + 4 + 2), "gelu_fwd_kernel": T * 4 * W * 4,
            "colsum_kernel<true": T * 4 * W * 6, "colsum_kernel<false": T * 4 * W * 2}
-    note = "per launch, T=32832 tokens, W=1024 (tools/gpu_dev_ew_time.py)"
+    note = "per launch, T=32832 tokens, W=1024 (tools/probes/gpu_dev_ew_time.py)"
 def mean_counter(path, name):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):

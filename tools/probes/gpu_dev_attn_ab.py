@@ -1,7 +1,7 @@
 """Dev probe: A/B/C.. of library builds on the attention kernels, interleaved (ABCABC...) so that clock drift cancels.
-usage: python3 tools/gpu_dev_attn_ab.py n rounds lib_a.so lib_b.so ...   ("default" = the in-tree library; one child process per library and round)"""
+usage: python3 tools/probes/gpu_dev_attn_ab.py n rounds lib_a.so lib_b.so ...   ("default" = the in-tree library; one child process per library and round)"""
 import sys, os, subprocess, re, statistics
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 n, rounds, libs = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
 res = {l: {} for l in libs}
 for _ in range(rounds):

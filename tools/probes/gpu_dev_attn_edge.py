@@ -1,6 +1,6 @@
 """Dev probe: the edge token's three gradient rows (sequence length 128 j + 1) against an fp32 reference."""
 import sys, os, math
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch
 from npcd.hip import attention as A

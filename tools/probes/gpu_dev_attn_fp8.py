@@ -1,7 +1,7 @@
 """Dev probe: the fp8 (e4m3, block-scaled MFMA) attention forward against the bf16 kernel and an fp32 reference: error and time.
-usage: python3 tools/gpu_dev_attn_fp8.py [n] [B] [reps]"""
+usage: python3 tools/probes/gpu_dev_attn_fp8.py [n] [B] [reps]"""
 import sys, os, math
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch
 from npcd.hip import attention as A

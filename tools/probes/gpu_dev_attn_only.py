@@ -1,6 +1,6 @@
 """Dev probe: the three attention kernels alone at cfg-D (meant to be run under rocprofv3 --pmc)."""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch
 from npcd.hip.attention import attention_qkvpacked

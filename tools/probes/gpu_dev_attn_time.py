@@ -1,7 +1,7 @@
 """Dev probe: per-kernel time of the attention kernels at cfg-D (B=64, n=513, H=16, d=64) + error vs an fp32 reference.
-usage: python3 tools/gpu_dev_attn_time.py [reps]"""
+usage: python3 tools/probes/gpu_dev_attn_time.py [reps]"""
 import sys, os, math
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch
 from npcd.hip import attention as A

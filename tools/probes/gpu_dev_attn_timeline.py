@@ -1,6 +1,6 @@
 """Dev probe (diagnostic build -DNPCD_TIMELINE=<block>): s_memtime stamps of one wave of the dK/dV pass."""
 import sys, os, math, ctypes
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch
 from npcd.hip import attention as A, lib

@@ -1,6 +1,6 @@
 """Dev probe: is the small per-GPU-batch step launch-bound?  wall vs enqueue time, run under rocprofv3 for the GPU-busy sum."""
 import sys, os, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch, bench
 dev = torch.device("cuda", 0)

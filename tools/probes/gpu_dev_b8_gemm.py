@@ -1,7 +1,7 @@
 """Dev probe: the GEMMs of one block's backward at small per-GPU batch (T = B x 513 tokens): weight-gradient split factors and
 dgrad || wgrad on two streams.  usage: gpu_dev_b8_gemm.py [B ...]"""
 import os, sys, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch
 import torch.cuda.tunable as tun

@@ -1,7 +1,7 @@
 """Dev probe: training step at BASELINE configs[4] shape (2048 points x 256-d latents, 8-layer denoiser, width 1024 / 16 heads,
 per-GPU batch 32 of the 8-GPU batch 256); NPCD_ATTN_FP8=1 runs the attention forward on the fp8 kernel."""
 import sys, os, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch
 from npcd.models.diffusion import DiffusionModel

@@ -1,6 +1,6 @@
 """Dev probe: which host ops launch the small device-to-device copies in the step?"""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch, bench
 from torch.profiler import profile, ProfilerActivity

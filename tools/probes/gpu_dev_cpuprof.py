@@ -1,6 +1,6 @@
 """Dev probe: cProfile of the host side of one denoiser training step (per-GPU batch argv[1])."""
 import sys, os, time, cProfile, pstats
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch, bench
 dev = torch.device("cuda", 0)

@@ -1,6 +1,6 @@
 """Dev probe: time + effective HBM rate of the elementwise kernels at cfg-D (T = 32832, W = 1024)."""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch
 from npcd.hip import elementwise as ew

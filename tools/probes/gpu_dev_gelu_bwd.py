@@ -1,7 +1,7 @@
 """Dev probe: GELU backward + bias-gradient column partials (colsum_kernel<true>) at cfg-D (T = 32832, N = 4096): time, effective HBM
 rate, error against an fp64 reference.  NPCD_GELU_BWD_VARIANT selects the kernel variant (read once per process)."""
 import os, sys
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch
 from npcd.hip import elementwise as ew

@@ -1,6 +1,6 @@
 """Developer probe: fused explicit runtime vs nn.Module/autograd path at full scale (cfg-D), same data/noise."""
 import sys, os, time, copy
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch, bench
 from npcd.models.diffusion import DiffusionModel

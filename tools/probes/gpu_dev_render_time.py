@@ -1,6 +1,6 @@
 """Dev probe: wall time of a 128x128 render (NPCD_RENDERS back-to-back calls; NPCD_ZERO_DATA=1 zeroes weights and features for the clock check)."""
 import sys, os, time
-R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R_ = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R_); sys.path.insert(0, os.path.join(R_, "neural-point-cloud-diffusion_amd"))
 import torch
 from npcd.utils import synthetic as orr

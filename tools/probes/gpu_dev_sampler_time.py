@@ -1,6 +1,6 @@
 """Dev probe: time of one DDPM reverse step (denoiser forward + posterior update) at cfg-D model size, batch 16."""
 import sys, os, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch
 from npcd.models.diffusion import DiffusionModel

@@ -1,6 +1,6 @@
 """Dev probe (diagnostic build -DNPCD_SHADE_TL=<block>): s_memtime stamps of one tile of one workgroup of shade_pairs."""
 import sys, os, ctypes
-R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R_ = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R_); sys.path.insert(0, os.path.join(R_, "neural-point-cloud-diffusion_amd"))
 import torch
 from npcd.utils import synthetic as orr

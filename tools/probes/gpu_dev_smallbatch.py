@@ -1,6 +1,6 @@
 """Dev probe: denoiser step time at per-GPU batch 64 / 32 / 16 / 8 on one GPU (what each rank of a strong-scaling run computes)."""
 import sys, os, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch, bench
 import torch.cuda.tunable as tun

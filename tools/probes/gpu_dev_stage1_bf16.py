@@ -1,6 +1,6 @@
 """Dev probe: the stage-1 training step of bench.py in its bf16 matrix-core form alone (23 steps; meant for rocprofv3 --kernel-trace --stats)."""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch, bench
 r = bench.bench_stage1(torch.device("cuda", 0), mlp_dtype=torch.bfloat16)

@@ -1,6 +1,6 @@
 """Dev probe: stage-1 step, enqueue (CPU) time vs wall time, and the top CPU functions of one step."""
 import sys, os, time, cProfile, pstats
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch, bench
 from npcd.models import NPCD

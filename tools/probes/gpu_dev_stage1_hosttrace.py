@@ -1,7 +1,7 @@
 """Dev probe: where the HOST spends its time inside _RowSplitLinear.backward of the stage-1 step (no device syncs added): wraps the
 torch / library calls it makes with wall-clock timers.  NPCD_ROWSPLIT_MIN selects which layers take that path."""
 import sys, os, time, collections
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch, bench
 from npcd.models.pointnerf import train_path as tp

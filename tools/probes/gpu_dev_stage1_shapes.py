@@ -1,7 +1,7 @@
 """Dev probe: which aten matrix products of the stage-1 training step (bf16 form) run which library kernel, with their shapes
 (torch.profiler, record_shapes) - to see which calls are left on slow library tiles."""
 import sys, os, collections
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch, bench
 from torch.profiler import profile, ProfilerActivity

@@ -1,6 +1,6 @@
 """Developer probe: time one denoiser training step (cfg-D) with the simple module path."""
 import sys, os, time
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch
 from npcd.models.diffusion import DiffusionModel

@@ -18,7 +18,7 @@ def run(tag):
     print(f"{tag} total/layer {tot:.3f} ms -> x24 {tot*24:.1f} ms", flush=True)
 run("default")
 tun.enable(True); tun.tuning_enable(True); tun.set_max_tuning_duration(30); tun.set_max_tuning_iterations(20)
-tun.set_filename(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "gpurun_out", "tunableop_results.csv"))
+tun.set_filename(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "gpurun_out", "tunableop_results.csv"))
 t0 = time.time(); run("tuning "); print("tuning took", time.time() - t0)
 tun.tuning_enable(False); run("tuned  ")
 tun.write_file()

@@ -1,7 +1,7 @@
 """Dev probe: row-split weight-gradient GEMM (bf16 in, fp32 out) + npcd_sum_slices for S = 1, 2, 4, 8 slices, the four Linear shapes
 of a block at T = 32832 tokens (what fused._wgrad runs); each timed right after a data-gradient GEMM on the same operands."""
 import sys, os
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch
 from npcd.hip import elementwise as ew
