@@ -61,6 +61,29 @@ def synthetic_batch(global_batch, rank, world, device):
     return coords[sl].to(device), feats[sl].to(device)
 
 
+def query_roofline(S, query_ms, launches):
+    """The neighbour-query kernel (grid_query_wave_kernel, csrc/geometry.hip) is neither HBM- nor MFMA-bound: its inputs are a
+    6 KB cloud and a 1 MB voxel table, its work is integer / fp32 vector instructions.  Its bound is VECTOR ISSUE: a SIMD issues at
+    most one vector wave-instruction per 2 cycles (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles on a SIMD-32), 1,024 SIMDs.
+    Wave-instruction counts per launch come from a committed rocprofv3 --pmc pass over the same scene (profiles/r3_render_sq_pmc.json:
+    SQ_INSTS_VALU and friends; bench.py cannot collect counters); the duration is measured here with HIP events around the C call
+    (which also enqueues the 4-byte counter fill)."""
+    fp = os.path.join(ROOT, "profiles", "r3_render_sq_pmc.json")
+    if not os.path.exists(fp):
+        return {"kernel": "grid_query_wave_kernel", "avg_ms": query_ms, "launches": launches, "bound": "valu-issue", "achieved": None}
+    pj = json.load(open(fp)).get(f"S{S}", {}).get("grid_query_wave_kernel")
+    if not pj:
+        return {"kernel": "grid_query_wave_kernel", "avg_ms": query_ms, "launches": launches, "bound": "valu-issue", "achieved": None}
+    clock_ghz = 2.4
+    peak = 1024 * clock_ghz / 2.0                                  # G vector wave-instructions / s
+    ach = pj["insts_valu"] / (query_ms * 1e-3) / 1e9
+    return {"kernel": "grid_query_wave_kernel (+ counter fill)", "bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "G wave-instr/s",
+            "frac": ach / peak, "avg_ms": query_ms, "launches": launches,
+            "vector_wave_instructions_per_launch": pj["insts_valu"], "all_wave_instructions_per_launch": pj.get("insts_all"),
+            "counters_source": "profiles/r3_render_sq_pmc.json (rocprofv3 --pmc, same scene / pose / depth samples)",
+            "peak_basis": "1,024 SIMDs x 2.4 GHz / 2 cycles per wave64 vector instruction"}
+
+
 def bench_render(device, n_iters=100, burn_in=5):
     """pointnerf_evaluation.py:217-224 protocol: sync, t0, render, sync, t1; burn-in renders discarded (the reference drops 3
     and then renders 251 views per object: the timed region here is 100 back-to-back renders, i.e. the sustained rate).
@@ -102,20 +125,23 @@ def bench_render(device, n_iters=100, burn_in=5):
             # the renderer's dominant kernels (shade_pairs_kernel + shade_points_kernel, f16 MFMA) on their own: HIP events on the
             # launch stream around the one C call that enqueues both, 20 renders, against the dense f16 MFMA peak
             from npcd.hip import render as hrender
-            hrender.SHADE_EVENTS = []
+            hrender.SHADE_EVENTS, hrender.QUERY_EVENTS = [], []
             net.renderer.count_pairs = False
             for _ in range(22):
                 net.render(c, f, extr, intr, 128)
             torch.cuda.synchronize()
             ev, hrender.SHADE_EVENTS = hrender.SHADE_EVENTS[2:], None
+            qev, hrender.QUERY_EVENTS = hrender.QUERY_EVENTS[2:], None
             shade_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
+            query_ms = sum(a.elapsed_time(b) for a, b in qev) / max(1, len(qev))
             per_s[S] = {"rays_per_s": 128 * 128 / dt, "rays_per_s_8_views_per_call": 8 * 128 * 128 / dt8, "ms_per_view": dt * 1e3,
                         "shading_points": P, "pairs": Q, "mlp_tflops_whole_view": flops / dt / 1e12,
                         "roofline_shading": {"kernel": "shade_pairs_kernel + shade_points_kernel (csrc/shade.hip)", "bound": "mfma",
                                              "achieved": flops / (shade_ms * 1e-3) / 1e12, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                              "frac": flops / (shade_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "avg_ms": shade_ms,
                                              "algorithmic_flops_per_view": flops, "launches": len(ev),
-                                             "note": "f16 operands, fp32 accumulation (same dense peak as bf16); FLOPs as executed: the linear last aggregator layer on points, not pairs"}}
+                                             "note": "f16 operands, fp32 accumulation (same dense peak as bf16); FLOPs as executed: the linear last aggregator layer on points, not pairs"},
+                        "roofline_query": query_roofline(S, query_ms, len(qev))}
     r = dict(per_s[128])
     r.update({"timed_renders": n_iters, "resolution": 128, "depth_samples": 128, "k": 8,
               "depth_samples_64": per_s[64],
@@ -156,6 +182,121 @@ def bench_stage1(device, n_iters=20, burn_in=3, mlp_dtype=None):
     return {"steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "ms_per_step_min_median_max": [per_it[0], per_it[n_iters // 2], per_it[-1]],
             "timed_iterations": n_iters, "objects": B, "views_per_object": T, "rays_per_view": net.pointnerf.renderer.ray_subsamples,
             "loss": float(loss), "differentiable_part": tr.describe()}
+
+
+class ClockSampler:
+    """Shader-clock / board-power datum for the timed region, so that a reader can tell a slow box from slow code: a host thread
+    reads the amdgpu sysfs files of the GPU this rank runs on every 20 ms while the timed loop runs (no GPU work, no sync):
+    `pp_dpm_sclk` (the level marked '*') and hwmon `power1_average` / `power1_input`.  sysfs reports the DPM state the
+    firmware holds, which under an MFMA-dense load reads up to ~10 % above the in-kernel clock (MI355X_MICROARCH.md, 'DVFS
+    give-back' item 6): a box-to-box comparison datum, not a cycle count."""
+
+    def __init__(self, local_rank=0, period_s=0.02):
+        import glob
+        import threading
+        self.period = period_s
+        self.sclk, self.power = [], []
+        self._stop = threading.Event()
+        self._thread = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        self.sclk_file = cards[min(local_rank, len(cards) - 1)] if cards else None
+        self.power_file = None
+        if self.sclk_file:
+            dev = os.path.dirname(self.sclk_file)
+            for nm in ("power1_average", "power1_input"):
+                hits = sorted(glob.glob(os.path.join(dev, "hwmon", "hwmon*", nm)))
+                if hits:
+                    self.power_file = hits[0]
+                    break
+
+    def _read(self):
+        try:
+            with open(self.sclk_file) as fh:
+                for line in fh:
+                    if "*" in line:
+                        self.sclk.append(float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip()))
+                        break
+            if self.power_file:
+                with open(self.power_file) as fh:
+                    self.power.append(float(fh.read().strip()) / 1e6)
+        except (OSError, ValueError, IndexError):
+            pass
+
+    def _loop(self):
+        while not self._stop.is_set():
+            self._read()
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        import threading
+        if self.sclk_file:
+            self._thread = threading.Thread(target=self._loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+
+    def summary(self):
+        if not self.sclk:
+            return None
+        q = lambda v: [min(v), sorted(v)[len(v) // 2], max(v)]
+        out = {"sclk_mhz_min_median_max": q(self.sclk), "samples": len(self.sclk), "source": self.sclk_file,
+               "note": "amdgpu sysfs DPM state sampled every 20 ms by a host thread during the timed loop; reads above the in-kernel clock under MFMA load"}
+        if self.power:
+            out["board_power_w_min_median_max"] = q(self.power)
+        return out
+
+
+def bench_cfg5(device, steps=6, warmup=2):
+    """BASELINE configs[4] as ONE rank of its 8-GPU job computes it (no communication): 2048 points x 256-d latents, 8-layer
+    denoiser (width 1024 / 16 heads: BASELINE leaves W / H open, SURVEY 8(d) takes the yaml's), sequence 2049, per-GPU batch
+    32 of the global 256 -- the training step with the attention forward on the bf16 kernel and on the fp8 (e4m3, block-scaled
+    MFMA) kernel (backward: bf16 kernels both ways).  tests/test_gpu_fused.py::test_stress_config_step_at_per_gpu_batch_32_...
+    holds the parity bars of both modes against the fp32 oracle."""
+    from npcd.hip import attention as hattn
+    from npcd.models.diffusion import DiffusionModel
+    from npcd.train import DiffusionTrainer
+    B, N, F_, W, L, H = 32, 2048, 256, 1024, 8, 16
+    g = torch.Generator().manual_seed(7)
+    c = torch.randn(B, 3, N, generator=g).to(device)
+    f = (torch.rand(B, F_, N, generator=g) * 2 - 1).to(device)
+    n = N + 1
+    flops = 3 * B * (L * (24 * n * W * W + 4 * n * n * W) + 2 * N * 2 * (3 + F_) * W + 16 * W * W)
+    out = {"config": f"{N} points x {F_}-d latents, {L} layers, width {W}, {H} heads (seq {n}), per-GPU batch {B} of the global 256, "
+                     f"bf16 autocast, one rank's step without communication", "timed_steps": steps, "algorithmic_flops_per_step": flops}
+    saved = hattn.FWD_FP8
+    try:
+        for mode in ("bf16", "fp8"):
+            hattn.FWD_FP8 = mode == "fp8"
+            torch.manual_seed(0)
+            m = DiffusionModel(3, F_, N, W, L, H, True)
+            torch.nn.init.normal_(m.denoiser.output_proj.weight, std=0.02)
+            tr = DiffusionTrainer(m.to(device).train())
+            assert tr.native and m.denoiser.backbone.fused_engine is not None
+            torch.manual_seed(3)
+            for _ in range(warmup):
+                tr.step(c, f)
+            torch.cuda.synchronize()
+            hattn.KERNEL_EVENTS = {k: [] for k in hattn.KERNEL_TAGS}
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                loss, _ = tr.step(c, f)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            ev, hattn.KERNEL_EVENTS = hattn.KERNEL_EVENTS, None
+            kms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ev.items() if v}
+            U = 2 * B * H * n * n * 64
+            out[f"attention_forward_{mode}"] = {"ms_per_step": dt * 1e3, "step_tflops": flops / dt / 1e12, "loss": float(loss),
+                                                "attention_kernel_ms": kms,
+                                                "attention_fwd_tflops": 2 * U / (kms["fwd"] * 1e-3) / 1e12 if "fwd" in kms else None}
+            del tr, m
+            torch.cuda.empty_cache()
+    finally:
+        hattn.FWD_FP8, hattn.KERNEL_EVENTS = saved, None
+    return out
 
 
 def host_cpu_info():
@@ -313,6 +454,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-render", action="store_true")
     ap.add_argument("--no-proxy", action="store_true", help="skip the one-GPU strong-scaling proxy (per-GPU batch 64/32/16/8)")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the BASELINE configs[4] step (2048 points x 256-d, per-GPU batch 32)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -368,11 +510,12 @@ def main():
     barrier()
     hattn.KERNEL_EVENTS = {k: [] for k in hattn.KERNEL_TAGS}
     hew.KERNEL_EVENTS = {"add_ln_fwd": [], "ln_bwd": [], "gelu_fwd": [], "gelu_bwd": []}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = trainer.step(coords, feats)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    with ClockSampler(local_rank) as clocks:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss, _ = trainer.step(coords, feats)
+        barrier()
+        elapsed = time.perf_counter() - t0
     events, hattn.KERNEL_EVENTS = hattn.KERNEL_EVENTS, None
     ew_events, hew.KERNEL_EVENTS = hew.KERNEL_EVENTS, None
     if world > 1:
@@ -466,6 +609,7 @@ def main():
         "roofline_hbm": hbm,
         "loss": float(loss),
         "tuned_gemm_file": "profiles/tunableop_gfx950.csv" if use_tuned else None,
+        "clock": clocks.summary(),
     }
     if world == 1 and not args.no_proxy:
         try:
@@ -484,15 +628,23 @@ def main():
             r["rays_per_s_all_gpus"] = float(tt)
         result["render"] = r
         try:
-            # primary figure: bf16 operands / fp32 accumulation, per-pair MLP on the matrix cores (csrc/pairs_mlp.hip);
-            # the reference's numerics (all fp32, library GEMMs at the fp32 matrix rate) beside it
-            s1 = bench_stage1(device, mlp_dtype=torch.bfloat16)
-            s1["numerics"] = "bf16 operands, fp32 accumulation, fp32 weight gradients and optimizer (PointNeRFTrainer(mlp_dtype=torch.bfloat16))"
-            ref32 = bench_stage1(device)
-            s1["fp32_reference_numerics"] = {k: ref32[k] for k in ("steps_per_s", "ms_per_step", "ms_per_step_min_median_max", "loss")}
+            # lead figure: the reference's numerics -- stage 1 trains in fp32 (train_pointnerf.py has no autocast): fp32 operands,
+            # library GEMMs at the fp32 matrix rate.  The bf16-operand / fp32-accumulate form with the per-pair MLP on the matrix
+            # cores (csrc/pairs_mlp.hip) is an opt-in (PointNeRFTrainer(mlp_dtype=torch.bfloat16)) and reported beside it.
+            s1 = bench_stage1(device)
+            s1["numerics"] = "fp32 operands and accumulation like the reference's train_pointnerf.py (PointNeRFTrainer(mlp_dtype=None))"
+            opt = bench_stage1(device, mlp_dtype=torch.bfloat16)
+            s1["bf16_operands_opt_in"] = {k: opt[k] for k in ("steps_per_s", "ms_per_step", "ms_per_step_min_median_max", "loss", "differentiable_part")}
+            s1["bf16_operands_opt_in"]["numerics"] = ("bf16 operands, fp32 accumulation, fp32 weight gradients and optimizer: NARROWER than the "
+                                                      "reference's fp32 -- not the creditable figure")
             result["stage1_pointnerf_training"] = s1
         except Exception as e:                      # noqa: BLE001
             result["stage1_pointnerf_training"] = {"error": f"{type(e).__name__}: {e}"}
+    if world == 1 and not args.no_cfg5:
+        try:
+            result["cfg5_stress_step"] = bench_cfg5(device)
+        except Exception as e:                      # noqa: BLE001
+            result["cfg5_stress_step"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

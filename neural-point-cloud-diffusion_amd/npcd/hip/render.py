@@ -55,6 +55,11 @@ def ray_gen(extr: torch.Tensor, intr: torch.Tensor, res: int, box: float = 1.0, 
     return o, d, t0, t1
 
 
+# When set to a list, every query_compact() call (counter fill + the neighbour-query kernel, one C call) is bracketed by HIP events
+# recorded on the launch stream (bench.py: roofline entry of the renderer's second-largest kernel).
+QUERY_EVENTS = None
+
+
 class HipVoxelGrid:
     """Device-side state of a torch_knnquery.VoxelGrid: parameters + the workspace written by
     set_pointset (per point fine-voxel coordinates / kept flag, per example coarse occupancy)."""
@@ -134,9 +139,16 @@ class HipVoxelGrid:
         ray_bits = torch.empty(B * R, dtype=torch.int64, device=dev)
         nb = torch.empty((capacity, k), dtype=_i32, device=dev)
         cpts = torch.empty((capacity, 3), dtype=_f32, device=dev)
+        ev = None
+        if QUERY_EVENTS is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         check(lib().npcd_grid_query_compact(ctypes.byref(self.params), ptr(self.workspace), ptr(pts_t), B, N, R, int(S), int(M), int(k),
                                             float(r), ptr(o), ptr(d), ptr(t0), ptr(t1), ptr(counter), int(capacity), ptr(ray_base),
                                             ptr(ray_nsel), ptr(ray_bits), ptr(nb), ptr(cpts), stream_ptr()), "npcd_grid_query_compact")
+        if ev is not None:
+            ev[1].record()
+            QUERY_EVENTS.append(ev)
         return counter, ray_base, ray_nsel, ray_bits, nb, cpts
 
     def query(self, x: torch.Tensor, k: int, r: float, max_shading_pts: int):

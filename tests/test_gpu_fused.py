@@ -292,6 +292,57 @@ def test_stress_config_shape_step():
     assert rel(ta.flat.flat, tb.flat.flat) < 1e-3
 
 
+def test_stress_config_step_at_per_gpu_batch_32_fp8_and_bf16_attention():
+    """BASELINE configs[4] as one rank of its 8-GPU job runs it: 2048 points x 256-d latents, 8-layer denoiser (width 1024, 16 heads,
+    sequence 2049), PER-GPU batch 32 of the global 256; one DiffusionTrainer.step with the attention forward on the fp8 (e4m3,
+    block-scaled MFMA) kernel and one on the bf16 kernel, same weights and draws.  Bars: both losses finite, |loss(fp8) - loss(bf16)|
+    <= 2e-2 relative (measured 1e-3), eps-hat of sample 0 against the fp32 CPU oracle (oracle.denoiser, the same weights): rel-L2
+    <= 3e-2 with bf16 attention (measured 6e-3) and <= 8e-2 with fp8 attention (the attention-level bar of test_attention_fp8_forward)."""
+    import copy
+    from npcd.hip import attention as hattn
+    from npcd.models.diffusion import DiffusionModel
+    from npcd.train import DiffusionTrainer
+    from oracle import denoiser as od
+    torch.manual_seed(0)
+    base = DiffusionModel(3, 256, 2048, 1024, 8, 16, True)
+    with torch.no_grad():
+        base.denoiser.output_proj.weight.normal_(0, 0.02)
+    g = torch.Generator().manual_seed(1)
+    B = 32
+    c, f = torch.randn(B, 3, 2048, generator=g), torch.randn(B, 256, 2048, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    cn, fn = torch.randn(B, 3, 2048, generator=g), torch.randn(B, 256, 2048, generator=g)
+    params = {k: v.detach().clone() for k, v in base.denoiser.state_dict().items()}
+    x_c = base.diffusion_process.q_sample(c, t, cn)
+    x_f = base.diffusion_process.q_sample(f, t, fn)
+    with torch.no_grad():
+        ref_c, ref_f = od.denoiser_forward(params, x_c[:1], x_f[:1], t[:1], 16)      # one sample through the fp32 oracle
+    ref = torch.cat((ref_c, ref_f), dim=1)
+    losses, errs = {}, {}
+    saved = hattn.FWD_FP8
+    try:
+        for mode in ("bf16", "fp8"):
+            hattn.FWD_FP8 = mode == "fp8"
+            m = copy.deepcopy(base).cuda().train()
+            tr = DiffusionTrainer(m)
+            assert tr.native and m.denoiser.backbone.fused_engine is not None
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                e_c, e_f = m.denoiser(x_c[:1].cuda(), x_f[:1].cuda(), t[:1].cuda())
+            errs[mode] = rel(torch.cat((e_c, e_f), dim=1).float().cpu(), ref)
+            loss, _ = tr.step(c.cuda(), f.cuda(), t=t.cuda(), coords_noise=cn.cuda(), feats_noise=fn.cuda())
+            losses[mode] = float(loss)
+            assert math.isfinite(losses[mode])
+            loss2, _ = tr.step(c.cuda(), f.cuda(), t=t.cuda(), coords_noise=cn.cuda(), feats_noise=fn.cuda())
+            assert math.isfinite(float(loss2))
+            del tr, m
+            torch.cuda.empty_cache()
+    finally:
+        hattn.FWD_FP8 = saved
+    print(f"cfg-5 per-GPU batch 32: loss bf16 {losses['bf16']:.5f} fp8 {losses['fp8']:.5f}; eps-hat rel-L2 vs oracle bf16 {errs['bf16']:.2e} fp8 {errs['fp8']:.2e}")
+    assert abs(losses["fp8"] - losses["bf16"]) <= 2e-2 * abs(losses["bf16"])
+    assert errs["bf16"] <= 3e-2 and errs["fp8"] <= 8e-2
+
+
 def test_float16_training_with_dynamic_loss_scale():
     """dtype=float16 (the reference's default --dtype): scaled backward, overflow -> skipped step and halved scale."""
     from npcd.train import DiffusionTrainer

@@ -1,4 +1,5 @@
-"""Dev probe: wall time of a 128x128 render (NPCD_RENDERS back-to-back calls; NPCD_ZERO_DATA=1 zeroes weights and features for the clock check)."""
+"""Dev probe: wall time of a 128x128 render, one view per call (NPCD_RENDERS back-to-back calls; NPCD_S = depth samples per ray, default 128;
+NPCD_ZERO_DATA=1 zeroes weights and features for the clock check)."""
 import sys, os, time
 R_ = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R_); sys.path.insert(0, os.path.join(R_, "neural-point-cloud-diffusion_amd"))
@@ -14,9 +15,10 @@ if os.environ.get("NPCD_ZERO_DATA"):      # clock check: all-zero weights and fe
         for p_ in model.field.parameters(): p_.zero_()
     f.zero_()
 N_ = int(os.environ.get("NPCD_RENDERS", "10"))
+model.renderer.depth_resolution = int(os.environ.get("NPCD_S", "128"))
 with torch.no_grad():
     for _ in range(3): out = model.render(c, f, extr, intr, 128)
     torch.cuda.synchronize(); t = time.time()
     for _ in range(N_): out = model.render(c, f, extr, intr, 128)
     torch.cuda.synchronize(); dt = (time.time() - t) / N_
-print("128^2 view: %.3f ms  %.2f Mrays/s  P=%d Q=%d" % (dt*1e3, 16384/dt/1e6, out["num_shading_points"], out["num_pairs"]))
+print("128^2 view, S=%d: %.3f ms  %.2f Mrays/s  P=%d Q=%d" % (model.renderer.depth_resolution, dt*1e3, 16384/dt/1e6, out["num_shading_points"], out["num_pairs"]))
