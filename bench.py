@@ -143,6 +143,21 @@ def bench_render(device, n_iters=100, burn_in=5):
                                              "note": "f16 operands, fp32 accumulation (same dense peak as bf16); FLOPs as executed: the linear last aggregator layer on points, not pairs"},
                         "roofline_query": query_roofline(S, query_ms, len(qev))}
     r = dict(per_s[128])
+    # continuity with rounds 1-2, which ran the FINE-grid reading of torch_knnquery (fewer shading points with a neighbour, i.e.
+    # less work per view): the same view at grid_level "fine" (DESIGN.md section 3 has the evidence for the default)
+    level = net.voxel_grid.grid_level
+    other = "fine" if level == "scaled" else "scaled"
+    net.voxel_grid.set_grid_level(other)
+    net.renderer.depth_resolution = 128
+    with torch.no_grad():
+        net.renderer.count_pairs = False
+        dt_o = timed(lambda: net.render(c, f, extr, intr, 128), 50, burn_in)
+        net.renderer.count_pairs = True
+        out_o = net.render(c, f, extr, intr, 128)
+    net.voxel_grid.set_grid_level(level)
+    r["grid_level"] = level
+    r[f"grid_level_{other}"] = {"rays_per_s": 128 * 128 / dt_o, "ms_per_view": dt_o * 1e3, "shading_points": int(out_o["num_shading_points"]),
+                                "pairs": int(out_o["num_pairs"])}
     r.update({"timed_renders": n_iters, "resolution": 128, "depth_samples": 128, "k": 8,
               "depth_samples_64": per_s[64],
               "note": "mlp_tflops_whole_view = shading FLOPs / whole-view wall time (all kernels of the view), not a per-kernel roofline"})

@@ -137,7 +137,18 @@ typedef struct npcd_grid_params {
     float range_max[3];
     int32_t dims[3];         /* fine grid dimensions, computed by the host */
     int32_t cdims[3];        /* coarse grid dimensions                      */
+    /* Which grid the point lists, the point cap and the candidate window live on (the source of torch_knnquery is not
+     * available: DESIGN.md section 3 states both readings and the evidence for each):
+     *   NPCD_GRID_FINE   (0): <= max_points_per_voxel points per FINE voxel (voxel_size), candidates = the kernel_size window of
+     *                         fine voxels around the sample; occupancy on the coarse grid (fine // voxel_scale), dilated by kernel_size.
+     *   NPCD_GRID_SCALED (1): everything on ONE grid of edge voxel_size * voxel_scale with ceil(dims / voxel_scale) cells per
+     *                         axis: point lists (<= max_points_per_voxel per cell), the max_occ_voxels cap, occupancy dilated by
+     *                         kernel_size, and the kernel_size candidate window.
+     * The query radius is r * max(voxel_size) -- the UNSCALED edge (aggregator.py:20) -- in both. */
+    int32_t grid_level;
 } npcd_grid_params;
+#define NPCD_GRID_FINE 0
+#define NPCD_GRID_SCALED 1
 
 /* bytes of device workspace npcd_grid_build needs for (B, N): per point {ix,iy,iz,kept} + the
  * coarse occupancy bitmaps */

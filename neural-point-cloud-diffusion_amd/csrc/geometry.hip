@@ -1015,8 +1015,30 @@ extern "C" int npcd_ray_gen_subset(const float* extr, const float* intr, int V, 
     return ray_gen_launch(extr, intr, V, res, box, pixel_ids, n_ids, rays_o, rays_d, t0, t1, limits_ws, stream);
 }
 
+// The grid the kernels work on.  NPCD_GRID_SCALED is the fine-grid machinery run on ONE grid of edge voxel_size * voxel_scale
+// (one fp32 product per axis) with the coarse dimensions and voxel_scale 1: lists, caps, occupancy and the candidate window all
+// live there.  The query radius always comes from the caller's UNSCALED voxel_size (grid_radius).
+static inline npcd_grid_params effective_grid(const npcd_grid_params& g) {
+    if (g.grid_level != NPCD_GRID_SCALED) return g;
+    npcd_grid_params e = g;
+    for (int a = 0; a < 3; ++a) {
+        e.voxel_size[a] = g.voxel_size[a] * (float)g.voxel_scale[a];
+        e.voxel_scale[a] = 1;
+        e.dims[a] = g.cdims[a];
+    }
+    e.grid_level = NPCD_GRID_FINE;
+    return e;
+}
+static inline float grid_radius(const npcd_grid_params& g, float r) {
+    float vmax = g.voxel_size[0];
+    if (g.voxel_size[1] > vmax) vmax = g.voxel_size[1];
+    if (g.voxel_size[2] > vmax) vmax = g.voxel_size[2];
+    return (float)((double)r * (double)vmax);   // aggregator.py:20, evaluated in float64 then rounded
+}
+
 static int grid_check(const npcd_grid_params* g, int B, int N) {
     if (!g || B <= 0 || N <= 0) return NPCD_ERR_ARG;
+    if (g->grid_level != NPCD_GRID_FINE && g->grid_level != NPCD_GRID_SCALED) return NPCD_ERR_ARG;
     for (int a = 0; a < 3; ++a) {
         if (g->dims[a] <= 0 || g->dims[a] > 1023 || g->cdims[a] <= 0) return NPCD_ERR_UNSUPPORTED;
         if (g->voxel_scale[a] <= 0 || g->kernel_size[a] <= 0 || (g->kernel_size[a] & 1) == 0) return NPCD_ERR_ARG;
@@ -1031,14 +1053,21 @@ static inline int64_t table_offset(const npcd_grid_params& g, int B, int N) {   
     return (((int64_t)B * N * 4 + (int64_t)B * occ_words(g) * 4) + 15) / 16 * 16;
 }
 
-extern "C" int64_t npcd_grid_workspace_bytes(const npcd_grid_params* g, int B, int N) {
+extern "C" int64_t npcd_grid_workspace_bytes(const npcd_grid_params* g_in, int B, int N) {
+    if (grid_check(g_in, B, N) != NPCD_OK) return -1;
+    const npcd_grid_params ge = effective_grid(*g_in);
+    const npcd_grid_params* g = &ge;
     if (grid_check(g, B, N) != NPCD_OK) return -1;
     return table_offset(*g, B, N) + (table_ok(*g) ? (int64_t)B * table_voxels(*g) * 8 : 0);
 }
 
-extern "C" int npcd_grid_build(const npcd_grid_params* g, const float* points, const int32_t* counts, int B, int N,
+extern "C" int npcd_grid_build(const npcd_grid_params* g_in, const float* points, const int32_t* counts, int B, int N,
                                void* workspace, void* stream) {
-    int rc = grid_check(g, B, N);
+    int rc = grid_check(g_in, B, N);
+    if (rc != NPCD_OK) return rc;
+    const npcd_grid_params ge = effective_grid(*g_in);
+    const npcd_grid_params* g = &ge;
+    rc = grid_check(g, B, N);
     if (rc != NPCD_OK) return rc;
     if (!points || !workspace) return NPCD_ERR_ARG;
     const int nwords = occ_words(*g);
@@ -1058,11 +1087,15 @@ extern "C" int npcd_grid_build(const npcd_grid_params* g, const float* points, c
     return NPCD_OK;
 }
 
-extern "C" int npcd_grid_query(const npcd_grid_params* g, const void* workspace, const float* points, int B, int N, int R, int S,
+extern "C" int npcd_grid_query(const npcd_grid_params* g_in, const void* workspace, const float* points, int B, int N, int R, int S,
                                int M, int k, float r, int mode, const float* x, const float* rays_o, const float* rays_d,
                                const float* t0, const float* t1, int32_t* sample_idx, float* sample_loc, int32_t* slot_sample,
                                int32_t* nsel, void* stream) {
-    int rc = grid_check(g, B, N);
+    int rc = grid_check(g_in, B, N);
+    if (rc != NPCD_OK) return rc;
+    const npcd_grid_params ge = effective_grid(*g_in);
+    const npcd_grid_params* g = &ge;
+    rc = grid_check(g, B, N);
     if (rc != NPCD_OK) return rc;
     if (!points || !sample_idx || !sample_loc || !slot_sample || !nsel) return NPCD_ERR_ARG;
     // explicit positions may come one per "ray" (the TV loss queries every point's own neighbourhood); depth sampling along
@@ -1081,13 +1114,7 @@ extern "C" int npcd_grid_query(const npcd_grid_params* g, const void* workspace,
                   ? reinterpret_cast<const int16_t*>(static_cast<const unsigned char*>(workspace) + table_offset(*g, B, N)) : nullptr;
     a.points = points;
     a.B = B; a.N = N; a.R = R; a.S = S; a.M = M; a.k = k;
-    float radius = r;
-    if (mode == 0) {
-        float vmax = g->voxel_size[0];
-        if (g->voxel_size[1] > vmax) vmax = g->voxel_size[1];
-        if (g->voxel_size[2] > vmax) vmax = g->voxel_size[2];
-        radius = (float)((double)r * (double)vmax);   // aggregator.py:20, evaluated in float64 then rounded
-    }
+    const float radius = mode == 0 ? grid_radius(*g_in, r) : r;
     a.r2 = radius * radius;
     a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t0 = t0; a.t1 = t1;
     a.sample_idx = sample_idx; a.sample_loc = sample_loc; a.slot_sample = slot_sample; a.nsel = nsel;
@@ -1153,11 +1180,15 @@ extern "C" int npcd_ray_march_bwd(const float* sigma, const float* rgb, const ui
 // Fused-render form of the neighbour query: compact shading-point lists instead of the dense [ray, slot]
 // arrays.  counter[0] receives the number of compact points, counter[1] an overflow flag (capacity too small;
 // nothing is written for the overflowing rays).  Rows of one ray are contiguous and in slot order.
-extern "C" int npcd_grid_query_compact(const npcd_grid_params* g, const void* workspace, const float* points, int B, int N, int R, int S,
+extern "C" int npcd_grid_query_compact(const npcd_grid_params* g_in, const void* workspace, const float* points, int B, int N, int R, int S,
                                        int M, int k, float r, const float* rays_o, const float* rays_d, const float* t0, const float* t1,
                                        int32_t* counter, int32_t capacity, int32_t* ray_base, int32_t* ray_nsel, uint64_t* ray_bits,
                                        int32_t* nb_idx, float* pts, void* stream) {
-    int rc = grid_check(g, B, N);
+    int rc = grid_check(g_in, B, N);
+    if (rc != NPCD_OK) return rc;
+    const npcd_grid_params ge = effective_grid(*g_in);
+    const npcd_grid_params* g = &ge;
+    rc = grid_check(g, B, N);
     if (rc != NPCD_OK) return rc;
     if (!workspace || !points || !rays_o || !rays_d || !t0 || !t1 || !counter || !ray_base || !ray_nsel || !ray_bits || !nb_idx || !pts)
         return NPCD_ERR_ARG;
@@ -1171,10 +1202,7 @@ extern "C" int npcd_grid_query_compact(const npcd_grid_params* g, const void* wo
     a.table = table_ok(*g) ? reinterpret_cast<const int16_t*>(static_cast<const unsigned char*>(workspace) + table_offset(*g, B, N)) : nullptr;
     a.points = points;
     a.B = B; a.N = N; a.R = R; a.S = S; a.M = M; a.k = k;
-    float vmax = g->voxel_size[0];
-    if (g->voxel_size[1] > vmax) vmax = g->voxel_size[1];
-    if (g->voxel_size[2] > vmax) vmax = g->voxel_size[2];
-    const float radius = (float)((double)r * (double)vmax);
+    const float radius = grid_radius(*g_in, r);
     a.r2 = radius * radius;
     a.rays_o = rays_o; a.rays_d = rays_d; a.t0 = t0; a.t1 = t1;
     CompactOut co{};

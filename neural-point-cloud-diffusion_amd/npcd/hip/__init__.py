@@ -15,6 +15,7 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__fi
 LIB_PATH = os.environ.get("NPCD_HIP_LIB") or os.path.join(_PKG_ROOT, "lib", "libnpcd_hip.so")
 
 NPCD_BF16, NPCD_F16, NPCD_F32 = 0, 1, 2
+NPCD_GRID_FINE, NPCD_GRID_SCALED = 0, 1
 _DTYPE_CODE = {torch.bfloat16: NPCD_BF16, torch.float16: NPCD_F16, torch.float32: NPCD_F32}
 
 
@@ -22,7 +23,8 @@ class GridParams(ctypes.Structure):
     """struct npcd_grid_params (include/npcd_hip.h)."""
     _fields_ = [("voxel_size", c_float * 3), ("voxel_scale", c_int32 * 3), ("kernel_size", c_int32 * 3),
                 ("max_points_per_voxel", c_int32), ("max_occ_voxels_per_example", c_int32),
-                ("range_min", c_float * 3), ("range_max", c_float * 3), ("dims", c_int32 * 3), ("cdims", c_int32 * 3)]
+                ("range_min", c_float * 3), ("range_max", c_float * 3), ("dims", c_int32 * 3), ("cdims", c_int32 * 3),
+                ("grid_level", c_int32)]
 
 
 _P = c_void_p

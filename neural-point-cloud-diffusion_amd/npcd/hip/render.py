@@ -1,5 +1,6 @@
 """Render-path operators on the HIP kernels (csrc/geometry.hip, csrc/shade.hip)."""
 import ctypes
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -9,8 +10,18 @@ from . import GridParams, check, lib, ptr, require_gpu, stream_ptr
 _i32, _f32 = torch.int32, torch.float32
 
 
-def make_grid_params(voxel_size, voxel_scale, kernel_size, max_points_per_voxel, max_occ_voxels_per_example, ranges) -> GridParams:
+GRID_LEVELS = {"fine": 0, "scaled": 1}
+# Which reading of the (unavailable) torch_knnquery source the grid follows when the caller does not say: DESIGN.md section 3.
+DEFAULT_GRID_LEVEL = os.environ.get("NPCD_GRID_LEVEL", "scaled")
+
+
+def make_grid_params(voxel_size, voxel_scale, kernel_size, max_points_per_voxel, max_occ_voxels_per_example, ranges,
+                     grid_level=None) -> GridParams:
     g = GridParams()
+    level = DEFAULT_GRID_LEVEL if grid_level is None else grid_level
+    if level not in GRID_LEVELS:
+        raise ValueError(f"grid_level must be one of {sorted(GRID_LEVELS)}; got {level!r}")
+    g.grid_level = GRID_LEVELS[level]
     for a in range(3):
         g.voxel_size[a] = float(voxel_size[a])
         g.voxel_scale[a] = int(voxel_scale[a])
@@ -64,13 +75,25 @@ class HipVoxelGrid:
     """Device-side state of a torch_knnquery.VoxelGrid: parameters + the workspace written by
     set_pointset (per point fine-voxel coordinates / kept flag, per example coarse occupancy)."""
 
-    def __init__(self, voxel_size, voxel_scale, kernel_size, max_points_per_voxel, max_occ_voxels_per_example, ranges):
+    def __init__(self, voxel_size, voxel_scale, kernel_size, max_points_per_voxel, max_occ_voxels_per_example, ranges, grid_level=None):
+        """The six arguments of torch_knnquery.VoxelGrid (pointnerf.py:147-153).  `grid_level` ("fine" / "scaled"; default
+        DEFAULT_GRID_LEVEL, env NPCD_GRID_LEVEL) selects which reading of the unavailable upstream source is followed: see
+        include/npcd_hip.h (npcd_grid_params.grid_level) and DESIGN.md section 3."""
         self.params = make_grid_params(voxel_size, voxel_scale, kernel_size, max_points_per_voxel,
-                                       max_occ_voxels_per_example, ranges)
+                                       max_occ_voxels_per_example, ranges, grid_level)
+        self.grid_level = "scaled" if self.params.grid_level == 1 else "fine"
         self.vsize_tup = tuple(float(v) for v in voxel_size)
         self.points: Optional[torch.Tensor] = None
         self.workspace: Optional[torch.Tensor] = None
         self._built_from = None          # (tensor sharing the storage the grid was built from, its version, geometry)
+
+    def set_grid_level(self, grid_level: str):
+        """Switch between the two readings ("fine" / "scaled") on an existing grid; the next set_pointset rebuilds."""
+        if grid_level not in GRID_LEVELS:
+            raise ValueError(f"grid_level must be one of {sorted(GRID_LEVELS)}; got {grid_level!r}")
+        self.params.grid_level = GRID_LEVELS[grid_level]
+        self.grid_level = grid_level
+        self._built_from, self.points = None, None
 
     def set_pointset(self, points: torch.Tensor, counts: Optional[torch.Tensor] = None):
         """Build the grid's device-side state for a batch of clouds.  Rendering many views of the same cloud (the evaluation

@@ -19,7 +19,8 @@ Params = Dict[str, torch.Tensor]
 
 DEFAULT_GRID = dict(voxel_size=(0.04, 0.04, 0.04), voxel_scale=(2, 2, 2), kernel_size=(3, 3, 3),
                     max_points_per_voxel=4, max_occ_voxels_per_example=5000,
-                    ranges=(-1.0, -1.0, -1.0, 1.0, 1.0, 1.0))          # pointnerf.py:147-153
+                    ranges=(-1.0, -1.0, -1.0, 1.0, 1.0, 1.0),          # pointnerf.py:147-153
+                    grid_level="scaled")                                # the reading of the absent torch_knnquery source (voxel_grid.py)
 
 
 # ------------------------------------------------------------------ rays ---------------------

@@ -23,8 +23,14 @@ f32 = np.float32
 class VoxelGridOracle:
     def __init__(self, voxel_size=(0.04, 0.04, 0.04), voxel_scale=(2, 2, 2), kernel_size=(3, 3, 3),
                  max_points_per_voxel=4, max_occ_voxels_per_example=5000,
-                 ranges=(-1.0, -1.0, -1.0, 1.0, 1.0, 1.0)):
-        self.vsize_tup = tuple(float(v) for v in voxel_size)
+                 ranges=(-1.0, -1.0, -1.0, 1.0, 1.0, 1.0), grid_level="scaled"):
+        """grid_level "fine": point lists / cap / candidate window on the voxel_size grid, occupancy on the grid coarsened by
+        voxel_scale.  grid_level "scaled": ONE grid of edge fp32(voxel_size) * voxel_scale (one fp32 product) with
+        ceil(dims / voxel_scale) cells per axis carries lists, caps, occupancy and window -- the fine-grid algorithm below run
+        with that edge and voxel_scale 1.  The query radius is r * max(voxel_size), the UNSCALED edge (aggregator.py:20), in both."""
+        assert grid_level in ("fine", "scaled")
+        self.grid_level = grid_level
+        self.vsize_tup = tuple(float(v) for v in voxel_size)          # what aggregator.py:20 reads: never scaled
         self.vsize = np.asarray(voxel_size, dtype=f32)
         self.scale = np.asarray(voxel_scale, dtype=np.int64)
         self.kernel = np.asarray(kernel_size, dtype=np.int64)
@@ -37,6 +43,10 @@ class VoxelGridOracle:
         self.dims = np.array([int(round((float(ranges[3 + a]) - float(ranges[a])) / float(voxel_size[a])))
                               for a in range(3)], dtype=np.int64)
         self.cdims = (self.dims + self.scale - 1) // self.scale
+        if grid_level == "scaled":
+            self.vsize = (self.vsize * self.scale.astype(f32)).astype(f32)
+            self.dims = self.cdims.copy()
+            self.scale = np.ones(3, dtype=np.int64)
 
     # ---- fine voxel coordinates ------------------------------------------------------------
     def fine_coords(self, p: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:

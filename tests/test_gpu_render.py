@@ -66,8 +66,9 @@ def test_ray_gen_all_miss_keeps_sentinels():
     assert (t0.cpu() == -1).all() and (t1.cpu() == -2).all()
 
 
+@pytest.mark.parametrize("level", ["fine", "scaled"])
 @pytest.mark.parametrize("N,seed", [(512, 0), (64, 3), (2048, 5)])
-def test_grid_query_bit_exact(N, seed):
+def test_grid_query_bit_exact(N, seed, level):
     from npcd.hip import render as hr
     res, S, M, k = 24, 128, 50, 8
     coords, _, extr, intr = _scene(res, 2, N, 32, seed)
@@ -76,10 +77,11 @@ def test_grid_query_bit_exact(N, seed):
     V, R = o.shape[:2]
     ro, rd, rs, re = o.reshape(1, V * R, 3), d.reshape(1, V * R, 3), s.reshape(1, V * R), e.reshape(1, V * R)
     x = (ro[:, :, None] + orr.depth_samples(rs[..., None], re[..., None], S)[..., None] * rd[:, :, None]).numpy()
-    g = ovg.VoxelGridOracle()
+    cfg = dict(orr.DEFAULT_GRID, grid_level=level)
+    g = ovg.VoxelGridOracle(**cfg)
     g.set_pointset(coords.numpy(), np.array([N], dtype=np.int32))
     ridx, rloc, rnsel, rss = g.query_dense(x, k, 2.0, M)
-    hg = hr.HipVoxelGrid(**orr.DEFAULT_GRID)
+    hg = hr.HipVoxelGrid(**cfg)
     hg.set_pointset(coords.cuda(), torch.full((1,), N, dtype=torch.int32, device="cuda"))
     for kw in (dict(rays=(ro.cuda(), rd.cuda(), rs.cuda(), re.cuda()), S=S), dict(x=T(x).cuda())):
         idx, loc, ss, nsel = hg.query_dense(k, 2.0, M, **kw)
@@ -90,8 +92,8 @@ def test_grid_query_bit_exact(N, seed):
     assert (ridx[..., 0] >= 0).sum() > 1000
     # the torch_knnquery.VoxelGrid.query contract (compaction over rays)
     from torch_knnquery import VoxelGrid
-    vg = VoxelGrid(**orr.DEFAULT_GRID)
-    assert vg.vsize_tup == (0.04, 0.04, 0.04)
+    vg = VoxelGrid(**cfg)
+    assert vg.vsize_tup == (0.04, 0.04, 0.04) and vg.grid_level == level
     vg.set_pointset(coords.cuda(), torch.full((1,), N, dtype=torch.int32, device="cuda"))
     sidx, sloc, ray_mask = vg.query(T(x).cuda(), k, 2.0, M)
     oidx, oloc, omask = g.query(x, k, 2.0, M)
@@ -118,8 +120,8 @@ def test_grid_capacity_limits_and_batches():
     pts[2, 7] = [1.0, 1.0, 1.0]                     # exactly on the upper bound -> outside
     counts = np.array([N, N - 10, N], dtype=np.int32)
     x = (pts[:, rng.integers(0, N, size=40)][:, :, None, :] + rng.normal(0, 0.03, size=(B, 40, 24, 3))).astype(np.float32)
-    for cap in (5000, 20):
-        cfg = dict(orr.DEFAULT_GRID, max_occ_voxels_per_example=cap)
+    for cap, level in ((5000, "fine"), (20, "fine"), (5000, "scaled"), (6, "scaled")):
+        cfg = dict(orr.DEFAULT_GRID, max_occ_voxels_per_example=cap, grid_level=level)
         g = ovg.VoxelGridOracle(**cfg)
         g.set_pointset(pts, counts)
         ridx, rloc, rnsel, rss = g.query_dense(x, 8, 2.0, 10)
@@ -130,12 +132,20 @@ def test_grid_capacity_limits_and_batches():
         np.testing.assert_array_equal(nsel.cpu().numpy(), rnsel)
         np.testing.assert_array_equal(ss.cpu().numpy(), rss)
     # k < 8 and M < 8 paths
-    g = ovg.VoxelGridOracle(); g.set_pointset(pts, counts)
-    hg = hr.HipVoxelGrid(**orr.DEFAULT_GRID); hg.set_pointset(T(pts).cuda(), T(counts).cuda())
-    ridx, _, rnsel, _ = g.query_dense(x, 3, 2.0, 5)
-    idx, _, _, nsel = hg.query_dense(3, 2.0, 5, x=T(x).cuda())
-    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
-    np.testing.assert_array_equal(nsel.cpu().numpy(), rnsel)
+    for level in ("fine", "scaled"):
+        cfg = dict(orr.DEFAULT_GRID, grid_level=level)
+        g = ovg.VoxelGridOracle(**cfg); g.set_pointset(pts, counts)
+        hg = hr.HipVoxelGrid(**cfg); hg.set_pointset(T(pts).cuda(), T(counts).cuda())
+        ridx, _, rnsel, _ = g.query_dense(x, 3, 2.0, 5)
+        idx, _, _, nsel = hg.query_dense(3, 2.0, 5, x=T(x).cuda())
+        np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+        np.testing.assert_array_equal(nsel.cpu().numpy(), rnsel)
+        # switching the level on an existing grid rebuilds it
+        other = "scaled" if level == "fine" else "fine"
+        hg.set_grid_level(other); hg.set_pointset(T(pts).cuda(), T(counts).cuda())
+        g2 = ovg.VoxelGridOracle(**dict(cfg, grid_level=other)); g2.set_pointset(pts, counts)
+        np.testing.assert_array_equal(hg.query_dense(3, 2.0, 5, x=T(x).cuda())[0].cpu().numpy(), g2.query_dense(x, 3, 2.0, 5)[0])
+        hg.set_grid_level(level); hg.set_pointset(T(pts).cuda(), T(counts).cuda())
     with pytest.raises(RuntimeError, match="unsupported"):
         hg.query_dense(9, 2.0, 5, x=T(x).cuda())
 
@@ -372,14 +382,16 @@ def test_shade_kernels_clamp_device_count_to_allocated_rows():
 
 
 def test_grid_render_is_tied_to_the_pinned_brute_force_branch():
-    """The voxel-grid semantics of torch_knnquery are a spec of this build (third-party source absent: DESIGN section 2);
+    """The voxel-grid semantics of torch_knnquery are a spec of this build (third-party source absent: DESIGN section 2 / 3);
     the reference's in-repo branch (`voxel_grid is None`, aggregator.py:42-58: exact radius ball) IS pinned end to end by
-    render_brute.npz.  This test ties the two ON THE GPU, on the benchmark scene (bench.py render leg: 512-point
-    ellipsoid, 128 x 128, k = 8, M = 50, S = 128 and 64):
+    render_brute.npz.  This test ties BOTH readings of the grid (grid_level "fine" / "scaled", include/npcd_hip.h) to that branch
+    ON THE GPU, on the benchmark scene (bench.py render leg: 512-point ellipsoid, 128 x 128, k = 8, M = 50, S = 128 and 64):
       * every grid neighbour lies inside the radius ball of its shading point (grid result is a subset of the in-radius set),
       * a shading slot of the grid path that the brute-force path also has carries the same position, and where the
-        in-radius set has at most k members inside the 3^3 voxel window the two neighbour lists are equal,
-      * the two renders agree to PSNR >= 27 dB (random MLP weights); mismatch rates and PSNR are printed for DESIGN.md."""
+        in-radius set has fewer than k members the grid list is a subset of it,
+      * identical-neighbour-set rate, keypoints dropped by the per-voxel cap, keypoints the TV loss's self-query
+        (neural_point_cloud_tv_loss.py:41-43) loses, and PSNR(grid render, brute render) are printed per reading for DESIGN.md;
+        bars: fine > 0.25 identical, scaled > 0.35 identical, PSNR > 27 dB both (random MLP weights)."""
     from npcd.hip import render as hr
     res, M, k = 128, 50, 8
     coords, feats, extr, intr = _scene(res, 1, 512, 32, seed=0, B=1)
@@ -390,56 +402,64 @@ def test_grid_render_is_tied_to_the_pinned_brute_force_branch():
     m = _model(32, 512, p)
     agg = m.field.aggregator
     grid = agg.voxel_grid
-    for S in (128, 64):
-        m.renderer.depth_resolution = S
+    bars = {"fine": (0.25, 27.0), "scaled": (0.35, 27.0)}
+    for level in ("fine", "scaled"):
+        grid.set_grid_level(level)
         with torch.no_grad():
             grid.set_pointset(coords.cuda(), None)
-            o, d, t0, t1 = hr.ray_gen(extr.flatten(0, 1).cuda(), intr.flatten(0, 1).cuda(), res, 1.0)
-            rays = (o, d, t0, t1)
-            gi, gl, gs, gn = grid.query_dense(k, agg.r, M, rays=rays, S=S, mode=0)
-            bi, bl, bs, bn = grid.query_dense(k, agg.scaled_r, M, rays=rays, S=S, mode=1)
-            out_g = m.renderer(coords.cuda(), feats.cuda(), extr.cuda(), intr.cuda(), res, False, knn_mode=0)
-            out_b = m.renderer(coords.cuda(), feats.cuda(), extr.cuda(), intr.cuda(), res, False, knn_mode=1)
-        kp = coords.cuda().reshape(-1, 3)
-        r2 = torch.tensor(agg.scaled_r, dtype=torch.float32) ** 2
-        # (1) subset: every grid neighbour is within the radius of its shading point
-        valid = gi >= 0
-        dist2 = ((gl[..., None, :] - kp[gi.clamp_min(0).long()]) ** 2).sum(-1)
-        assert bool((dist2[valid] < float(r2) * (1 + 1e-6)).all())
-        # (2) slot-by-slot: match the two paths through the depth-sample number of each slot
-        R = gi.shape[1]
-        gmap = torch.full((R, S), -1, dtype=torch.long, device="cuda")
-        rr = torch.arange(R, device="cuda")[:, None].expand(R, M)
-        gv = gs[0] >= 0
-        gmap[rr[gv], gs[0][gv].long()] = torch.arange(M, device="cuda")[None].expand(R, M)[gv]
-        bv = bs[0] >= 0
-        slot_in_grid = gmap[rr[bv], bs[0][bv].long()]                       # grid slot of every brute-force slot (or -1)
-        # a brute-force slot (has an in-radius neighbour) may be absent from the grid path only when the grid ran out of slots
-        # earlier on that ray (its M slots also hold neighbour-less samples) or when no neighbour lies in the 3^3 window
-        present = slot_in_grid >= 0
-        b_idx = bi[0][bv]
-        g_idx = gi[0][rr[bv][present], slot_in_grid[present]]
-        b_sorted = torch.sort(torch.where(b_idx[present] < 0, torch.full_like(b_idx[present], 1 << 30), b_idx[present]), dim=1).values
-        g_sorted = torch.sort(torch.where(g_idx < 0, torch.full_like(g_idx, 1 << 30), g_idx), dim=1).values
-        same = (b_sorted == g_sorted).all(dim=1)
-        assert torch.equal(gl[0][rr[bv][present], slot_in_grid[present]], bl[0][bv][present])    # same sample position, bit for bit
-        n_b, n_present, n_same = int(bv.sum()), int(present.sum()), int(same.sum())
-        img_g = orr.unflatten_image(out_g["channels"].cpu())
-        img_b = orr.unflatten_image(out_b["channels"].cpu())
-        psnr = orr.psnr(img_g, img_b)
-        print(f"\n[grid-vs-brute S={S}] brute slots {n_b}, present in grid path {n_present} ({n_present / n_b:.4f}), "
-              f"identical neighbour sets {n_same} ({n_same / max(n_present, 1):.4f}); grid slots {int((gi[..., 0] >= 0).sum())}; "
-              f"PSNR(grid render, brute render) = {psnr:.2f} dB; max |rgb diff| = "
-              f"{float((out_g['channels'] - out_b['channels']).abs().max()):.4f}")
-        # where the radius ball holds fewer than k points the brute-force list IS the ball: the grid list must be a subset
-        few = (b_idx[present] >= 0).sum(dim=1) < k
-        sub = ((g_idx[few][:, :, None] == b_idx[present][few][:, None, :]).any(-1) | (g_idx[few] < 0)).all(dim=1)
-        assert bool(sub.all())
-        # measured (oracle on the CPU, same scene): 99.95 % / 100 % of the brute-force slots exist in the grid path, 30-31 % of
-        # those carry the identical neighbour set (radius 0.08 = 2 voxels reaches past the 3^3 window and a voxel keeps 4
-        # points), PSNR 29.8 / 29.1 dB with random MLP weights
-        assert n_present / n_b > 0.99 and n_same / n_present > 0.25
-        assert psnr > 27.0
+            kept = (grid.workspace[:512 * 4].view(torch.int32) >> 30) & 1
+            ti, _, _, _ = grid.query_dense(k, agg.r, 1, x=coords.cuda().view(1, 512, 1, 3), mode=0)       # the TV loss's self-query
+        n_dropped, n_lost = int((kept == 0).sum()), int((ti[0, :, 0, 0] < 0).sum())
+        print(f"\n[grid_level={level}] keypoints dropped by the {grid.params.max_points_per_voxel}-per-voxel cap: {n_dropped} / 512; "
+              f"keypoints without any neighbour on their own position: {n_lost}")
+        for S in (128, 64):
+            m.renderer.depth_resolution = S
+            with torch.no_grad():
+                grid.set_pointset(coords.cuda(), None)
+                o, d, t0, t1 = hr.ray_gen(extr.flatten(0, 1).cuda(), intr.flatten(0, 1).cuda(), res, 1.0)
+                rays = (o, d, t0, t1)
+                gi, gl, gs, gn = grid.query_dense(k, agg.r, M, rays=rays, S=S, mode=0)
+                bi, bl, bs, bn = grid.query_dense(k, agg.scaled_r, M, rays=rays, S=S, mode=1)
+                out_g = m.renderer(coords.cuda(), feats.cuda(), extr.cuda(), intr.cuda(), res, False, knn_mode=0)
+                out_b = m.renderer(coords.cuda(), feats.cuda(), extr.cuda(), intr.cuda(), res, False, knn_mode=1)
+            kp = coords.cuda().reshape(-1, 3)
+            r2 = torch.tensor(agg.scaled_r, dtype=torch.float32) ** 2
+            # (1) subset: every grid neighbour is within the radius of its shading point
+            valid = gi >= 0
+            dist2 = ((gl[..., None, :] - kp[gi.clamp_min(0).long()]) ** 2).sum(-1)
+            assert bool((dist2[valid] < float(r2) * (1 + 1e-6)).all())
+            # (2) slot-by-slot: match the two paths through the depth-sample number of each slot
+            R = gi.shape[1]
+            gmap = torch.full((R, S), -1, dtype=torch.long, device="cuda")
+            rr = torch.arange(R, device="cuda")[:, None].expand(R, M)
+            gv = gs[0] >= 0
+            gmap[rr[gv], gs[0][gv].long()] = torch.arange(M, device="cuda")[None].expand(R, M)[gv]
+            bv = bs[0] >= 0
+            slot_in_grid = gmap[rr[bv], bs[0][bv].long()]                       # grid slot of every brute-force slot (or -1)
+            # a brute-force slot (has an in-radius neighbour) may be absent from the grid path only when the grid ran out of slots
+            # earlier on that ray (its M slots also hold neighbour-less samples) or when no neighbour lies in the window
+            present = slot_in_grid >= 0
+            b_idx = bi[0][bv]
+            g_idx = gi[0][rr[bv][present], slot_in_grid[present]]
+            b_sorted = torch.sort(torch.where(b_idx[present] < 0, torch.full_like(b_idx[present], 1 << 30), b_idx[present]), dim=1).values
+            g_sorted = torch.sort(torch.where(g_idx < 0, torch.full_like(g_idx, 1 << 30), g_idx), dim=1).values
+            same = (b_sorted == g_sorted).all(dim=1)
+            assert torch.equal(gl[0][rr[bv][present], slot_in_grid[present]], bl[0][bv][present])    # same sample position, bit for bit
+            n_b, n_present, n_same = int(bv.sum()), int(present.sum()), int(same.sum())
+            img_g = orr.unflatten_image(out_g["channels"].cpu())
+            img_b = orr.unflatten_image(out_b["channels"].cpu())
+            psnr = orr.psnr(img_g, img_b)
+            print(f"[grid-vs-brute grid_level={level} S={S}] brute slots {n_b}, present in grid path {n_present} ({n_present / n_b:.4f}), "
+                  f"identical neighbour sets {n_same} ({n_same / max(n_present, 1):.4f}); grid slots with a neighbour {int((gi[..., 0] >= 0).sum())}; "
+                  f"PSNR(grid render, brute render) = {psnr:.2f} dB; max |rgb diff| = "
+                  f"{float((out_g['channels'] - out_b['channels']).abs().max()):.4f}")
+            # where the radius ball holds fewer than k points the brute-force list IS the ball: the grid list must be a subset
+            few = (b_idx[present] >= 0).sum(dim=1) < k
+            sub = ((g_idx[few][:, :, None] == b_idx[present][few][:, None, :]).any(-1) | (g_idx[few] < 0)).all(dim=1)
+            assert bool(sub.all())
+            assert n_present / n_b > 0.98 and n_same / n_present > bars[level][0]
+            assert psnr > bars[level][1]
+    grid.set_grid_level(hr.DEFAULT_GRID_LEVEL)
 
 
 def test_pointnerf_forward_surface():

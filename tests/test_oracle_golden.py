@@ -221,13 +221,15 @@ def test_unflatten_and_psnr(golden):
 
 
 # ------------------------------------------------------------------ voxel grid spec ---------
-def test_voxel_grid_spec_properties():
+@pytest.mark.parametrize("level", ["fine", "scaled"])
+def test_voxel_grid_spec_properties(level):
     """The grid branch is parity-unpinned upstream; check the spec's own invariants and its
-    relation to the exact radius query (grid result is a subset of the in-radius set)."""
+    relation to the exact radius query (grid result is a subset of the in-radius set), for both readings of the grid."""
     coords, _ = orr.synthetic_cloud(256, 4, seed=2)
-    grid = ovg.VoxelGridOracle()
-    assert tuple(grid.dims) == (50, 50, 50) and tuple(grid.cdims) == (25, 25, 25)
-    assert max(grid.vsize_tup) * 2 == pytest.approx(0.08)
+    grid = ovg.VoxelGridOracle(grid_level=level)
+    assert tuple(grid.cdims) == (25, 25, 25) and tuple(grid.dims) == ((50, 50, 50) if level == "fine" else (25, 25, 25))
+    assert max(grid.vsize_tup) * 2 == pytest.approx(0.08)          # the radius always comes from the UNSCALED edge
+    assert float(grid.vsize[0]) == pytest.approx(0.04 if level == "fine" else 0.08)
     grid.set_pointset(coords.numpy(), np.array([256], dtype=np.int32))
     rng = np.random.default_rng(0)
     base = coords.numpy()[0][rng.integers(0, 256, size=(40, 1))]             # near the surface
@@ -248,11 +250,75 @@ def test_voxel_grid_spec_properties():
     assert sidx.shape == (int(ray_mask.sum()), 10, 8) and sloc.shape == (int(ray_mask.sum()), 10, 3)
 
 
-def test_voxel_grid_capacity_limits():
+def test_scaled_grid_with_uncapped_lists_is_the_reference_brute_force_branch():
+    """Radius 0.08 = one cell of the scaled grid, so the 3^3 window of scaled cells CONTAINS the radius ball: with lists that
+    drop nothing (max_points_per_voxel large) the scaled reading returns, for every sample that has a neighbour, exactly the
+    list of the reference's pinned brute-force branch (aggregator.py:42-58) -- same indices in the same (dist^2, index) order.
+    The fine reading cannot: its 3^3 window of 0.04 voxels does not cover the ball."""
+    coords, _ = orr.synthetic_cloud(512, 4, seed=0)
+    rng = np.random.default_rng(1)
+    base = coords.numpy()[0][rng.integers(0, 512, size=(64, 1))]
+    x = (base + rng.normal(0, 0.05, size=(64, 16, 3))).astype(np.float32)[None]
+    bidx, _, _ = ovg.brute_force_query(x.reshape(1, 64 * 16, 1, 3), coords.numpy(), 8, 0.08, 1)      # one slot per sample
+    bidx = bidx.reshape(64, 16, 8)
+    rates = {}
+    for level in ("fine", "scaled"):
+        g = ovg.VoxelGridOracle(max_points_per_voxel=64, grid_level=level)
+        g.set_pointset(coords.numpy(), np.array([512], dtype=np.int32))
+        assert g.kept.all()
+        idx, _, nsel, sel = g.query_dense(x, 8, 2.0, 16)
+        same = total = 0
+        for r in range(64):
+            for m in range(int(nsel[0, r])):
+                sm = sel[0, r, m]
+                if bidx[r, sm, 0] < 0:
+                    assert (idx[0, r, m] < 0).all()        # a selected sample without any in-radius point stays neighbour-less
+                    continue
+                total += 1
+                same += int(np.array_equal(idx[0, r, m], bidx[r, sm]))
+        rates[level] = same / total
+        assert total > 300
+    assert rates["scaled"] == 1.0 and rates["fine"] < 0.9, rates
+
+
+def test_self_query_of_the_tv_loss_loses_keypoints_only_on_the_scaled_grid():
+    """neural_point_cloud_tv_loss.py:41-43 queries every keypoint's own position and notes 'VoxelGrid looses keypoints sometimes'
+    (a point comes back without any neighbour).  On the FINE grid that cannot happen for an in-range point: a kept point finds
+    itself (distance 0), and a point dropped by the 4-per-voxel cap shares its 0.04 voxel (diagonal 0.069 < radius 0.08) with four
+    kept ones.  On the SCALED grid (0.08 cells, diagonal 0.139) a dropped point can be farther than the radius from every kept
+    point: the comment describes that reading.  Both are checked on the bench cloud; the scaled loss is forced on a built case."""
+    coords, _ = orr.synthetic_cloud(512, 4, seed=0)
+    c = coords.numpy()
+    lost = {}
+    for level in ("fine", "scaled"):
+        g = ovg.VoxelGridOracle(grid_level=level)
+        g.set_pointset(c, np.array([512], dtype=np.int32))
+        idx, _, nsel, _ = g.query_dense(c.reshape(1, 512, 1, 3), 8, 2.0, 50)
+        assert (nsel == 1).all()                            # every keypoint's own cell is occupied
+        lost[level] = int((idx[0, :, 0, 0] < 0).sum())
+        dropped = int((~g.kept).sum())
+        print(f"[tv self-query, {level}] keypoints dropped by the cap {dropped} / 512, keypoints without any neighbour {lost[level]}")
+    assert lost["fine"] == 0
+    # built case: six points in one scaled cell, the last two > 0.08 away from the first four and from everything else
+    # (cell edges sit at -1 + 0.08 i: [0.04, 0.12) is one scaled cell = eight fine voxels)
+    pts = np.array([[[0.041, 0.041, 0.041], [0.042, 0.041, 0.041], [0.041, 0.042, 0.041], [0.041, 0.041, 0.042],
+                     [0.119, 0.119, 0.119], [0.118, 0.119, 0.119]]], dtype=np.float32)
+    g = ovg.VoxelGridOracle(grid_level="scaled")
+    g.set_pointset(pts, np.array([6], dtype=np.int32))
+    assert g.kept[0].tolist() == [True] * 4 + [False] * 2
+    idx, _, _, _ = g.query_dense(pts.reshape(1, 6, 1, 3), 8, 2.0, 50)
+    assert (idx[0, :4, 0, 0] >= 0).all() and (idx[0, 4:, 0] < 0).all()          # the two dropped keypoints are lost
+    gf = ovg.VoxelGridOracle(grid_level="fine")
+    gf.set_pointset(pts, np.array([6], dtype=np.int32))
+    assert gf.kept.all() and (gf.query_dense(pts.reshape(1, 6, 1, 3), 8, 2.0, 50)[0][0, :, 0, 0] >= 0).all()
+
+
+@pytest.mark.parametrize("level", ["fine", "scaled"])
+def test_voxel_grid_capacity_limits(level):
     pts = np.zeros((1, 12, 3), dtype=np.float32)
     pts[0, :, 0] = 0.01                                                  # 12 points in ONE fine voxel
     pts[0, :, 1] = np.linspace(0.001, 0.03, 12)
-    g = ovg.VoxelGridOracle(max_points_per_voxel=4)
+    g = ovg.VoxelGridOracle(max_points_per_voxel=4, grid_level=level)
     g.set_pointset(pts, np.array([12], dtype=np.int32))
     assert g.kept[0].tolist() == [True] * 4 + [False] * 8
     x = np.array([[[[0.01, 0.01, 0.0]]]], dtype=np.float32)
@@ -260,6 +326,6 @@ def test_voxel_grid_capacity_limits():
     assert nsel[0, 0] == 1 and set(idx[0, 0, 0][idx[0, 0, 0] >= 0].tolist()) <= {0, 1, 2, 3}
     # voxel cap: keep only the 2 occupied voxels with the smallest linear id
     pts2 = np.array([[[0.5, 0.5, 0.5], [-0.5, -0.5, -0.5], [0.0, 0.0, 0.0], [1.5, 0, 0]]], dtype=np.float32)
-    g2 = ovg.VoxelGridOracle(max_occ_voxels_per_example=2)
+    g2 = ovg.VoxelGridOracle(max_occ_voxels_per_example=2, grid_level=level)
     g2.set_pointset(pts2, np.array([4], dtype=np.int32))
     assert g2.kept[0].tolist() == [False, True, True, False]            # last point is out of range
