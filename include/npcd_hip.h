@@ -58,6 +58,17 @@ int npcd_attn_fwd(const void* q, const void* k, const void* v, void* out, float*
                   int64_t out_sb, int64_t out_sn, int64_t out_sh,
                   float scale, int dtype, void* stream);
 
+/* The same with caller-provided scratch (uninitialised): npcd_attn_fwd_workspace_floats(B, n, H) floats, 0 when the shape needs none.
+ * With it, a sequence of 256 j + 1 tokens (the denoiser's 512 points + timestep token) runs without a workgroup for its last query
+ * row: the waves of each (batch, head) split that row's keys and a small second kernel merges their partial softmax states.
+ * workspace == NULL is npcd_attn_fwd. */
+int64_t npcd_attn_fwd_workspace_floats(int B, int n, int H);
+int npcd_attn_fwd_ws(const void* q, const void* k, const void* v, void* out, float* lse, float* workspace,
+                     int B, int n, int H, int d,
+                     int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh,
+                     int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                     float scale, int dtype, void* stream);
+
 /* The same forward with fp8 (e4m3) operands on the block-scaled matrix instruction (v_mfma_scale_f32_32x32x64_f8f6f4; BASELINE
  * configs[4] names fp8 attention; opt-in, csrc/attention.hip attn_fwd_fp8_kernel): k is quantised to e4m3 and v to e4m3
  * transposed by a packing pass into `workspace`, q and P (with a 2^-8 block scale) inside the kernel (npcd_attn_fwd_fp8_workspace_bytes(B, n, H)

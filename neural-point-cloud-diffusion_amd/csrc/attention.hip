@@ -29,9 +29,12 @@
 
 namespace npcd {
 
+#if defined(NPCD_TIMELINE64) && !defined(NPCD_TIMELINE)
+#define NPCD_TIMELINE NPCD_TIMELINE64      // (the stamps of the 64-row forward: same buffer, same read-back entry point)
+#endif
 #ifdef NPCD_TIMELINE
 // diagnostic build only: s_memtime stamps of one wave (block NPCD_TIMELINE, wave 0), read back with npcd_debug_read
-__device__ long long g_timeline[64];
+__device__ long long g_timeline[80];
 #define NPCD_TS(i)                                                                       \
     do {                                                                                 \
         if (tl_on) tl[(i)] = __builtin_amdgcn_s_memtime();                               \
@@ -53,6 +56,9 @@ struct AttnParams {
     // optional by-product of the backward (npcd_attn_bwd_colsum): per-wave column sums of the stored dq / dk / dv rows, one fp32 row of
     // 3 H 64 columns (the packed c_qkv order: h, {q, k, v}, d) per (batch, 128-row block, wave) [+ one per batch for the edge token]
     float* colsum;
+    // optional scratch of the forward (npcd_attn_fwd_ws): partial softmax states of the LAST query row of a sequence of 256 j + 1
+    // tokens, one record of kRowxFloats floats per (batch, head, 64-key tile); see rowx_tile
+    float* rowx;
 };
 
 // Rows past the end of a sequence are CLAMPED to the last valid row instead of being predicated (the duplicated rows are
@@ -735,6 +741,475 @@ __global__ __launch_bounds__(256, NPCD_FWD_WAVES) void attn_fwd_kernel(AttnParam
     E* orow0 = static_cast<E*>(p.o_w) + b * p.osb + (int64_t)q0 * p.osn + h * p.osh;
     store_rows_staged<TR>(smem + wave * 4096, orow0, p.osn, n - q0, o0, o1, 1.f / l, lane);
     if (qrow < n && hh == 0) p.lse[(int64_t)(b * p.H + h) * n + qrow] = m * kLn2 + logf(l);
+}
+
+// ============================================================================================
+// forward, second form (default): 64 query rows per wave
+// ============================================================================================
+// What the counters of the 32-row form say: 12 vector instructions per matrix instruction, every K / V fragment read
+// from LDS feeds ONE matrix instruction, one softmax chain per wave.  This form changes all three:
+//   * a wave owns TWO 32-row query blocks A and B (workgroup = 4 waves = 256 rows, two workgroups per CU = two waves per SIMD):
+//     every K / V fragment feeds two matrix instructions, and the two blocks are two independent chains -- the vector work of one
+//     block is issued behind the matrix instructions of the other (stage = [S_A, PV_A(prev) || softmax B(prev)], [S_B, PV_B(prev) ||
+//     softmax A]);
+//   * the running maximum is not tracked per tile: P = exp2(c S - m) and its lane sum come first, and only when a lane sum leaves
+//     (0, kTrigger] (a score more than ~2^7 above the stored maximum, or the very first tile) the exact row maximum is taken, O / l
+//     are rescaled and P is recomputed.  P <= kTrigger on the fast path (16-bit relative precision is scale-free).
+// Per 32 x 32 score block that leaves 16 fma + 16 exp2 + 16 adds + 8 packed conversions + one compare for 8 matrix instructions
+// (the 32-row form: 12 vector instructions per matrix instruction; this one 7).
+// (Tried: scores in the exp2 domain straight from the matrix instruction -- q pre-multiplied by scale * log2(e) in the 16-bit type,
+//  -m as the C operand of the first score product.  The C operand costs 32 registers the kernel does not have (243 spills), and
+//  the pre-multiplied q rounds COHERENTLY for a query whose elements are equal: a logit of 72 moved by 0.2, 15 % in P.  Dropped.)
+struct QBlk {
+    f32x16 o0, o1;   // O^T accumulators: head dimensions 0..31 / 32..63 x 32 queries
+    float m, l;
+};
+constexpr float kTrigger = 128.f;
+
+// exact maximum of the block's scores -> move b.m up to it and rescale l / O.  b.m starts at -inf: the first tile comes here
+// (exp2(s + inf) = inf trips the check below), alpha = exp2(-inf) = 0 multiplies the zero state, m becomes the tile's maximum.
+__device__ __forceinline__ void blk_advance_max(const f32x16& s, QBlk& b, float c) {
+    float mx = fmaxf(s[0], s[1]);
+#pragma unroll
+    for (int i = 2; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s[i]), s[i + 1]);
+    const float mn = fmaxf(b.m, half_max(mx) * c);      // c = scale * log2(e) > 0: m lives in the exp2 domain
+    const float alpha = __builtin_amdgcn_exp2f(b.m - mn);
+    b.m = mn;
+    b.l *= alpha;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        b.o0[i] *= alpha;
+        b.o1[i] *= alpha;
+    }
+}
+
+// scores (exp2 domain) -> exp2(s - m) as packed 16-bit P operands + this lane's partial row sum; no state is touched
+#ifndef NPCD_DIAG_F64
+#define NPCD_DIAG_F64 0      // DIAGNOSTIC builds (wrong results, timing only): 1 no softmax arithmetic, 2 no matrix instructions in the
+#endif                       // stages, 3 no LDS fragment reads in the stages, 4 no ring refill / barrier per tile
+template <class TR>
+__device__ __forceinline__ float blk_exp(const f32x16& s, float m, float c, u32x4 (&pw)[2]) {
+#if NPCD_DIAG_F64 == 1
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pw[j >> 2][j & 3] = pack2<TR>(s[2 * j], s[2 * j + 1]);
+    return 1.f;
+#endif
+    float pr[16];
+    float rs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        pr[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j], c, -m));
+        rs += pr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pw[j >> 2][j & 3] = pack2<TR>(pr[2 * j], pr[2 * j + 1]);
+    return rs;
+}
+// one block, checked on its own (ragged tail, flush)
+template <class TR>
+__device__ __forceinline__ void blk_softmax(const f32x16& s, QBlk& b, float c, u32x4 (&pw)[2], bool force) {
+    if (force) blk_advance_max(s, b, c);
+    float rs = blk_exp<TR>(s, b.m, c, pw);
+    if (__any(!(rs <= kTrigger))) {                   // wave-uniform; !(<=) also catches inf / nan
+        blk_advance_max(s, b, c);
+        rs = blk_exp<TR>(s, b.m, c, pw);
+    }
+    b.l += rs;
+}
+
+// One stage = one 32-key half tile (SLOT, KB) for both blocks: the two score chains share the K fragments, PV of the PREVIOUS half
+// (PSLOT, PKB; its P operands in pwA / pwB) shares the V^T fragments and rides on the matrix pipe while the vector ALU turns the new
+// scores into the next P operands.  The fast path is ONE basic block (one check for both blocks at its end), so that the
+// scheduler can lay the vector work of one block beside the matrix instructions of the other.
+template <class TR, int SLOT, int KB, int PSLOT, int PKB, bool ACC>
+__device__ __forceinline__ void fwd64_stage(const FragAddr& fa, const typename TR::vec8 (&qA)[4], const typename TR::vec8 (&qB)[4], QBlk& A, QBlk& B,
+                                            u32x4 (&pwA)[2], u32x4 (&pwB)[2], float c) {
+    using V8 = typename TR::vec8;
+    constexpr int KT = SLOT * 16384 + KB * 4096, PV = PSLOT * 16384 + 8192;
+    u32x4 kr[4];
+    TrPair vt[2][2];
+#if NPCD_DIAG_F64 == 3
+    for (int s = 0; s < 4; ++s) kr[s] = __builtin_bit_cast(u32x4, qA[s]);
+    for (int g = 0; g < 2; ++g)
+        for (int h2 = 0; h2 < 2; ++h2) { vt[g][h2].lo = u32x2{pwA[0][0], pwA[0][1]}; vt[g][h2].hi = u32x2{pwB[0][0], pwB[0][1]}; }
+#else
+    kr[0] = lds_b128_issue<KT>(fa.row[0]);
+    kr[1] = lds_b128_issue<KT>(fa.row[1]);
+    kr[2] = lds_b128_issue<KT>(fa.row[2]);
+    kr[3] = lds_b128_issue<KT>(fa.row[3]);
+    if (ACC) {
+        vt[0][0] = tr_issue_at<PV, PKB * 2>(fa, 0);     vt[0][1] = tr_issue_at<PV, PKB * 2>(fa, 1);
+        vt[1][0] = tr_issue_at<PV, PKB * 2 + 1>(fa, 0); vt[1][1] = tr_issue_at<PV, PKB * 2 + 1>(fa, 1);
+    }
+    tr_wait();
+#endif
+    f32x16 sA = {0}, sB = {0};
+#if NPCD_DIAG_F64 == 2
+    for (int i = 0; i < 16; ++i) { sA[i] = __uint_as_float(kr[i & 3][i >> 2]) * 1e-30f; sB[i] = __uint_as_float(kr[(i + 1) & 3][i >> 2]) * 1e-30f; }
+    if (ACC) { asm volatile("" ::"v"(vt[0][0].lo), "v"(vt[0][1].lo), "v"(vt[1][0].lo), "v"(vt[1][1].lo), "v"(vt[0][0].hi), "v"(vt[0][1].hi), "v"(vt[1][0].hi), "v"(vt[1][1].hi)); }
+    if (false) {
+#else
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sA = TR::mfma32(__builtin_bit_cast(V8, kr[s]), qA[s], sA);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sB = TR::mfma32(__builtin_bit_cast(V8, kr[s]), qB[s], sB);
+    if (ACC) {
+#endif
+        A.o0 = TR::mfma32(tr_vec<TR>(vt[0][0]), __builtin_bit_cast(V8, pwA[0]), A.o0);
+        A.o1 = TR::mfma32(tr_vec<TR>(vt[0][1]), __builtin_bit_cast(V8, pwA[0]), A.o1);
+        A.o0 = TR::mfma32(tr_vec<TR>(vt[1][0]), __builtin_bit_cast(V8, pwA[1]), A.o0);
+        A.o1 = TR::mfma32(tr_vec<TR>(vt[1][1]), __builtin_bit_cast(V8, pwA[1]), A.o1);
+        B.o0 = TR::mfma32(tr_vec<TR>(vt[0][0]), __builtin_bit_cast(V8, pwB[0]), B.o0);
+        B.o1 = TR::mfma32(tr_vec<TR>(vt[0][1]), __builtin_bit_cast(V8, pwB[0]), B.o1);
+        B.o0 = TR::mfma32(tr_vec<TR>(vt[1][0]), __builtin_bit_cast(V8, pwB[1]), B.o0);
+        B.o1 = TR::mfma32(tr_vec<TR>(vt[1][1]), __builtin_bit_cast(V8, pwB[1]), B.o1);
+    }
+    u32x4 nA[2], nB[2];
+    float rsA = blk_exp<TR>(sA, A.m, c, nA);
+    float rsB = blk_exp<TR>(sB, B.m, c, nB);
+    if (__any(!(rsA <= kTrigger) || !(rsB <= kTrigger))) {      // rare (always on the first tile): exact maxima, rescale, redo
+        blk_advance_max(sA, A, c);
+        blk_advance_max(sB, B, c);
+        rsA = blk_exp<TR>(sA, A.m, c, nA);
+        rsB = blk_exp<TR>(sB, B.m, c, nB);
+    }
+    A.l += rsA;
+    B.l += rsB;
+    pwA[0] = nA[0]; pwA[1] = nA[1];
+    pwB[0] = nB[0]; pwB[1] = nB[1];
+}
+// after the last full stage: PV of the last half for both blocks
+template <class TR, int PSLOT, int PKB>
+__device__ __forceinline__ void fwd64_flush(const FragAddr& fa, QBlk& A, QBlk& B, const u32x4 (&pwA)[2], const u32x4 (&pwB)[2]) {
+    using V8 = typename TR::vec8;
+    constexpr int PV = PSLOT * 16384 + 8192;
+    TrPair vt[2][2];
+    vt[0][0] = tr_issue_at<PV, PKB * 2>(fa, 0);     vt[0][1] = tr_issue_at<PV, PKB * 2>(fa, 1);
+    vt[1][0] = tr_issue_at<PV, PKB * 2 + 1>(fa, 0); vt[1][1] = tr_issue_at<PV, PKB * 2 + 1>(fa, 1);
+    tr_wait();
+    A.o0 = TR::mfma32(tr_vec<TR>(vt[0][0]), __builtin_bit_cast(V8, pwA[0]), A.o0);
+    A.o1 = TR::mfma32(tr_vec<TR>(vt[0][1]), __builtin_bit_cast(V8, pwA[0]), A.o1);
+    A.o0 = TR::mfma32(tr_vec<TR>(vt[1][0]), __builtin_bit_cast(V8, pwA[1]), A.o0);
+    A.o1 = TR::mfma32(tr_vec<TR>(vt[1][1]), __builtin_bit_cast(V8, pwA[1]), A.o1);
+    B.o0 = TR::mfma32(tr_vec<TR>(vt[0][0]), __builtin_bit_cast(V8, pwB[0]), B.o0);
+    B.o1 = TR::mfma32(tr_vec<TR>(vt[0][1]), __builtin_bit_cast(V8, pwB[0]), B.o1);
+    B.o0 = TR::mfma32(tr_vec<TR>(vt[1][0]), __builtin_bit_cast(V8, pwB[1]), B.o0);
+    B.o1 = TR::mfma32(tr_vec<TR>(vt[1][1]), __builtin_bit_cast(V8, pwB[1]), B.o1);
+}
+// ---- the last query row of a sequence of 256 j + 1 tokens, without a workgroup of its own ----------------------------------------
+// A workgroup for that single row costs as much slot time as a full one (it streams every K / V tile: +26 us of 119 at cfg-D).
+// Instead, the nk / 64 waves that work on a (batch, head) anyway split the row's KEYS: wave w takes the 64 keys of tile w while that
+// tile sits in the ring -- a matrix-VECTOR problem, done on the vector ALU from the LDS-resident tile: lane j holds key j (64-deep
+// dot product, v_dot2c), wave maximum / sum by DPP-free shuffles (once per item), then lane (d-pair, key parity) accumulates
+// sum_j p_j v_j over its 32 keys.  ~250 instructions per wave per item, 2 registers of state.  The wave's partial state
+// (m, l, O[64]) goes to scratch; attn_fwd_rowx_merge_kernel combines the partials of a (batch, head), adds the pair (x, x) and writes
+// the row and its LSE.
+constexpr int kRowxFloats = 68;        // O[64], m, l, pad (272 B: records stay 16-byte aligned)
+__host__ __device__ inline bool rowx_mode(int n) { return NPCD_SEED_TAIL && n > 256 && ((n - 1) & 255) == 0; }
+
+// wave-wide max / sum on the vector ALU (no LDS crossbar): four DPP row rotations inside the 16-lane rows, then v_permlane16_swap
+// and v_permlane32_swap across them; every lane ends with the result
+template <class Op>
+__device__ __forceinline__ float wave_reduce64(float x, Op op) {
+    x = op(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128 /* row_ror:8 */, 0xf, 0xf, false)));
+    x = op(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124 /* row_ror:4 */, 0xf, 0xf, false)));
+    x = op(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122 /* row_ror:2 */, 0xf, 0xf, false)));
+    x = op(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121 /* row_ror:1 */, 0xf, 0xf, false)));
+    const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = op(__uint_as_float(r16[0]), __uint_as_float(r16[1]));
+    const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return op(__uint_as_float(r32[0]), __uint_as_float(r32[1]));
+}
+__device__ __forceinline__ float wave_max64(float x) { return wave_reduce64(x, [](float a, float b) { return fmaxf(a, b); }); }
+__device__ __forceinline__ float wave_sum64(float x) { return wave_reduce64(x, [](float a, float b) { return a + b; }); }
+template <class TR, int SLOT, int RING = 3>
+__device__ __forceinline__ void rowx_tile(unsigned char* smem, float c, int lane_in, int wave, float* rec) {
+    // Everything lane-dependent in here is derived from an OPAQUE copy of the lane number: otherwise the compiler hoists the ~100
+    // loop-invariant LDS addresses of the three ring-slot instances out of the tile loop and spills them (82 spilled registers,
+    // the whole kernel 20 % slower).  Ring slot and row numbers go into the instructions' immediate offsets.
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    constexpr int KT = SLOT * 16384, VT = SLOT * 16384 + 8192;
+    const uint32_t base = lds_addr(smem);
+    const uint32_t scr = base + RING * 16384 + wave * 256, qxa = base + RING * 16384 + 1024;
+    // scores: lane j = key j of the tile; its 128-byte row against the last query row (a 128-byte LDS copy made by the prologue,
+    // every lane reads the same address), two 16-byte chunks at a time so that the main loop's state stays in registers
+    const uint32_t krow = base + lane * 128, ksw = (uint32_t)tile_swz(lane) << 4;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int c4 = 0; c4 < 8; c4 += 4) {                   // (between two stages ~100 registers are free: 32 of them here)
+        u32x4 kv[4], qv[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) kv[ch] = lds_b128_issue<KT>(krow + (((uint32_t)(c4 + ch) << 4) ^ ksw));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qv[0]) : "v"(qxa), "n"(c4 * 16) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qv[1]) : "v"(qxa), "n"(c4 * 16 + 16) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qv[2]) : "v"(qxa), "n"(c4 * 16 + 32) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qv[3]) : "v"(qxa), "n"(c4 * 16 + 48) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kv[0]), "+v"(kv[1]), "+v"(kv[2]), "+v"(kv[3]), "+v"(qv[0]), "+v"(qv[1]), "+v"(qv[2]), "+v"(qv[3])::"memory");
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            s0 = TR::dot2(kv[ch][0], qv[ch][0], s0);
+            s1 = TR::dot2(kv[ch][1], qv[ch][1], s1);
+            s0 = TR::dot2(kv[ch][2], qv[ch][2], s0);
+            s1 = TR::dot2(kv[ch][3], qv[ch][3], s1);
+        }
+    }
+    const float sc = (s0 + s1) * c;                       // exp2 domain
+    const float m = wave_max64(sc);
+    const float pj = __builtin_amdgcn_exp2f(sc - m);
+    const float l = wave_sum64(pj);
+    asm volatile("ds_write_b32 %0, %1" ::"v"(scr + lane * 4), "v"(pj) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // O[d] = sum_j p_j v_j[d]: lane = (key parity, d-pair); V row j = 2 i + parity, elements 2 dp, 2 dp + 1.  tile_swz(j) only
+    // depends on i, so a read's address is one lane register XOR a constant + an immediate.  Eight keys per batch in flight.
+    const int dp = lane & 31, par = lane >> 5;
+    const uint32_t vrow = base + par * 128 + (dp & 3) * 4, vch = (uint32_t)(dp >> 2) << 4, prow = scr + par * 4;
+    float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+    for (int i0 = 0; i0 < 32; i0 += 16) {
+        uint32_t vv[16];
+        float pp[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ii = i0 + i;
+            const uint32_t swz = (uint32_t)((((ii & 1) << 2) | ((ii >> 1) & 3)) << 4);       // tile_swz(2 ii + parity) << 4
+            const uint32_t va = vrow + (vch ^ swz);
+            switch (ii) {     // (immediates must be literal)
+#define NPCD_RX(I) case I: asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(vv[i]) : "v"(va), "n"(VT + (I) * 256) : "memory"); \
+                           asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(pp[i]) : "v"(prow), "n"((I) * 8) : "memory"); break;
+                NPCD_RX(0) NPCD_RX(1) NPCD_RX(2) NPCD_RX(3) NPCD_RX(4) NPCD_RX(5) NPCD_RX(6) NPCD_RX(7) NPCD_RX(8) NPCD_RX(9) NPCD_RX(10)
+                NPCD_RX(11) NPCD_RX(12) NPCD_RX(13) NPCD_RX(14) NPCD_RX(15) NPCD_RX(16) NPCD_RX(17) NPCD_RX(18) NPCD_RX(19) NPCD_RX(20)
+                NPCD_RX(21) NPCD_RX(22) NPCD_RX(23) NPCD_RX(24) NPCD_RX(25) NPCD_RX(26) NPCD_RX(27) NPCD_RX(28) NPCD_RX(29) NPCD_RX(30)
+                NPCD_RX(31)
+#undef NPCD_RX
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7]), "+v"(pp[0]), "+v"(pp[1]),
+                       "+v"(pp[2]), "+v"(pp[3]), "+v"(pp[4]), "+v"(pp[5]), "+v"(pp[6]), "+v"(pp[7])::"memory");
+        asm volatile("" : "+v"(vv[8]), "+v"(vv[9]), "+v"(vv[10]), "+v"(vv[11]), "+v"(vv[12]), "+v"(vv[13]), "+v"(vv[14]), "+v"(vv[15]), "+v"(pp[8]), "+v"(pp[9]),
+                       "+v"(pp[10]), "+v"(pp[11]), "+v"(pp[12]), "+v"(pp[13]), "+v"(pp[14]), "+v"(pp[15]));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            o0 = __builtin_fmaf(pp[i], TR::lo(vv[i]), o0);
+            o1 = __builtin_fmaf(pp[i], TR::hi(vv[i]), o1);
+        }
+    }
+    o0 = half_sum(o0);
+    o1 = half_sum(o1);
+    if (lane < 32) *reinterpret_cast<float2*>(rec + 2 * dp) = make_float2(o0, o1);
+    if (lane == 0) *reinterpret_cast<float2*>(rec + 64) = make_float2(m, l);
+}
+// one 64-thread block per (batch, head): combine the nw partial states, add the pair (x, x), write the row and its LSE
+template <class E>
+__global__ __launch_bounds__(64) void attn_fwd_rowx_merge_kernel(AttnParams p, int nw) {
+    const int bh = blockIdx.x, h = bh % p.H, b = bh / p.H, d = threadIdx.x, x = p.n - 1;
+    const E* qx = static_cast<const E*>(p.q) + b * p.sb + (int64_t)x * p.sn + h * p.sh;
+    const E* kx = static_cast<const E*>(p.k) + b * p.sb + (int64_t)x * p.sn + h * p.sh;
+    const E* vx = static_cast<const E*>(p.v) + b * p.sb + (int64_t)x * p.sn + h * p.sh;
+    const float* rec = p.rowx + (int64_t)bh * nw * kRowxFloats;
+    const float sxx = wave_sum64((float)qx[d] * (float)kx[d]) * p.scale_log2;
+    float M = sxx;
+    for (int w = 0; w < nw; ++w) M = fmaxf(M, rec[w * kRowxFloats + 64]);
+    const float pxx = __builtin_amdgcn_exp2f(sxx - M);
+    float L = pxx, O = pxx * (float)vx[d];
+    for (int w = 0; w < nw; ++w) {
+        const float a = __builtin_amdgcn_exp2f(rec[w * kRowxFloats + 64] - M);
+        L += a * rec[w * kRowxFloats + 65];
+        O += a * rec[w * kRowxFloats + d];
+    }
+    E* orow = static_cast<E*>(p.o_w) + b * p.osb + (int64_t)x * p.osn + h * p.osh;
+    orow[d] = (E)(O / L);
+    if (d == 0) p.lse[(int64_t)bh * p.n + x] = M * kLn2 + logf(L);
+}
+
+template <class TR, int SLOT>
+__device__ __forceinline__ void fwd64_step(unsigned char* smem, const FragAddr& fa, const DmaLane& dl, const typename TR::elem* kb,
+                                           const typename TR::elem* vb, int64_t sn, int t, int nt, int n, int wave, int lane,
+                                           const typename TR::vec8 (&qA)[4], const typename TR::vec8 (&qB)[4], QBlk& A, QBlk& B,
+                                           u32x4 (&pwA)[2], u32x4 (&pwB)[2], int xt, float c, float* xrec) {
+    constexpr int PREV = (SLOT + 2) % 3;
+    fwd64_stage<TR, SLOT, 0, PREV, 1, true>(fa, qA, qB, A, B, pwA, pwB, c);
+#if NPCD_DIAG_F64 != 4
+    kv_mid<typename TR::elem, SLOT>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
+#endif
+    fwd64_stage<TR, SLOT, 1, SLOT, 0, true>(fa, qA, qB, A, B, pwA, pwB, c);
+    if (t == xt) rowx_tile<TR, SLOT>(smem, c, lane, wave, xrec);      // (wave-uniform) this wave's share of the last query row
+}
+// one 32-key half of the ragged last key tile for one block: masked, exact maximum, not pipelined
+template <class TR, int SLOT, int KB>
+__device__ __forceinline__ void fwd64_half_masked(const FragAddr& fa, const typename TR::vec8 (&qf)[4], QBlk& b, float c, int key0, int n, int hh) {
+    using V8 = typename TR::vec8;
+    constexpr int KT = SLOT * 16384 + KB * 4096, VT = SLOT * 16384 + 8192;
+    f32x16 s0 = {0};
+    s0 = TR::mfma32(lds_frag_at<TR, KT>(fa.row[0]), qf[0], s0);
+    s0 = TR::mfma32(lds_frag_at<TR, KT>(fa.row[1]), qf[1], s0);
+    s0 = TR::mfma32(lds_frag_at<TR, KT>(fa.row[2]), qf[2], s0);
+    s0 = TR::mfma32(lds_frag_at<TR, KT>(fa.row[3]), qf[3], s0);
+    TrPair vt[2][2];
+    vt[0][0] = tr_issue_at<VT, KB * 2>(fa, 0);
+    vt[0][1] = tr_issue_at<VT, KB * 2>(fa, 1);
+    vt[1][0] = tr_issue_at<VT, KB * 2 + 1>(fa, 0);
+    vt[1][1] = tr_issue_at<VT, KB * 2 + 1>(fa, 1);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (key0 + KB * 32 + acc_row(i, hh) >= n) s0[i] = -INFINITY;
+    u32x4 pw[2];
+    blk_softmax<TR>(s0, b, c, pw, true);
+    tr_wait();
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        b.o0 = TR::mfma32(tr_vec<TR>(vt[g][0]), __builtin_bit_cast(V8, pw[g]), b.o0);
+        b.o1 = TR::mfma32(tr_vec<TR>(vt[g][1]), __builtin_bit_cast(V8, pw[g]), b.o1);
+    }
+}
+template <class TR, int SLOT>
+__device__ __forceinline__ void fwd64_tail(const FragAddr& fa, const typename TR::vec8 (&qA)[4], const typename TR::vec8 (&qB)[4], QBlk& A, QBlk& B,
+                                           float c, int key0, int n, int hh) {
+    fwd64_half_masked<TR, SLOT, 0>(fa, qA, A, c, key0, n, hh);
+    fwd64_half_masked<TR, SLOT, 0>(fa, qB, B, c, key0, n, hh);
+    if (key0 + 32 < n) {
+        fwd64_half_masked<TR, SLOT, 1>(fa, qA, A, c, key0, n, hh);
+        fwd64_half_masked<TR, SLOT, 1>(fa, qB, B, c, key0, n, hh);
+    }
+}
+
+template <class TR>
+__global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(AttnParams p) {
+    using E = typename TR::elem;
+    using V8 = typename TR::vec8;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 16384 + 1024 + 256];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool seeded = NPCD_SEED_TAIL && (p.n & 63) == 1 && p.n > 64;          // kernel-uniform (see attn_fwd_kernel)
+    const int n = p.n, nk = seeded ? n - 1 : n, nt = (nk + 63) >> 6, nfull = nk >> 6;
+    // 256 j + 1 tokens with scratch: no workgroup for the last query row, the waves of the (batch, head) split its keys (rowx_tile)
+    const bool rowx = p.rowx != nullptr && rowx_mode(p.n);                       // kernel-uniform
+    const int nqt = rowx ? nk >> 8 : (n + 255) >> 8;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = bid % nqt, bh = bid / nqt, h = bh % p.H, b = bh / p.H;
+    const E* qb = static_cast<const E*>(p.q) + b * p.sb + h * p.sh;
+    const E* kb = static_cast<const E*>(p.k) + b * p.sb + h * p.sh;
+    const E* vb = static_cast<const E*>(p.v) + b * p.sb + h * p.sh;
+    const int q0 = qt * 256 + wave * 64;
+    const bool wave_active = q0 < n;
+    const float c = p.scale_log2;
+    const DmaLane dl = dma_lane<E>(p.sn, lane);
+    const int xt = rowx ? qt * 4 + wave : -1;                   // the key tile this wave takes for the last query row
+    float* xrec = rowx ? p.rowx + ((int64_t)bh * nt + xt) * kRowxFloats : nullptr;
+
+    u32x4 qrawA[4], qrawB[4], keraw[4] = {};
+    uint32_t vx0 = 0, vx1 = 0;
+    row_bcast_issue(qb + (int64_t)min(q0 + r, n - 1) * p.sn, hh, qrawA);            // (one row per lane, not a broadcast)
+    row_bcast_issue(qb + (int64_t)min(q0 + 32 + r, n - 1) * p.sn, hh, qrawB);
+    if (seeded) {
+        row_bcast_issue(kb + (int64_t)(n - 1) * p.sn, hh, keraw);
+        vx0 = gload_u16(vb + (int64_t)(n - 1) * p.sn + r);
+        vx1 = gload_u16(vb + (int64_t)(n - 1) * p.sn + 32 + r);
+    }
+#ifdef NPCD_TIMELINE64
+    const bool tl_on = (blockIdx.x == NPCD_TIMELINE64) && wave == 0;
+    long long tl[40];
+    for (int i = 0; i < 40; ++i) tl[i] = 0;
+    NPCD_TS(0);
+#endif
+    if (nt > 0) dma_tile_pair(smem, kb, p.sn, vb, p.sn, 0, nk, wave, lane);
+    if (nt > 1) dma_tile_pair(smem + 16384, kb, p.sn, vb, p.sn, 64, nk, wave, lane);
+#ifdef NPCD_TIMELINE64
+    NPCD_TS(1);
+#endif
+    if (nt > 1) vm_wait<8>();
+    else if (nt > 0) vm_wait<4>();
+    else vm_wait<0>();
+    V8 qA[4], qB[4];
+    arrived4(qrawA, qA);
+    arrived4(qrawB, qB);
+#ifdef NPCD_TIMELINE64
+    NPCD_TS(2);
+#endif
+    QBlk A, B;
+    A.o0 = A.o1 = B.o0 = B.o1 = f32x16{0};
+    A.m = B.m = -INFINITY;
+    A.l = B.l = 0.f;
+    if (seeded) {
+        V8 ke[4];
+        arrived4(keraw, ke);
+        NPCD_ARRIVED(vx0);
+        NPCD_ARRIVED(vx1);
+        A.m = mfma_dot<TR>(ke, qA) * c;               // the exp2 domain, like every later maximum
+        B.m = mfma_dot<TR>(ke, qB) * c;
+        A.l = B.l = 0.5f;                             // P = 1; the two half-wave partial sums are added at the end
+        outer_seed<TR>(vx0, vx1, 1.f, lane, A.o0, A.o1);
+        outer_seed<TR>(vx0, vx1, 1.f, lane, B.o0, B.o1);
+    }
+    if (rowx && wave == 0)       // the last query row -> LDS (128 B, lanes 32..63 repeat lanes 0..31): lands with the first tiles
+        dma4_issue(qb + (int64_t)(n - 1) * p.sn, (uint32_t)((lane & 31) * 4), __builtin_amdgcn_readfirstlane(lds_addr(smem) + 3 * 16384 + 1024));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (!wave_active) {                                          // wave-uniform
+        kv_idle_loop<E>(smem, kb, vb, p.sn, nfull, nt, nk, wave, lane, dl);
+        return;
+    }
+    const FragAddr fa = frag_addr(smem, lane);
+    u32x4 pwA[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}}, pwB[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+#ifdef NPCD_TIMELINE64
+    NPCD_TS(3);
+#define NPCD_TS_TILE(t) do { if (tl_on && (t) < 14) { __builtin_amdgcn_sched_barrier(0); tl[4 + (t)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define NPCD_TS_TILE(t) do { } while (0)
+#endif
+    if (nfull > 0) {
+        fwd64_stage<TR, 0, 0, 2, 1, false>(fa, qA, qB, A, B, pwA, pwB, c);
+        kv_mid<E, 0>(smem, kb, vb, p.sn, 0, nt, nk, wave, lane, dl);
+        fwd64_stage<TR, 0, 1, 0, 0, true>(fa, qA, qB, A, B, pwA, pwB, c);
+        if (xt == 0) rowx_tile<TR, 0>(smem, c, lane, wave, xrec);
+        NPCD_TS_TILE(0);
+        for (int t = 1; t < nfull; t += 3) {
+            fwd64_step<TR, 1>(smem, fa, dl, kb, vb, p.sn, t, nt, nk, wave, lane, qA, qB, A, B, pwA, pwB, xt, c, xrec);
+            NPCD_TS_TILE(t);
+            if (t + 1 < nfull) fwd64_step<TR, 2>(smem, fa, dl, kb, vb, p.sn, t + 1, nt, nk, wave, lane, qA, qB, A, B, pwA, pwB, xt, c, xrec);
+            NPCD_TS_TILE(t + 1);
+            if (t + 2 < nfull) fwd64_step<TR, 0>(smem, fa, dl, kb, vb, p.sn, t + 2, nt, nk, wave, lane, qA, qB, A, B, pwA, pwB, xt, c, xrec);
+            NPCD_TS_TILE(t + 2);
+        }
+        const int last = (nfull - 1) % 3;
+        if (last == 0) fwd64_flush<TR, 0, 1>(fa, A, B, pwA, pwB);
+        else if (last == 1) fwd64_flush<TR, 1, 1>(fa, A, B, pwA, pwB);
+        else fwd64_flush<TR, 2, 1>(fa, A, B, pwA, pwB);
+    } else {
+        NPCD_DMA_WAIT_BARRIER(0);
+    }
+    if (nfull < nt) {        // ragged last tile: landed at the mid-point of tile nfull-1 (or in the prologue)
+        const int slot = nfull % 3;
+        if (slot == 0) fwd64_tail<TR, 0>(fa, qA, qB, A, B, c, nfull * 64, nk, hh);
+        else if (slot == 1) fwd64_tail<TR, 1>(fa, qA, qB, A, B, c, nfull * 64, nk, hh);
+        else fwd64_tail<TR, 2>(fa, qA, qB, A, B, c, nfull * 64, nk, hh);
+    }
+#ifdef NPCD_TIMELINE64
+    NPCD_TS(20);
+#endif
+    A.l = half_sum(A.l);
+    B.l = half_sum(B.l);
+    __builtin_amdgcn_s_barrier();     // every wave has left the ring: 4 KiB of it per wave stage the output rows
+#ifdef NPCD_TIMELINE64
+    NPCD_TS(21);
+#endif
+    E* orow0 = static_cast<E*>(p.o_w) + b * p.osb + (int64_t)q0 * p.osn + h * p.osh;
+    store_rows_staged<TR>(smem + wave * 4096, orow0, p.osn, n - q0, A.o0, A.o1, 1.f / A.l, lane);
+    if (q0 + 32 < n) store_rows_staged<TR>(smem + wave * 4096, orow0 + 32 * p.osn, p.osn, n - q0 - 32, B.o0, B.o1, 1.f / B.l, lane);
+    float* lrow = p.lse + (int64_t)(b * p.H + h) * n;
+    if (hh == 0) {
+        if (q0 + r < n) lrow[q0 + r] = A.m * kLn2 + logf(A.l);
+        if (q0 + 32 + r < n) lrow[q0 + 32 + r] = B.m * kLn2 + logf(B.l);
+    }
+#ifdef NPCD_TIMELINE64
+    NPCD_TS(22);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    NPCD_TS(23);
+    if (tl_on && lane == 0)
+        for (int i = 0; i < 40; ++i) g_timeline[i] = tl[i];
+#endif
 }
 
 // ============================================================================================
@@ -2088,9 +2563,19 @@ extern "C" int npcd_debug_read(long long* out, int count) {
 }
 #endif
 
-extern "C" int npcd_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int n, int H, int d,
-                             int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
-                             float scale, int dtype, void* stream) {
+// which form of the forward a sequence length takes (NPCD_ATTN_FWD=32 / 64 forces one; see attn_fwd_launch)
+static bool fwd_rows32(int n) {
+    const char* form = getenv("NPCD_ATTN_FWD");
+    return form ? form[0] == '3' : n < 1024;
+}
+extern "C" int64_t npcd_attn_fwd_workspace_floats(int B, int n, int H) {
+    if (B <= 0 || n <= 0 || H <= 0) return -1;
+    return (rowx_mode(n) && !fwd_rows32(n)) ? (int64_t)B * H * ((n - 1) / 64) * kRowxFloats : 0;
+}
+
+static int attn_fwd_launch(const void* q, const void* k, const void* v, void* out, float* lse, float* workspace, int B, int n, int H, int d,
+                           int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                           float scale, int dtype, void* stream) {
     if (dtype == NPCD_F32) {   // inference-only exact fp32 path (no LSE, no backward)
         if (B <= 0 || n <= 0 || H <= 0 || !q || !k || !v || !out) return NPCD_ERR_ARG;
         if (d != 64) return NPCD_ERR_UNSUPPORTED;
@@ -2112,12 +2597,37 @@ extern "C" int npcd_attn_fwd(const void* q, const void* k, const void* v, void* 
     p.sb = qkv_sb; p.sn = qkv_sn; p.sh = qkv_sh;
     p.osb = out_sb; p.osn = out_sn; p.osh = out_sh;
     p.scale = scale; p.scale_log2 = scale * kLog2e;
-    const int grid = B * H * ceil_div(n, 128);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == NPCD_BF16) hipLaunchKernelGGL(attn_fwd_kernel<BF16>, dim3(grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(attn_fwd_kernel<F16>, dim3(grid), dim3(256), 0, st, p);
+    // Two forms of the forward (measured in one process, tools/probes/gpu_dev_fwd_ab.py): 64 query rows per wave wins
+    // on long sequences (n = 2049: 597-614 against 640-653 us), 32 rows per wave on short ones, where a workgroup's start-up and
+    // wind-down dominate and its finer grid fills the chip better (n = 513: 113 against 117 us).  NPCD_ATTN_FWD=32 / 64 forces one.
+    if (fwd_rows32(n)) {
+        const int grid = B * H * ceil_div(n, 128);
+        if (dtype == NPCD_BF16) hipLaunchKernelGGL(attn_fwd_kernel<BF16>, dim3(grid), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(attn_fwd_kernel<F16>, dim3(grid), dim3(256), 0, st, p);
+    } else {
+        p.rowx = (workspace && rowx_mode(n)) ? workspace : nullptr;
+        const int grid = B * H * (p.rowx ? (n - 1) / 256 : ceil_div(n, 256));
+        if (dtype == NPCD_BF16) hipLaunchKernelGGL(attn_fwd64_kernel<BF16>, dim3(grid), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(attn_fwd64_kernel<F16>, dim3(grid), dim3(256), 0, st, p);
+        if (p.rowx) {
+            if (dtype == NPCD_BF16) hipLaunchKernelGGL(attn_fwd_rowx_merge_kernel<__bf16>, dim3(B * H), dim3(64), 0, st, p, (n - 1) / 64);
+            else hipLaunchKernelGGL(attn_fwd_rowx_merge_kernel<_Float16>, dim3(B * H), dim3(64), 0, st, p, (n - 1) / 64);
+        }
+    }
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
+}
+
+extern "C" int npcd_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse, int B, int n, int H, int d,
+                             int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                             float scale, int dtype, void* stream) {
+    return attn_fwd_launch(q, k, v, out, lse, nullptr, B, n, H, d, qkv_sb, qkv_sn, qkv_sh, out_sb, out_sn, out_sh, scale, dtype, stream);
+}
+extern "C" int npcd_attn_fwd_ws(const void* q, const void* k, const void* v, void* out, float* lse, float* workspace, int B, int n, int H,
+                                int d, int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
+                                float scale, int dtype, void* stream) {
+    return attn_fwd_launch(q, k, v, out, lse, workspace, B, n, H, d, qkv_sb, qkv_sn, qkv_sh, out_sb, out_sn, out_sh, scale, dtype, stream);
 }
 
 // fp8 forward (opt-in): workspace = the e4m3 copies of k and v^T

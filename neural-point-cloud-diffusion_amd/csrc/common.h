@@ -38,6 +38,13 @@ struct BF16 {
     static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    // c + a.lo * b.lo + a.hi * b.hi on a packed pair (v_dot2c_f32_bf16)
+    static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 v2;
+        return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
+    }
+    static __device__ __forceinline__ float lo(uint32_t a) { return __uint_as_float(a << 16); }
+    static __device__ __forceinline__ float hi(uint32_t a) { return __uint_as_float(a & 0xffff0000u); }
 };
 struct F16 {
     using elem = _Float16;
@@ -48,6 +55,18 @@ struct F16 {
     }
     static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float dot2(uint32_t a, uint32_t b, float c) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2, a), __builtin_bit_cast(v2, b), c, false);
+    }
+    static __device__ __forceinline__ float lo(uint32_t a) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+        return (float)__builtin_bit_cast(v2, a)[0];
+    }
+    static __device__ __forceinline__ float hi(uint32_t a) {
+        typedef __attribute__((ext_vector_type(2))) _Float16 v2;
+        return (float)__builtin_bit_cast(v2, a)[1];
     }
 };
 

@@ -34,6 +34,8 @@ SIGNATURES = {
     "npcd_error_string": (c_char_p, [c_int]),
     "npcd_last_hip_error": (c_char_p, []),
     "npcd_attn_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int] + [c_int64] * 6 + [c_float, c_int, _P]),
+    "npcd_attn_fwd_workspace_floats": (c_int64, [c_int, c_int, c_int]),
+    "npcd_attn_fwd_ws": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int] + [c_int64] * 6 + [c_float, c_int, _P]),
     "npcd_ray_march_bwd": (c_int, [_P] * 8 + [c_int, c_int, c_int] + [_P] * 6 + [_P]),
     "npcd_leaky_bwd_blocks": (c_int, [c_int64]),
     "npcd_leaky_bwd_colsum": (c_int, [_P, _P, _P, _P, c_int64, c_int, c_float, c_int, _P]),

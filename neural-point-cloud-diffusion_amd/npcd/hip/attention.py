@@ -26,9 +26,11 @@ def _fwd(q, k, v, scale):
                                                                 q.stride(0), q.stride(1), q.stride(2), out.stride(0), out.stride(1),
                                                                 out.stride(2), scale, dtype_code(q), stream_ptr())), "npcd_attn_fwd_fp8")
             return out, lse
-    check(_timed("fwd", lambda: lib().npcd_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), B, n, H, d,
-                                                    q.stride(0), q.stride(1), q.stride(2), out.stride(0), out.stride(1),
-                                                    out.stride(2), scale, dtype_code(q), stream_ptr())), "npcd_attn_fwd")
+    nws = lib().npcd_attn_fwd_workspace_floats(B, n, H) if FWD_WS else 0
+    ws = torch.empty(nws, dtype=torch.float32, device=q.device) if nws > 0 else None
+    check(_timed("fwd", lambda: lib().npcd_attn_fwd_ws(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(ws), B, n, H, d,
+                                                       q.stride(0), q.stride(1), q.stride(2), out.stride(0), out.stride(1),
+                                                       out.stride(2), scale, dtype_code(q), stream_ptr())), "npcd_attn_fwd_ws")
     return out, lse
 
 
@@ -53,6 +55,8 @@ import os
 
 # "fused": the single-pass backward (attn_bwd_fused_kernel, 5 products); "twopass": dq pass + dk/dv pass (7 products)
 BWD_MODE = os.environ.get("NPCD_ATTN_BWD", "twopass")
+# "0": no scratch for the forward (a sequence of 256 j + 1 tokens then runs a workgroup for its last query row: A/B switch)
+FWD_WS = os.environ.get("NPCD_ATTN_FWD_WS", "1") != "0"
 # "1": the forward with fp8 (e4m3) operands (BASELINE configs[4] names fp8 attention); the backward stays on the bf16 kernels
 FWD_FP8 = os.environ.get("NPCD_ATTN_FP8", "") == "1"
 

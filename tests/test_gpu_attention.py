@@ -64,9 +64,20 @@ def check(qkv16, heads, gout16, tag):
             assert el < 3e-2, f"{tag}: d{name} of the last token rel-L2 {el:.3e}"
 
 
+@pytest.fixture(params=["auto", "32", "64"])
+def fwd_form(request, monkeypatch):
+    """The forward has two forms (csrc/attention.hip: 32 / 64 query rows per wave; the library picks by sequence length and reads
+    NPCD_ATTN_FWD at every call): the parity tests run with the automatic choice and with each form forced."""
+    if request.param == "auto":
+        monkeypatch.delenv("NPCD_ATTN_FWD", raising=False)
+    else:
+        monkeypatch.setenv("NPCD_ATTN_FWD", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("tag", ["n513_h1_d64", "n130_h4_d64"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_attention_golden(golden, tag, dtype):
+def test_attention_golden(golden, tag, dtype, fwd_form):
     g = golden("attention_" + tag)
     qkv16 = torch.from_numpy(g["qkv"]).to(dtype)
     gout16 = torch.from_numpy(g["gout"]).to(dtype)
@@ -76,8 +87,8 @@ def test_attention_golden(golden, tag, dtype):
     assert rel_l2(out, torch.from_numpy(g["out"])) < 2e-2
 
 
-@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 192, 193, 256, 384, 448, 513, 576, 700, 1025, 2049])
-def test_attention_ragged_lengths(n):      # 513 = BASELINE configs[1] (512 points + time token), 2049 = configs[4] (2048 points)
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 33, 63, 64, 65, 96, 127, 128, 129, 192, 193, 256, 257, 384, 448, 513, 576, 700, 1025, 2049])
+def test_attention_ragged_lengths(n, fwd_form):      # 513 = BASELINE configs[1] (512 points + time token), 2049 = configs[4] (2048 points)
     gen = torch.Generator().manual_seed(n)
     B, H = 2, 3
     qkv = (torch.randn(B, n, 3 * H * 64, generator=gen) * 1.5).bfloat16()
@@ -85,7 +96,7 @@ def test_attention_ragged_lengths(n):      # 513 = BASELINE configs[1] (512 poin
     check(qkv, H, gout, f"n={n}")
 
 
-def test_attention_forced_rescale():
+def test_attention_forced_rescale(fwd_form):
     """One key (in the LAST tile) dominates one query: the running max must jump late."""
     gen = torch.Generator().manual_seed(3)
     n, H = 200, 1
