@@ -297,6 +297,21 @@ int npcd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* sha
                    float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                    float ema_decay, int zero_grad, void* stream);
 int npcd_cast_f32_bf16(const float* src, void* dst, int64_t numel, void* stream);
+/* The same kernels for either 16-bit activation type of a training run: dtype = NPCD_BF16 (bf16 autocast; the names above) or
+ * NPCD_F16 (float16 autocast with loss scaling -- the reference's default --dtype, train_diffusion.py:78,
+ * train/diffusion_training.py:60-62).  Same arguments otherwise; shadow_dtype = the type of the 16-bit parameter shadow. */
+int npcd_add_ln_fwd_dt(const float* x_in, const void* delta, const float* gamma, const float* beta,
+                       float* x_out, void* y, float* mean, float* rstd, int T, int W, float eps, int dtype, void* stream);
+int npcd_ln_bwd_dt(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                   const float* dres, float* dx, void* dxb, float* part_gamma, float* part_beta,
+                   float* part_col, int T, int W, int dtype, void* stream);
+int npcd_gelu_fwd_dt(const void* h, void* g, int64_t numel, int dtype, void* stream);
+int npcd_gelu_bwd_dt(const void* dg, const void* h, void* dh, float* part, int T, int N, int dtype, void* stream);
+int npcd_colsum_dt(const void* a, float* part, int T, int N, int dtype, void* stream);
+int npcd_adamw_ema_dt(float* p, float* g, float* m, float* v, float* ema, void* shadow, int shadow_dtype, int64_t numel,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                      float ema_decay, int zero_grad, void* stream);
+int npcd_cast_f32_dt(const float* src, void* dst, int64_t numel, int dtype, void* stream);
 
 /* out[i] = part[0 * numel + i] + ... + part[(S - 1) * numel + i], fp32, added in slice order (S = 2, 4 or 8; numel % 4 == 0;
  * 16-byte aligned): the sum of the row-split weight-gradient partials of the fused backbone (replaces torch.sum(part, dim=0)

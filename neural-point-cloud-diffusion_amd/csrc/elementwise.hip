@@ -39,8 +39,18 @@ __device__ __forceinline__ float wave_sum(float x) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 #endif
 }
-__device__ __forceinline__ f32x4 bf16x4_to_f32(bf16x4 v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
-__device__ __forceinline__ bf16x4 f32_to_bf16x4(f32x4 v) { return bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]}; }
+// the 16-bit activation type of a training run: __bf16 (bf16 autocast) or _Float16 (the reference's default --dtype, with loss scaling)
+template <class E>
+struct V {
+    typedef E x4 __attribute__((ext_vector_type(4)));
+    typedef E x8 __attribute__((ext_vector_type(8)));
+};
+template <class X4>
+__device__ __forceinline__ f32x4 to_f32(X4 v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+template <class E>
+__device__ __forceinline__ typename V<E>::x4 from_f32(f32x4 v) { return typename V<E>::x4{(E)v[0], (E)v[1], (E)v[2], (E)v[3]}; }
+__device__ __forceinline__ f32x4 bf16x4_to_f32(bf16x4 v) { return to_f32(v); }
+__device__ __forceinline__ bf16x4 f32_to_bf16x4(f32x4 v) { return from_f32<__bf16>(v); }
 
 // ============================================================================================
 // x_out = x_in (+ delta);  y = LayerNorm(x_out) * gamma + beta  (bf16);  mean / rstd saved
@@ -48,22 +58,23 @@ __device__ __forceinline__ bf16x4 f32_to_bf16x4(f32x4 v) { return bf16x4{(__bf16
 // ============================================================================================
 // A wave walks rows g, g + NW, g + 2 NW, ... (NW waves in the grid: the grid streams one contiguous band of rows at a time) and
 // loads row r + NW before it reduces and stores row r; the affine parameters stay in registers.
-template <int NCH>
-__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ x_in, const __bf16* __restrict__ delta,
+template <class E, int NCH>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ x_in, const E* __restrict__ delta,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* __restrict__ x_out, __bf16* __restrict__ y, float* __restrict__ mean,
+                                                         float* __restrict__ x_out, E* __restrict__ y, float* __restrict__ mean,
                                                          float* __restrict__ rstd, int T, int W, float eps) {
+    using e4 = typename V<E>::x4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int NW = gridDim.x * 4;
     int row = blockIdx.x * 4 + wave;
     if (row >= T) return;
     f32x4 gm[NCH], bt[NCH], v[NCH], nx[NCH];
-    bf16x4 nd[NCH];
+    e4 nd[NCH];
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int c = ch * 256 + lane * 4;
         gm[ch] = bt[ch] = nx[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
-        nd[ch] = bf16x4{0, 0, 0, 0};
+        nd[ch] = e4{0, 0, 0, 0};
         if (c < W) {
             gm[ch] = *reinterpret_cast<const f32x4*>(gamma + c);
             bt[ch] = *reinterpret_cast<const f32x4*>(beta + c);
@@ -76,7 +87,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
             const int c = ch * 256 + lane * 4;
             if (c < W) {
                 nx[ch] = *reinterpret_cast<const f32x4*>(x_in + base + c);
-                if (delta) nd[ch] = *reinterpret_cast<const bf16x4*>(delta + base + c);
+                if (delta) nd[ch] = *reinterpret_cast<const e4*>(delta + base + c);
             }
         }
     };
@@ -87,7 +98,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             v[ch] = nx[ch];
-            if (delta) v[ch] += bf16x4_to_f32(nd[ch]);
+            if (delta) v[ch] += to_f32(nd[ch]);
         }
         if (row + NW < T) load_row(row + NW);
 #pragma unroll
@@ -112,7 +123,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int c = ch * 256 + lane * 4;
-            if (c < W) *reinterpret_cast<bf16x4*>(y + base + c) = f32_to_bf16x4((v[ch] - mu) * rs * gm[ch] + bt[ch]);
+            if (c < W) *reinterpret_cast<e4*>(y + base + c) = from_f32<E>((v[ch] - mu) * rs * gm[ch] + bt[ch]);
         }
         if (lane == 0) {
             mean[row] = mu;
@@ -137,12 +148,13 @@ static inline int ln_rows_per_wave(int T) {
     return 16;
 }
 
-template <int NCH>
-__global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const __bf16* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+template <class E, int NCH>
+__global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const E* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                                     const float* __restrict__ dres, float* __restrict__ dx, __bf16* __restrict__ dxb,
+                                                     const float* __restrict__ dres, float* __restrict__ dx, E* __restrict__ dxb,
                                                      float* __restrict__ part_gamma, float* __restrict__ part_beta,
                                                      float* __restrict__ part_col, int T, int W, int rows_per_wave) {
+    using e4 = typename V<E>::x4;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
     float* red = reinterpret_cast<float*>(dsmem);  // [3][4 waves][W]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -155,10 +167,10 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const __bf16* __restrict
     const int nrows = row0 < T ? min(rows_per_wave, (T - row0 + NW - 1) / NW) : 0;
     // The row loop is software-pipelined: the loads of row r+1 are issued before row r is reduced and stored, so that
     // every wave keeps ~10 KB of reads in flight all the time (the kernel is a pure HBM stream: 536 MB per call at cfg-D).
-    bf16x4 dyA[NCH], dyB[NCH];
+    e4 dyA[NCH], dyB[NCH];
     f32x4 xA[NCH], xB[NCH], rA[NCH], rB[NCH];
     float muA = 0.f, rsA = 0.f, muB = 0.f, rsB = 0.f;
-    auto load_row = [&](int row, bf16x4 (&dyr)[NCH], f32x4 (&xr)[NCH], f32x4 (&rr2)[NCH], float& mu, float& rs) {
+    auto load_row = [&](int row, e4 (&dyr)[NCH], f32x4 (&xr)[NCH], f32x4 (&rr2)[NCH], float& mu, float& rs) {
         const int64_t base = (int64_t)row * W;
         mu = mean[row];
         rs = rstd[row];
@@ -166,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const __bf16* __restrict
         for (int ch = 0; ch < NCH; ++ch) {
             const int c = ch * 256 + lane * 4;
             if (c < W) {
-                dyr[ch] = *reinterpret_cast<const bf16x4*>(dy + base + c);
+                dyr[ch] = *reinterpret_cast<const e4*>(dy + base + c);
                 xr[ch] = *reinterpret_cast<const f32x4*>(x + base + c);
                 if (dres) rr2[ch] = *reinterpret_cast<const f32x4*>(dres + base + c);
             }
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const __bf16* __restrict
             const int c = ch * 256 + lane * 4;
             gy[ch] = xh[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (c < W) {
-                const f32x4 d = bf16x4_to_f32(dyA[ch]);
+                const f32x4 d = to_f32(dyA[ch]);
                 xh[ch] = (xA[ch] - mu) * rs;
                 ag[ch] += d * xh[ch];
                 ab[ch] += d;
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void ln_bwd_kernel(const __bf16* __restrict
                 f32x4 o = (gy[ch] - c1 - xh[ch] * c2) * rs;
                 if (dres) o += rA[ch];
                 *reinterpret_cast<f32x4*>(dx + base + c) = o;
-                if (dxb) *reinterpret_cast<bf16x4*>(dxb + base + c) = f32_to_bf16x4(o);
+                if (dxb) *reinterpret_cast<e4*>(dxb + base + c) = from_f32<E>(o);
                 ac[ch] += o;
             }
         }
@@ -318,13 +330,14 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return x * __builtin_fmaf(0.5f, copysignf(erf_abs, x), 0.5f);
 }
 
-template <int VARIANT>
-__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16x8* __restrict__ h, bf16x8* __restrict__ g, int64_t n8) {
+template <class E, int VARIANT>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const typename V<E>::x8* __restrict__ h, typename V<E>::x8* __restrict__ g, int64_t n8) {
+    using e8 = typename V<E>::x8;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
-        const bf16x8 v = h[i];
-        bf16x8 o;
+        const e8 v = h[i];
+        e8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (__bf16)(VARIANT == 0 ? gelu_f((float)v[j]) : gelu_fast((float)v[j]));
+        for (int j = 0; j < 8; ++j) o[j] = (E)(VARIANT == 0 ? gelu_f((float)v[j]) : gelu_fast((float)v[j]));
         g[i] = o;
     }
 }
@@ -357,9 +370,10 @@ __device__ __forceinline__ float gelu_grad_fast(float x) {
 
 // VARIANT (GELU only): 0 = libm erff; 1 = gelu_grad_fast; 2 = gelu_grad_fast, two rows per trip with all four loads issued first;
 // 3 = gelu_grad_fast with non-temporal loads of the two once-read inputs
-template <bool GELU, int VARIANT = 1>
-__global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ a, const __bf16* __restrict__ hpre, __bf16* __restrict__ out,
+template <class E, bool GELU, int VARIANT = 1>
+__global__ __launch_bounds__(256) void colsum_kernel(const E* __restrict__ a, const E* __restrict__ hpre, E* __restrict__ out,
                                                      float* __restrict__ part, int T, int N, int rows) {
+    using e8 = typename V<E>::x8;
     const int col = (blockIdx.x * 256 + threadIdx.x) * 8;
     if (col >= N) return;
     // workgroup y takes rows y, y + G, y + 2G, ... (G = gridDim.y): at any moment the grid reads ONE contiguous band of G rows.
@@ -368,15 +382,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    auto one = [&](const bf16x8 v, const bf16x8 hp, int64_t off) {
-        bf16x8 o;
+    auto one = [&](const e8 v, const e8 hp, int64_t off) {
+        e8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float gp = VARIANT == 0 ? gelu_grad_f((float)hp[j]) : gelu_grad_fast((float)hp[j]);
-            o[j] = (__bf16)((float)v[j] * gp);
+            o[j] = (E)((float)v[j] * gp);
             acc[j] += (float)o[j];      // the bias gradient sums the SAME rounded values the GEMMs see
         }
-        *reinterpret_cast<bf16x8*>(out + off) = o;
+        *reinterpret_cast<e8*>(out + off) = o;
     };
     if (GELU && VARIANT == 2) {
         int rr = 0;
@@ -384,8 +398,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
             const int r0 = rr * gridDim.y + blockIdx.y, r1 = r0 + gridDim.y;
             if (r1 >= T) break;
             const int64_t o0 = (int64_t)r0 * N + col, o1 = (int64_t)r1 * N + col;
-            const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(a + o0), h0 = *reinterpret_cast<const bf16x8*>(hpre + o0);
-            const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(a + o1), h1 = *reinterpret_cast<const bf16x8*>(hpre + o1);
+            const e8 v0 = *reinterpret_cast<const e8*>(a + o0), h0 = *reinterpret_cast<const e8*>(hpre + o0);
+            const e8 v1 = *reinterpret_cast<const e8*>(a + o1), h1 = *reinterpret_cast<const e8*>(hpre + o1);
             one(v0, h0, o0);
             one(v1, h1, o1);
         }
@@ -393,18 +407,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const __bf16* __restrict__ 
             const int row = rr * gridDim.y + blockIdx.y;
             if (row >= T) break;
             const int64_t off = (int64_t)row * N + col;
-            one(*reinterpret_cast<const bf16x8*>(a + off), *reinterpret_cast<const bf16x8*>(hpre + off), off);
+            one(*reinterpret_cast<const e8*>(a + off), *reinterpret_cast<const e8*>(hpre + off), off);
         }
     } else {
         for (int rr = 0; rr < rows; ++rr) {
             const int row = rr * gridDim.y + blockIdx.y;
             if (row >= T) break;
             const int64_t off = (int64_t)row * N + col;
-            const bf16x8 v = (GELU && VARIANT == 3) ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(a + off))
-                                                    : *reinterpret_cast<const bf16x8*>(a + off);
+            const e8 v = (GELU && VARIANT == 3) ? __builtin_nontemporal_load(reinterpret_cast<const e8*>(a + off))
+                                                    : *reinterpret_cast<const e8*>(a + off);
             if (GELU) {
-                one(v, VARIANT == 3 ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(hpre + off))
-                                    : *reinterpret_cast<const bf16x8*>(hpre + off), off);
+                one(v, VARIANT == 3 ? __builtin_nontemporal_load(reinterpret_cast<const e8*>(hpre + off))
+                                    : *reinterpret_cast<const e8*>(hpre + off), off);
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
@@ -475,8 +489,9 @@ __device__ __forceinline__ void adamw_one(f32x4& pp, const f32x4 gg, f32x4& mm, 
 
 // Two float4 per thread and trip: all ten loads of a trip are issued before the first dependent use (the kernel is a pure
 // stream of 5 reads + 6 writes per element; more bytes in flight per wave is the only lever).
+template <class E>
 __global__ __launch_bounds__(256) void adamw_ema_kernel(f32x4* __restrict__ p, f32x4* __restrict__ g, f32x4* __restrict__ m, f32x4* __restrict__ v,
-                                                        f32x4* __restrict__ ema, bf16x4* __restrict__ shadow, int64_t n4, AdamArgs a, int zero_grad) {
+                                                        f32x4* __restrict__ ema, typename V<E>::x4* __restrict__ shadow, int64_t n4, AdamArgs a, int zero_grad) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     for (; i + stride < n4; i += 2 * stride) {
@@ -492,7 +507,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(f32x4* __restrict__ p, f
         m[i] = m0; m[k] = m1;
         v[i] = v0; v[k] = v1;
         if (ema) { ema[i] = e0 + (p0 - e0) * a.ema_w; ema[k] = e1 + (p1 - e1) * a.ema_w; }
-        if (shadow) { shadow[i] = f32_to_bf16x4(p0); shadow[k] = f32_to_bf16x4(p1); }
+        if (shadow) { shadow[i] = from_f32<E>(p0); shadow[k] = from_f32<E>(p1); }
         if (zero_grad) { g[i] = f32x4{0.f, 0.f, 0.f, 0.f}; g[k] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
     if (i < n4) {
@@ -507,13 +522,14 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(f32x4* __restrict__ p, f
             const f32x4 e = ema[i];
             ema[i] = e + (pp - e) * a.ema_w;
         }
-        if (shadow) shadow[i] = f32_to_bf16x4(pp);
+        if (shadow) shadow[i] = from_f32<E>(pp);
         if (zero_grad) g[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
-__global__ __launch_bounds__(256) void cast_bf16_kernel(const f32x4* __restrict__ src, bf16x4* __restrict__ dst, int64_t n4) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) dst[i] = f32_to_bf16x4(src[i]);
+template <class E>
+__global__ __launch_bounds__(256) void cast_kernel(const f32x4* __restrict__ src, typename V<E>::x4* __restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) dst[i] = from_f32<E>(src[i]);
 }
 
 // out[i] = part[0][i] + part[1][i] + ... + part[S - 1][i] (fp32, added in slice order): the row-split weight-gradient GEMMs of the
@@ -564,47 +580,71 @@ using namespace npcd;
 // rows are interleaved over the waves of a grid of at most 2048 workgroups (8 per CU)
 static inline int ln_fwd_blocks(int T) { const int b = (T + 3) / 4; return b < 2048 ? b : 2048; }
 
-extern "C" int npcd_add_ln_fwd(const float* x_in, const void* delta, const float* gamma, const float* beta, float* x_out, void* y,
-                               float* mean, float* rstd, int T, int W, float eps, void* stream) {
+// `dtype` (NPCD_BF16 / NPCD_F16) = the 16-bit activation type of the run; the names without _dt are the bf16 forms
+static inline bool dt16(int dtype) { return dtype == NPCD_BF16 || dtype == NPCD_F16; }
+
+extern "C" int npcd_add_ln_fwd_dt(const float* x_in, const void* delta, const float* gamma, const float* beta, float* x_out, void* y,
+                                  float* mean, float* rstd, int T, int W, float eps, int dtype, void* stream) {
     if (!x_in || !gamma || !beta || !y || !mean || !rstd || T <= 0 || W <= 0) return NPCD_ERR_ARG;
-    if (W % 4 != 0 || W > 256 * kMaxChunks) return NPCD_ERR_UNSUPPORTED;
+    if (W % 4 != 0 || W > 256 * kMaxChunks || !dt16(dtype)) return NPCD_ERR_UNSUPPORTED;
     if (!al16(x_in) || !al16(gamma) || !al16(beta) || (x_out && !al16(x_out)) || (reinterpret_cast<uintptr_t>(y) & 7) ||
         (delta && (reinterpret_cast<uintptr_t>(delta) & 7)))
         return NPCD_ERR_ARG;
-#define NPCD_LAUNCH_LN_FWD(NCH)                                                                                               \
-    hipLaunchKernelGGL(add_ln_fwd_kernel<NCH>, dim3(ln_fwd_blocks(T)), dim3(256), 0, static_cast<hipStream_t>(stream), x_in,        \
-                       static_cast<const __bf16*>(delta), gamma, beta, x_out, static_cast<__bf16*>(y), mean, rstd, T, W, eps)
-    if (W <= 256) NPCD_LAUNCH_LN_FWD(1);
-    else if (W <= 512) NPCD_LAUNCH_LN_FWD(2);
-    else if (W <= 1024) NPCD_LAUNCH_LN_FWD(4);
-    else NPCD_LAUNCH_LN_FWD(8);
+#define NPCD_LAUNCH_LN_FWD(E, NCH)                                                                                            \
+    hipLaunchKernelGGL((add_ln_fwd_kernel<E, NCH>), dim3(ln_fwd_blocks(T)), dim3(256), 0, static_cast<hipStream_t>(stream), x_in, \
+                       static_cast<const E*>(delta), gamma, beta, x_out, static_cast<E*>(y), mean, rstd, T, W, eps)
+#define NPCD_LN_FWD_W(E)                     \
+    do {                                     \
+        if (W <= 256) NPCD_LAUNCH_LN_FWD(E, 1);      \
+        else if (W <= 512) NPCD_LAUNCH_LN_FWD(E, 2); \
+        else if (W <= 1024) NPCD_LAUNCH_LN_FWD(E, 4);\
+        else NPCD_LAUNCH_LN_FWD(E, 8);               \
+    } while (0)
+    if (dtype == NPCD_BF16) NPCD_LN_FWD_W(__bf16);
+    else NPCD_LN_FWD_W(_Float16);
+#undef NPCD_LN_FWD_W
 #undef NPCD_LAUNCH_LN_FWD
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }
+extern "C" int npcd_add_ln_fwd(const float* x_in, const void* delta, const float* gamma, const float* beta, float* x_out, void* y,
+                               float* mean, float* rstd, int T, int W, float eps, void* stream) {
+    return npcd_add_ln_fwd_dt(x_in, delta, gamma, beta, x_out, y, mean, rstd, T, W, eps, NPCD_BF16, stream);
+}
 
 extern "C" int npcd_ln_bwd_blocks(int T) { const int r = ln_rows_per_wave(T); return (T + 4 * r - 1) / (4 * r); }
 
-extern "C" int npcd_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
-                           float* dx, void* dxb, float* part_gamma, float* part_beta, float* part_col, int T, int W, void* stream) {
+extern "C" int npcd_ln_bwd_dt(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
+                              float* dx, void* dxb, float* part_gamma, float* part_beta, float* part_col, int T, int W, int dtype, void* stream) {
     if (!dy || !x || !mean || !rstd || !gamma || !dx || T <= 0 || W <= 0) return NPCD_ERR_ARG;
-    if (W % 4 != 0 || W > 256 * kMaxChunks) return NPCD_ERR_UNSUPPORTED;
+    if (W % 4 != 0 || W > 256 * kMaxChunks || !dt16(dtype)) return NPCD_ERR_UNSUPPORTED;
     if (!al16(x) || !al16(gamma) || !al16(dx) || (dres && !al16(dres))) return NPCD_ERR_ARG;
     const int nblk = npcd_ln_bwd_blocks(T);
     const size_t lds = (size_t)3 * 4 * W * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static DynLds lds_attr;   // W = 2048 needs 96 KiB of dynamic LDS
-    NPCD_HIP_CHECK(lds_attr.ensure(reinterpret_cast<const void*>(ln_bwd_kernel<8>), 3 * 4 * 2048 * 4));
-#define NPCD_LAUNCH_LN_BWD(NCH)                                                                                                \
-    hipLaunchKernelGGL(ln_bwd_kernel<NCH>, dim3(nblk), dim3(256), lds, st, static_cast<const __bf16*>(dy), x, mean, rstd, gamma, \
-                       dres, dx, static_cast<__bf16*>(dxb), part_gamma, part_beta, part_col, T, W, ln_rows_per_wave(T))
-    if (W <= 256) NPCD_LAUNCH_LN_BWD(1);
-    else if (W <= 512) NPCD_LAUNCH_LN_BWD(2);
-    else if (W <= 1024) NPCD_LAUNCH_LN_BWD(4);
-    else NPCD_LAUNCH_LN_BWD(8);
+    static DynLds lds_attr_b, lds_attr_h;   // W = 2048 needs 96 KiB of dynamic LDS
+    if (dtype == NPCD_BF16) NPCD_HIP_CHECK(lds_attr_b.ensure(reinterpret_cast<const void*>(ln_bwd_kernel<__bf16, 8>), 3 * 4 * 2048 * 4));
+    else NPCD_HIP_CHECK(lds_attr_h.ensure(reinterpret_cast<const void*>(ln_bwd_kernel<_Float16, 8>), 3 * 4 * 2048 * 4));
+#define NPCD_LAUNCH_LN_BWD(E, NCH)                                                                                             \
+    hipLaunchKernelGGL((ln_bwd_kernel<E, NCH>), dim3(nblk), dim3(256), lds, st, static_cast<const E*>(dy), x, mean, rstd, gamma, \
+                       dres, dx, static_cast<E*>(dxb), part_gamma, part_beta, part_col, T, W, ln_rows_per_wave(T))
+#define NPCD_LN_BWD_W(E)                     \
+    do {                                     \
+        if (W <= 256) NPCD_LAUNCH_LN_BWD(E, 1);      \
+        else if (W <= 512) NPCD_LAUNCH_LN_BWD(E, 2); \
+        else if (W <= 1024) NPCD_LAUNCH_LN_BWD(E, 4);\
+        else NPCD_LAUNCH_LN_BWD(E, 8);               \
+    } while (0)
+    if (dtype == NPCD_BF16) NPCD_LN_BWD_W(__bf16);
+    else NPCD_LN_BWD_W(_Float16);
+#undef NPCD_LN_BWD_W
 #undef NPCD_LAUNCH_LN_BWD
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
+}
+extern "C" int npcd_ln_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma, const float* dres,
+                           float* dx, void* dxb, float* part_gamma, float* part_beta, float* part_col, int T, int W, void* stream) {
+    return npcd_ln_bwd_dt(dy, x, mean, rstd, gamma, dres, dx, dxb, part_gamma, part_beta, part_col, T, W, NPCD_BF16, stream);
 }
 
 // `part` must have room for kFinSlices extra rows after its nblk rows (npcd_colsum_scratch_rows()):
@@ -640,51 +680,66 @@ extern "C" int npcd_colsum_finalize(const float* part, int nblk, int N, float* o
     return npcd_colsum_finalize_batch(&job, 1, stream);
 }
 
-extern "C" int npcd_gelu_fwd(const void* h, void* g, int64_t numel, void* stream) {
+extern "C" int npcd_gelu_fwd_dt(const void* h, void* g, int64_t numel, int dtype, void* stream) {
     if (!h || !g || numel <= 0) return NPCD_ERR_ARG;
-    if (numel % 8 != 0 || !al16(h) || !al16(g)) return NPCD_ERR_UNSUPPORTED;
+    if (numel % 8 != 0 || !al16(h) || !al16(g) || !dt16(dtype)) return NPCD_ERR_UNSUPPORTED;
     const int64_t n8 = numel / 8;
     const int grid = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
     static const int variant = [] { const char* e = getenv("NPCD_GELU_FWD_VARIANT"); return e ? atoi(e) : 1; }();   // A/B probes only
-    if (variant == 0)
-        hipLaunchKernelGGL(gelu_fwd_kernel<0>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16x8*>(h),
-                           static_cast<bf16x8*>(g), n8);
-    else
-        hipLaunchKernelGGL(gelu_fwd_kernel<1>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const bf16x8*>(h),
-                           static_cast<bf16x8*>(g), n8);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define NPCD_LAUNCH_GELU_FWD(E, VV)                                                                                                 \
+    hipLaunchKernelGGL((gelu_fwd_kernel<E, VV>), dim3(grid), dim3(256), 0, st, static_cast<const typename V<E>::x8*>(h), \
+                       static_cast<typename V<E>::x8*>(g), n8)
+    if (dtype == NPCD_BF16) {
+        if (variant == 0) NPCD_LAUNCH_GELU_FWD(__bf16, 0);
+        else NPCD_LAUNCH_GELU_FWD(__bf16, 1);
+    } else {
+        NPCD_LAUNCH_GELU_FWD(_Float16, 1);
+    }
+#undef NPCD_LAUNCH_GELU_FWD
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }
+extern "C" int npcd_gelu_fwd(const void* h, void* g, int64_t numel, void* stream) { return npcd_gelu_fwd_dt(h, g, numel, NPCD_BF16, stream); }
 
 extern "C" int npcd_colsum_blocks(int T) { const int r = col_rows(T); return (T + r - 1) / r; }
 
-// dh = dg * gelu'(h) (bf16) and column partials of dh: part [npcd_colsum_blocks(T)][N]
-extern "C" int npcd_gelu_bwd(const void* dg, const void* h, void* dh, float* part, int T, int N, void* stream) {
+// dh = dg * gelu'(h) (16 bit) and column partials of dh: part [npcd_colsum_blocks(T)][N]
+extern "C" int npcd_gelu_bwd_dt(const void* dg, const void* h, void* dh, float* part, int T, int N, int dtype, void* stream) {
     if (!dg || !h || !dh || !part || T <= 0 || N <= 0) return NPCD_ERR_ARG;
-    if (N % 8 != 0 || !al16(dg) || !al16(h) || !al16(dh) || !al16(part)) return NPCD_ERR_UNSUPPORTED;
+    if (N % 8 != 0 || !al16(dg) || !al16(h) || !al16(dh) || !al16(part) || !dt16(dtype)) return NPCD_ERR_UNSUPPORTED;
     dim3 grid((N / 8 + 255) / 256, npcd_colsum_blocks(T));
     static const int variant = [] { const char* e = getenv("NPCD_GELU_BWD_VARIANT"); return e ? atoi(e) : 1; }();   // A/B probes only
-#define NPCD_LAUNCH_GELU_BWD(V)                                                                                                       \
-    hipLaunchKernelGGL((colsum_kernel<true, V>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const __bf16*>(dg), \
-                       static_cast<const __bf16*>(h), static_cast<__bf16*>(dh), part, T, N, col_rows(T))
-    if (variant == 0) NPCD_LAUNCH_GELU_BWD(0);
-    else if (variant == 2) NPCD_LAUNCH_GELU_BWD(2);
-    else if (variant == 3) NPCD_LAUNCH_GELU_BWD(3);
-    else NPCD_LAUNCH_GELU_BWD(1);
+#define NPCD_LAUNCH_GELU_BWD(E, VV)                                                                                                    \
+    hipLaunchKernelGGL((colsum_kernel<E, true, VV>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const E*>(dg), \
+                       static_cast<const E*>(h), static_cast<E*>(dh), part, T, N, col_rows(T))
+    if (dtype == NPCD_F16) NPCD_LAUNCH_GELU_BWD(_Float16, 1);
+    else if (variant == 0) NPCD_LAUNCH_GELU_BWD(__bf16, 0);
+    else if (variant == 2) NPCD_LAUNCH_GELU_BWD(__bf16, 2);
+    else if (variant == 3) NPCD_LAUNCH_GELU_BWD(__bf16, 3);
+    else NPCD_LAUNCH_GELU_BWD(__bf16, 1);
 #undef NPCD_LAUNCH_GELU_BWD
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }
+extern "C" int npcd_gelu_bwd(const void* dg, const void* h, void* dh, float* part, int T, int N, void* stream) {
+    return npcd_gelu_bwd_dt(dg, h, dh, part, T, N, NPCD_BF16, stream);
+}
 
-extern "C" int npcd_colsum_bf16(const void* a, float* part, int T, int N, void* stream) {
+extern "C" int npcd_colsum_dt(const void* a, float* part, int T, int N, int dtype, void* stream) {
     if (!a || !part || T <= 0 || N <= 0) return NPCD_ERR_ARG;
-    if (N % 8 != 0 || !al16(a) || !al16(part)) return NPCD_ERR_UNSUPPORTED;
+    if (N % 8 != 0 || !al16(a) || !al16(part) || !dt16(dtype)) return NPCD_ERR_UNSUPPORTED;
     dim3 grid((N / 8 + 255) / 256, npcd_colsum_blocks(T));
-    hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const __bf16*>(a),
-                       static_cast<const __bf16*>(nullptr), static_cast<__bf16*>(nullptr), part, T, N, col_rows(T));
+    if (dtype == NPCD_BF16)
+        hipLaunchKernelGGL((colsum_kernel<__bf16, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const __bf16*>(a),
+                           static_cast<const __bf16*>(nullptr), static_cast<__bf16*>(nullptr), part, T, N, col_rows(T));
+    else
+        hipLaunchKernelGGL((colsum_kernel<_Float16, false>), grid, dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const _Float16*>(a),
+                           static_cast<const _Float16*>(nullptr), static_cast<_Float16*>(nullptr), part, T, N, col_rows(T));
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }
+extern "C" int npcd_colsum_bf16(const void* a, float* part, int T, int N, void* stream) { return npcd_colsum_dt(a, part, T, N, NPCD_BF16, stream); }
 
 extern "C" int npcd_small_wgrad_blocks(int T) { return T <= 0 ? -1 : (T + 255) / 256 < 1024 ? (T + 255) / 256 : 1024; }
 
@@ -706,11 +761,11 @@ extern "C" int npcd_small_wgrad(const void* dy, const void* x, float* part, int 
     return NPCD_OK;
 }
 
-extern "C" int npcd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* shadow_bf16, int64_t numel, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int step, float ema_decay, int zero_grad, void* stream) {
+extern "C" int npcd_adamw_ema_dt(float* p, float* g, float* m, float* v, float* ema, void* shadow, int shadow_dtype, int64_t numel, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int step, float ema_decay, int zero_grad, void* stream) {
     if (!p || !g || !m || !v || numel <= 0 || step <= 0) return NPCD_ERR_ARG;
     if (numel % 4 != 0 || !al16(p) || !al16(g) || !al16(m) || !al16(v) || (ema && !al16(ema)) ||
-        (shadow_bf16 && (reinterpret_cast<uintptr_t>(shadow_bf16) & 7)))
+        (shadow && ((reinterpret_cast<uintptr_t>(shadow) & 7) || !dt16(shadow_dtype))))
         return NPCD_ERR_UNSUPPORTED;
     AdamArgs a;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
@@ -719,11 +774,21 @@ extern "C" int npcd_adamw_ema(float* p, float* g, float* m, float* v, float* ema
     a.ema_w = 1.f - ema_decay;
     const int64_t n4 = numel / 4;
     const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<f32x4*>(p),
-                       reinterpret_cast<f32x4*>(g), reinterpret_cast<f32x4*>(m), reinterpret_cast<f32x4*>(v), reinterpret_cast<f32x4*>(ema),
-                       static_cast<bf16x4*>(shadow_bf16), n4, a, zero_grad);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (shadow && shadow_dtype == NPCD_F16)
+        hipLaunchKernelGGL(adamw_ema_kernel<_Float16>, dim3(grid), dim3(256), 0, st, reinterpret_cast<f32x4*>(p), reinterpret_cast<f32x4*>(g),
+                           reinterpret_cast<f32x4*>(m), reinterpret_cast<f32x4*>(v), reinterpret_cast<f32x4*>(ema),
+                           static_cast<V<_Float16>::x4*>(shadow), n4, a, zero_grad);
+    else
+        hipLaunchKernelGGL(adamw_ema_kernel<__bf16>, dim3(grid), dim3(256), 0, st, reinterpret_cast<f32x4*>(p), reinterpret_cast<f32x4*>(g),
+                           reinterpret_cast<f32x4*>(m), reinterpret_cast<f32x4*>(v), reinterpret_cast<f32x4*>(ema),
+                           static_cast<V<__bf16>::x4*>(shadow), n4, a, zero_grad);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
+}
+extern "C" int npcd_adamw_ema(float* p, float* g, float* m, float* v, float* ema, void* shadow_bf16, int64_t numel, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int step, float ema_decay, int zero_grad, void* stream) {
+    return npcd_adamw_ema_dt(p, g, m, v, ema, shadow_bf16, NPCD_BF16, numel, lr, beta1, beta2, eps, weight_decay, step, ema_decay, zero_grad, stream);
 }
 
 extern "C" int npcd_ddpm_reverse_step(const float* x_t, const void* eps, int eps_dtype, const float* noise, float* x_prev, float* x0_out,
@@ -858,13 +923,17 @@ extern "C" int npcd_sum_slices(const float* part, float* out, int S, int64_t num
     return NPCD_OK;
 }
 
-extern "C" int npcd_cast_f32_bf16(const float* src, void* dst, int64_t numel, void* stream) {
+extern "C" int npcd_cast_f32_dt(const float* src, void* dst, int64_t numel, int dtype, void* stream) {
     if (!src || !dst || numel <= 0) return NPCD_ERR_ARG;
-    if (numel % 4 != 0 || !al16(src) || (reinterpret_cast<uintptr_t>(dst) & 7)) return NPCD_ERR_UNSUPPORTED;
+    if (numel % 4 != 0 || !al16(src) || (reinterpret_cast<uintptr_t>(dst) & 7) || !dt16(dtype)) return NPCD_ERR_UNSUPPORTED;
     const int64_t n4 = numel / 4;
     const int grid = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), reinterpret_cast<const f32x4*>(src),
-                       static_cast<bf16x4*>(dst), n4);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == NPCD_BF16)
+        hipLaunchKernelGGL(cast_kernel<__bf16>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const f32x4*>(src), static_cast<V<__bf16>::x4*>(dst), n4);
+    else
+        hipLaunchKernelGGL(cast_kernel<_Float16>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const f32x4*>(src), static_cast<V<_Float16>::x4*>(dst), n4);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }
+extern "C" int npcd_cast_f32_bf16(const float* src, void* dst, int64_t numel, void* stream) { return npcd_cast_f32_dt(src, dst, numel, NPCD_BF16, stream); }

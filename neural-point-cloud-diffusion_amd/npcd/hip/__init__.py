@@ -78,6 +78,13 @@ SIGNATURES = {
     "npcd_colsum_bf16": (c_int, [_P, _P, c_int, c_int, _P]),
     "npcd_adamw_ema": (c_int, [_P] * 6 + [c_int64] + [c_float] * 5 + [c_int, c_float, c_int, _P]),
     "npcd_cast_f32_bf16": (c_int, [_P, _P, c_int64, _P]),
+    "npcd_add_ln_fwd_dt": (c_int, [_P] * 8 + [c_int, c_int, c_float, c_int, _P]),
+    "npcd_ln_bwd_dt": (c_int, [_P] * 11 + [c_int, c_int, c_int, _P]),
+    "npcd_gelu_fwd_dt": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "npcd_gelu_bwd_dt": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "npcd_colsum_dt": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "npcd_adamw_ema_dt": (c_int, [_P] * 6 + [c_int, c_int64] + [c_float] * 5 + [c_int, c_float, c_int, _P]),
+    "npcd_cast_f32_dt": (c_int, [_P, _P, c_int64, c_int, _P]),
     "npcd_sum_slices": (c_int, [_P, _P, c_int, c_int64, _P]),
     "npcd_small_wgrad_blocks": (c_int, [c_int]),
     "npcd_small_wgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),

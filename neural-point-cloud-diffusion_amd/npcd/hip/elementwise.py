@@ -3,9 +3,9 @@ import ctypes
 
 import torch
 
-from . import check, lib, ptr, require_gpu, stream_ptr
+from . import check, dtype_code, lib, ptr, require_gpu, stream_ptr
 
-_f32, _bf16 = torch.float32, torch.bfloat16
+_f32, _bf16, _f16 = torch.float32, torch.bfloat16, torch.float16
 MAX_JOBS = 8          # NPCD_COLSUM_MAX_JOBS
 
 # When set to a dict {"add_ln_fwd": [], "ln_bwd": [], "gelu_fwd": [], "gelu_bwd": []}, the main launch of each of these
@@ -58,18 +58,20 @@ def _finish(batch, part, nblk, N, out):
         check(lib().npcd_colsum_finalize(ptr(part), nblk, N, ptr(out), 0, stream_ptr()), "npcd_colsum_finalize")
 
 
-def add_ln_fwd(x_in, delta, gamma, beta, eps=1e-5, want_sum=True):
-    """x_out = x_in + delta (fp32; None when delta is None), y = LayerNorm(x_out) bf16, mean, rstd."""
+def add_ln_fwd(x_in, delta, gamma, beta, eps=1e-5, want_sum=True, dtype=_bf16):
+    """x_out = x_in + delta (fp32; None when delta is None), y = LayerNorm(x_out) in the 16-bit `dtype` (that of delta), mean, rstd."""
     require_gpu(x_in)
     T, W = x_in.shape
     dev = x_in.device
+    if delta is not None:
+        dtype = delta.dtype
     x_out = torch.empty_like(x_in) if (delta is not None and want_sum) else None
-    y = torch.empty((T, W), dtype=_bf16, device=dev)
+    y = torch.empty((T, W), dtype=dtype, device=dev)
     mean = torch.empty(T, dtype=_f32, device=dev)
     rstd = torch.empty(T, dtype=_f32, device=dev)
     check(_timed("add_ln_fwd" if delta is not None and want_sum else "ln_fwd",
-                 lambda: lib().npcd_add_ln_fwd(ptr(x_in), ptr(delta), ptr(gamma), ptr(beta), ptr(x_out), ptr(y), ptr(mean), ptr(rstd), T, W,
-                                               float(eps), stream_ptr())), "npcd_add_ln_fwd")
+                 lambda: lib().npcd_add_ln_fwd_dt(ptr(x_in), ptr(delta), ptr(gamma), ptr(beta), ptr(x_out), ptr(y), ptr(mean), ptr(rstd), T, W,
+                                                  float(eps), dtype_code(y), stream_ptr())), "npcd_add_ln_fwd")
     return x_out, y, mean, rstd
 
 
@@ -81,12 +83,12 @@ def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma_out, dbeta_out, dcol_out=None,
     L = lib()
     nblk = L.npcd_ln_bwd_blocks(T)
     dx = torch.empty((T, W), dtype=_f32, device=dev)
-    dxb = torch.empty((T, W), dtype=_bf16, device=dev) if want_bf16 else None
+    dxb = torch.empty((T, W), dtype=dy.dtype, device=dev) if want_bf16 else None          # (the run's 16-bit type)
     parts = torch.empty((3, nblk + L.npcd_colsum_scratch_rows(), W), dtype=_f32, device=dev)
     full = dres is not None and want_bf16          # the shape bench.py prices: dy, x, dres read; dx, dx(bf16) written
     check(_timed("ln_bwd" if full else "ln_bwd_partial",
-                 lambda: L.npcd_ln_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(dxb), ptr(parts[0]),
-                                       ptr(parts[1]), ptr(parts[2]) if dcol_out is not None else ptr(None), T, W, stream_ptr())),
+                 lambda: L.npcd_ln_bwd_dt(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(dxb), ptr(parts[0]),
+                                          ptr(parts[1]), ptr(parts[2]) if dcol_out is not None else ptr(None), T, W, dtype_code(dy), stream_ptr())),
           "npcd_ln_bwd")
     _finish(batch, parts[0], nblk, W, dgamma_out)
     _finish(batch, parts[1], nblk, W, dbeta_out)
@@ -97,7 +99,7 @@ def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma_out, dbeta_out, dcol_out=None,
 
 def gelu_fwd(h):
     g = torch.empty_like(h)
-    check(_timed("gelu_fwd", lambda: lib().npcd_gelu_fwd(ptr(h), ptr(g), h.numel(), stream_ptr())), "npcd_gelu_fwd")
+    check(_timed("gelu_fwd", lambda: lib().npcd_gelu_fwd_dt(ptr(h), ptr(g), h.numel(), dtype_code(h), stream_ptr())), "npcd_gelu_fwd")
     return g
 
 
@@ -108,27 +110,27 @@ def gelu_bwd(dg, h, dbias_out, batch=None):
     nblk = L.npcd_colsum_blocks(T)
     dh = torch.empty_like(h)
     part = torch.empty((nblk + L.npcd_colsum_scratch_rows(), N), dtype=_f32, device=h.device)
-    check(_timed("gelu_bwd", lambda: L.npcd_gelu_bwd(ptr(dg), ptr(h), ptr(dh), ptr(part), T, N, stream_ptr())), "npcd_gelu_bwd")
+    check(_timed("gelu_bwd", lambda: L.npcd_gelu_bwd_dt(ptr(dg), ptr(h), ptr(dh), ptr(part), T, N, dtype_code(h), stream_ptr())), "npcd_gelu_bwd")
     _finish(batch, part, nblk, N, dbias_out)
     return dh
 
 
 def colsum_bf16(a, out, batch=None):
-    """out[N] (fp32) = column sum of the bf16 matrix a [T,N]."""
+    """out[N] (fp32) = column sum of the 16-bit (bf16 / f16) matrix a [T,N]."""
     T, N = a.shape
     L = lib()
     nblk = L.npcd_colsum_blocks(T)
     part = torch.empty((nblk + L.npcd_colsum_scratch_rows(), N), dtype=_f32, device=a.device)
-    check(L.npcd_colsum_bf16(ptr(a), ptr(part), T, N, stream_ptr()), "npcd_colsum_bf16")
+    check(L.npcd_colsum_dt(ptr(a), ptr(part), T, N, dtype_code(a), stream_ptr()), "npcd_colsum")
     _finish(batch, part, nblk, N, out)
     return out
 
 
 def adamw_ema(p, g, m, v, ema, shadow, lr, beta1, beta2, eps, weight_decay, step, ema_decay, zero_grad=True):
     require_gpu(p)
-    check(lib().npcd_adamw_ema(ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), ptr(shadow), p.numel(), float(lr), float(beta1), float(beta2),
-                               float(eps), float(weight_decay), int(step), float(ema_decay if ema_decay is not None else 0.0),
-                               int(bool(zero_grad)), stream_ptr()), "npcd_adamw_ema")
+    check(lib().npcd_adamw_ema_dt(ptr(p), ptr(g), ptr(m), ptr(v), ptr(ema), ptr(shadow), dtype_code(shadow) if shadow is not None else 0,
+                                  p.numel(), float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step),
+                                  float(ema_decay if ema_decay is not None else 0.0), int(bool(zero_grad)), stream_ptr()), "npcd_adamw_ema")
 
 
 def small_wgrad(dy, x):
@@ -157,7 +159,8 @@ def sum_slices(part, out):
 
 
 def cast_f32_bf16(src, dst):
-    check(lib().npcd_cast_f32_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr()), "npcd_cast_f32_bf16")
+    """fp32 -> the 16-bit type of dst (bf16 or f16)"""
+    check(lib().npcd_cast_f32_dt(ptr(src), ptr(dst), src.numel(), dtype_code(dst), stream_ptr()), "npcd_cast_f32")
     return dst
 
 

@@ -125,6 +125,7 @@ class FusedBackboneEngine:
         # beside fresh LayerNorm ones.
         self.block_ranges, self.wait_range = None, None      # set by a trainer with lazily gathered parameters (engine.py)
         self._flat, self._shadow = flat, shadow
+        self.dtype = shadow.dtype                            # the run's 16-bit activation type: bf16, or f16 (with loss scaling)
         self._stamped = [p for e in self.blocks for p in e["params"]]
         self._stamp = self._versions()
 
@@ -174,9 +175,9 @@ class InferenceWeights:
         return self.blocks
 
 
-def backbone_forward(x, blocks, heads):
+def backbone_forward(x, blocks, heads, dtype=_bf16):
     """Forward only (sampler, evaluation): the kernels of the training forward, nothing kept for a backward.
-    x [B, n, W] fp32 -> [B, n, W] fp32."""
+    x [B, n, W] fp32 -> [B, n, W] fp32.  `dtype`: the 16-bit type of the weights in `blocks`."""
     B, n, W = x.shape
     T, d = B * n, W // heads
     scale = 1.0 / math.sqrt(d)
@@ -184,7 +185,7 @@ def backbone_forward(x, blocks, heads):
         xs = x.reshape(T, W).contiguous()
         delta = None
         for e in blocks:
-            x1, y1, _, _ = ew.add_ln_fwd(xs, delta, e["ln_1_weight"], e["ln_1_bias"])
+            x1, y1, _, _ = ew.add_ln_fwd(xs, delta, e["ln_1_weight"], e["ln_1_bias"], dtype=dtype)
             x_cur = xs if x1 is None else x1
             q4 = _linear(e["attn_c_qkv_bias_16"], y1, e["attn_c_qkv_weight_16"]).view(B, n, heads, 3 * d)
             a, _ = hattn._fwd(q4[..., :d], q4[..., d:2 * d], q4[..., 2 * d:], scale)
@@ -210,7 +211,7 @@ class _BackboneFn(torch.autograd.Function):
             for bi, e in enumerate(eng.blocks):
                 if eng.wait_range is not None:
                     eng.wait_range(*eng.block_ranges[bi])        # this block's parameters (gathered lazily by the sharded optimizer)
-                x1, y1, mean1, rstd1 = ew.add_ln_fwd(xs, delta, e["ln_1_weight"], e["ln_1_bias"])
+                x1, y1, mean1, rstd1 = ew.add_ln_fwd(xs, delta, e["ln_1_weight"], e["ln_1_bias"], dtype=eng.dtype)
                 x_cur = xs if x1 is None else x1
                 qkv = _linear(e["attn_c_qkv_bias_16"], y1, e["attn_c_qkv_weight_16"])
                 q4 = qkv.view(B, n, H, 3 * d)
@@ -233,7 +234,7 @@ class _BackboneFn(torch.autograd.Function):
         T = B * n
         with torch.autocast("cuda", enabled=False):
             dx = dout.reshape(T, W).contiguous().float()
-            dxb = dx.to(_bf16)
+            dxb = dx.to(eng.dtype)
             last = eng.blocks[-1]
             last["mlp_c_proj_bias_g"].copy_(dx.sum(dim=0))
             for bi in range(len(eng.blocks) - 1, -1, -1):

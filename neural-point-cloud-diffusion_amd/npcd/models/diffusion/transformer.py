@@ -105,19 +105,21 @@ class Transformer(nn.Module):
 
     def forward(self, x):
         eng = self.fused_engine
-        if (x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled()
-                and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+        if x.is_cuda and x.dtype == torch.float32 and torch.is_autocast_enabled():
+            act = torch.get_autocast_dtype("cuda")
             if torch.is_grad_enabled():
-                if eng is not None:
+                if eng is not None and eng.dtype == act:       # bf16, or f16 with the trainer's loss scaling
                     return eng(x)
-            else:
-                # sampling / evaluation under bf16 autocast: fused forward-only kernels (fused.backbone_forward)
+            elif eng is not None and eng.dtype == act:
+                # sampling / evaluation under the trainer's autocast type: fused forward-only kernels on its 16-bit shadow
                 from . import fused
-                if eng is not None:
-                    if eng.wait_range is not None:
-                        eng.wait_range()
-                    eng.sync_shadow()
-                    return fused.backbone_forward(x, eng.blocks, eng.heads)
+                if eng.wait_range is not None:
+                    eng.wait_range()
+                eng.sync_shadow()
+                return fused.backbone_forward(x, eng.blocks, eng.heads, eng.dtype)
+            elif eng is None and act == torch.bfloat16:
+                # sampling / evaluation of a model without a trainer under bf16 autocast (fused.backbone_forward on cached weights)
+                from . import fused
                 if self._infer_weights is None:
                     self._infer_weights = fused.InferenceWeights(self)
                 return fused.backbone_forward(x, self._infer_weights.current(), self._infer_weights.heads)
@@ -160,7 +162,7 @@ class _TimeTokenCat(torch.autograd.Function):
 
 class _LayerNormToBF16(torch.autograd.Function):
     """ln_post on the fused backbone's LayerNorm kernels (csrc/elementwise.hip): fp32 statistics and normalisation like the
-    reference's fp32 nn.LayerNorm under autocast (transformer.py:249), the result rounded to bf16 once -- exactly what the
+    reference's fp32 nn.LayerNorm under autocast (transformer.py:249), the result rounded to the autocast type (bf16 / f16) once -- exactly what the
     following Linear's autocast does to the fp32 output -- and a backward of 92 us instead of torch's 190 us pair of kernels."""
 
     @staticmethod
@@ -168,7 +170,7 @@ class _LayerNormToBF16(torch.autograd.Function):
         from ...hip import elementwise as ew
         B, n, W = x.shape
         x2 = x.reshape(B * n, W).contiguous()
-        _, y, mean, rstd = ew.add_ln_fwd(x2, None, gamma, beta, eps=eps)
+        _, y, mean, rstd = ew.add_ln_fwd(x2, None, gamma, beta, eps=eps, dtype=torch.get_autocast_dtype("cuda"))
         ctx.save_for_backward(x2, mean, rstd, gamma)
         return y.view(B, n, W)
 
@@ -204,8 +206,8 @@ class NPCDTransformer(nn.Module):
         x = torch.cat((coords, feats), dim=1).transpose(1, 2)
         temb = self.time_embed(timestep_embedding(t, self.backbone.width))               # [B,W]
         # (the column-sum kernel behind _TimeTokenCat's backward takes bf16 rows of a multiple of 8 columns)
-        if (x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16
-                and self.backbone.width % 8 == 0 and not _NO_FAST_GLUE):
+        if (x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16) and self.backbone.width % 8 == 0 and not _NO_FAST_GLUE):
             tokens = F.linear(x, self.input_proj.weight, self.input_proj.bias.detach())  # [B,N,W] bf16; the bias gradient comes from _TimeTokenCat
             h = _TimeTokenCat.apply(temb.to(tokens.dtype), tokens, self.input_proj.bias)
         else:
@@ -214,7 +216,8 @@ class NPCDTransformer(nn.Module):
         h = self.backbone(self.ln_pre(h))
         W = h.shape[-1]
         if (h.is_cuda and h.dtype == torch.float32 and torch.is_grad_enabled() and torch.is_autocast_enabled() and W % 4 == 0 and W <= 2048
-                and torch.get_autocast_dtype("cuda") == torch.bfloat16 and self.ln_post.weight.dtype == torch.float32 and not _NO_FAST_GLUE):
+                and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16) and self.ln_post.weight.dtype == torch.float32
+                and not _NO_FAST_GLUE):
             h = _LayerNormToBF16.apply(h, self.ln_post.weight, self.ln_post.bias, self.ln_post.eps)
         else:
             h = self.ln_post(h)

@@ -200,11 +200,15 @@ class DiffusionTrainer:
             self._ew = ew
             self.exp_avg = torch.zeros_like(self.flat.flat)
             self.exp_avg_sq = torch.zeros_like(self.flat.flat)
-            self.shadow = torch.empty(self.flat.numel, dtype=torch.bfloat16, device=self.flat.flat.device)
+            # the 16-bit shadow the GEMMs read is kept in the run's autocast type: bf16, or f16 (the reference's default --dtype,
+            # train_diffusion.py:78 -- trained with the loss scaling below); any other dtype trains through the module path
+            half = dtype if dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
+            self.shadow = torch.empty(self.flat.numel, dtype=half, device=self.flat.flat.device)
             ew.cast_f32_bf16(self.flat.flat, self.shadow)
             denoiser = getattr(diffusion, "denoiser", None)
             fused_ids = set()
-            if denoiser is not None and dtype == torch.bfloat16 and denoiser.backbone.width // denoiser.backbone.resblocks[0].attn.heads == 64:
+            if (denoiser is not None and dtype in (torch.bfloat16, torch.float16)
+                    and denoiser.backbone.width // denoiser.backbone.resblocks[0].attn.heads == 64):
                 denoiser.backbone.fused_engine = FusedBackboneEngine(denoiser.backbone, self.flat, self.shadow, self.reducer)
                 fused_ids = {id(p) for e in denoiser.backbone.fused_engine.blocks for p in e["params"]}
             # parameters whose gradients ACCUMULATE through autograd (everything outside the fused backbone, which overwrites):
@@ -281,7 +285,7 @@ class DiffusionTrainer:
         if not getattr(self, "_pending", None):
             return
         fused_training = (self._fused_engine is not None and torch.is_grad_enabled() and torch.is_autocast_enabled()
-                          and torch.get_autocast_dtype("cuda") == torch.bfloat16 and args and args[0].is_cuda)
+                          and torch.get_autocast_dtype("cuda") == self._fused_engine.dtype and args and args[0].is_cuda)
         if not fused_training:
             self.wait_params()
             return

@@ -142,11 +142,13 @@ def test_fused_backbone_matches_module_path():
 
 
 @pytest.mark.parametrize("tag", ["f32_w64", "f128_w64"])
-def test_fused_engine_matches_reference_golden_directly(golden, tag):
-    """The BENCHMARKED code path (_BackboneFn: one autograd node, hand-written backward, flat buffers, bf16 shadow) against
+@pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
+def test_fused_engine_matches_reference_golden_directly(golden, tag, half):
+    """The BENCHMARKED code path (_BackboneFn: one autograd node, hand-written backward, flat buffers, 16-bit shadow) against
     the reference's own fp32 outputs and parameter gradients (fixtures denoiser_*.npz, generated by importing
     /root/reference) -- no detour over this package's module path.  Bars as for the module path: eps rel-L2 <= 2e-2,
-    every parameter gradient rel-L2 <= 5e-2 (bf16 GEMM inputs against an fp32 reference)."""
+    every parameter gradient rel-L2 <= 5e-2 (16-bit GEMM inputs against an fp32 reference).  Both activation types of the
+    engine: bf16, and f16 (the reference's default --dtype; the golden loss is O(1), so no loss scaling is needed here)."""
     from npcd.hip import elementwise as ew
     from npcd.models.diffusion import NPCDTransformer
     from npcd.models.diffusion.fused import FusedBackboneEngine
@@ -158,15 +160,16 @@ def test_fused_engine_matches_reference_golden_directly(golden, tag):
     net.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith("w:")})
     net = net.cuda()
     flat = FlatBuffers(net)
-    shadow = torch.empty(flat.numel, dtype=torch.bfloat16, device="cuda")
+    shadow = torch.empty(flat.numel, dtype=half, device="cuda")
     ew.cast_f32_bf16(flat.flat, shadow)
     net.backbone.fused_engine = FusedBackboneEngine(net.backbone, flat, shadow)
+    assert net.backbone.fused_engine.dtype == half
     calls = []
     import npcd.models.diffusion.fused as fused
     orig = fused._BackboneFn.apply
     fused._BackboneFn.apply = staticmethod(lambda *a: (calls.append(1), orig(*a))[1])
     try:
-        with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.autocast("cuda", dtype=half):
             ec, ef = net(T(g["coords"]).cuda(), T(g["feats"]).cuda(), T(g["t"]).cuda())
             loss = (ec.float() * T(g["gc"]).cuda()).sum() + (ef.float() * T(g["gf"]).cuda()).sum()
         loss.backward()
@@ -344,18 +347,28 @@ def test_stress_config_step_at_per_gpu_batch_32_fp8_and_bf16_attention():
 
 
 def test_float16_training_with_dynamic_loss_scale():
-    """dtype=float16 (the reference's default --dtype): scaled backward, overflow -> skipped step and halved scale."""
+    """dtype=float16 (the reference's default --dtype, train_diffusion.py:78): the fused backbone engine IS engaged (f16 shadow,
+    f16 activations through the same kernels), scaled backward, overflow -> skipped step and halved scale."""
     from npcd.train import DiffusionTrainer
+    import npcd.models.diffusion.fused as fused
     a, b = _models()
     tr = DiffusionTrainer(a, dtype=torch.float16)
     ref = DiffusionTrainer(b, dtype=torch.bfloat16, fused=False)
-    assert tr.loss_scale == 65536.0 and a.denoiser.backbone.fused_engine is None        # fp16 runs the module path
+    eng = a.denoiser.backbone.fused_engine
+    assert tr.loss_scale == 65536.0 and tr.native and eng is not None and eng.dtype == torch.float16 and tr.shadow.dtype == torch.float16
+    calls = []
+    orig = fused._BackboneFn.apply
+    fused._BackboneFn.apply = staticmethod(lambda *x: (calls.append(1), orig(*x))[1])
     g = torch.Generator().manual_seed(2)
     B, N, F_ = 3, 48, 32
     c0, f0 = torch.randn(B, 3, N, generator=g).cuda(), torch.randn(B, F_, N, generator=g).cuda()
     t = torch.tensor([7, 400, 900]).cuda()
     cn, fn = torch.randn(B, 3, N, generator=g).cuda(), torch.randn(B, F_, N, generator=g).cuda()
-    l16, _ = tr.step(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
+    try:
+        l16, _ = tr.step(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
+    finally:
+        fused._BackboneFn.apply = orig
+    assert calls, "float16 training did not go through the fused backbone node"
     lref, _ = ref.step(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
     assert torch.isfinite(l16) and abs(float(l16) - float(lref)) < 2e-2 * abs(float(lref))
     assert tr.skipped_steps == 0 and tr.iteration == 1
