@@ -313,6 +313,14 @@ int npcd_adamw_ema_dt(float* p, float* g, float* m, float* v, float* ema, void* 
                       float ema_decay, int zero_grad, void* stream);
 int npcd_cast_f32_dt(const float* src, void* dst, int64_t numel, int dtype, void* stream);
 
+/* Weight gradient of a Linear layer (the nn.Linear weight gradients of transformer.py:67-72, :107-115, :118-137, which autograd
+ * computes in the reference): dW [N, K] fp32 = dy[T, N]^T x[T, K], dy / x row-major in the 16-bit `dtype`, fp32 accumulation and
+ * output; N % 256 == 0, K % 256 == 0, any T.  The token range is split over npcd_wgrad_slices(T, N, K) workgroup slices that write
+ * fp32 slabs (`workspace`: that many x N x K floats, unused when it is 1) which a second kernel adds in slice order: bitwise
+ * reproducible.  NPCD_ERR_UNSUPPORTED for other shapes (the caller then uses the library). */
+int npcd_wgrad_slices(int T, int N, int K);
+int npcd_wgrad(const void* dy, const void* x, float* out, float* workspace, int T, int N, int K, int dtype, void* stream);
+
 /* out[i] = part[0 * numel + i] + ... + part[(S - 1) * numel + i], fp32, added in slice order (S = 2, 4 or 8; numel % 4 == 0;
  * 16-byte aligned): the sum of the row-split weight-gradient partials of the fused backbone (replaces torch.sum(part, dim=0)
  * there; the reference's nn.Linear weight gradient, summed over token slices). */

@@ -34,6 +34,7 @@ SOURCES = {
     # activation fragments (matrix-instruction operands only) in AGPRs
     "shade_rows.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "elementwise.hip": [],
+    "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "pairs.hip": ["-ffp-contract=off"],
     "pairs_mlp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
 }

@@ -85,6 +85,8 @@ SIGNATURES = {
     "npcd_colsum_dt": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "npcd_adamw_ema_dt": (c_int, [_P] * 6 + [c_int, c_int64] + [c_float] * 5 + [c_int, c_float, c_int, _P]),
     "npcd_cast_f32_dt": (c_int, [_P, _P, c_int64, c_int, _P]),
+    "npcd_wgrad_slices": (c_int, [c_int, c_int, c_int]),
+    "npcd_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "npcd_sum_slices": (c_int, [_P, _P, c_int, c_int64, _P]),
     "npcd_small_wgrad_blocks": (c_int, [c_int]),
     "npcd_small_wgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),

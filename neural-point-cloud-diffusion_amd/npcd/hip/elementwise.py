@@ -149,6 +149,20 @@ def small_wgrad(dy, x):
     return out
 
 
+def wgrad(dy, x, out):
+    """out [N, K] fp32 = dy[T, N]^T @ x[T, K] on the own split-T kernel (csrc/gemm.hip); False if the shape is not covered."""
+    T, N = dy.shape
+    K = x.shape[1]
+    if (N % 256 or K % 256 or dy.dtype != x.dtype or dy.dtype not in (_bf16, _f16) or not dy.is_contiguous() or not x.is_contiguous()
+            or not out.is_contiguous() or out.dtype != _f32):
+        return False
+    L = lib()
+    S = L.npcd_wgrad_slices(T, N, K)
+    ws = torch.empty((S, N, K), dtype=_f32, device=dy.device) if S > 1 else None
+    check(L.npcd_wgrad(ptr(dy), ptr(x), ptr(out), ptr(ws), T, N, K, dtype_code(dy), stream_ptr()), "npcd_wgrad")
+    return True
+
+
 def sum_slices(part, out):
     """out = part.sum(dim=0) for fp32 part [S, ...] (S in 2, 4, 8), slices added in order; False if the shape is not covered."""
     S, n = part.shape[0], out.numel()

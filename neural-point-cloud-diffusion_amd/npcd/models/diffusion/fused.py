@@ -39,6 +39,9 @@ _SPLIT = 0 if os.environ.get("NPCD_NO_GEMM_SPLIT") else 256       # (the env swi
 _SPLIT_MIN = int(os.environ.get("NPCD_GEMM_SPLIT_MIN", "16000"))
 _ATTN_COLSUM = not os.environ.get("NPCD_NO_ATTN_COLSUM")      # c_qkv bias gradient from the attention backward itself (A/B switch)
 _SUM_KERNEL = not os.environ.get("NPCD_NO_SUM_KERNEL")          # the weight-gradient partials summed by csrc/elementwise.hip (A/B switch)
+# opt-in: the weight gradients on the own split-T kernel (csrc/gemm.hip: at parity with the library's row-split form -- both are
+# bound by the L2 -> LDS stream of a 256 x 256 tile -- bitwise reproducible, no library call)
+_OWN_WGRAD = bool(os.environ.get("NPCD_OWN_WGRAD"))
 
 
 def _split_gemm(fn, T):
@@ -81,6 +84,8 @@ def _wgrad(dy, x, out):
     (Tried: the weight gradients on a second HIP stream, so that they run beside the HBM-bound GELU / LayerNorm backward
     kernels of the critical path -- 84.39 -> 84.14 ms per step on the same box, i.e. nothing: the GEMM's workgroups hold
     every CU and the other stream's kernels are dispatched as they drain.)"""
+    if _OWN_WGRAD and ew.wgrad(dy, x, out):
+        return
     T = dy.shape[0]
     small = out.numel() <= (1 << 20)
     S = 8 if small else 4

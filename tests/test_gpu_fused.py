@@ -346,6 +346,25 @@ def test_stress_config_step_at_per_gpu_batch_32_fp8_and_bf16_attention():
     assert errs["bf16"] <= 3e-2 and errs["fp8"] <= 8e-2
 
 
+@pytest.mark.parametrize("T,N,K", [(513 * 8, 1024, 1024), (2052, 768, 256), (700, 256, 512), (32, 256, 256)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_own_weight_gradient_kernel(T, N, K, dtype):
+    """npcd_wgrad (csrc/gemm.hip: dW = dy^T x, split over the token range, slabs added in slice order) against the fp64 product of
+    the same 16-bit operands: fp32 accumulation -> 1e-5 of the largest entry; token counts that are no multiple of the 32-token
+    ring stage (rows past T come from a zero page); bitwise reproducible."""
+    from npcd.hip import elementwise as ew
+    g = torch.Generator().manual_seed(T + N)
+    dy = torch.randn(T, N, generator=g).to(dtype).cuda()
+    x = torch.randn(T, K, generator=g).to(dtype).cuda()
+    out = torch.full((N, K), float("nan"), device="cuda")
+    assert ew.wgrad(dy, x, out)
+    ref = dy.double().t() @ x.double()
+    assert float((out.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    out2 = torch.empty_like(out)
+    assert ew.wgrad(dy, x, out2) and torch.equal(out, out2)
+    assert not ew.wgrad(dy[:, :100].contiguous(), x, torch.empty(100, K, device="cuda"))      # shapes it does not cover: the caller's fallback
+
+
 def test_float16_training_with_dynamic_loss_scale():
     """dtype=float16 (the reference's default --dtype, train_diffusion.py:78): the fused backbone engine IS engaged (f16 shadow,
     f16 activations through the same kernels), scaled backward, overflow -> skipped step and halved scale."""

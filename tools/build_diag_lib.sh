@@ -13,6 +13,7 @@ COMMON="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-gpu-rdc -fno-fast-math"
 /opt/rocm/bin/hipcc $COMMON -mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans "$@" -c $C/shade.hip -o $O/shade.o &
 wait
 /opt/rocm/bin/hipcc $COMMON "$@" -c $C/elementwise.hip -o $O/elementwise.o &
+/opt/rocm/bin/hipcc $COMMON -mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans "$@" -c $C/gemm.hip -o $O/gemm.o &
 /opt/rocm/bin/hipcc $COMMON -ffp-contract=off "$@" -c $C/pairs.hip -o $O/pairs.o &
 /opt/rocm/bin/hipcc $COMMON -mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans "$@" -c $C/pairs_mlp.hip -o $O/pairs_mlp.o &
 /opt/rocm/bin/hipcc $COMMON -mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans "$@" -c $C/shade_rows.hip -o $O/shade_rows.o &
