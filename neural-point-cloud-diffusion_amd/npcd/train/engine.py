@@ -59,10 +59,16 @@ class GradReducer:
     produces them); a bucket's collective is launched from the post-accumulate-grad hook of its last
     parameter to become ready.  `finish()` waits for all of them."""
 
-    def __init__(self, flat: FlatBuffers, group=None, bucket_bytes: int = 64 << 20, always_reduce: bool = False):
+    def __init__(self, flat: FlatBuffers, group=None, bucket_bytes: int = 64 << 20, always_reduce: bool = False,
+                 comm_dtype: Optional[torch.dtype] = None):
         """always_reduce: run the collectives also on a one-rank group (lets a single-GPU box exercise the RCCL code path:
-        ReduceOp.AVG, async work handles, stream ordering -- RCCL refuses two ranks on one device)."""
+        ReduceOp.AVG, async work handles, stream ordering -- RCCL refuses two ranks on one device).
+        comm_dtype=torch.bfloat16: the gradient buckets travel as bf16 (half the bytes of the reduce-scatter / all-reduce: 0.62
+        instead of 1.24 GB per step at cfg-D); a bucket is rounded once before the collective, the averaged result is widened
+        back into the fp32 gradient buffer / shard, the optimizer stays fp32.  Default (None): fp32 on the wire."""
         self.flat, self.group = flat, group
+        self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
+        self.wire_bytes = 0             # bytes this rank handed to gradient collectives in the current step (bookkeeping for DESIGN 6)
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.active = self.world > 1 or (always_reduce and dist.is_available() and dist.is_initialized())
         self.rank = dist.get_rank(group) if self.active else 0
@@ -113,22 +119,44 @@ class GradReducer:
         self.handles = []
         self.launched = []          # bucket index of every handle, in launch order
         self._left = list(self.pending)
+        self.wire_bytes = 0
 
     def _launch(self, b):
+        """handles: (work, post) -- post() runs right after the wait: division for back ends without a native average, widening of
+        a bf16 bucket back into the fp32 buffer"""
         self.launched.append(b)
         s, e = self.buckets[b]
         buf = self.flat.grad[s:e]
         if self._avg is None:       # RCCL has a native average; gloo (CPU tests) does not
             self._avg = dist.get_backend(self.group) == "nccl"
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        scale = None if self._avg else 1.0 / self.world
+        wire = buf if self.comm_dtype is None else buf.to(self.comm_dtype)          # (one rounding of the local bucket)
+        self.wire_bytes += wire.numel() * wire.element_size()
         if self.shard:
             out = self.gshard[s // self.world:e // self.world]
-            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-            self.handles.append((dist.reduce_scatter_tensor(out, buf, op=op, group=self.group, async_op=True), None if self._avg else out))
+            if self.comm_dtype is None:
+                h = dist.reduce_scatter_tensor(out, wire, op=op, group=self.group, async_op=True)
+                post = (lambda o=out: o.mul_(scale)) if scale is not None else None
+            else:
+                out16 = torch.empty(out.shape, dtype=self.comm_dtype, device=out.device)
+                h = dist.reduce_scatter_tensor(out16, wire, op=op, group=self.group, async_op=True)
+
+                def post(o=out, o16=out16, w=wire):          # (w: keeps the send buffer alive until the collective is done)
+                    o.copy_(o16)
+                    if scale is not None:
+                        o.mul_(scale)
+            self.handles.append((h, post))
             return
-        if self._avg:
-            self.handles.append((dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
+        h = dist.all_reduce(wire, op=op, group=self.group, async_op=True)
+        if self.comm_dtype is None:
+            post = (lambda t=buf: t.mul_(scale)) if scale is not None else None
         else:
-            self.handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf))
+            def post(t=buf, w=wire):
+                t.copy_(w)
+                if scale is not None:
+                    t.mul_(scale)
+        self.handles.append((h, post))
 
     def mark_ready(self, p):
         """For gradients written outside autograd (the fused backbone backward)."""
@@ -151,10 +179,10 @@ class GradReducer:
             if left > 0:
                 self._launch(b)
                 self._left[b] = 0
-        for (h, buf), b in zip(self.handles, self.launched):
+        for (h, post), b in zip(self.handles, self.launched):
             h.wait()
-            if buf is not None:
-                buf.div_(self.world)
+            if post is not None:
+                post()
             if on_bucket_ready is not None:
                 on_bucket_ready(*self.buckets[b])
         self.handles = []
@@ -166,7 +194,8 @@ class DiffusionTrainer:
 
     def __init__(self, diffusion: nn.Module, lr: float = 7e-5, weight_decay: float = 0.01, ema_decay: Optional[float] = 0.9999,
                  dtype: Optional[torch.dtype] = torch.bfloat16, group=None, bucket_bytes: int = 64 << 20, max_grad_norm=None,
-                 fused: bool = True, always_reduce: bool = False, shard_optimizer: Optional[bool] = None):
+                 fused: bool = True, always_reduce: bool = False, shard_optimizer: Optional[bool] = None,
+                 comm_dtype: Optional[torch.dtype] = None):
         """shard_optimizer (default: on whenever gradients are exchanged on the native path without clipping / loss scaling):
         ZeRO-1 style -- reduce-scatter instead of all-reduce, each rank runs AdamW + EMA on 1/world of every bucket, the updated
         parameters are all-gathered.  Same bytes on the wire as the all-reduce, optimizer pass divided by the number of ranks."""
@@ -178,7 +207,9 @@ class DiffusionTrainer:
         self._loss_kwargs = ({"want_pointwise": False}
                              if "want_pointwise" in inspect.signature(diffusion.compute_loss).parameters else {})
         self.flat = FlatBuffers(diffusion)
-        self.reducer = GradReducer(self.flat, group, bucket_bytes, always_reduce)
+        if comm_dtype is None and os.environ.get("NPCD_COMM_BF16"):
+            comm_dtype = torch.bfloat16
+        self.reducer = GradReducer(self.flat, group, bucket_bytes, always_reduce, comm_dtype)
         self.lr, self.weight_decay, self.betas, self.eps = lr, weight_decay, (0.9, 0.999), 1e-8
         self.ema_decay = ema_decay
         self.ema = self.flat.flat.clone() if ema_decay is not None else None

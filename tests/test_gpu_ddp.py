@@ -82,6 +82,27 @@ def _worker(rank, world, port, out):
         with torch.no_grad():
             e_ref = tr2.model.denoiser(c0[sl], f0[sl], t[sl])[0]
         assert torch.equal(e_lazy, e_ref), "forward after a sharded step read parameters of a gather still in flight"
+        # bf16 gradient buckets on the wire (comm_dtype): ranks stay bit-identical (every rank receives the same reduced shard /
+        # gathered parameters), and three steps track the fp32-wire run: loss within 2e-3 relative, update direction cosine > 0.99
+        losses = {}
+        upd = {}
+        for cd in (None, torch.bfloat16):
+            trc = DiffusionTrainer(_build(), bucket_bytes=256 << 10, shard_optimizer=True, comm_dtype=cd)
+            p0 = trc.flat.flat.clone()
+            for _ in range(3):
+                lc, _ = trc.step(c0[sl], f0[sl], t=t[sl], coords_noise=cn[sl], feats_noise=fn[sl])
+            trc.wait_params()
+            torch.cuda.synchronize()
+            losses[cd] = float(lc)
+            upd[cd] = (trc.flat.flat - p0).cpu()
+            if cd is not None:
+                assert trc.reducer.wire_bytes * 2 == trc.flat.numel * 4
+                gathered = [torch.empty_like(upd[cd]) for _ in range(world)]
+                dist.all_gather(gathered, upd[cd])
+                assert torch.equal(gathered[0], gathered[1]), "ranks diverged with bf16 gradient buckets"
+        assert abs(losses[torch.bfloat16] - losses[None]) <= 2e-3 * abs(losses[None]), losses
+        cosw = float((upd[None] * upd[torch.bfloat16]).sum() / (upd[None].norm() * upd[torch.bfloat16].norm()))
+        assert cosw > 0.99, cosw
         assert torch.equal(res[True][0], res[False][0]), "sharded optimizer diverged from the all-reduce path (parameters)"
         assert torch.equal(res[True][1], res[False][1]), "sharded optimizer diverged from the all-reduce path (EMA)"
         assert torch.equal(res[True][3], res[False][3]), "bf16 shadow of the parameters differs"
