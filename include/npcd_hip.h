@@ -195,6 +195,18 @@ int npcd_grid_query_compact(const npcd_grid_params* g, const void* workspace, co
                             int32_t* counter, int32_t capacity, int32_t* ray_base, int32_t* ray_nsel,
                             uint64_t* ray_bits, int32_t* nb_idx, float* pts, void* stream);
 
+/* The same query with the compact rows laid out in RAY ORDER: the query kernel leaves each ray's rows and count in `order_ws`
+ * (npcd_grid_query_order_ws_bytes(B, R, M, k) bytes of device scratch, 16-byte aligned, uninitialised), a second launch turns the
+ * counts into ray_base by a prefix sum and moves the rows.  No atomics: ray_base / nb_idx / pts are bit-identical from run to run
+ * (torch_knnquery.VoxelGrid.query returns its rows in ray order as well: aggregator.py:63-73 indexes them by the ray mask).
+ * Rows past `capacity` are not written and counter[1] is raised; counter needs no initialisation. */
+int64_t npcd_grid_query_order_ws_bytes(int B, int R, int M, int k);
+int npcd_grid_query_compact_ordered(const npcd_grid_params* g, const void* workspace, const float* points,
+                                    int B, int N, int R, int S, int M, int k, float r,
+                                    const float* rays_o, const float* rays_d, const float* t0, const float* t1,
+                                    int32_t* counter, int32_t capacity, int32_t* ray_base, int32_t* ray_nsel,
+                                    uint64_t* ray_bits, int32_t* nb_idx, float* pts, void* order_ws, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Ray generation + box limits (ray_sampler.py:10-49, math_utils.py:46-97, renderer.py:36-47).
  * extr [V,4,4] world2cam fp32, intr [V,3,3] fp32 -> rays_o/rays_d [V,res*res,3], t0/t1 [V,res*res].

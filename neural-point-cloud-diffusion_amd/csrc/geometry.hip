@@ -424,6 +424,13 @@ struct CompactOut {
     unsigned long long* ray_bits;  // [B*R] valid-slot mask
     int32_t* nb;          // [capacity][k]
     float* pts;           // [capacity][3]
+    // ordered form (npcd_grid_query_compact_ordered): the query kernel leaves a ray's rows at [ray][0 .. cnt) of a per-ray staging
+    // area and its count in ray_cnt; compact_ordered_kernel turns the counts into bases by a prefix sum IN RAY ORDER and moves the
+    // rows -- no atomics, the lists are bit-identical from run to run
+    int32_t* ray_cnt;     // [B*R] or nullptr (atomic form)
+    int32_t* blk_sum;     // [ceil(B*R / 64)] sums of ray_cnt over groups of 64 rays (zeroed before the query kernel)
+    int32_t* st_nb;       // [B*R][M][k]
+    float* st_pts;        // [B*R][M][3]
 };
 
 template <bool COMPACT>
@@ -634,7 +641,22 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
     } else {
         for (int slot = 0; slot < nsel; ++slot) process(slot, u32x2{0u, 0u});
     }
-    if (COMPACT) {
+    if (COMPACT && co.ray_cnt) {
+        // ordered form: rows to this ray's staging area, count to ray_cnt; bases come from compact_ordered_kernel
+        const int cnt = __popcll(valid_bits);
+        if (lane < nsel && ((valid_bits >> lane) & 1ull)) {
+            const int64_t row = ray * a.M + __popcll(valid_bits & ((1ull << lane) - 1ull));
+            for (int t = 0; t < a.k; ++t) co.st_nb[row * a.k + t] = stage_idx[(wave * 64 + lane) * 8 + t];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) co.st_pts[row * 3 + c] = stage_pos[(wave * 64 + lane) * 4 + c];
+        }
+        if (lane == 0) {
+            co.ray_cnt[ray] = cnt;
+            if (cnt > 0) atomicAdd(&co.blk_sum[ray >> 6], cnt);
+            co.ray_nsel[ray] = nsel;
+            co.ray_bits[ray] = valid_bits;
+        }
+    } else if (COMPACT) {
         const int cnt = __popcll(valid_bits);
         int base = 0;
         if (cnt > 0) {
@@ -667,6 +689,68 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
             out_ss[slot] = -1;
         }
         if (lane == 0) a.nsel[ray] = nsel;
+    }
+}
+
+// Ordered compaction (second launch of npcd_grid_query_compact_ordered).  Workgroup j owns the 64 rays [64 j, 64 j + 64).  Its
+// base is the sum of the group sums before it: the query kernel has added every ray's count to blk_sum[ray / 64] (integer
+// atomics: the SUM does not depend on their order), so a workgroup reads at most nrays / 64 integers, no flags / spinning between
+// workgroups.  A wave scan over the own 64 counts gives every ray its base; then one thread per OUTPUT row finds its ray (the
+// last one whose base is <= the row: binary search over the 64 bases in LDS) and moves the row -- all loads of a thread are
+// independent of other rows.  Rows past `capacity` are not written and raise the overflow flag (the host retries with larger
+// lists), the total goes to counter[0].
+constexpr int kOrdRays = 64;
+__global__ __launch_bounds__(256) void compact_ordered_kernel(CompactOut co, int nrays, int M, int k) {
+    __shared__ int red[4];
+    __shared__ int scan[kOrdRays + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int first = blockIdx.x * kOrdRays;
+    int acc = 0;
+    for (int i = tid; i < (int)blockIdx.x; i += 256) acc += co.blk_sum[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    const int base0 = (red[0] + red[1]) + (red[2] + red[3]);
+    if (wave == 0) {
+        const int ray = first + lane;
+        const int cnt = ray < nrays ? co.ray_cnt[ray] : 0;
+        int inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += v;
+        }
+        const int base = base0 + inc - cnt;
+        scan[lane] = base;
+        if (lane == 63) scan[64] = base0 + inc;
+        if (ray < nrays) co.ray_base[ray] = base;
+        if (ray == nrays - 1) {
+            co.counter[0] = base + cnt;
+            co.counter[1] = (base + cnt > co.capacity) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    const int end = min(scan[64], co.capacity);
+    const int nloc = min(kOrdRays, nrays - first);
+    for (int row = base0 + tid; row < end; row += 256) {
+        int lo = 0, hi = nloc - 1;                       // largest r with scan[r] <= row (an empty ray shares its base with its
+        while (lo < hi) {                                // successor: the LAST of equal bases is the one that owns the row)
+            const int mid = (lo + hi + 1) >> 1;
+            if (scan[mid] <= row) lo = mid; else hi = mid - 1;
+        }
+        const int64_t src = (int64_t)(first + lo) * M + (row - scan[lo]);
+        if (k == 8) {
+            const int4* sp = reinterpret_cast<const int4*>(co.st_nb + src * 8);
+            int4* dp = reinterpret_cast<int4*>(co.nb + (int64_t)row * 8);
+            const int4 a = sp[0], b = sp[1];
+            dp[0] = a;
+            dp[1] = b;
+        } else {
+            for (int t = 0; t < k; ++t) co.nb[(int64_t)row * k + t] = co.st_nb[src * k + t];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) co.pts[(int64_t)row * 3 + c] = co.st_pts[src * 3 + c];
     }
 }
 
@@ -1180,10 +1264,10 @@ extern "C" int npcd_ray_march_bwd(const float* sigma, const float* rgb, const ui
 // Fused-render form of the neighbour query: compact shading-point lists instead of the dense [ray, slot]
 // arrays.  counter[0] receives the number of compact points, counter[1] an overflow flag (capacity too small;
 // nothing is written for the overflowing rays).  Rows of one ray are contiguous and in slot order.
-extern "C" int npcd_grid_query_compact(const npcd_grid_params* g_in, const void* workspace, const float* points, int B, int N, int R, int S,
-                                       int M, int k, float r, const float* rays_o, const float* rays_d, const float* t0, const float* t1,
-                                       int32_t* counter, int32_t capacity, int32_t* ray_base, int32_t* ray_nsel, uint64_t* ray_bits,
-                                       int32_t* nb_idx, float* pts, void* stream) {
+static int grid_query_compact_launch(const npcd_grid_params* g_in, const void* workspace, const float* points, int B, int N, int R, int S,
+                                     int M, int k, float r, const float* rays_o, const float* rays_d, const float* t0, const float* t1,
+                                     int32_t* counter, int32_t capacity, int32_t* ray_base, int32_t* ray_nsel, uint64_t* ray_bits,
+                                     int32_t* nb_idx, float* pts, void* order_ws, void* stream) {
     int rc = grid_check(g_in, B, N);
     if (rc != NPCD_OK) return rc;
     const npcd_grid_params ge = effective_grid(*g_in);
@@ -1213,10 +1297,45 @@ extern "C" int npcd_grid_query_compact(const npcd_grid_params* g_in, const void*
     hipStream_t st = static_cast<hipStream_t>(stream);
     static DynLds lds_attr;
     if (lds > 65536) NPCD_HIP_CHECK(lds_attr.ensure(reinterpret_cast<const void*>(grid_query_wave_kernel<true>), lds));
-    NPCD_HIP_CHECK(hipMemsetAsync(counter, 0, 2 * sizeof(int32_t), st));
-    hipLaunchKernelGGL(grid_query_wave_kernel<true>, dim3(B * bpe), dim3(256), lds, st, a, co, bpe);
+    if (order_ws) {
+        // staging: group sums, [B R] counts (each padded to 16 bytes), [B R][M][k] indices, [B R][M][3] positions
+        const int64_t nrays = (int64_t)B * R, nblk = (nrays + kOrdRays - 1) / kOrdRays;
+        unsigned char* w = static_cast<unsigned char*>(order_ws);
+        co.blk_sum = reinterpret_cast<int32_t*>(w);
+        w += (nblk * 4 + 15) / 16 * 16;
+        co.ray_cnt = reinterpret_cast<int32_t*>(w);
+        co.st_nb = reinterpret_cast<int32_t*>(w + (nrays * 4 + 15) / 16 * 16);
+        co.st_pts = reinterpret_cast<float*>(co.st_nb + nrays * M * k);
+        NPCD_HIP_CHECK(hipMemsetAsync(co.blk_sum, 0, nblk * sizeof(int32_t), st));
+        hipLaunchKernelGGL(grid_query_wave_kernel<true>, dim3(B * bpe), dim3(256), lds, st, a, co, bpe);
+        hipLaunchKernelGGL(compact_ordered_kernel, dim3((unsigned)nblk), dim3(256), 0, st, co, (int)nrays, M, k);
+    } else {
+        NPCD_HIP_CHECK(hipMemsetAsync(counter, 0, 2 * sizeof(int32_t), st));
+        hipLaunchKernelGGL(grid_query_wave_kernel<true>, dim3(B * bpe), dim3(256), lds, st, a, co, bpe);
+    }
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
+}
+
+extern "C" int npcd_grid_query_compact(const npcd_grid_params* g_in, const void* workspace, const float* points, int B, int N, int R, int S,
+                                       int M, int k, float r, const float* rays_o, const float* rays_d, const float* t0, const float* t1,
+                                       int32_t* counter, int32_t capacity, int32_t* ray_base, int32_t* ray_nsel, uint64_t* ray_bits,
+                                       int32_t* nb_idx, float* pts, void* stream) {
+    return grid_query_compact_launch(g_in, workspace, points, B, N, R, S, M, k, r, rays_o, rays_d, t0, t1, counter, capacity, ray_base, ray_nsel,
+                                     ray_bits, nb_idx, pts, nullptr, stream);
+}
+extern "C" int64_t npcd_grid_query_order_ws_bytes(int B, int R, int M, int k) {
+    if (B <= 0 || R <= 0 || M <= 0 || k <= 0) return -1;
+    const int64_t nrays = (int64_t)B * R;
+    return ((nrays + kOrdRays - 1) / kOrdRays * 4 + 15) / 16 * 16 + (nrays * 4 + 15) / 16 * 16 + nrays * M * (int64_t)(k * 4 + 12);
+}
+extern "C" int npcd_grid_query_compact_ordered(const npcd_grid_params* g_in, const void* workspace, const float* points, int B, int N, int R,
+                                               int S, int M, int k, float r, const float* rays_o, const float* rays_d, const float* t0,
+                                               const float* t1, int32_t* counter, int32_t capacity, int32_t* ray_base, int32_t* ray_nsel,
+                                               uint64_t* ray_bits, int32_t* nb_idx, float* pts, void* order_ws, void* stream) {
+    if (!order_ws || (reinterpret_cast<uintptr_t>(order_ws) & 15) || (reinterpret_cast<uintptr_t>(nb_idx) & 15)) return NPCD_ERR_ARG;
+    return grid_query_compact_launch(g_in, workspace, points, B, N, R, S, M, k, r, rays_o, rays_d, t0, t1, counter, capacity, ray_base, ray_nsel,
+                                     ray_bits, nb_idx, pts, order_ws, stream);
 }
 
 // Ray march on the compact layout produced by npcd_grid_query_compact.

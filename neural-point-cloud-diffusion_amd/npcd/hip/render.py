@@ -70,6 +70,12 @@ def ray_gen(extr: torch.Tensor, intr: torch.Tensor, res: int, box: float = 1.0, 
 # recorded on the launch stream (bench.py: roofline entry of the renderer's second-largest kernel).
 QUERY_EVENTS = None
 
+# The compact lists of shading points are laid out in RAY ORDER by a prefix sum over the per-ray counts (two launches, no atomics):
+# a render is bit-identical from run to run.  NPCD_COMPACT_ORDERED=0 selects the one-launch form whose list order is the order in
+# which the rays' waves reach an atomic counter (same per-ray content, ~2 % faster, last bits of the image vary between runs
+# through the order of the float atomics in the weight gradients only -- the forward is order-independent either way).
+COMPACT_ORDERED = os.environ.get("NPCD_COMPACT_ORDERED", "1") != "0"
+
 
 class HipVoxelGrid:
     """Device-side state of a torch_knnquery.VoxelGrid: parameters + the workspace written by
@@ -162,13 +168,23 @@ class HipVoxelGrid:
         ray_bits = torch.empty(B * R, dtype=torch.int64, device=dev)
         nb = torch.empty((capacity, k), dtype=_i32, device=dev)
         cpts = torch.empty((capacity, 3), dtype=_f32, device=dev)
+        order_ws = None
+        if COMPACT_ORDERED:
+            order_ws = torch.empty(lib().npcd_grid_query_order_ws_bytes(B, R, int(M), int(k)), dtype=torch.uint8, device=dev)
         ev = None
         if QUERY_EVENTS is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        check(lib().npcd_grid_query_compact(ctypes.byref(self.params), ptr(self.workspace), ptr(pts_t), B, N, R, int(S), int(M), int(k),
-                                            float(r), ptr(o), ptr(d), ptr(t0), ptr(t1), ptr(counter), int(capacity), ptr(ray_base),
-                                            ptr(ray_nsel), ptr(ray_bits), ptr(nb), ptr(cpts), stream_ptr()), "npcd_grid_query_compact")
+        if COMPACT_ORDERED:
+            check(lib().npcd_grid_query_compact_ordered(
+                ctypes.byref(self.params), ptr(self.workspace), ptr(pts_t), B, N, R, int(S), int(M), int(k), float(r), ptr(o), ptr(d),
+                ptr(t0), ptr(t1), ptr(counter), int(capacity), ptr(ray_base), ptr(ray_nsel), ptr(ray_bits), ptr(nb), ptr(cpts),
+                ptr(order_ws), stream_ptr()), "npcd_grid_query_compact_ordered")
+        else:
+            check(lib().npcd_grid_query_compact(
+                ctypes.byref(self.params), ptr(self.workspace), ptr(pts_t), B, N, R, int(S), int(M), int(k), float(r), ptr(o), ptr(d),
+                ptr(t0), ptr(t1), ptr(counter), int(capacity), ptr(ray_base), ptr(ray_nsel), ptr(ray_bits), ptr(nb), ptr(cpts),
+                stream_ptr()), "npcd_grid_query_compact")
         if ev is not None:
             ev[1].record()
             QUERY_EVENTS.append(ev)

@@ -322,12 +322,59 @@ def test_render_vs_oracle_grid(res, B, views, shade_form):
     assert orr.psnr(img_h, img_r) > 50.0
 
 
-def test_compact_list_overflow_retries_without_out_of_bounds_access():
+def test_compact_lists_are_in_ray_order_and_reproducible(monkeypatch):
+    """npcd_grid_query_compact_ordered: ray_base is the exclusive prefix sum of the per-ray counts (ray order), the rows of a ray are
+    the valid slots of the dense query in slot order, two calls give identical buffers bit for bit, and the one-launch atomic form
+    (NPCD_COMPACT_ORDERED=0) holds the same rows per ray at whatever base the race gave it.  Ragged: R is not a multiple of 256
+    and the first / last rays miss the cloud."""
+    from npcd.hip import render as hr
+    res, M, k, S = 50, 50, 8, 64                                   # 2500 rays per view, 2 views, 2 clouds
+    coords, feats, extr, intr = _scene(res, 2, 512, 32, seed=2, B=2)
+    coords[1] = coords[1].flip(-1) * 0.7
+    m = _model(32, 512, orr.init_field_params(32, seed=0))
+    agg = m.field.aggregator
+    grid = agg.voxel_grid
+    B, V = 2, 2
+    with torch.no_grad():
+        grid.set_pointset(coords.cuda(), None)
+        o, d, t0, t1 = hr.ray_gen(extr.flatten(0, 1).cuda(), intr.flatten(0, 1).cuda(), res, 1.0)
+        rays = tuple(t.reshape(B, V * res * res, *t.shape[2:]) for t in (o, d, t0, t1))
+        idx, loc, _, nsel = grid.query_dense(k, agg.r, M, rays=rays, S=S)
+        cap = B * V * res * res * M
+        assert hr.COMPACT_ORDERED
+        c1, base1, nsel1, bits1, nb1, pts1 = grid.query_compact(k, agg.r, M, rays, S, cap)
+        c2, base2, _, bits2, nb2, pts2 = grid.query_compact(k, agg.r, M, rays, S, cap)
+        monkeypatch.setattr(hr, "COMPACT_ORDERED", False)
+        c3, base3, _, bits3, nb3, pts3 = grid.query_compact(k, agg.r, M, rays, S, cap)
+    torch.cuda.synchronize()
+    valid = (idx[..., 0] >= 0).flatten(0, 1)                         # [B*R, M]
+    cnt = valid.sum(1)
+    P = int(cnt.sum())
+    assert int(c1[0]) == P and int(c1[1]) == 0 and int(c3[0]) == P and P > 1000
+    assert int((cnt == 0).sum()) > 100                               # rays that miss
+    assert torch.equal(base1.long(), torch.cumsum(cnt, 0) - cnt)
+    assert torch.equal(nsel1, nsel.flatten())
+    rows_nb, rows_pts = idx.flatten(0, 1)[valid], loc.flatten(0, 1)[valid]      # ray-major, slot order: the ordered layout
+    assert torch.equal(nb1[:P], rows_nb) and torch.equal(pts1[:P], rows_pts)
+    for a, b in ((c1, c2), (base1, base2), (bits1, bits2), (nb1[:P], nb2[:P]), (pts1[:P], pts2[:P])):
+        assert torch.equal(a, b)
+    # atomic form: same masks, same rows per ray at its own base
+    assert torch.equal(bits3, bits1)
+    ray_of_row = torch.repeat_interleave(torch.arange(cnt.numel(), device="cuda"), cnt)
+    within = torch.arange(P, device="cuda") - (torch.cumsum(cnt, 0) - cnt)[ray_of_row]
+    src = base3.long()[ray_of_row] + within
+    assert torch.equal(nb3[src], rows_nb) and torch.equal(pts3[src], rows_pts)
+
+
+@pytest.mark.parametrize("ordered", [True, False])
+def test_compact_list_overflow_retries_without_out_of_bounds_access(ordered, monkeypatch):
     """The compact shading-point lists are sized for a FRACTION of the worst case once a call is too large for worst-case
     buffers; when they overflow the query only raises a flag and keeps counting, the shading / ray-march kernels run on the
     clamped lists, and the host retries with worst-case buffers.  Force that path (sync_free_points = 0, a fraction far
     below the ~10 % slot fill of this scene) and require the result to equal the worst-case-buffer render bit for bit;
     canaries allocated right behind the first attempt's buffers must stay untouched."""
+    from npcd.hip import render as hr
+    monkeypatch.setattr(hr, "COMPACT_ORDERED", ordered)
     res = 64
     coords, feats, extr, intr = _scene(res, 2, 512, 32, seed=1, B=1)
     p = orr.init_field_params(32, seed=0)
