@@ -2273,8 +2273,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnParams p, fl
 constexpr int kF32Pad = 65;
 
 __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                                                           float* __restrict__ out, int B, int n, int H, int64_t sb, int64_t sn, int64_t sh,
-                                                           int64_t osb, int64_t osn, int64_t osh, float scale) {
+                                                           float* __restrict__ out, float* __restrict__ lse, int B, int n, int H, int64_t sb,
+                                                           int64_t sn, int64_t sh, int64_t osb, int64_t osn, int64_t osh, float scale) {
     __shared__ float Ks[64 * kF32Pad];
     __shared__ float Vs[64 * 64];
     __shared__ float Qs[16 * 64];
@@ -2341,6 +2341,186 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
     for (int rq = 0; rq < 4; ++rq) {
         const int row = qt * 16 + wave * 4 + rq;
         if (row < n) out[b * osb + row * osn + h * osh + lane] = acc[rq] / l[rq];
+        if (lse && row < n && lane == 0) lse[(int64_t)(b * H + h) * n + row] = m[rq] + logf(l[rq]);     // natural log, scaled scores
+    }
+}
+
+// ============================================================================================
+// fp32 backward (`--dtype float32` training: the reference differentiates its fp32 einsum attention, transformer.py:76-81).
+// fp32 operands on the fp32 matrix instruction v_mfma_f32_32x32x2_f32 (lane (i, g) = (l & 31, l >> 5) gives A[i][g] and B[g][i],
+// the accumulator register r of lane (j, g) is C[acc_row(r, g)][j]); nothing is rounded to 16 bits.  Two kernels, as in the
+// 16-bit path, both with the OWNED index on the lanes (accumulator columns) and the index that is summed over on the rows:
+//   dq kernel    : a wave owns 32 query rows (q and dO fragments in registers, their own q on the lane), loops over 32-key tiles
+//                  in LDS:  S^T = K Q^T,  dP^T = V dO^T,  dS^T = P^T (dP^T - delta) scale,  dQ^T += K^T dS^T;
+//   dk/dv kernel : a wave owns 32 keys (k and v fragments in registers), loops over 32-query tiles:  S = Q K^T,  dP = dO V^T,
+//                  dV^T += dO^T P,  dK^T += Q^T dS.
+// The contraction order inside a product is free, which removes every transposition: (1) over the 64 features, lane half g takes
+// features 8 u + 4 g + e (u = 0..7, e = 0..3): the register-resident fragment is eight float4 loads of the lane's own row, the LDS
+// side one ds_read_b128 per u (rows padded to 68 floats: conflict-free); (2) over the 32 rows of a score block, step r pairs the
+// two rows acc_row(r, 0), acc_row(r, 1) -- exactly what the lanes of the two halves hold in accumulator register r, so P / dS
+// are the B operand as they stand, and the A side reads row acc_row(r, g) of the LDS tile with the feature on the lane.
+// delta = rowsum(dO . O) is formed by the dq kernel (its rows' dO are in registers) and handed to the dk/dv kernel through
+// `delta`.  Deterministic: no atomics, fixed summation order.
+// ============================================================================================
+constexpr int kB32St = 68;   // floats per LDS row of a 32 x 64 tile
+
+struct AttnF32Bwd {
+    const float *q, *k, *v, *o, *dout, *lse;
+    float *dq, *dk, *dv, *delta;
+    int B, n, H;
+    int64_t sb, sn, sh, osb, osn, osh, gsb, gsn, gsh;
+    float scale;
+};
+
+// 32 rows x 64 floats from row0 of a [n][64] strided matrix into LDS (rows past n: zero), 256 threads
+__device__ __forceinline__ void f32_tile_load(float* dst, const float* base, int row0, int n, int64_t sn, int tid) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int c = tid + it * 256, row = c >> 4, col = (c & 15) * 4;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + row < n) x = *reinterpret_cast<const float4*>(base + (int64_t)(row0 + row) * sn + col);
+        *reinterpret_cast<float4*>(dst + row * kB32St + col) = x;
+    }
+}
+// the lane's own row as the register-resident operand: features 8 u + 4 g + e
+__device__ __forceinline__ void f32_row_frag(float (&f)[32], const float* row, bool ok, int g) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) x = *reinterpret_cast<const float4*>(row + 8 * u + 4 * g);
+        f[4 * u + 0] = x.x; f[4 * u + 1] = x.y; f[4 * u + 2] = x.z; f[4 * u + 3] = x.w;
+    }
+}
+// C[tile row][lane's row] += sum over the 64 features of tile[row][.] * frag[.]
+__device__ __forceinline__ f32x16 f32_scores(const float* tile, const float (&frag)[32], int i, int g) {
+    f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const float4 a = *reinterpret_cast<const float4*>(tile + i * kB32St + 8 * u + 4 * g);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, frag[4 * u + 0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, frag[4 * u + 1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, frag[4 * u + 2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, frag[4 * u + 3], c, 0, 0, 0);
+    }
+    return c;
+}
+// acc[blk][feature 32 blk + .][lane's row] += sum over the 32 tile rows of tile[row][feature] * w[row][lane's row]
+__device__ __forceinline__ void f32_accumulate(f32x16 (&acc)[2], const float* tile, const f32x16& w, int i, int g) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float* rowp = tile + acc_row(r, g) * kB32St + i;
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(rowp[0], w[r], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(rowp[32], w[r], acc[1], 0, 0, 0);
+    }
+}
+// the lane's row of a [n][64] gradient from the transposed accumulators: features 32 blk + 8 (r >> 2) + 4 g + (0..3)
+__device__ __forceinline__ void f32_store_row(float* row, const f32x16 (&acc)[2], int g) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+            *reinterpret_cast<float4*>(row + 32 * blk + 8 * r4 + 4 * g) =
+                make_float4(acc[blk][4 * r4], acc[blk][4 * r4 + 1], acc[blk][4 * r4 + 2], acc[blk][4 * r4 + 3]);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_f32_dq_kernel(AttnF32Bwd p) {
+    __shared__ float Ks[32 * kB32St];
+    __shared__ float Vs[32 * kB32St];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, g = lane >> 5;
+    const int n = p.n, nqt = (n + 127) / 128;
+    const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt, h = bh % p.H, b = bh / p.H;
+    const int qrow = qt * 128 + wave * 32 + i;
+    const bool ok = qrow < n;
+    float qf[32], gf[32];
+    f32_row_frag(qf, p.q + b * p.sb + (int64_t)qrow * p.sn + h * p.sh, ok, g);
+    f32_row_frag(gf, p.dout + b * p.osb + (int64_t)qrow * p.osn + h * p.osh, ok, g);
+    float delta = 0.f;
+    {
+        float of[32];
+        f32_row_frag(of, p.o + b * p.osb + (int64_t)qrow * p.osn + h * p.osh, ok, g);
+#pragma unroll
+        for (int e = 0; e < 32; ++e) delta = fmaf(gf[e], of[e], delta);
+        delta += __shfl_xor(delta, 32, 64);
+    }
+    const float lse2 = ok ? p.lse[(int64_t)bh * n + qrow] * kLog2e : INFINITY;
+    if (ok && g == 0) p.delta[(int64_t)bh * n + qrow] = delta;
+    const float c = p.scale * kLog2e;
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    const float* kb = p.k + b * p.sb + h * p.sh;
+    const float* vb = p.v + b * p.sb + h * p.sh;
+    const int nt = (n + 31) / 32;
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();
+        f32_tile_load(Ks, kb, t * 32, n, p.sn, tid);
+        f32_tile_load(Vs, vb, t * 32, n, p.sn, tid);
+        __syncthreads();
+        const f32x16 st = f32_scores(Ks, qf, i, g);       // S^T[key][q]
+        const f32x16 dpt = f32_scores(Vs, gf, i, g);      // dP^T[key][q]
+        f32x16 ds;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool key_ok = t * 32 + acc_row(r, g) < n;
+            const float pr = key_ok ? exp2f(fmaf(st[r], c, -lse2)) : 0.f;
+            ds[r] = pr * (dpt[r] - delta) * p.scale;
+        }
+        f32_accumulate(acc, Ks, ds, i, g);                // dQ^T[d][q] += K[key][d] dS^T[key][q]
+    }
+    if (ok) f32_store_row(p.dq + b * p.gsb + (int64_t)qrow * p.gsn + h * p.gsh, acc, g);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_f32_dkdv_kernel(AttnF32Bwd p) {
+    __shared__ float Qs[32 * kB32St];
+    __shared__ float Gs[32 * kB32St];
+    __shared__ __attribute__((aligned(16))) float Ls[32];
+    __shared__ __attribute__((aligned(16))) float Ds[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, g = lane >> 5;
+    const int n = p.n, nkt = (n + 127) / 128;
+    const int kt = blockIdx.x % nkt, bh = blockIdx.x / nkt, h = bh % p.H, b = bh / p.H;
+    const int krow = kt * 128 + wave * 32 + i;
+    const bool ok = krow < n;
+    float kf[32], vf[32];
+    f32_row_frag(kf, p.k + b * p.sb + (int64_t)krow * p.sn + h * p.sh, ok, g);
+    f32_row_frag(vf, p.v + b * p.sb + (int64_t)krow * p.sn + h * p.sh, ok, g);
+    const float c = p.scale * kLog2e;
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+    const float* qb = p.q + b * p.sb + h * p.sh;
+    const float* gb = p.dout + b * p.osb + h * p.osh;
+    const int nt = (n + 31) / 32;
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();
+        f32_tile_load(Qs, qb, t * 32, n, p.sn, tid);
+        f32_tile_load(Gs, gb, t * 32, n, p.osn, tid);
+        if (tid < 32) {
+            const int row = t * 32 + tid;
+            Ls[tid] = row < n ? p.lse[(int64_t)bh * n + row] * kLog2e : INFINITY;      // rows past the end: P = 0
+            Ds[tid] = row < n ? p.delta[(int64_t)bh * n + row] : 0.f;
+        }
+        __syncthreads();
+        const f32x16 sc = f32_scores(Qs, kf, i, g);       // S[q][key]
+        const f32x16 dp = f32_scores(Gs, vf, i, g);       // dP[q][key]
+        f32x16 pr, ds;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const float4 l4 = *reinterpret_cast<const float4*>(Ls + 8 * r4 + 4 * g);
+            const float4 d4 = *reinterpret_cast<const float4*>(Ds + 8 * r4 + 4 * g);
+            const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * r4 + e;
+                pr[r] = exp2f(fmaf(sc[r], c, -lv[e]));
+                ds[r] = pr[r] * (dp[r] - dl[e]) * p.scale;
+            }
+        }
+        f32_accumulate(dv, Gs, pr, i, g);                 // dV^T[d][key] += dO[q][d] P[q][key]
+        f32_accumulate(dk, Qs, ds, i, g);                 // dK^T[d][key] += Q[q][d] dS[q][key]
+    }
+    if (ok) {
+        f32_store_row(p.dk + b * p.gsb + (int64_t)krow * p.gsn + h * p.gsh, dk, g);
+        f32_store_row(p.dv + b * p.gsb + (int64_t)krow * p.gsn + h * p.gsh, dv, g);
     }
 }
 
@@ -2576,13 +2756,13 @@ extern "C" int64_t npcd_attn_fwd_workspace_floats(int B, int n, int H) {
 static int attn_fwd_launch(const void* q, const void* k, const void* v, void* out, float* lse, float* workspace, int B, int n, int H, int d,
                            int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
                            float scale, int dtype, void* stream) {
-    if (dtype == NPCD_F32) {   // inference-only exact fp32 path (no LSE, no backward)
+    if (dtype == NPCD_F32) {   // exact fp32 path (lse [B, H, n] written when given: natural log of the row sums of exp(scaled scores))
         if (B <= 0 || n <= 0 || H <= 0 || !q || !k || !v || !out) return NPCD_ERR_ARG;
         if (d != 64) return NPCD_ERR_UNSUPPORTED;
         const int grid32 = B * H * ceil_div(n, 16);
         hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(grid32), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float*>(q),
-                           static_cast<const float*>(k), static_cast<const float*>(v), static_cast<float*>(out), B, n, H, qkv_sb, qkv_sn,
-                           qkv_sh, out_sb, out_sn, out_sh, scale);
+                           static_cast<const float*>(k), static_cast<const float*>(v), static_cast<float*>(out), lse, B, n, H, qkv_sb,
+                           qkv_sn, qkv_sh, out_sb, out_sn, out_sh, scale);
         NPCD_HIP_CHECK(hipGetLastError());
         return NPCD_OK;
     }
@@ -2723,6 +2903,27 @@ static int attn_bwd_launch(int passes, const void* q, const void* k, const void*
                            void* dq, void* dk, void* dv, float* delta, int B, int n, int H, int d,
                            int64_t qkv_sb, int64_t qkv_sn, int64_t qkv_sh, int64_t out_sb, int64_t out_sn, int64_t out_sh,
                            int64_t g_sb, int64_t g_sn, int64_t g_sh, float scale, int dtype, void* stream, float* colsum = nullptr) {
+    if (dtype == NPCD_F32) {
+        if (B <= 0 || n <= 0 || H <= 0 || !q || !k || !v || !out || !dout || !lse || !delta || colsum) return NPCD_ERR_ARG;
+        if (d != 64) return NPCD_ERR_UNSUPPORTED;
+        if (((passes & 1) && !dq) || ((passes & 2) && (!dk || !dv))) return NPCD_ERR_ARG;
+        const int64_t strides[] = {qkv_sb, qkv_sn, qkv_sh, out_sb, out_sn, out_sh, g_sb, g_sn, g_sh};
+        for (int64_t x : strides)
+            if (x % 4 != 0) return NPCD_ERR_ARG;
+        if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out) || !aligned16(dout) || !aligned16(dq) || !aligned16(dk) ||
+            !aligned16(dv))
+            return NPCD_ERR_ARG;
+        AttnF32Bwd a{static_cast<const float*>(q), static_cast<const float*>(k), static_cast<const float*>(v),
+                     static_cast<const float*>(out), static_cast<const float*>(dout), lse,
+                     static_cast<float*>(dq), static_cast<float*>(dk), static_cast<float*>(dv), delta, B, n, H,
+                     qkv_sb, qkv_sn, qkv_sh, out_sb, out_sn, out_sh, g_sb, g_sn, g_sh, scale};
+        const int grid = B * H * ceil_div(n, 128);
+        hipStream_t st32 = static_cast<hipStream_t>(stream);
+        if (passes & 1) hipLaunchKernelGGL(attn_bwd_f32_dq_kernel, dim3(grid), dim3(256), 0, st32, a);      // also writes delta
+        if (passes & 2) hipLaunchKernelGGL(attn_bwd_f32_dkdv_kernel, dim3(grid), dim3(256), 0, st32, a);
+        NPCD_HIP_CHECK(hipGetLastError());
+        return NPCD_OK;
+    }
     int rc = check_common(B, n, H, d, dtype);
     if (rc != NPCD_OK) return rc;
     if (!q || !k || !v || !out || !dout || !lse || !delta) return NPCD_ERR_ARG;

@@ -108,40 +108,46 @@ def _check_input(x):
         raise RuntimeError(f"HIP attention supports bf16/f16 (MFMA kernels) and fp32; got {x.dtype}")
 
 
-def _fwd_f32(q, k, v, scale):
+def _fwd_f32(q, k, v, scale, want_lse=False):
     B, n, H, d = q.shape
     out = torch.empty((B, n, H, d), dtype=torch.float32, device=q.device)
-    check(lib().npcd_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(None), B, n, H, d, q.stride(0), q.stride(1), q.stride(2),
+    lse = torch.empty((B, H, n), dtype=torch.float32, device=q.device) if want_lse else None
+    check(lib().npcd_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), B, n, H, d, q.stride(0), q.stride(1), q.stride(2),
                               out.stride(0), out.stride(1), out.stride(2), scale, dtype_code(q), stream_ptr()), "npcd_attn_fwd(f32)")
-    return out
+    return (out, lse) if want_lse else out
+
+
+def _f32_layout_ok(q, k, v):
+    return (q.stride() == k.stride() == v.stride() and q.stride(3) == 1 and all(s % 4 == 0 for s in q.stride()[:3])
+            and q.data_ptr() % 16 == 0 and k.data_ptr() % 16 == 0 and v.data_ptr() % 16 == 0)
 
 
 class _AttnF32(torch.autograd.Function):
     """fp32 attention with gradients (`--dtype float32` training, where the reference runs its einsum path in fp32,
-    transformer.py:77-83).  Forward: the exact-fp32 HIP kernel.  Backward: NOT a hand-written kernel -- the probabilities are
-    recomputed and the four products are fp32 library GEMMs on the device (B*H*n^2 floats of workspace: 1.1 GB at cfg-D).
-    The benchmarked training configuration is bf16 autocast and never comes here."""
+    transformer.py:76-83).  Forward: the exact-fp32 HIP kernel (+ the log-sum-exp of every row); backward: the two fp32
+    matrix-instruction kernels of csrc/attention.hip (attn_bwd_f32_dq_kernel / attn_bwd_f32_dkdv_kernel: nothing is rounded to
+    16 bits, deterministic).  The benchmarked training configuration is bf16 autocast and never comes here."""
 
     @staticmethod
     def forward(ctx, q, k, v, scale):
-        if not (q.stride() == k.stride() == v.stride() and q.stride(3) == 1):
+        if not _f32_layout_ok(q, k, v):
             q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        out = _fwd_f32(q, k, v, scale)
-        ctx.save_for_backward(q, k, v, out)
+        out, lse = _fwd_f32(q, k, v, scale, want_lse=True)
+        ctx.save_for_backward(q, k, v, out, lse)
         ctx.scale = scale
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        q, k, v, out = ctx.saved_tensors
-        scale = ctx.scale
-        p = torch.softmax(torch.einsum("bthd,bshd->bhts", q, k) * scale, dim=-1)
-        dv = torch.einsum("bhts,bthd->bshd", p, gout)
-        dp = torch.einsum("bthd,bshd->bhts", gout, v)
-        delta = (gout * out).sum(dim=-1).permute(0, 2, 1).unsqueeze(-1)          # [B, H, n, 1]
-        ds = p * (dp - delta) * scale
-        dq = torch.einsum("bhts,bshd->bthd", ds, k)
-        dk = torch.einsum("bhts,bthd->bshd", ds, q)
+        q, k, v, out, lse = ctx.saved_tensors
+        B, n, H, d = q.shape
+        gout = gout.contiguous()
+        dq, dk, dv = (torch.empty((B, n, H, d), dtype=torch.float32, device=q.device) for _ in range(3))
+        delta = torch.empty(B * H * n, dtype=torch.float32, device=q.device)
+        check(lib().npcd_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(gout), ptr(lse), ptr(dq), ptr(dk), ptr(dv), ptr(delta),
+                                  B, n, H, d, q.stride(0), q.stride(1), q.stride(2), out.stride(0), out.stride(1), out.stride(2),
+                                  dq.stride(0), dq.stride(1), dq.stride(2), ctx.scale, dtype_code(q), stream_ptr()),
+              "npcd_attn_bwd(f32)")
         return dq, dk, dv, None
 
 

@@ -254,8 +254,9 @@ def test_unsupported_shapes_fail_loudly():
 
 @pytest.mark.parametrize("name", ["attention_n130_h4_d64", "attention_n513_h1_d64"])
 def test_attention_fp32_training_matches_reference_golden(golden, name):
-    """`--dtype float32` training: exact-fp32 HIP forward, gradients from fp32 library GEMMs on the device, against the
-    reference's own fp32 attention output and qkv gradient (fixture G1)."""
+    """`--dtype float32` training: exact-fp32 HIP forward, gradients from the fp32 matrix-instruction backward kernels
+    (attn_bwd_f32_dq_kernel / attn_bwd_f32_dkdv_kernel), against the reference's own fp32 attention output and qkv gradient
+    (fixture G1)."""
     from npcd.hip.attention import attention_qkvpacked
     g = golden(name)
     H = int(g["heads"])
@@ -265,6 +266,27 @@ def test_attention_fp32_training_matches_reference_golden(golden, name):
     ref_o, ref_g = torch.from_numpy(g["out"]), torch.from_numpy(g["dqkv"])
     assert float((out.detach().cpu() - ref_o).abs().max()) < 2e-5 * max(1.0, float(ref_o.abs().max()))
     assert float((qkv.grad.cpu() - ref_g).abs().max()) < 2e-5 * max(1.0, float(ref_g.abs().max()))
+
+
+@pytest.mark.parametrize("n,H,B", [(1, 1, 1), (31, 2, 2), (32, 1, 1), (33, 3, 1), (127, 2, 1), (129, 1, 2), (257, 2, 1), (513, 2, 2)])
+def test_attention_fp32_backward_kernel_ragged_lengths(n, H, B):
+    """The fp32 backward kernels on lengths around their 32-row / 128-row tile edges against float64 autograd of the oracle's
+    einsum attention (transformer.py:76-83), 2e-5 relative to the largest gradient entry; q / k / v are strided views of the
+    packed projection (no copies) and a second call gives the same bits (no atomics)."""
+    from npcd.hip.attention import attention_qkvpacked
+    gen = torch.Generator().manual_seed(1000 + n)
+    qkv = torch.randn(B, n, 3 * H * 64, generator=gen) * 1.2
+    gout = torch.randn(B, n, H * 64, generator=gen)
+    ref_in = qkv.double().requires_grad_(True)
+    (od.attention_qkvpacked(ref_in, H) * gout.double()).sum().backward()
+    grads = []
+    for _ in range(2):
+        x = qkv.cuda().requires_grad_(True)
+        (attention_qkvpacked(x, H) * gout.cuda()).sum().backward()
+        grads.append(x.grad)
+    ref_g = ref_in.grad.float()
+    assert float((grads[0].cpu() - ref_g).abs().max()) < 2e-5 * max(1.0, float(ref_g.abs().max()))
+    assert torch.equal(grads[0], grads[1])
 
 
 @pytest.mark.parametrize("tag", ["f32_w64", "f128_w64"])
