@@ -2423,6 +2423,64 @@ __device__ __forceinline__ void f32_store_row(float* row, const f32x16 (&acc)[2]
                 make_float4(acc[blk][4 * r4], acc[blk][4 * r4 + 1], acc[blk][4 * r4 + 2], acc[blk][4 * r4 + 3]);
 }
 
+// fp32 forward on the same instruction, same layout as the dq kernel: a wave owns 32 query rows (q on the lane), S^T = K Q^T per
+// 32-key tile, online softmax down the accumulator COLUMN (16 registers + the other lane half: the running maximum and sum of a
+// query are one scalar per lane), O^T += V^T P^T with P^T as the B operand as it stands.  Exact fp32, deterministic.
+__global__ __launch_bounds__(256) void attn_fwd_f32_mfma_kernel(AttnF32Bwd p) {
+    __shared__ float Ks[32 * kB32St];
+    __shared__ float Vs[32 * kB32St];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 31, g = lane >> 5;
+    const int n = p.n, nqt = (n + 127) / 128;
+    const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt, h = bh % p.H, b = bh / p.H;
+    const int qrow = qt * 128 + wave * 32 + i;
+    const bool ok = qrow < n;
+    float qf[32];
+    f32_row_frag(qf, p.q + b * p.sb + (int64_t)qrow * p.sn + h * p.sh, ok, g);
+    const float c = p.scale * kLog2e;
+    float m = -INFINITY, l = 0.f;          // l: this lane half's share of the row sum
+    f32x16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    const float* kb = p.k + b * p.sb + h * p.sh;
+    const float* vb = p.v + b * p.sb + h * p.sh;
+    const int nt = (n + 31) / 32;
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();
+        f32_tile_load(Ks, kb, t * 32, n, p.sn, tid);
+        f32_tile_load(Vs, vb, t * 32, n, p.sn, tid);
+        __syncthreads();
+        f32x16 st = f32_scores(Ks, qf, i, g);             // S^T[key][q]
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] = (t * 32 + acc_row(r, g) < n) ? st[r] * c : -INFINITY;
+            mx = fmaxf(mx, st[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);                    // finite from the first tile on (key 0 exists)
+        const float alpha = exp2f(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] = exp2f(st[r] - mn);
+            ps += st[r];
+        }
+        l = fmaf(l, alpha, ps);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] *= alpha; acc[1][r] *= alpha; }
+        f32_accumulate(acc, Vs, st, i, g);                // O^T[d][q] += V[key][d] P^T[key][q]
+    }
+    l += __shfl_xor(l, 32, 64);
+    if (ok) {
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] *= inv; acc[1][r] *= inv; }
+        f32_store_row(p.dq + b * p.gsb + (int64_t)qrow * p.gsn + h * p.gsh, acc, g);
+        if (p.delta && g == 0) p.delta[(int64_t)bh * n + qrow] = (m + log2f(l)) * kLn2;      // lse, natural log of sum exp(scaled scores)
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_f32_dq_kernel(AttnF32Bwd p) {
     __shared__ float Ks[32 * kB32St];
     __shared__ float Vs[32 * kB32St];
@@ -2759,6 +2817,19 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* ou
     if (dtype == NPCD_F32) {   // exact fp32 path (lse [B, H, n] written when given: natural log of the row sums of exp(scaled scores))
         if (B <= 0 || n <= 0 || H <= 0 || !q || !k || !v || !out) return NPCD_ERR_ARG;
         if (d != 64) return NPCD_ERR_UNSUPPORTED;
+        static const bool valu_form = getenv("NPCD_ATTN_F32_VALU") != nullptr;
+        const bool vec_ok = !(qkv_sb % 4 || qkv_sn % 4 || qkv_sh % 4 || out_sb % 4 || out_sn % 4 || out_sh % 4) && aligned16(q) &&
+                            aligned16(k) && aligned16(v) && aligned16(out);
+        if (vec_ok && !valu_form) {        // matrix-instruction form (needs 16-byte rows); the vector-ALU form below takes any layout
+            AttnF32Bwd a{};
+            a.q = static_cast<const float*>(q); a.k = static_cast<const float*>(k); a.v = static_cast<const float*>(v);
+            a.dq = static_cast<float*>(out); a.delta = lse;
+            a.B = B; a.n = n; a.H = H; a.sb = qkv_sb; a.sn = qkv_sn; a.sh = qkv_sh; a.gsb = out_sb; a.gsn = out_sn; a.gsh = out_sh;
+            a.scale = scale;
+            hipLaunchKernelGGL(attn_fwd_f32_mfma_kernel, dim3(B * H * ceil_div(n, 128)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+            NPCD_HIP_CHECK(hipGetLastError());
+            return NPCD_OK;
+        }
         const int grid32 = B * H * ceil_div(n, 16);
         hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(grid32), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float*>(q),
                            static_cast<const float*>(k), static_cast<const float*>(v), static_cast<float*>(out), lse, B, n, H, qkv_sb,
