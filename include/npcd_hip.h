@@ -241,6 +241,15 @@ int npcd_shade_points(const void* wpack, int feat_dim, int n_freqs, int hidden,
                       const int32_t* n_points_dev, int max_points, int k,
                       float* sigma, float* rgb, void* workspace, void* stream);
 
+/* The same with the reference's use_view_dir option (models/npcd.py:8 -> fields/mlp.py:30-36,67-70): the first colour layer sees
+ * [feat | enc(ray direction)].  Its direction part is the same for every shading point of a ray, so the caller passes it per RAY:
+ * dir_bias [n_rays, hidden] fp32 = enc(d) . W[:, hidden:]^T (16-byte aligned), point_ray [max_points] int32 = the ray of every compact
+ * row; wpack holds that layer packed from its first `hidden` columns.  Added to the fp32 accumulators of the layer. */
+int npcd_shade_points_dir(const void* wpack, int feat_dim, int n_freqs, int hidden,
+                          const int32_t* nb_idx, const float* pts, const float* kp_pos, const float* kp_feat,
+                          const int32_t* n_points_dev, int max_points, int k,
+                          float* sigma, float* rgb, void* workspace, const float* dir_bias, const int32_t* point_ray, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Ray marching (renderer.py:96-110,120-185, volume_renderer.py:23-39) on the dense slot layout:
  * sigma/rgb are COMPACT per valid slot (row-major over [ray, slot]); slot_valid [Nr,M] uint8,

@@ -107,7 +107,6 @@ __device__ unsigned char g_zero_page[128];      // (zero-initialised device memo
 template <class TR>
 __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
     using E = typename TR::elem;
-    using V8 = typename TR::vec8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // kRing stages x 32 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

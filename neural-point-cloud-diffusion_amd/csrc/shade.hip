@@ -320,6 +320,7 @@ __device__ __forceinline__ float softplus_m1(float x) {
     return x > 20.f ? x : log1pf(expf(x));  // F.softplus(beta=1, threshold=20)
 }
 
+template <bool DIR>
 __global__ __launch_bounds__(256, 2) void shade_points_kernel(ShadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
     unsigned char* H = dsmem;
@@ -373,6 +374,21 @@ __global__ __launch_bounds__(256, 2) void shade_points_kernel(ShadeArgs a) {
             // (closed form instead of L.w[6 + l] / L.bias[6 + l]: see pair_layers)
             const int64_t w_off = L.w[6] + (int64_t)l * (8 * (kHidden / 16) * kFragBytes), b_off = L.bias[6] + (int64_t)l * (kHidden * 4);
             layer_mfma<16>(H, a.wpack + w_off, reinterpret_cast<const float*>(a.wpack + b_off), wave, lane, acc);
+            if (DIR && l == 0) {       // + the view-direction part of the first colour layer (per ray, fp32)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb) {
+                    const int p = tile * kRows + cb * 32 + r;
+                    const float* db = a.dir_bias + (int64_t)(p < P ? a.point_ray[p] : 0) * kHidden + 4 * hh;
+#pragma unroll
+                    for (int oi = 0; oi < 2; ++oi)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(db + (2 * wave + oi) * 32 + 8 * g);
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) acc[oi][cb][4 * g + b] += v[b];
+                        }
+                }
+            }
             if (l < 3) {
                 __syncthreads();
                 layer_store<true>(H, wave, lane, acc);
@@ -517,12 +533,13 @@ extern "C" int npcd_shade_pack_weights(const float* const* weights_host, const f
     return NPCD_OK;
 }
 
-extern "C" int npcd_shade_points(const void* wpack, int feat_dim, int n_freqs, int hidden, const int32_t* nb_idx, const float* pts,
-                                 const float* kp_pos, const float* kp_feat, const int32_t* n_points_dev, int max_points, int k,
-                                 float* sigma, float* rgb, void* workspace, void* stream) {
+static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int hidden, const int32_t* nb_idx, const float* pts,
+                               const float* kp_pos, const float* kp_feat, const int32_t* n_points_dev, int max_points, int k,
+                               float* sigma, float* rgb, void* workspace, const float* dir_bias, const int32_t* point_ray, void* stream) {
     int rc = shade_check(feat_dim, n_freqs, hidden);
     if (rc != NPCD_OK) return rc;
     if (!wpack || !nb_idx || !pts || !kp_pos || !kp_feat || !n_points_dev || !sigma || !rgb || !workspace) return NPCD_ERR_ARG;
+    if ((dir_bias != nullptr) != (point_ray != nullptr) || (reinterpret_cast<uintptr_t>(dir_bias) & 15)) return NPCD_ERR_ARG;
     if (k <= 0 || k > 8) return NPCD_ERR_UNSUPPORTED;
     if (max_points <= 0) return NPCD_OK;
     ShadeArgs a{};
@@ -533,13 +550,15 @@ extern "C" int npcd_shade_points(const void* wpack, int feat_dim, int n_freqs, i
     a.max_points = max_points;
     a.G = static_cast<_Float16*>(workspace);
     a.sigma = sigma; a.rgb = rgb;
+    a.dir_bias = dir_bias; a.point_ray = point_ray;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ldsA = kRows * kRowBytes + kRows * 4 + 32 * 4;   // activations, row weights, per-point packed-row ranges
     const int ldsB = kRows * kRowBytes + 4 * kRows * 4 * 4;
-    static DynLds lds_a32, lds_a128, lds_b;
+    static DynLds lds_a32, lds_a128, lds_b, lds_bd;
     NPCD_HIP_CHECK(lds_a32.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<32>), ldsA));
     NPCD_HIP_CHECK(lds_a128.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<128>), ldsA));
-    NPCD_HIP_CHECK(lds_b.ensure(reinterpret_cast<const void*>(shade_points_kernel), ldsB));
+    NPCD_HIP_CHECK(lds_b.ensure(reinterpret_cast<const void*>(shade_points_kernel<false>), ldsB));
+    NPCD_HIP_CHECK(lds_bd.ensure(reinterpret_cast<const void*>(shade_points_kernel<true>), ldsB));
     // persistent-style grids: 2 workgroups per CU, tiles strided over the grid; the tile count is
     // read from device memory so that no host round trip is needed after the neighbour query
     const int tilesA = (max_points + 15) / 16, tilesB = (max_points + kRows - 1) / kRows;
@@ -553,7 +572,23 @@ extern "C" int npcd_shade_points(const void* wpack, int feat_dim, int n_freqs, i
         if (rc != NPCD_OK) return rc;
     } else if (feat_dim == 32) hipLaunchKernelGGL(shade_pairs_kernel<32>, dim3(gridA), dim3(256), ldsA, st, a);
     else hipLaunchKernelGGL(shade_pairs_kernel<128>, dim3(gridA), dim3(256), ldsA, st, a);
-    hipLaunchKernelGGL(shade_points_kernel, dim3(gridB), dim3(256), ldsB, st, a);
+    if (dir_bias) hipLaunchKernelGGL(shade_points_kernel<true>, dim3(gridB), dim3(256), ldsB, st, a);
+    else hipLaunchKernelGGL(shade_points_kernel<false>, dim3(gridB), dim3(256), ldsB, st, a);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
+}
+
+extern "C" int npcd_shade_points(const void* wpack, int feat_dim, int n_freqs, int hidden, const int32_t* nb_idx, const float* pts,
+                                 const float* kp_pos, const float* kp_feat, const int32_t* n_points_dev, int max_points, int k,
+                                 float* sigma, float* rgb, void* workspace, void* stream) {
+    return shade_points_launch(wpack, feat_dim, n_freqs, hidden, nb_idx, pts, kp_pos, kp_feat, n_points_dev, max_points, k, sigma, rgb,
+                               workspace, nullptr, nullptr, stream);
+}
+extern "C" int npcd_shade_points_dir(const void* wpack, int feat_dim, int n_freqs, int hidden, const int32_t* nb_idx, const float* pts,
+                                     const float* kp_pos, const float* kp_feat, const int32_t* n_points_dev, int max_points, int k,
+                                     float* sigma, float* rgb, void* workspace, const float* dir_bias, const int32_t* point_ray,
+                                     void* stream) {
+    if (!dir_bias || !point_ray) return NPCD_ERR_ARG;
+    return shade_points_launch(wpack, feat_dim, n_freqs, hidden, nb_idx, pts, kp_pos, kp_feat, n_points_dev, max_points, k, sigma, rgb,
+                               workspace, dir_bias, point_ray, stream);
 }

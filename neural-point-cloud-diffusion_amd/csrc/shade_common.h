@@ -51,6 +51,11 @@ struct ShadeArgs {
     int max_points;  // rows allocated in nb_idx / pts / G / sigma / rgb: the device-side count is clamped to it
     _Float16* G;  // [max_points][256] aggregated hidden features (workspace)
     float *sigma, *rgb;
+    // use_view_dir (fields/mlp.py:67-70): the first colour layer sees [feat | enc(ray direction)]; the direction part of its
+    // pre-activation is the same for every point of a ray, so the caller hands it over per RAY (dir_bias [n_rays][256] fp32 =
+    // enc(d) . W[:, 256:]^T) together with the ray of every compact point; nullptr = published configuration (no view direction)
+    const float* dir_bias;
+    const int32_t* point_ray;
 };
 
 // ---- positional-encoding column q (0..63) of the [x_rel(3) | per coord: sin f0..9, cos f0..9 | 0] block

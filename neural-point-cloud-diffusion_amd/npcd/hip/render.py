@@ -226,9 +226,14 @@ SHADE_EVENTS = None
 
 
 def shade_points(wpack: torch.Tensor, feat_dim: int, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch.Tensor,
-                 kp_feat: torch.Tensor, n_points: Optional[torch.Tensor] = None, n_freqs: int = 10, hidden: int = 256):
-    """nb_idx [P,k] int32 (global indices, -1 pad), pts [P,3], kp_pos [B*N,3], kp_feat [B*N,F] -> sigma [P], rgb [P,3]."""
+                 kp_feat: torch.Tensor, n_points: Optional[torch.Tensor] = None, n_freqs: int = 10, hidden: int = 256,
+                 dir_bias: Optional[torch.Tensor] = None, point_ray: Optional[torch.Tensor] = None):
+    """nb_idx [P,k] int32 (global indices, -1 pad), pts [P,3], kp_pos [B*N,3], kp_feat [B*N,F] -> sigma [P], rgb [P,3].
+    use_view_dir (fields/mlp.py:67-70): dir_bias [n_rays, hidden] fp32 = the direction part of the first colour layer's
+    pre-activation per ray, point_ray [P] int32 = the ray of every compact point (npcd_shade_points_dir)."""
     require_gpu(wpack, nb_idx, pts, kp_pos, kp_feat)
+    if (dir_bias is None) != (point_ray is None):
+        raise ValueError("dir_bias and point_ray go together")
     P, k = nb_idx.shape
     dev = pts.device
     nb_idx = nb_idx.to(_i32).contiguous()
@@ -246,8 +251,17 @@ def shade_points(wpack: torch.Tensor, feat_dim: int, nb_idx: torch.Tensor, pts: 
     if SHADE_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    check(L.npcd_shade_points(ptr(wpack), feat_dim, n_freqs, hidden, ptr(nb_idx), ptr(pts), ptr(kp_pos), ptr(kp_feat),
-                              ptr(n_points), P, k, ptr(sigma), ptr(rgb), ptr(work), stream_ptr()), "npcd_shade_points")
+    if dir_bias is None:
+        check(L.npcd_shade_points(ptr(wpack), feat_dim, n_freqs, hidden, ptr(nb_idx), ptr(pts), ptr(kp_pos), ptr(kp_feat),
+                                  ptr(n_points), P, k, ptr(sigma), ptr(rgb), ptr(work), stream_ptr()), "npcd_shade_points")
+    else:
+        require_gpu(dir_bias, point_ray)
+        dir_bias = dir_bias.to(_f32).contiguous()
+        point_ray = point_ray.to(_i32).contiguous()
+        assert dir_bias.shape[1] == hidden and point_ray.shape[0] == P
+        check(L.npcd_shade_points_dir(ptr(wpack), feat_dim, n_freqs, hidden, ptr(nb_idx), ptr(pts), ptr(kp_pos), ptr(kp_feat),
+                                      ptr(n_points), P, k, ptr(sigma), ptr(rgb), ptr(work), ptr(dir_bias), ptr(point_ray),
+                                      stream_ptr()), "npcd_shade_points_dir")
     if ev is not None:
         ev[1].record()
         SHADE_EVENTS.append(ev)

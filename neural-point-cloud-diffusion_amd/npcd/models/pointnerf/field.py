@@ -97,31 +97,55 @@ class Aggregator(nn.Module):
         return torch.arange(n, device=valid_neighbor_mask.device)[:, None].expand_as(valid_neighbor_mask)[valid_neighbor_mask]
 
 
+def encode_dir(d: torch.Tensor, n_freqs: int) -> torch.Tensor:
+    """PositionalEncoder1D of the ray directions (utils/positional_encoder.py:16-20): [d, per coordinate sin(d_c 2^i pi) (i < n),
+    cos(d_c 2^i pi) (i < n)] -> 3 (1 + 2 n) columns; n = 0: the directions as they are (fields/mlp.py:30)."""
+    if n_freqs <= 0:
+        return d
+    spec = d[..., None] * ((2 ** torch.arange(n_freqs, device=d.device)) * torch.pi)
+    return torch.cat((d, torch.cat((spec.sin(), spec.cos()), dim=-1).flatten(start_dim=-2)), dim=-1)
+
+
 class Field(nn.Module):
     def __init__(self, in_dim: int, voxel_grid, aggregator: dict, feat_freqs=0, dir_freqs=8, channel_layers=(256,) * 4,
                  shape_layers=(256,), activation="LeakyReLU", layer_norm=False, nerf=True, use_dir=False, **unused):
         super().__init__()
-        if use_dir or feat_freqs or layer_norm or not nerf:
-            raise NotImplementedError("HIP shading implements the published configuration: use_view_dir=False "
-                                      "(configs/npcd_srncars.yaml:8), feat_freqs=0, layer_norm=False, nerf=True")
+        if feat_freqs or layer_norm or not nerf:
+            raise NotImplementedError("HIP shading implements feat_freqs=0, layer_norm=False, nerf=True (pointnerf.py:155-165)")
         self.aggregator = Aggregator(in_dim, voxel_grid, **aggregator["kwargs"])
         self.hid_dim = self.aggregator.out_dim
-        self.nerf, self.use_dir = nerf, use_dir
-        self.channel_net = define_mlp(list(channel_layers), self.hid_dim, 3, activation)
+        self.nerf, self.use_dir, self.dir_freqs = nerf, use_dir, dir_freqs
+        # use_view_dir (fields/mlp.py:30-36,67-70): the colour head sees [feat | enc(ray direction)]
+        self.dir_dim = (3 * (1 + 2 * dir_freqs) if dir_freqs > 0 else 3) if use_dir else 0
+        self.channel_net = define_mlp(list(channel_layers), self.hid_dim + self.dir_dim, 3, activation)
         self.shape_net = define_mlp(list(shape_layers), self.hid_dim, 1, activation)
         self._pack: Optional[torch.Tensor] = None
         self._pack_key = None
 
     def packed_weights(self, device) -> torch.Tensor:
-        """fp16 fragment-ordered copy of all 12 Linear layers; rebuilt when a parameter changed."""
+        """fp16 fragment-ordered copy of all 12 Linear layers; rebuilt when a parameter changed.  With use_dir the first colour
+        layer is packed without its direction columns (those enter through dir_bias)."""
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._pack is None or key != self._pack_key:
-            self._pack = hr.pack_field_weights(self.state_dict(), self.aggregator.in_dim, device, self.aggregator.n_freqs, self.hid_dim)
+            state = self.state_dict()
+            if self.use_dir:
+                state = dict(state)
+                state["channel_net.0.weight"] = state["channel_net.0.weight"][:, :self.hid_dim]
+            self._pack = hr.pack_field_weights(state, self.aggregator.in_dim, device, self.aggregator.n_freqs, self.hid_dim)
             self._pack_key = key
         return self._pack
 
-    def shade(self, nb_idx, pts, kp_pos, kp_feat):
-        """compact shading points -> sigma [P] (softplus(x-1) applied), rgb [P,3] (sigmoid applied)."""
+    def dir_bias(self, rays_d: torch.Tensor) -> Optional[torch.Tensor]:
+        """rays_d [n_rays, 3] -> [n_rays, hid] fp32: the view-direction part of the first colour layer's pre-activation, the same
+        for every shading point of a ray (enc(d) . W[:, hid:]^T); None without use_dir."""
+        if not self.use_dir:
+            return None
+        w = self.channel_net[0].weight[:, self.hid_dim:]
+        return (encode_dir(rays_d.float(), self.dir_freqs) @ w.detach().float().t()).contiguous()
+
+    def shade(self, nb_idx, pts, kp_pos, kp_feat, dir_bias=None, point_ray=None):
+        """compact shading points -> sigma [P] (softplus(x-1) applied), rgb [P,3] (sigmoid applied).  With use_dir: dir_bias
+        [n_rays, hid] (Field.dir_bias) and point_ray [P] int32, the ray of every compact point."""
         return hr.shade_points(self.packed_weights(pts.device), self.aggregator.in_dim, nb_idx, pts,
                                kp_pos.reshape(-1, 3), kp_feat.reshape(-1, kp_feat.shape[-1]),
-                               n_freqs=self.aggregator.n_freqs, hidden=self.hid_dim)
+                               n_freqs=self.aggregator.n_freqs, hidden=self.hid_dim, dir_bias=dir_bias, point_ray=point_ray)

@@ -11,10 +11,10 @@ class VolumeRenderer(nn.Module):
     def __init__(self, field, cube_scale: float, depth_resolution: int, ray_limits=None, ray_subsamples: int = 0,
                  disparity_space_sampling: bool = False, white_back: bool = False):
         super().__init__()
-        if ray_limits is not None or disparity_space_sampling:
-            raise NotImplementedError("HIP renderer implements the published configuration (pointnerf.py:181-190)")
         self.field = field                     # registered twice like the reference (renderer.py:26) -> duplicated keys
         self.cube_scale, self.depth_resolution = cube_scale, depth_resolution
+        self.ray_limits = None if ray_limits is None else (float(ray_limits[0]), float(ray_limits[1]))    # renderer.py:44-46
+        self.disparity_space_sampling = bool(disparity_space_sampling)                                    # renderer.py:60-68
         self.ray_subsamples, self.white_back = ray_subsamples, white_back
         self.randomize_depth_samples = False
         self.capacity_fraction = 0.25      # compact shading-point buffers: fraction of rays*slots reserved up front ...
@@ -22,37 +22,62 @@ class VolumeRenderer(nn.Module):
         #                                    then the buffers take the worst case (44 B of lists + 512 B of workspace per point)
         self.count_pairs = False           # also report the number of (point, neighbour) pairs (an extra reduction + sync, ~8 % of a view)
 
+    def limits(self, t0: torch.Tensor, t1: torch.Tensor):
+        """Box limits from the ray kernel, or the fixed (near, far) of `ray_limits` for every ray (renderer.py:36-47)."""
+        if self.ray_limits is None:
+            return t0, t1
+        return torch.full_like(t0, self.ray_limits[0]), torch.full_like(t1, self.ray_limits[1])
+
+    def disparity_depths(self, t0: torch.Tensor, t1: torch.Tensor, jitter=None):
+        """renderer.py:60-68: S samples evenly spaced in 1 / depth between the limits, each moved by U(0, 1) of one spacing -- the
+        reference jitters this mode always, also in evaluation.  t0 / t1 [...] -> depths [..., S]; `jitter` [..., S] replays
+        given draws."""
+        S = self.depth_resolution
+        u = torch.arange(S, dtype=torch.float32, device=t0.device) / (S - 1)
+        u = u + (torch.rand(t0.shape + (S,), device=t0.device) if jitter is None else jitter.to(t0.device)) * (1.0 / (S - 1))
+        return 1.0 / (1.0 / t0[..., None] * (1.0 - u) + 1.0 / t1[..., None] * u)
+
     def forward(self, kp_pos, kp_feat, extr, intr, resolution: int, sample: bool, return_channels: bool = True,
                 return_kp_weights: bool = False, knn_mode: int = 0, rng=None):
         """kp_pos [B,N,3], kp_feat [B,N,F], extr [B,T,4,4] world2cam, intr [B,T,3,3] ->
-        AttrDict(mask [B,T,R,1], depth [B,T,R,1], channels [B,T,R,3])   (renderer.py:202-268)."""
+        AttrDict(mask [B,T,R,1], depth [B,T,R,1], channels [B,T,R,3], optional kp_weights [B,T,R,N])   (renderer.py:202-268).
+        rng: dictionary of random draws to replay (tests): ray_perm / jitter / valid_perm in training mode (train_path.py),
+        `jitter_disp` [B,T,R,S] for disparity-space sampling."""
         if sample or self.randomize_depth_samples:
             # training mode (random ray subset, jittered depths, gradients): npcd.models.pointnerf.train_path
             if return_kp_weights or not return_channels:
                 raise NotImplementedError("training-mode rendering returns channels and no key-point weights")
             from .train_path import render_train
             return render_train(self, kp_pos, kp_feat, extr, intr, resolution, sample, rng=rng, knn_mode=knn_mode)
-        if return_kp_weights:
-            raise NotImplementedError("return_kp_weights")
         B, T = extr.shape[:2]
-        agg = self.field.aggregator
+        field, agg = self.field, self.field.aggregator
         grid = agg.voxel_grid
         o, d, t0, t1 = hr.ray_gen(extr.flatten(0, 1), intr.flatten(0, 1), resolution, self.cube_scale)
+        t0, t1 = self.limits(t0, t1)
         R = o.shape[1]
+        Nr = B * T * R
         rays = (o.view(B, T * R, 3), d.view(B, T * R, 3), t0.view(B, T * R), t1.view(B, T * R))
         M = agg.max_shading_pts
-        if knn_mode == 0:
+        dir_bias = field.dir_bias(d.view(-1, 3))           # None unless use_view_dir
+        kp_weights = None
+        if knn_mode == 0 and not self.disparity_space_sampling and not return_kp_weights:
             # fused path: compact shading-point lists are produced on the device; the shading kernels read the
             # point count from device memory, so nothing round-trips through the host until the result is used
+            if dir_bias is not None and not hr.COMPACT_ORDERED:
+                raise RuntimeError("use_view_dir needs the ray-ordered compact lists (NPCD_COMPACT_ORDERED=0 is set)")
             worst = B * T * R * M                              # every slot of every ray valid
             sync_free = worst <= self.sync_free_points
             capacity = worst if sync_free else max(4096, int(worst * self.capacity_fraction))
             while True:
                 counter, ray_base, _, ray_bits, nb, pts = grid.query_compact(agg.k, agg.r, M, rays, self.depth_resolution, capacity,
                                                                            points=kp_pos)
-                sigma, rgb = hr.shade_points(self.field.packed_weights(kp_pos.device), agg.in_dim, nb, pts, kp_pos.reshape(-1, 3),
+                point_ray = None
+                if dir_bias is not None:       # lists are in ray order: row p belongs to the last ray whose base is <= p
+                    point_ray = (torch.searchsorted(ray_base, torch.arange(capacity, dtype=torch.int32, device=ray_base.device),
+                                                    right=True) - 1).clamp_(min=0).to(torch.int32)
+                sigma, rgb = hr.shade_points(field.packed_weights(kp_pos.device), agg.in_dim, nb, pts, kp_pos.reshape(-1, 3),
                                              kp_feat.reshape(-1, kp_feat.shape[-1]), n_points=counter[:1], n_freqs=agg.n_freqs,
-                                             hidden=self.field.hid_dim)
+                                             hidden=field.hid_dim, dir_bias=dir_bias, point_ray=point_ray)
                 mask, depth, chan = hr.ray_march_compact(sigma, rgb, ray_bits, pts, ray_base, o.view(-1, 3), d.view(-1, 3), t1.reshape(-1),
                                                          M, self.white_back)
                 if sync_free:
@@ -66,19 +91,55 @@ class VolumeRenderer(nn.Module):
                 capacity = worst
             n_pairs = int((nb[:int(P)] >= 0).sum()) if self.count_pairs else -1
         else:
-            idx, loc, _, _ = grid.query_dense(agg.k, agg.scaled_r, M, rays=rays, S=self.depth_resolution, mode=knn_mode, points=kp_pos)
-            valid = (idx[..., 0] >= 0).view(B * T * R, M)
+            # dense path: the reference's voxel_grid=None branch (knn_mode 1), explicit sample positions (disparity-space sampling)
+            # and the key-point weights; per-ray slot tables on the device, compaction by torch indexing (host round trips)
+            if self.disparity_space_sampling:
+                jit = None if not rng or "jitter_disp" not in rng else rng["jitter_disp"].reshape(B, T * R, self.depth_resolution)
+                dep = self.disparity_depths(rays[2], rays[3], jit)                                   # [B, T R, S]
+                x = rays[0][:, :, None, :] + dep[..., None] * rays[1][:, :, None, :]
+                idx, loc, _, _ = grid.query_dense(agg.k, agg.scaled_r if knn_mode else agg.r, M, x=x.contiguous(), mode=knn_mode,
+                                                  points=kp_pos)
+            else:
+                idx, loc, _, _ = grid.query_dense(agg.k, agg.scaled_r if knn_mode else agg.r, M, rays=rays, S=self.depth_resolution,
+                                                  mode=knn_mode, points=kp_pos)
+            valid = (idx[..., 0] >= 0).view(Nr, M)
             per_ray = valid.sum(dim=1, dtype=torch.int32)
             base = torch.cumsum(per_ray, dim=0, dtype=torch.int32) - per_ray
-            nb = idx.view(B * T * R, M, agg.k)[valid]                     # compact, row-major over [ray, slot]
-            pts = loc.view(B * T * R, M, 3)[valid]
-            sigma, rgb = self.field.shade(nb, pts, kp_pos, kp_feat)
-            mask, depth, chan = hr.ray_march(sigma, rgb, valid, loc.view(B * T * R, M, 3), base, o.view(-1, 3), d.view(-1, 3),
-                                             t1.reshape(-1), self.white_back)
+            nb = idx.view(Nr, M, agg.k)[valid]                            # compact, row-major over [ray, slot]
+            pts = loc.view(Nr, M, 3)[valid]
+            point_ray = torch.nonzero(valid)[:, 0].to(torch.int32)        # the ray of every compact point
+            sigma, rgb = field.shade(nb, pts, kp_pos, kp_feat, dir_bias, None if dir_bias is None else point_ray)
+            march = (valid, loc.view(Nr, M, 3), base, o.view(-1, 3), d.view(-1, 3), t1.reshape(-1), self.white_back)
+            mask, depth, chan = hr.ray_march(sigma, rgb, *march)
             P, n_pairs = int(nb.shape[0]), int((nb >= 0).sum())
+            if return_kp_weights:
+                kp_weights = self._kp_weights(sigma, rgb, march, nb, pts, point_ray, kp_pos).view(B, T, R, kp_pos.shape[1])
         out = AttrDict(mask=mask.view(B, T, R, 1), depth=depth.view(B, T, R, 1))
         if return_channels:
             out["channels"] = chan.view(B, T, R, 3)
+        if kp_weights is not None:
+            out["kp_weights"] = kp_weights
         out["num_shading_points"] = P
         out["num_pairs"] = n_pairs
         return out
+
+    @staticmethod
+    def _kp_weights(sigma, rgb, march, nb, pts, point_ray, kp_pos):
+        """renderer.py:177-184 + aggregators/mlp.py:84,93-98: per ray and key point, the sum over the ray's shading points of
+        (ray-march weight of the point) x (normalised inverse-distance weight of the pair) -> [Nr, N].  The march weight of a
+        point is d channels[ray, 0] / d rgb[point, 0] -- read off the ray-march backward kernel instead of a second march."""
+        Nr, N = march[0].shape[0], kp_pos.shape[1]
+        with torch.enable_grad():
+            rgb_g = rgb.detach().requires_grad_(True)
+            _, _, chan = hr.ray_march_train(sigma.detach(), rgb_g, *march)
+            w_point = torch.autograd.grad(chan[:, 0].sum(), rgb_g)[0][:, 0]                          # [P]
+        pair = nb >= 0
+        owner = torch.nonzero(pair)[:, 0]
+        flat = nb[pair].long()
+        rel = pts[owner] - kp_pos.reshape(-1, 3)[flat]
+        w = 1.0 / (rel.norm(dim=-1) + 1e-5)
+        norm = torch.zeros(nb.shape[0], device=w.device).index_add_(0, owner, w)
+        w = w / norm[owner]
+        out = torch.zeros(Nr * N, device=w.device)
+        out.index_add_(0, point_ray.long()[owner] * N + flat % N, w_point[owner] * w)
+        return out.view(Nr, N)

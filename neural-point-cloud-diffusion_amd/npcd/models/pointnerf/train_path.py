@@ -148,10 +148,12 @@ def fused_pair_mlp_ok(field, mlp_dtype) -> bool:
             and all(isinstance(lf[i], torch.nn.LeakyReLU) and lf[i].negative_slope == 0.01 for i in (1, 3, 5, 7)))
 
 
-def shade_autograd(field, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch.Tensor, kp_feat: torch.Tensor):
+def shade_autograd(field, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch.Tensor, kp_feat: torch.Tensor,
+                   point_dir: Optional[torch.Tensor] = None):
     """Compact shading points -> sigma [P] (softplus(x - 1)), rgb [P, 3] (sigmoid), differentiable w.r.t. kp_feat and the
     field's parameters.  nb_idx [P, k] global point indices (-1 pad), pts [P, 3]; positions are constants (the point
-    coordinates are frozen in stage 1: pointnerf.py:24,68, aggregators/mlp.py:58-59)."""
+    coordinates are frozen in stage 1: pointnerf.py:24,68, aggregators/mlp.py:58-59).  point_dir [P, 3]: the ray direction of
+    every point, needed with use_view_dir (fields/mlp.py:67-70: the colour head sees [feat | enc(direction)])."""
     agg = field.aggregator
     P, k = nb_idx.shape
     valid = nb_idx >= 0
@@ -176,7 +178,11 @@ def shade_autograd(field, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch
         x0, w = hr.pair_input(kp_feat.reshape(-1, kp_feat.shape[-1]), flat, owner, pts, kp_pos.detach().reshape(-1, 3), agg.n_freqs)
         local = _mlp(agg.local_field, x0, mlp_dtype).float()
         agg_feat = hr.pair_aggregate(local, w, off, cnt)         # weighted mean over each point's pairs (HIP fwd + bwd)
-    shape, chan = _mlp(field.shape_net, agg_feat, mlp_dtype).float(), _mlp(field.channel_net, agg_feat, mlp_dtype).float()
+    chan_in = agg_feat
+    if field.use_dir:
+        from .field import encode_dir
+        chan_in = torch.cat((agg_feat, encode_dir(point_dir, field.dir_freqs)), dim=-1)
+    shape, chan = _mlp(field.shape_net, agg_feat, mlp_dtype).float(), _mlp(field.channel_net, chan_in, mlp_dtype).float()
     sigma = F.softplus(shape - 1.0)[:, 0]
     rgb = torch.sigmoid(chan)
     return sigma, rgb
@@ -228,12 +234,20 @@ def render_train(renderer, kp_pos, kp_feat, extr, intr, resolution: int, sample:
         o, d, t0, t1 = hr.ray_gen(extr.flatten(0, 1), intr.flatten(0, 1), resolution, renderer.cube_scale)
     o, d = o.view(B, T, -1, 3), d.view(B, T, -1, 3)
     Rs = o.shape[2]
+    t0, t1 = renderer.limits(t0, t1)                # fixed (near, far) when the renderer has ray_limits
     start, end = t0.view(B, T, Rs, 1), t1.view(B, T, Rs, 1)
     S = renderer.depth_resolution
     jitter = None
     if renderer.randomize_depth_samples:
         jitter = rng["jitter"].to(dev).reshape(B, T, Rs, S) if "jitter" in rng else torch.rand(B, T, Rs, S, device=dev)
-    dep = jittered_depths(start, end, S, jitter)
+    if renderer.disparity_space_sampling:
+        # renderer.py:60-75: evenly spaced in 1 / depth with a jitter of its own (always), then the training jitter on top
+        jd = rng["jitter_disp"].to(dev).reshape(B, T, Rs, S) if "jitter_disp" in rng else None
+        dep = renderer.disparity_depths(start[..., 0], end[..., 0], jd)
+        if jitter is not None:
+            dep = dep + jitter * ((end - start) / (S - 1))
+    else:
+        dep = jittered_depths(start, end, S, jitter)
     x = o[..., None, :] + dep[..., None] * d[..., None, :]                       # [B,T,Rs,S,3]
     M = agg.max_shading_pts
     grid = agg.voxel_grid
@@ -252,7 +266,8 @@ def render_train(renderer, kp_pos, kp_feat, extr, intr, resolution: int, sample:
     idx_s, loc_s, valid_s = idx.view(-1, M, agg.k)[sel], loc.view(-1, M, 3)[sel], slot_valid.view(-1, M)[sel]
     rows = torch.nonzero(valid_s, as_tuple=True)                                 # valid (ray, slot) cells, row-major
     nb, pts = idx_s[rows], loc_s[rows]
-    sigma_c, rgb_c = shade_autograd(field, nb, pts, kp_pos, kp_feat)
+    point_dir = d.reshape(-1, 3)[sel][rows[0]] if field.use_dir else None       # the ray direction of every compact point
+    sigma_c, rgb_c = shade_autograd(field, nb, pts, kp_pos, kp_feat, point_dir)
     # ray march on the compact densities / colours, HIP forward and backward (no dense scatter, no per-slot depth tensors)
     per_ray = valid_s.sum(dim=1, dtype=torch.int32)
     base = torch.cumsum(per_ray, 0, dtype=torch.int32) - per_ray

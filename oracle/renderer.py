@@ -214,9 +214,10 @@ def psnr(pred: torch.Tensor, target: torch.Tensor, data_range: float = 1.0) -> f
     return float("inf") if mse == 0 else 10.0 * math.log10(data_range ** 2 / mse)
 
 
-def init_field_params(feats_dim: int = 32, seed: int = 0, n_freqs: int = 10, hidden: int = 256) -> Params:
+def init_field_params(feats_dim: int = 32, seed: int = 0, n_freqs: int = 10, hidden: int = 256, dir_dim: int = 0) -> Params:
     """Synthetic PointNeRF field weights with PyTorch's default nn.Linear init (the reference builds
-    its MLPs with utils/model.py:22-36 and never re-initialises them)."""
+    its MLPs with utils/model.py:22-36 and never re-initialises them).  dir_dim: extra input columns of the first colour
+    layer (use_view_dir: 51 = 3 (1 + 2 x 8 frequencies), fields/mlp.py:33-35)."""
     g = torch.Generator().manual_seed(seed)
     p: Params = {}
 
@@ -232,7 +233,7 @@ def init_field_params(feats_dim: int = 32, seed: int = 0, n_freqs: int = 10, hid
     lin("shape_net.0", hidden, hidden)                                    # pointnerf.py:162
     lin("shape_net.2", 1, hidden)
     for n in range(4):                                                    # pointnerf.py:161
-        lin(f"channel_net.{2 * n}", hidden, hidden)
+        lin(f"channel_net.{2 * n}", hidden, hidden + (dir_dim if n == 0 else 0))
     lin("channel_net.8", 3, hidden)
     return p
 

@@ -181,18 +181,18 @@ def gen_diffusion(ref):
 
 
 # --------------------------------------------------------------------------------------------
-def build_field(ref, feats_dim, k=8, r=0.08, M=50, seed=0):
+def build_field(ref, feats_dim, k=8, r=0.08, M=50, seed=0, use_dir=False):
     ED = ref.EasyDict
     agg = ED(network="MLP", kwargs=ED(k=k, r=r, max_shading_pts=M, ray_subsamples=128, n_freqs=10, freq_mult=1,
                                       out_dim=256, layers=[256, 256, 256, 256], activation="LeakyReLU",
                                       layer_norm=False))
     field = ref.fields.MLP(feats_dim, None, agg, feat_freqs=0, dir_freqs=8, channel_layers=[256, 256, 256, 256],
-                           shape_layers=[256], activation="LeakyReLU", layer_norm=False, use_dir=False, nerf=True)
+                           shape_layers=[256], activation="LeakyReLU", layer_norm=False, use_dir=use_dir, nerf=True)
     # weights come from the oracle's deterministic initialiser (CPU torch.Generator), so the fixture
     # only needs to carry a checksum instead of 2.4 MB of weights
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
     from oracle.renderer import init_field_params
-    missing, unexpected = field.load_state_dict(init_field_params(feats_dim, seed=seed), strict=True)
+    missing, unexpected = field.load_state_dict(init_field_params(feats_dim, seed=seed, dir_dim=51 if use_dir else 0), strict=True)
     return field.eval()
 
 
@@ -299,6 +299,42 @@ def gen_render(ref, ref_root):
     save("unflatten", channels=ch, image=ref.util.unflatten_pred(ch))
 
 
+def gen_render_options(ref, ref_root):
+    """The renderer options outside the published configuration (models/npcd.py:8 use_view_dir; renderers/renderer.py:20-23,
+    36-47,177-184,198): the reference's own voxel_grid=None branch with each option on, same small scene as render_brute."""
+    poses = torch.from_numpy(np.load(os.path.join(ref_root, "data/srncars_test_poses.npy")))
+    intr = torch.from_numpy(np.load(os.path.join(ref_root, "data/srncars_test_intrinsics.npy"))).float()
+    F_, N, res, S, M, k, r = 32, 64, 16, 32, 12, 8, 0.08
+    coords, feats = ellipsoid_cloud(N, F_, seed=1)
+    K = intr[:1].clone(); K[:, 0, 0] = K[:, 1, 1] = 131.25 * res / 128; K[:, 0, 2] = K[:, 1, 2] = res / 2
+    extr = poses[[0, 100]][None]
+    Kb = K[None].expand(1, 2, 3, 3).contiguous()
+    arrays = {"coords": coords, "feats": feats, "extr": extr, "intr": Kb, "res": res, "S": S, "M": M, "k": k, "r": r, "field_seed": 5}
+    with torch.no_grad():
+        # (a) view directions in the colour head
+        field = build_field(ref, F_, k=k, r=r, M=M, seed=5, use_dir=True)
+        ren = ref.renderers.VolumeRenderer(field, cube_scale=1.0, depth_resolution=S, white_back=True).eval()
+        out = ren(coords, feats, extr, Kb, res, sample=False)
+        arrays.update(dir_mask=out["mask"], dir_depth=out["depth"], dir_channels=out["channels"])
+        # (b) fixed ray limits, (c) composite key-point weights
+        field = build_field(ref, F_, k=k, r=r, M=M, seed=5)
+        ren = ref.renderers.VolumeRenderer(field, cube_scale=1.0, depth_resolution=S, white_back=True, ray_limits=(0.85, 1.8)).eval()
+        out = ren(coords, feats, extr, Kb, res, sample=False)
+        arrays.update(lim_near=0.85, lim_far=1.8, lim_mask=out["mask"], lim_depth=out["depth"], lim_channels=out["channels"])
+        ren = ref.renderers.VolumeRenderer(field, cube_scale=1.0, depth_resolution=S, white_back=True).eval()
+        out = ren(coords, feats, extr, Kb, res, sample=False, return_kp_weights=True)
+        arrays.update(kpw=out["kp_weights"], kpw_mask=out["mask"], kpw_channels=out["channels"])
+        # (d) disparity-space sampling: record whether the reference's branch runs at all
+        ren = ref.renderers.VolumeRenderer(field, cube_scale=1.0, depth_resolution=S, white_back=True, disparity_space_sampling=True).eval()
+        try:
+            ren(coords, feats, extr, Kb, res, sample=False)
+            arrays["disparity_runs"] = 1
+        except RuntimeError as e:
+            print("disparity_space_sampling in the reference raises:", str(e)[:200])
+            arrays["disparity_runs"] = 0
+    save("render_options", **arrays)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -312,6 +348,7 @@ def main():
     gen_diffusion(ref)
     gen_rays(ref, args.ref)
     gen_render(ref, args.ref)
+    gen_render_options(ref, args.ref)
 
 
 if __name__ == "__main__":
