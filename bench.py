@@ -214,7 +214,19 @@ class ClockSampler:
         self._stop = threading.Event()
         self._thread = None
         cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-        self.sclk_file = cards[min(local_rank, len(cards) - 1)] if cards else None
+        self.sclk_file = None
+        # the DRM card of THIS rank's device, by PCI address (a box may expose one GPU of several: card0 is then somebody else's)
+        try:
+            pr = torch.cuda.get_device_properties(local_rank)
+            want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+            for c in cards:
+                if os.path.basename(os.path.realpath(os.path.dirname(c))).startswith(want):
+                    self.sclk_file = c
+        except (AttributeError, RuntimeError, AssertionError):
+            pass
+        self.matched_by_pci = self.sclk_file is not None
+        if self.sclk_file is None and cards:
+            self.sclk_file = cards[min(local_rank, len(cards) - 1)]
         self.power_file = None
         if self.sclk_file:
             dev = os.path.dirname(self.sclk_file)
@@ -259,6 +271,7 @@ class ClockSampler:
             return None
         q = lambda v: [min(v), sorted(v)[len(v) // 2], max(v)]
         out = {"sclk_mhz_min_median_max": q(self.sclk), "samples": len(self.sclk), "source": self.sclk_file,
+               "device_matched_by_pci_address": self.matched_by_pci,
                "note": "amdgpu sysfs DPM state sampled every 20 ms by a host thread during the timed loop; reads above the in-kernel clock under MFMA load"}
         if self.power:
             out["board_power_w_min_median_max"] = q(self.power)

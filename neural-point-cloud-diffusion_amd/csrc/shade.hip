@@ -40,7 +40,7 @@ __device__ __forceinline__ int act_off(int row, int chunk) { return row * kRowBy
 // NB (the number of 32-row blocks that hold packed rows) is a COMPILE-TIME parameter: as a run-time bound inside the k-loop it
 // split the loop body into one basic block per row block -- LDS read, wait, two matrix instructions, branch -- so that no read
 // was ever in flight behind a matrix instruction (round 2: the kernel ran at the latency of its LDS reads).
-template <int KSTEPS, int UNROLL = 4, int NB = 4>
+template <int KSTEPS, int UNROLL = 4, int NB = 4, int PF = 1>
 __device__ __forceinline__ void layer_mfma(const unsigned char* H, const unsigned char* wfrag, const float* bias, int wave, int lane,
                                            f32x16 (&acc)[2][4]) {
     const int r = lane & 31, hh = lane >> 5;
@@ -60,6 +60,30 @@ __device__ __forceinline__ void layer_mfma(const unsigned char* H, const unsigne
     const f16x8* w0 = reinterpret_cast<const f16x8*>(wfrag + (int64_t)(2 * wave) * KSTEPS * kFragBytes) + lane;
     const f16x8* w1 = reinterpret_cast<const f16x8*>(wfrag + (int64_t)(2 * wave + 1) * KSTEPS * kFragBytes) + lane;
     const unsigned char* hb = H + r * kRowBytes + hh * 16;      // B operand: row (cb*32 + r), chunk 2s + hh -> hb + const
+    if constexpr (PF > 1) {
+        // weight fragments PF k-steps ahead through a ring of 4 register pairs (the one-step form below leaves the loop at the
+        // latency of an L2 hit per k-step when few row blocks share a fragment)
+        static_assert(PF <= 3 && KSTEPS % 4 == 0, "ring of four");
+        f16x8 ra[4], rb[4];
+#pragma unroll
+        for (int d = 0; d < PF; ++d) { ra[d] = w0[d * 64]; rb[d] = w1[d * 64]; }
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            if (s + PF < KSTEPS) {
+                ra[(s + PF) & 3] = w0[(s + PF) * 64];
+                rb[(s + PF) & 3] = w1[(s + PF) * 64];
+            }
+            f16x8 b[NB];
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) b[cb] = *reinterpret_cast<const f16x8*>(hb + cb * 32 * kRowBytes + s * 32);
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+                acc[0][cb] = F16::mfma32(ra[s & 3], b[cb], acc[0][cb]);
+                acc[1][cb] = F16::mfma32(rb[s & 3], b[cb], acc[1][cb]);
+            }
+        }
+        return;
+    }
     f16x8 a0 = w0[0], a1 = w1[0];
 #pragma unroll UNROLL
     for (int s = 0; s < KSTEPS; ++s) {
@@ -320,127 +344,185 @@ __device__ __forceinline__ float softplus_m1(float x) {
     return x > 20.f ? x : log1pf(expf(x));  // F.softplus(beta=1, threshold=20)
 }
 
-template <bool DIR>
-__global__ __launch_bounds__(256, 2) void shade_points_kernel(ShadeArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
-    unsigned char* H = dsmem;
-    float* red = reinterpret_cast<float*>(dsmem + kRows * kRowBytes);  // [4 waves][128 rows][4]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+#ifndef NPCD_POINTS_PF
+#define NPCD_POINTS_PF 3
+#endif
+#ifdef NPCD_POINTS_TL          // DIAGNOSTIC: s_memtime stamps of the first pass of workgroup NPCD_POINTS_TL, wave 0
+__device__ long long g_points_tl[32];
+#define NPCD_PTS(i) do { if (blockIdx.x == NPCD_POINTS_TL && tid == 0 && g_points_tl[31] == 0) g_points_tl[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define NPCD_PTS(i) do { } while (0)
+#endif
+// One pass of the point-level layers over NB 32-row blocks (rows row0 .. row0 + 32 NB of the compact lists).
+struct PointsArgs {          // what a pass needs of ShadeArgs, passed BY VALUE (a reference to the kernel argument would be a scratch copy)
+    const unsigned char* wpack;
+    const _Float16* G;
+    float *sigma, *rgb;
+    const float* dir_bias;
+    const int32_t* point_ray;
+    int feat_dim;
+    int red_rows;    // rows per wave plane of the reduction buffer (32 x the kernel's largest pass)
+};
+// (not inlined: four inlined variants inside the range loop made the register allocator spill 64-92 registers)
+template <bool DIR, int NB>
+__device__ __noinline__ void points_pass(PointsArgs a, unsigned char* H, float* red, int row0, int P, int tid) {
     const ShadeLayout L = shade_layout(a.feat_dim);
-    const int P = min(*a.n_points, a.max_points);
-    const int ntiles = (P + kRows - 1) / kRows;
+    const int lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const float* s1 = reinterpret_cast<const float*>(a.wpack + L.s1);
     const float* c4 = reinterpret_cast<const float*>(a.wpack + L.c4);
-
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        // ---- load the aggregated features of 128 points -------------------------------------
+    NPCD_PTS(0);
+    // ---- load the aggregated features of 32 NB points ---------------------------------------
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int cidx = it * 256 + tid, row = cidx >> 5, chunk = cidx & 31;
-            const int p = tile * kRows + row;
-            u32x4 v = {0, 0, 0, 0};
-            if (p < P) v = *reinterpret_cast<const u32x4*>(a.G + (int64_t)p * kHidden + chunk * 8);
-            *reinterpret_cast<u32x4*>(H + act_off(row, chunk)) = v;
+    for (int it = 0; it < 4 * NB; ++it) {
+        const int cidx = it * 256 + tid, row = cidx >> 5, chunk = cidx & 31;
+        const int p = row0 + row;
+        u32x4 v = {0, 0, 0, 0};
+        if (p < P) v = *reinterpret_cast<const u32x4*>(a.G + (int64_t)p * kHidden + chunk * 8);
+        *reinterpret_cast<u32x4*>(H + act_off(row, chunk)) = v;
+    }
+    __syncthreads();
+    NPCD_PTS(1);
+    f32x16 acc[2][4];
+    // ---- last aggregator layer (linear): feat ------------------------------------------
+    layer_mfma<16, 4, NB, NPCD_POINTS_PF>(H, a.wpack + L.w[4], reinterpret_cast<const float*>(a.wpack + L.bias[4]), wave, lane, acc);
+    NPCD_PTS(2);
+    __syncthreads();
+    NPCD_PTS(3);
+    layer_store<false, NB>(H, wave, lane, acc);
+    NPCD_PTS(4);
+    __syncthreads();
+    NPCD_PTS(5);
+    // ---- density head: Linear(256,256) + LeakyReLU + Linear(256,1), softplus(x - 1) ------
+    layer_mfma<16, 4, NB, NPCD_POINTS_PF>(H, a.wpack + L.w[5], reinterpret_cast<const float*>(a.wpack + L.bias[5]), wave, lane, acc);
+    {
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            float part = 0.f;
+#pragma unroll
+            for (int oi = 0; oi < 2; ++oi)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float x = acc[oi][cb][i];
+                    x = x > 0.f ? x : kLeaky * x;
+                    part += x * s1[(2 * wave + oi) * 32 + acc_row(i, hh)];
+                }
+            part += swap_half(part);
+            if (hh == 0) red[(wave * a.red_rows + cb * 32 + r) * 4 + 3] = part;
         }
-        __syncthreads();
-        f32x16 acc[2][4];
-        // ---- last aggregator layer (linear): feat ------------------------------------------
-        layer_mfma<16>(H, a.wpack + L.w[4], reinterpret_cast<const float*>(a.wpack + L.bias[4]), wave, lane, acc);
-        __syncthreads();
-        layer_store<false>(H, wave, lane, acc);
-        __syncthreads();
-        // ---- density head: Linear(256,256) + LeakyReLU + Linear(256,1), softplus(x - 1) ------
-        layer_mfma<16>(H, a.wpack + L.w[5], reinterpret_cast<const float*>(a.wpack + L.bias[5]), wave, lane, acc);
-        {
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                float part = 0.f;
-#pragma unroll
-                for (int oi = 0; oi < 2; ++oi)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        float x = acc[oi][cb][i];
-                        x = x > 0.f ? x : kLeaky * x;
-                        part += x * s1[(2 * wave + oi) * 32 + acc_row(i, hh)];
-                    }
-                part += swap_half(part);
-                if (hh == 0) red[(wave * kRows + cb * 32 + r) * 4 + 3] = part;
-            }
-        }
-        // (H still holds feat: the density pass did not write activations)
-        // ---- colour head: 4 x [Linear(256,256) + LeakyReLU] + Linear(256,3), sigmoid ----------
+    }
+    NPCD_PTS(6);
+    // (H still holds feat: the density pass did not write activations)
+    // ---- colour head: 4 x [Linear(256,256) + LeakyReLU] + Linear(256,3), sigmoid ----------
 #pragma unroll 1
-        for (int l = 0; l < 4; ++l) {
-            // (closed form instead of L.w[6 + l] / L.bias[6 + l]: see pair_layers)
-            const int64_t w_off = L.w[6] + (int64_t)l * (8 * (kHidden / 16) * kFragBytes), b_off = L.bias[6] + (int64_t)l * (kHidden * 4);
-            layer_mfma<16>(H, a.wpack + w_off, reinterpret_cast<const float*>(a.wpack + b_off), wave, lane, acc);
-            if (DIR && l == 0) {       // + the view-direction part of the first colour layer (per ray, fp32)
+    for (int l = 0; l < 4; ++l) {
+        // (closed form instead of L.w[6 + l] / L.bias[6 + l]: see pair_layers)
+        const int64_t w_off = L.w[6] + (int64_t)l * (8 * (kHidden / 16) * kFragBytes), b_off = L.bias[6] + (int64_t)l * (kHidden * 4);
+        layer_mfma<16, 4, NB, NPCD_POINTS_PF>(H, a.wpack + w_off, reinterpret_cast<const float*>(a.wpack + b_off), wave, lane, acc);
+        if (DIR && l == 0) {       // + the view-direction part of the first colour layer (per ray, fp32)
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    const int p = tile * kRows + cb * 32 + r;
-                    const float* db = a.dir_bias + (int64_t)(p < P ? a.point_ray[p] : 0) * kHidden + 4 * hh;
-#pragma unroll
-                    for (int oi = 0; oi < 2; ++oi)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const f32x4 v = *reinterpret_cast<const f32x4*>(db + (2 * wave + oi) * 32 + 8 * g);
-#pragma unroll
-                            for (int b = 0; b < 4; ++b) acc[oi][cb][4 * g + b] += v[b];
-                        }
-                }
-            }
-            if (l < 3) {
-                __syncthreads();
-                layer_store<true>(H, wave, lane, acc);
-                __syncthreads();
-            }
-        }
-        {
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) {
-                float pr = 0.f, pg = 0.f, pb = 0.f;
+            for (int cb = 0; cb < NB; ++cb) {
+                const int p = row0 + cb * 32 + r;
+                const float* db = a.dir_bias + (int64_t)(p < P ? a.point_ray[p] : 0) * kHidden + 4 * hh;
 #pragma unroll
                 for (int oi = 0; oi < 2; ++oi)
 #pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        float x = acc[oi][cb][i];
-                        x = x > 0.f ? x : kLeaky * x;
-                        const int o = (2 * wave + oi) * 32 + acc_row(i, hh);
-                        pr += x * c4[o];
-                        pg += x * c4[kHidden + o];
-                        pb += x * c4[2 * kHidden + o];
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(db + (2 * wave + oi) * 32 + 8 * g);
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[oi][cb][4 * g + b] += v[b];
                     }
-                pr += swap_half(pr);
-                pg += swap_half(pg);
-                pb += swap_half(pb);
-                if (hh == 0) {
-                    float* q = red + (wave * kRows + cb * 32 + r) * 4;
-                    q[0] = pr; q[1] = pg; q[2] = pb;
-                }
             }
         }
-        __syncthreads();
-        if (tid < kRows) {
-            const int p = tile * kRows + tid;
-            if (p < P) {
-                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        NPCD_PTS(7 + 4 * l);
+        if (l < 3) {
+            __syncthreads();
+            NPCD_PTS(8 + 4 * l);
+            layer_store<true, NB>(H, wave, lane, acc);
+            NPCD_PTS(9 + 4 * l);
+            __syncthreads();
+            NPCD_PTS(10 + 4 * l);
+        }
+    }
+    {
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(red + (w * kRows + tid) * 4);
-                    t += v;
+        for (int cb = 0; cb < NB; ++cb) {
+            float pr = 0.f, pg = 0.f, pb = 0.f;
+#pragma unroll
+            for (int oi = 0; oi < 2; ++oi)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    float x = acc[oi][cb][i];
+                    x = x > 0.f ? x : kLeaky * x;
+                    const int o = (2 * wave + oi) * 32 + acc_row(i, hh);
+                    pr += x * c4[o];
+                    pg += x * c4[kHidden + o];
+                    pb += x * c4[2 * kHidden + o];
                 }
-                a.sigma[p] = softplus_m1(t[3] + s1[kHidden]);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) a.rgb[(int64_t)p * 3 + c] = 1.f / (1.f + expf(-(t[c] + c4[3 * kHidden + c])));
+            pr += swap_half(pr);
+            pg += swap_half(pg);
+            pb += swap_half(pb);
+            if (hh == 0) {
+                float* q = red + (wave * a.red_rows + cb * 32 + r) * 4;
+                q[0] = pr; q[1] = pg; q[2] = pb;
             }
         }
-        __syncthreads();
+    }
+    NPCD_PTS(21);
+    __syncthreads();
+    if (tid < 32 * NB) {
+        const int p = row0 + tid;
+        if (p < P) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(red + (w * a.red_rows + tid) * 4);
+                t += v;
+            }
+            a.sigma[p] = softplus_m1(t[3] + s1[kHidden]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.rgb[(int64_t)p * 3 + c] = 1.f / (1.f + expf(-(t[c] + c4[3 * kHidden + c])));
+        }
+    }
+    __syncthreads();
+    NPCD_PTS(20);
+    NPCD_PTS(31);
+}
+
+// kernel B: the point-level layers.  The compact points are cut into 32-row blocks and the blocks are dealt out EVENLY:
+// workgroup i takes the contiguous range [i q + min(i, rem), ...) of q or q + 1 blocks and walks it in passes of at most four blocks
+// (128 rows), the passes of a range as equal as possible (5 blocks = 3 + 2).  (Until round 3 the grid strode over 128-row tiles:
+// 584 tiles of a 128^2 view on 512 resident workgroups are two rounds for 1.14 rounds of work.)
+template <bool DIR, int MAXNB>
+__global__ __launch_bounds__(256, MAXNB == 4 ? 2 : 4) void shade_points_kernel(ShadeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+    unsigned char* H = dsmem;
+    float* red = reinterpret_cast<float*>(dsmem + MAXNB * 32 * kRowBytes);  // [4 waves][32 MAXNB rows][4]
+    const int tid = threadIdx.x;
+    const PointsArgs pa{a.wpack, a.G, a.sigma, a.rgb, a.dir_bias, a.point_ray, a.feat_dim, 32 * MAXNB};
+    const int P = min(*a.n_points, a.max_points);
+    const int nblk = (P + 31) >> 5, q = nblk / (int)gridDim.x, rem = nblk % (int)gridDim.x;
+    int b = (int)blockIdx.x * q + min((int)blockIdx.x, rem);
+    int left = q + ((int)blockIdx.x < rem ? 1 : 0);
+    while (left > 0) {
+        const int passes = (left + MAXNB - 1) / MAXNB, nb = (left + passes - 1) / passes;
+        if (MAXNB == 4 && nb >= 4) points_pass<DIR, MAXNB == 4 ? 4 : 1>(pa, H, red, b * 32, P, tid);
+        else if (MAXNB == 4 && nb == 3) points_pass<DIR, MAXNB == 4 ? 3 : 1>(pa, H, red, b * 32, P, tid);
+        else if (nb == 2) points_pass<DIR, 2>(pa, H, red, b * 32, P, tid);
+        else points_pass<DIR, 1>(pa, H, red, b * 32, P, tid);
+        b += nb;
+        left -= nb;
     }
 }
 
 }  // namespace npcd
 
 using namespace npcd;
+
+#ifdef NPCD_POINTS_TL
+extern "C" int npcd_points_debug_read(long long* out, int count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(npcd::g_points_tl), sizeof(long long) * count);
+}
+#endif
 
 static int shade_check(int feat_dim, int n_freqs, int hidden) {
     if (hidden != kHidden || n_freqs != kNFreqs) return NPCD_ERR_UNSUPPORTED;
@@ -553,16 +635,24 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
     a.dir_bias = dir_bias; a.point_ray = point_ray;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int ldsA = kRows * kRowBytes + kRows * 4 + 32 * 4;   // activations, row weights, per-point packed-row ranges
-    const int ldsB = kRows * kRowBytes + 4 * kRows * 4 * 4;
-    static DynLds lds_a32, lds_a128, lds_b, lds_bd;
+    // kernel B with 128-row passes at two workgroups per CU, or (NPCD_POINTS_NB2=1) 64-row passes at four
+    static const bool nb2 = getenv("NPCD_POINTS_NB2") != nullptr;
+    const int ldsB = (nb2 ? 64 : kRows) * (kRowBytes + 4 * 4 * 4);
+    static DynLds lds_a32, lds_a128, lds_b, lds_bd, lds_b2, lds_bd2;
     NPCD_HIP_CHECK(lds_a32.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<32>), ldsA));
     NPCD_HIP_CHECK(lds_a128.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<128>), ldsA));
-    NPCD_HIP_CHECK(lds_b.ensure(reinterpret_cast<const void*>(shade_points_kernel<false>), ldsB));
-    NPCD_HIP_CHECK(lds_bd.ensure(reinterpret_cast<const void*>(shade_points_kernel<true>), ldsB));
+    if (nb2) {
+        NPCD_HIP_CHECK(lds_b2.ensure(reinterpret_cast<const void*>(shade_points_kernel<false, 2>), ldsB));
+        NPCD_HIP_CHECK(lds_bd2.ensure(reinterpret_cast<const void*>(shade_points_kernel<true, 2>), ldsB));
+    } else {
+        NPCD_HIP_CHECK(lds_b.ensure(reinterpret_cast<const void*>(shade_points_kernel<false, 4>), ldsB));
+        NPCD_HIP_CHECK(lds_bd.ensure(reinterpret_cast<const void*>(shade_points_kernel<true, 4>), ldsB));
+    }
     // persistent-style grids: 2 workgroups per CU, tiles strided over the grid; the tile count is
     // read from device memory so that no host round trip is needed after the neighbour query
-    const int tilesA = (max_points + 15) / 16, tilesB = (max_points + kRows - 1) / kRows;
-    const int gridA = tilesA < 512 ? tilesA : 512, gridB = tilesB < 512 ? tilesB : 512;
+    const int tilesA = (max_points + 15) / 16, tilesB = (max_points + 31) / 32;       // B: 32-row blocks, dealt out evenly
+    const int slotsB = nb2 ? 1024 : 512;
+    const int gridA = tilesA < 512 ? tilesA : 512, gridB = tilesB < slotsB ? tilesB : slotsB;
     // kernel A: LDS tiles of 16 points (below), or with NPCD_SHADE_ROWS=1 the rows form (shade_rows.hip: activations in registers;
     // opt-in: as fast, but its matrix-product aggregation adds a point's rows in an order that depends on where the point sits in
     // the compact lists, so two renders agree to fp16 rounding instead of bit for bit -- DESIGN.md 5.3).  Read per call.
@@ -572,8 +662,13 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
         if (rc != NPCD_OK) return rc;
     } else if (feat_dim == 32) hipLaunchKernelGGL(shade_pairs_kernel<32>, dim3(gridA), dim3(256), ldsA, st, a);
     else hipLaunchKernelGGL(shade_pairs_kernel<128>, dim3(gridA), dim3(256), ldsA, st, a);
-    if (dir_bias) hipLaunchKernelGGL(shade_points_kernel<true>, dim3(gridB), dim3(256), ldsB, st, a);
-    else hipLaunchKernelGGL(shade_points_kernel<false>, dim3(gridB), dim3(256), ldsB, st, a);
+    if (nb2) {
+        if (dir_bias) hipLaunchKernelGGL((shade_points_kernel<true, 2>), dim3(gridB), dim3(256), ldsB, st, a);
+        else hipLaunchKernelGGL((shade_points_kernel<false, 2>), dim3(gridB), dim3(256), ldsB, st, a);
+    } else {
+        if (dir_bias) hipLaunchKernelGGL((shade_points_kernel<true, 4>), dim3(gridB), dim3(256), ldsB, st, a);
+        else hipLaunchKernelGGL((shade_points_kernel<false, 4>), dim3(gridB), dim3(256), ldsB, st, a);
+    }
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }
