@@ -214,7 +214,11 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
     long long tl[16];
     for (int i = 0; i < 16; ++i) tl[i] = 0;
 #endif
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // Tiles differ in cost (1-4 occupied row blocks) and a 128^2 view has ~9.1 tiles per resident workgroup: handed out through
+    // a counter the kernel ends when the LAST tile ends, not when the unluckiest stride does.
+    int* next_tile = pcount + 16;
+    for (int tile = blockIdx.x; tile < ntiles;) {
+        if (tid == 0) *next_tile = a.tile_counter ? (int)gridDim.x + atomicAdd(a.tile_counter, 1) : tile + (int)gridDim.x;
         NPCD_STS(0);
         // ---- prologue: build the layer-0 input rows -------------------------------------------
         // The tile's 16 x 8 (point, slot) candidates are PACKED: a valid pair takes the row number "valid pairs before
@@ -320,6 +324,8 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
         NPCD_STS(12);
         __syncthreads();
         NPCD_STS(13);
+        tile = *next_tile;          // written at the top of this iteration, several barriers ago
+        __syncthreads();            // ... and not overwritten before every thread has read it
     }
 #ifdef NPCD_SHADE_TL
     if (tl_on && lane == 0)
@@ -537,7 +543,7 @@ extern "C" int64_t npcd_shade_wpack_bytes(int feat_dim, int n_freqs, int hidden)
 
 extern "C" int64_t npcd_shade_workspace_bytes(int max_points, int hidden) {
     if (hidden != kHidden || max_points < 0) return -1;
-    return (int64_t)(max_points + kRows) * kHidden * 2 + shade_rows_workspace_bytes(max_points);
+    return (int64_t)(max_points + kRows) * kHidden * 2 + shade_rows_workspace_bytes(max_points) + 16;      // + the tile counter
 }
 
 // fragment order: [out block ob][k-step s][lane][8]  with  element = W[ob*32 + (lane&31)][16 s + 8 (lane>>5) + j]
@@ -634,7 +640,13 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
     a.sigma = sigma; a.rgb = rgb;
     a.dir_bias = dir_bias; a.point_ray = point_ray;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int ldsA = kRows * kRowBytes + kRows * 4 + 32 * 4;   // activations, row weights, per-point packed-row ranges
+    static const bool static_tiles = getenv("NPCD_SHADE_STATIC_TILES") != nullptr;
+    if (!static_tiles) {
+        a.tile_counter = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(workspace) + (int64_t)(max_points + kRows) * kHidden * 2 +
+                                                    shade_rows_workspace_bytes(max_points));
+        NPCD_HIP_CHECK(hipMemsetAsync(a.tile_counter, 0, sizeof(int32_t), st));
+    }
+    const int ldsA = kRows * kRowBytes + kRows * 4 + 32 * 4 + 16;   // activations, row weights, per-point packed-row ranges, next tile
     // kernel B with 128-row passes at two workgroups per CU, or (NPCD_POINTS_NB2=1) 64-row passes at four
     static const bool nb2 = getenv("NPCD_POINTS_NB2") != nullptr;
     const int ldsB = (nb2 ? 64 : kRows) * (kRowBytes + 4 * 4 * 4);

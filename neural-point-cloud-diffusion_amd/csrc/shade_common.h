@@ -56,6 +56,9 @@ struct ShadeArgs {
     // enc(d) . W[:, 256:]^T) together with the ray of every compact point; nullptr = published configuration (no view direction)
     const float* dir_bias;
     const int32_t* point_ray;
+    // pair kernel: next tile to hand out (zeroed before the launch; nullptr = tiles strided over the grid).  A workgroup takes
+    // tile blockIdx.x first and then whatever the counter says: which workgroup computes a tile changes nothing about its result
+    int32_t* tile_counter;
 };
 
 // ---- positional-encoding column q (0..63) of the [x_rel(3) | per coord: sin f0..9, cos f0..9 | 0] block
