@@ -102,6 +102,35 @@ def _wgrad(dy, x, out):
         torch.sum(part, dim=0, out=out)
 
 
+# A/B switch (measured, not the default: docs/experiments.md R3.9): the weight gradients of a block on a second HIP stream, beside
+# the HBM-bound GELU / LayerNorm backward kernels of the critical path.  NPCD_WGRAD_STREAM=1, NPCD_WGRAD_STREAM_PRIO=<priority>.
+_WGRAD_STREAM = bool(os.environ.get("NPCD_WGRAD_STREAM"))
+_side = {}
+
+
+def _side_stream(device):
+    s = _side.get(device)
+    if s is None:
+        s = _side[device] = torch.cuda.Stream(device=device, priority=int(os.environ.get("NPCD_WGRAD_STREAM_PRIO", "0")))
+    return s
+
+
+def _wgrad_maybe_async(dy, x, out):
+    if not _WGRAD_STREAM:
+        return _wgrad(dy, x, out)
+    side = _side_stream(dy.device)
+    side.wait_stream(torch.cuda.current_stream())
+    dy.record_stream(side)
+    x.record_stream(side)
+    with torch.cuda.stream(side):
+        _wgrad(dy, x, out)
+
+
+def _wgrad_join(device):
+    if _WGRAD_STREAM:
+        torch.cuda.current_stream().wait_stream(_side_stream(device))
+
+
 class FusedBackboneEngine:
     """Views into the flat fp32 parameter / gradient buffers and the bf16 shadow for every block."""
 
@@ -249,18 +278,18 @@ class _BackboneFn(torch.autograd.Function):
                 sums = ew.ColsumBatch()            # this block's 8 bias / LN-affine column sums: one finalize
                 # ---- MLP branch: x3 = x2 + c_proj(gelu(c_fc(ln_2(x2)))) ------------------------------
                 dg = _dgrad(dxb, e["mlp_c_proj_weight_16"])
-                _wgrad(dxb, g, e["mlp_c_proj_weight_g"])
+                _wgrad_maybe_async(dxb, g, e["mlp_c_proj_weight_g"])
                 dh = ew.gelu_bwd(dg, h, e["mlp_c_fc_bias_g"], batch=sums)
                 del dg, g, h
                 dy2 = _dgrad(dh, e["mlp_c_fc_weight_16"])
-                _wgrad(dh, y2, e["mlp_c_fc_weight_g"])
+                _wgrad_maybe_async(dh, y2, e["mlp_c_fc_weight_g"])
                 del dh, y2
                 dx2, dx2b = ew.ln_bwd(dy2, x2, mean2, rstd2, e["ln_2_weight"], dx, e["ln_2_weight_g"], e["ln_2_bias_g"],
                                       e["attn_c_proj_bias_g"], batch=sums)
                 del dy2, x2, dx, dxb
                 # ---- attention branch: x2 = x + c_proj(attn(c_qkv(ln_1(x)))) ---------------------------
                 da = _dgrad(dx2b, e["attn_c_proj_weight_16"])
-                _wgrad(dx2b, a, e["attn_c_proj_weight_g"])
+                _wgrad_maybe_async(dx2b, a, e["attn_c_proj_weight_g"])
                 dqkv = torch.empty_like(qkv)
                 q4, g4 = qkv.view(B, n, H, 3 * d), dqkv.view(B, n, H, 3 * d)
                 # the c_qkv bias gradient (column sums of dqkv) is a by-product of the attention backward's row stores
@@ -273,13 +302,14 @@ class _BackboneFn(torch.autograd.Function):
                 else:
                     ew.colsum_bf16(dqkv, e["attn_c_qkv_bias_g"], batch=sums)
                 dy1 = _dgrad(dqkv, e["attn_c_qkv_weight_16"])
-                _wgrad(dqkv, y1, e["attn_c_qkv_weight_g"])
+                _wgrad_maybe_async(dqkv, y1, e["attn_c_qkv_weight_g"])
                 del dqkv, y1
                 prev_bias_g = eng.blocks[bi - 1]["mlp_c_proj_bias_g"] if bi > 0 else None
                 dx, dxb = ew.ln_bwd(dy1, x_cur, mean1, rstd1, e["ln_1_weight"], dx2, e["ln_1_weight_g"], e["ln_1_bias_g"],
                                     prev_bias_g, want_bf16=bi > 0, batch=sums)
                 del dy1, dx2
                 sums.flush()
+                _wgrad_join(dx.device)
                 if eng.reducer is not None:
                     # this block's gradients are final (mlp.c_proj.bias was finished by the block above / the tail)
                     for p in e["params"]:
