@@ -311,6 +311,29 @@ def test_denoiser_matches_reference_golden(golden, tag):
     assert worst < 5e-2, f"worst param-grad rel-L2 {worst:.3e}"
 
 
+@pytest.mark.parametrize("tag", ["f32_w64", "f128_w64"])
+def test_denoiser_fp32_training_matches_reference_golden(golden, tag):
+    """`--dtype float32` (train_diffusion.py:78 choice, no autocast): the whole denoiser forward + backward in fp32 with the fp32
+    attention kernels (forward, dq, dk/dv on the fp32 matrix instruction) against the reference's own fp32 outputs and parameter
+    gradients: 1e-4 relative (the bf16-autocast form of this test holds 2e-2 / 5e-2)."""
+    from npcd.models.diffusion import NPCDTransformer
+    g = golden("denoiser_" + tag)
+    T = torch.from_numpy
+    F_ = g["feats"].shape[1]
+    net = NPCDTransformer(coords_dim=3, feats_dim=F_, width=64, layers=2 if tag == "f32_w64" else 1, heads=int(g["heads"]))
+    net.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith("w:")})
+    net = net.cuda()
+    ec, ef = net(T(g["coords"]).cuda(), T(g["feats"]).cuda(), T(g["t"]).cuda())
+    assert ec.dtype == torch.float32
+    ((ec * T(g["gc"]).cuda()).sum() + (ef * T(g["gf"]).cuda()).sum()).backward()
+    assert rel_l2(ec, T(g["eps_coords"])) < 1e-4 and rel_l2(ef, T(g["eps_feats"])) < 1e-4
+    worst = 0.0
+    for k, v in g.items():
+        if k.startswith("g:") and np.abs(v).max() > 1e-3:
+            worst = max(worst, rel_l2(dict(net.named_parameters())[k[2:]].grad, T(v)))
+    assert worst < 1e-4, f"worst param-grad rel-L2 {worst:.3e}"
+
+
 @pytest.mark.parametrize("n,H", [(1, 1), (17, 2), (64, 1), (130, 3), (513, 2)])
 def test_attention_fp32_inference_exact(n, H):
     """fp32 sampling path (the reference runs generate() with the fp32 einsum attention): exact fp32 math."""
