@@ -278,6 +278,55 @@ class ClockSampler:
         return out
 
 
+def bench_sampler(device, batch=16, steps=8, graph_steps=100):
+    """one DDPM reverse step (denoiser forward + posterior update, diffusion_model.py:108-133 /
+    gaussian_diffusion.py p_sample) at the benchmark's model size.  Lead figure: the reference's numerics (generate() runs the
+    denoiser in fp32 with the einsum attention) on the fp32 matrix-instruction attention kernels; beside it the bf16-autocast
+    opt-in through the forward-only fused backbone, eager and replayed from a HIP graph."""
+    import contextlib
+    from npcd.models.diffusion import DiffusionModel
+    torch.manual_seed(0)
+    m = DiffusionModel(3, CFG["feats_dim"], CFG["num_points"], CFG["width"], CFG["layers"], CFG["heads"], True).to(device).eval()
+    c = torch.randn(batch, 3, CFG["num_points"], device=device)
+    f = torch.randn(batch, CFG["feats_dim"], CFG["num_points"], device=device)
+    dp = m.diffusion_process
+
+    def run(n, ctx):
+        cc, ff = c, f
+        with torch.no_grad(), ctx:
+            for i in range(dp.num_timesteps - 1, dp.num_timesteps - 1 - n, -1):
+                t = torch.full((batch,), i, device=device, dtype=torch.long)
+                cc, _, ff, _ = dp.p_sample(m.denoiser, cc, ff, t, None, None)
+        return cc
+
+    out = {"batch": batch, "model": "benchmark denoiser (width %d, %d layers)" % (CFG["width"], CFG["layers"])}
+    for key, ctx in (("fp32_reference_numerics", contextlib.nullcontext()), ("bf16_autocast_opt_in", torch.autocast("cuda", dtype=torch.bfloat16))):
+        run(2, ctx)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = run(steps, ctx)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[key] = {"ms_per_reverse_step": dt * 1e3, "clouds_per_s_at_1000_steps": batch / (1000 * dt), "finite": bool(torch.isfinite(res).all())}
+    saved = dp.num_timesteps
+    try:
+        def loop(n, graph):
+            dp.num_timesteps = n
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                return dp.p_sample_loop(m.denoiser, c, f, (-3.0, 3.0), (-1.0, 1.0), use_graph=graph)
+        loop(4, True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = loop(graph_steps, True)[0]
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / graph_steps
+        out["bf16_fused_hip_graph"] = {"ms_per_reverse_step": dt * 1e3, "steps": graph_steps, "finite": bool(torch.isfinite(res).all()),
+                                       "note": "capture amortised over the steps"}
+    finally:
+        dp.num_timesteps = saved
+    return out
+
+
 def bench_cfg5(device, steps=6, warmup=2):
     """BASELINE configs[4] as ONE rank of its 8-GPU job computes it (no communication): 2048 points x 256-d latents, 8-layer
     denoiser (width 1024 / 16 heads: BASELINE leaves W / H open, SURVEY 8(d) takes the yaml's), sequence 2049, per-GPU batch
@@ -483,6 +532,7 @@ def main():
     ap.add_argument("--no-render", action="store_true")
     ap.add_argument("--no-proxy", action="store_true", help="skip the one-GPU strong-scaling proxy (per-GPU batch 64/32/16/8)")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the BASELINE configs[4] step (2048 points x 256-d, per-GPU batch 32)")
+    ap.add_argument("--no-sampler", action="store_true", help="skip the DDPM reverse-step timing (SURVEY 8(f) rank 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -673,6 +723,11 @@ def main():
             result["cfg5_stress_step"] = bench_cfg5(device)
         except Exception as e:                      # noqa: BLE001
             result["cfg5_stress_step"] = {"error": f"{type(e).__name__}: {e}"}
+    if world == 1 and not args.no_sampler:
+        try:
+            result["sampler_reverse_step"] = bench_sampler(device)
+        except Exception as e:                      # noqa: BLE001
+            result["sampler_reverse_step"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
