@@ -369,9 +369,12 @@ struct PointsArgs {          // what a pass needs of ShadeArgs, passed BY VALUE 
     int feat_dim;
     int red_rows;    // rows per wave plane of the reduction buffer (32 x the kernel's largest pass)
 };
-// (not inlined: four inlined variants inside the range loop made the register allocator spill 64-92 registers)
+// (inlined four times into the range loop.  The thread index is made opaque per pass: otherwise the lane-dependent LDS / weight
+// addresses of all four variants are hoisted out of the loop and held in registers across it -- 64-92 spilled registers; as a
+// real function call instead, the LDS pointers become generic and every LDS access a flat instruction)
 template <bool DIR, int NB>
-__device__ __noinline__ void points_pass(PointsArgs a, unsigned char* H, float* red, int row0, int P, int tid) {
+__device__ __forceinline__ void points_pass(PointsArgs a, unsigned char* H, float* red, int row0, int P, int tid) {
+    asm volatile("" : "+v"(tid));
     const ShadeLayout L = shade_layout(a.feat_dim);
     const int lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const float* s1 = reinterpret_cast<const float*>(a.wpack + L.s1);
@@ -498,11 +501,12 @@ __device__ __noinline__ void points_pass(PointsArgs a, unsigned char* H, float* 
 // workgroup i takes the contiguous range [i q + min(i, rem), ...) of q or q + 1 blocks and walks it in passes of at most four blocks
 // (128 rows), the passes of a range as equal as possible (5 blocks = 3 + 2).  (Until round 3 the grid strode over 128-row tiles:
 // 584 tiles of a 128^2 view on 512 resident workgroups are two rounds for 1.14 rounds of work.)
-template <bool DIR, int MAXNB>
-__global__ __launch_bounds__(256, MAXNB == 4 ? 2 : 4) void shade_points_kernel(ShadeArgs a) {
+template <bool DIR>
+__global__ __launch_bounds__(256, 2) void shade_points_kernel(ShadeArgs a) {
+    constexpr int MAXNB = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
     unsigned char* H = dsmem;
-    float* red = reinterpret_cast<float*>(dsmem + MAXNB * 32 * kRowBytes);  // [4 waves][32 MAXNB rows][4]
+    float* red = reinterpret_cast<float*>(dsmem + MAXNB * 32 * kRowBytes);  // [4 waves][128 rows][4]
     const int tid = threadIdx.x;
     const PointsArgs pa{a.wpack, a.G, a.sigma, a.rgb, a.dir_bias, a.point_ray, a.feat_dim, 32 * MAXNB};
     const int P = min(*a.n_points, a.max_points);
@@ -511,8 +515,8 @@ __global__ __launch_bounds__(256, MAXNB == 4 ? 2 : 4) void shade_points_kernel(S
     int left = q + ((int)blockIdx.x < rem ? 1 : 0);
     while (left > 0) {
         const int passes = (left + MAXNB - 1) / MAXNB, nb = (left + passes - 1) / passes;
-        if (MAXNB == 4 && nb >= 4) points_pass<DIR, MAXNB == 4 ? 4 : 1>(pa, H, red, b * 32, P, tid);
-        else if (MAXNB == 4 && nb == 3) points_pass<DIR, MAXNB == 4 ? 3 : 1>(pa, H, red, b * 32, P, tid);
+        if (nb >= 4) points_pass<DIR, 4>(pa, H, red, b * 32, P, tid);
+        else if (nb == 3) points_pass<DIR, 3>(pa, H, red, b * 32, P, tid);
         else if (nb == 2) points_pass<DIR, 2>(pa, H, red, b * 32, P, tid);
         else points_pass<DIR, 1>(pa, H, red, b * 32, P, tid);
         b += nb;
@@ -647,24 +651,16 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
         NPCD_HIP_CHECK(hipMemsetAsync(a.tile_counter, 0, sizeof(int32_t), st));
     }
     const int ldsA = kRows * kRowBytes + kRows * 4 + 32 * 4 + 16;   // activations, row weights, per-point packed-row ranges, next tile
-    // kernel B with 128-row passes at two workgroups per CU, or (NPCD_POINTS_NB2=1) 64-row passes at four
-    static const bool nb2 = getenv("NPCD_POINTS_NB2") != nullptr;
-    const int ldsB = (nb2 ? 64 : kRows) * (kRowBytes + 4 * 4 * 4);
-    static DynLds lds_a32, lds_a128, lds_b, lds_bd, lds_b2, lds_bd2;
+    const int ldsB = kRows * (kRowBytes + 4 * 4 * 4);
+    static DynLds lds_a32, lds_a128, lds_b, lds_bd;
     NPCD_HIP_CHECK(lds_a32.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<32>), ldsA));
     NPCD_HIP_CHECK(lds_a128.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<128>), ldsA));
-    if (nb2) {
-        NPCD_HIP_CHECK(lds_b2.ensure(reinterpret_cast<const void*>(shade_points_kernel<false, 2>), ldsB));
-        NPCD_HIP_CHECK(lds_bd2.ensure(reinterpret_cast<const void*>(shade_points_kernel<true, 2>), ldsB));
-    } else {
-        NPCD_HIP_CHECK(lds_b.ensure(reinterpret_cast<const void*>(shade_points_kernel<false, 4>), ldsB));
-        NPCD_HIP_CHECK(lds_bd.ensure(reinterpret_cast<const void*>(shade_points_kernel<true, 4>), ldsB));
-    }
+    NPCD_HIP_CHECK(lds_b.ensure(reinterpret_cast<const void*>(shade_points_kernel<false>), ldsB));
+    NPCD_HIP_CHECK(lds_bd.ensure(reinterpret_cast<const void*>(shade_points_kernel<true>), ldsB));
     // persistent-style grids: 2 workgroups per CU, tiles strided over the grid; the tile count is
     // read from device memory so that no host round trip is needed after the neighbour query
     const int tilesA = (max_points + 15) / 16, tilesB = (max_points + 31) / 32;       // B: 32-row blocks, dealt out evenly
-    const int slotsB = nb2 ? 1024 : 512;
-    const int gridA = tilesA < 512 ? tilesA : 512, gridB = tilesB < slotsB ? tilesB : slotsB;
+    const int gridA = tilesA < 512 ? tilesA : 512, gridB = tilesB < 512 ? tilesB : 512;
     // kernel A: LDS tiles of 16 points (below), or with NPCD_SHADE_ROWS=1 the rows form (shade_rows.hip: activations in registers;
     // opt-in: as fast, but its matrix-product aggregation adds a point's rows in an order that depends on where the point sits in
     // the compact lists, so two renders agree to fp16 rounding instead of bit for bit -- DESIGN.md 5.3).  Read per call.
@@ -674,13 +670,8 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
         if (rc != NPCD_OK) return rc;
     } else if (feat_dim == 32) hipLaunchKernelGGL(shade_pairs_kernel<32>, dim3(gridA), dim3(256), ldsA, st, a);
     else hipLaunchKernelGGL(shade_pairs_kernel<128>, dim3(gridA), dim3(256), ldsA, st, a);
-    if (nb2) {
-        if (dir_bias) hipLaunchKernelGGL((shade_points_kernel<true, 2>), dim3(gridB), dim3(256), ldsB, st, a);
-        else hipLaunchKernelGGL((shade_points_kernel<false, 2>), dim3(gridB), dim3(256), ldsB, st, a);
-    } else {
-        if (dir_bias) hipLaunchKernelGGL((shade_points_kernel<true, 4>), dim3(gridB), dim3(256), ldsB, st, a);
-        else hipLaunchKernelGGL((shade_points_kernel<false, 4>), dim3(gridB), dim3(256), ldsB, st, a);
-    }
+    if (dir_bias) hipLaunchKernelGGL(shade_points_kernel<true>, dim3(gridB), dim3(256), ldsB, st, a);
+    else hipLaunchKernelGGL(shade_points_kernel<false>, dim3(gridB), dim3(256), ldsB, st, a);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }
