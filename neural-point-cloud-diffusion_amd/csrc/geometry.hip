@@ -439,7 +439,11 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
     float4* pts = reinterpret_cast<float4*>(dsmem);
     uint32_t* bitmap = reinterpret_cast<uint32_t*>(pts + a.N);
     int* sel = reinterpret_cast<int*>(bitmap + a.nwords);          // [4][64]
-    int* stage_idx = sel + 4 * 64;                                 // [4][64][8]   (COMPACT)
+    // [4][64] position + packed cell (x | y << 10 | z << 20) of every selected sample, written by pass A: pass B used to
+    // recompute both per sample on all 64 lanes (two IEEE divisions per axis: ~80 of its ~300 instructions per trip)
+    float4* selp = reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(sel + 4 * 64) + ((16 - ((a.N * 16 + a.nwords * 4 + 4 * 64 * 4) & 15)) & 15));
+    unsigned long long* cpk = reinterpret_cast<unsigned long long*>(selp + 4 * 64);   // [4][64] a slot pair's in-radius candidates, packed
+    int* stage_idx = reinterpret_cast<int*>(cpk + 4 * 64);          // [4][64][8]   (COMPACT)
     float* stage_pos = reinterpret_cast<float*>(stage_idx + 4 * 64 * 8);  // [4][64][4]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / blocks_per_example;
@@ -461,24 +465,38 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
         t1 = a.t1[ray];
     }
     int* mysel = sel + wave * 64;
+    float4* myselp = selp + wave * 64;
     int nsel = 0;
     for (int s0 = 0; s0 < a.S && nsel < a.M; s0 += 64) {
         const int s = s0 + lane;
         bool occ = false;
+        float p[3] = {0.f, 0.f, 0.f};
+        int cell = 0;
         if (s < a.S) {
-            float p[3];
             sample_pos(a, ray, s, o, d, t0, t1, p);
             const FineCoord fc = fine_coord(a.g, p[0], p[1], p[2]);
             if (fc.ok) {
                 const int bit = ((fc.c[0] / a.g.voxel_scale[0]) * a.g.cdims[1] + fc.c[1] / a.g.voxel_scale[1]) * a.g.cdims[2] + fc.c[2] / a.g.voxel_scale[2];
                 occ = (bitmap[bit >> 5] >> (bit & 31)) & 1u;
+                cell = fc.c[0] | (fc.c[1] << 10) | (fc.c[2] << 20);
             }
         }
         const unsigned long long m = __ballot(occ);
         const int slot = nsel + __popcll(m & ((1ull << lane) - 1ull));
-        if (occ && slot < a.M) mysel[slot] = s;
+        if (occ && slot < a.M) {
+            mysel[slot] = s;
+            myselp[slot] = make_float4(p[0], p[1], p[2], __int_as_float(cell));
+        }
         nsel = min(a.M, nsel + __popcll(m));
     }
+    // what pass A left for slot `slot`: position and cell (a selected sample is in range by construction)
+    auto slot_geom = [&](int slot, float (&p)[3], FineCoord& fc) {
+        const float4 g4 = myselp[slot];                 // same-wave LDS write -> read is ordered
+        p[0] = g4.x; p[1] = g4.y; p[2] = g4.z;
+        const int cell = __float_as_int(g4.w);
+        fc.c[0] = cell & 1023; fc.c[1] = (cell >> 10) & 1023; fc.c[2] = (cell >> 20) & 1023;
+        fc.ok = true;
+    };
     const int hx = (a.g.kernel_size[0] - 1) / 2, hy = (a.g.kernel_size[1] - 1) / 2, hz = (a.g.kernel_size[2] - 1) / 2;
     const int gbase = b * a.N;
     int32_t* out_idx = COMPACT ? nullptr : a.sample_idx + ray * a.M * a.k;
@@ -488,8 +506,8 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
     auto process = [&](int slot, u32x2 raw_in) {
         const int s = mysel[slot];                     // same-wave LDS write -> read is ordered
         float p[3];
-        sample_pos(a, ray, s, o, d, t0, t1, p);       // wave-uniform values
-        const FineCoord fc = fine_coord(a.g, p[0], p[1], p[2]);
+        FineCoord fc;
+        slot_geom(slot, p, fc);                        // wave-uniform values
         uint32_t key_hi = 0xffffffffu, key_lo = 0xffffffffu;   // lanes 0..7 hold the sorted list
         // insert the lanes flagged in `cm` (dist^2 in d2, point index in jj) into the cross-lane sorted list
         auto insert_all = [&](unsigned long long cm, float d2, int jj) {
@@ -568,70 +586,118 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
     // Table path with a window of <= 32 voxels (the reference's 3^3): TWO slots per trip, one per 32-lane half.  Lanes 0..26 of
     // a half fetch its slot's window voxels, the sorted list of a half lives in its lanes 0..7, and one trip of the insertion
     // loop takes one candidate of each half.  Same arithmetic per slot as `process`, i.e. the same bits out.
+    // lane constants of the two-slot form: the window cell a lane fetches (relative), this example's table
+    const int w2_l = lane & 31, w2_ky = a.g.kernel_size[1], w2_kz = a.g.kernel_size[2], w2_nk = a.g.kernel_size[0] * w2_ky * w2_kz;
+    const int w2_dx = w2_l / (w2_ky * w2_kz) - hx, w2_dy = (w2_l / w2_kz) % w2_ky - hy, w2_dz = w2_l % w2_kz - hz;
+    const int16_t* w2_table = a.table ? a.table + (int64_t)b * a.g.dims[0] * a.g.dims[1] * a.g.dims[2] * 4 : nullptr;
     auto process2 = [&](int pair) {
         const int h = lane >> 5, l32 = lane & 31;
         const int slot = 2 * pair + h;
         const bool live = slot < nsel;                                  // uniform per half
         const int s = mysel[live ? slot : 2 * pair];
         float p[3];
-        sample_pos(a, ray, s, o, d, t0, t1, p);
-        const FineCoord fc = fine_coord(a.g, p[0], p[1], p[2]);
-        uint32_t key_hi = 0xffffffffu, key_lo = 0xffffffffu;
-        auto insert2 = [&](unsigned long long cm, float d2, int jj) {
-            uint32_t c0 = (uint32_t)cm, c1 = (uint32_t)(cm >> 32);
-            while (c0 | c1) {                                           // wave-uniform
-                const bool v0 = c0 != 0u, v1 = c1 != 0u;
-                const int b0 = v0 ? __ffs((int)c0) - 1 : 0, b1 = v1 ? __ffs((int)c1) - 1 : 0;
-                c0 &= c0 - 1u;                                          // (0 stays 0)
-                c1 &= c1 - 1u;
-                const uint32_t ch0 = __builtin_amdgcn_readlane(__float_as_uint(d2), b0), cl0 = (uint32_t)__builtin_amdgcn_readlane(jj, b0);
-                const uint32_t ch1 = __builtin_amdgcn_readlane(__float_as_uint(d2), 32 + b1), cl1 = (uint32_t)__builtin_amdgcn_readlane(jj, 32 + b1);
-                const uint32_t ch = h ? ch1 : ch0, cl = h ? cl1 : cl0;
-                const bool vv = h ? v1 : v0;
-                const bool le = (key_hi < ch) || (key_hi == ch && key_lo < cl);
-                const unsigned long long lm = __ballot(le);
-                const int pos = h ? __popc((uint32_t)(lm >> 32) & 0xffu) : __popc((uint32_t)lm & 0xffu);
-                const uint32_t up_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key_hi, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
-                const uint32_t up_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key_lo, 0x111, 0xf, 0xf, false);
-                if (vv && pos < 8) {
-                    if (l32 == pos) { key_hi = ch; key_lo = cl; }
-                    else if (l32 > pos) { key_hi = up_hi; key_lo = up_lo; }
-                }
-            }
-        };
-        const int ky = a.g.kernel_size[1], kz = a.g.kernel_size[2], nk = a.g.kernel_size[0] * ky * kz;
+        FineCoord fc;
+        slot_geom(live ? slot : 2 * pair, p, fc);
         int cand_idx[4] = {-1, -1, -1, -1};
-        if (live && l32 < nk) {
-            const int vx = fc.c[0] + l32 / (ky * kz) - hx, vy = fc.c[1] + (l32 / kz) % ky - hy, vz = fc.c[2] + l32 % kz - hz;
+        if (live && l32 < w2_nk) {
+            const int vx = fc.c[0] + w2_dx, vy = fc.c[1] + w2_dy, vz = fc.c[2] + w2_dz;
             if (vx >= 0 && vy >= 0 && vz >= 0 && vx < a.g.dims[0] && vy < a.g.dims[1] && vz < a.g.dims[2]) {
-                const int64_t vox = (int64_t)b * a.g.dims[0] * a.g.dims[1] * a.g.dims[2] + ((int64_t)vx * a.g.dims[1] + vy) * a.g.dims[2] + vz;
-                const u32x2 raw = *reinterpret_cast<const u32x2*>(a.table + vox * 4);
+                const int vox = (vx * a.g.dims[1] + vy) * a.g.dims[2] + vz;        // (the table has < 2^22 cells per example: table_ok)
+                const u32x2 raw = *reinterpret_cast<const u32x2*>(w2_table + (int64_t)vox * 4);
                 cand_idx[0] = (int)(int16_t)(raw[0] & 0xffffu); cand_idx[1] = (int)(int16_t)(raw[0] >> 16);
                 cand_idx[2] = (int)(int16_t)(raw[1] & 0xffffu); cand_idx[3] = (int)(int16_t)(raw[1] >> 16);
             }
         }
+        // Selection BY RANK: a candidate's place in the sorted list is the number of candidates of its half with a smaller
+        // (dist^2 bits, index) key -- keys are distinct, so ranks are too.  The in-radius candidates (a few of the up to 4 x 27
+        // fetched points) are first PACKED to the front of their half through LDS, one per lane; then every lane compares its
+        // candidate with all of its half, four broadcast keys per LDS read: ~3 vector instructions per candidate, where the
+        // sorted-insertion form shifted an eight-entry list across lanes for every candidate (~40).  Same neighbours in the
+        // same order.  (More than 32 candidates in a half -- dense clouds -- take the broadcast loop below.)
+        unsigned long long key[4];
+        uint32_t d2b[4];
+        unsigned long long cmask[4];
+        int n0 = 0, n1 = 0;                                             // candidates of the lower / upper half
+        unsigned long long* mycpk = cpk + wave * 64;
 #pragma unroll
         for (int qi = 0; qi < 4; ++qi) {
-            const int j = cand_idx[qi];
+            const int jq = cand_idx[qi];
             bool cand = false;
             float d2 = 0.f;
-            if (j >= 0) {
-                const float4 q = pts[j];
+            if (jq >= 0) {
+                const float4 q = pts[jq];
                 const float dx = p[0] - q.x, dy = p[1] - q.y, dz = p[2] - q.z;
                 d2 = (dx * dx + dy * dy) + dz * dz;
                 cand = d2 < a.r2;
             }
-            insert2(__ballot(cand), d2, j);
+            d2b[qi] = __float_as_uint(d2);
+            key[qi] = cand ? (((unsigned long long)d2b[qi] << 32) | (uint32_t)jq) : ~0ull;
+            cmask[qi] = __ballot(cand);
+            const uint32_t c0 = (uint32_t)cmask[qi], c1 = (uint32_t)(cmask[qi] >> 32);
+            // my place among the candidates of my half: those of earlier rounds + those of this round on lower lanes
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cmask[qi] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cmask[qi], 0u));
+            const int pos = (h ? n1 + below - __popc(c0) : n0 + below);
+            if (cand && pos < 32) mycpk[h * 32 + pos] = key[qi];
+            n0 += __popc(c0);
+            n1 += __popc(c1);
         }
-        const bool has = key_lo != 0xffffffffu;
-        const unsigned long long hm = __ballot(has);
-        if (COMPACT) {
-            if (live && l32 < 8) stage_idx[(wave * 64 + slot) * 8 + l32] = has ? gbase + (int)key_lo : -1;
-            if (live && l32 < 3) stage_pos[(wave * 64 + slot) * 4 + l32] = l32 == 0 ? p[0] : (l32 == 1 ? p[1] : p[2]);
-            if (hm & 1ull) valid_bits |= (1ull << (2 * pair));
-            if ((hm >> 32) & 1ull) valid_bits |= (1ull << (2 * pair + 1));          // a dead upper half has no entries
+        int rank[4] = {0, 0, 0, 0};
+        const int nmax = max(n0, n1);
+        const bool packed = nmax <= 32;
+        unsigned long long mine = ~0ull;                                // packed form: the candidate this lane ranks
+        if (packed) {
+            if (l32 < (h ? n1 : n0)) mine = mycpk[lane];                // same-wave LDS write -> read is ordered
+            const unsigned long long* half = mycpk + h * 32;
+            for (int i0 = 0; i0 < nmax; i0 += 4) {                      // wave-uniform; entries past a half's count are stale
+                const int nhh = h ? n1 : n0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned long long ck = (i0 + u < nhh) ? half[i0 + u] : ~0ull;     // broadcast read
+                    rank[0] += (ck < mine) ? 1 : 0;
+                }
+            }
         } else {
-            if (live && l32 < a.k) out_idx[slot * a.k + l32] = has ? gbase + (int)key_lo : -1;
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                uint32_t c0 = (uint32_t)cmask[qi], c1 = (uint32_t)(cmask[qi] >> 32);
+                while (c0 | c1) {                                       // wave-uniform
+                    const bool v0 = c0 != 0u, v1 = c1 != 0u;
+                    const int b0 = v0 ? __ffs((int)c0) - 1 : 0, b1 = v1 ? __ffs((int)c1) - 1 : 0;
+                    c0 &= c0 - 1u;                                      // (0 stays 0)
+                    c1 &= c1 - 1u;
+                    const uint32_t ch0 = __builtin_amdgcn_readlane(d2b[qi], b0), cl0 = (uint32_t)__builtin_amdgcn_readlane(cand_idx[qi], b0);
+                    const uint32_t ch1 = __builtin_amdgcn_readlane(d2b[qi], 32 + b1), cl1 = (uint32_t)__builtin_amdgcn_readlane(cand_idx[qi], 32 + b1);
+                    const unsigned long long k0 = v0 ? (((unsigned long long)ch0 << 32) | cl0) : ~0ull;      // scalar
+                    const unsigned long long k1 = v1 ? (((unsigned long long)ch1 << 32) | cl1) : ~0ull;
+                    const unsigned long long ck = h ? k1 : k0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rank[q] += (ck < key[q]) ? 1 : 0;
+                }
+            }
+        }
+        const int nh = h ? n1 : n0;
+        if (COMPACT) {
+            int* row = stage_idx + (wave * 64 + slot) * 8;
+            if (live && l32 < 8 && l32 >= nh) row[l32] = -1;
+            if (packed) {
+                if (mine != ~0ull && rank[0] < 8) row[rank[0]] = gbase + (int)(uint32_t)mine;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (key[q] != ~0ull && rank[q] < 8) row[rank[q]] = gbase + cand_idx[q];
+            }
+            if (live && l32 < 3) stage_pos[(wave * 64 + slot) * 4 + l32] = l32 == 0 ? p[0] : (l32 == 1 ? p[1] : p[2]);
+            if (n0 > 0) valid_bits |= (1ull << (2 * pair));
+            if (n1 > 0) valid_bits |= (1ull << (2 * pair + 1));          // a dead upper half has no candidates
+        } else {
+            if (live && l32 < a.k && l32 >= nh) out_idx[slot * a.k + l32] = -1;
+            if (packed) {
+                if (mine != ~0ull && rank[0] < a.k) out_idx[slot * a.k + rank[0]] = gbase + (int)(uint32_t)mine;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (key[q] != ~0ull && rank[q] < a.k) out_idx[slot * a.k + rank[q]] = gbase + cand_idx[q];
+            }
             if (live && l32 < 3) out_loc[slot * 3 + l32] = l32 == 0 ? p[0] : (l32 == 1 ? p[1] : p[2]);
             if (live && l32 == 0) out_ss[slot] = s;
         }
@@ -1203,7 +1269,7 @@ extern "C" int npcd_grid_query(const npcd_grid_params* g_in, const void* workspa
     a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t0 = t0; a.t1 = t1;
     a.sample_idx = sample_idx; a.sample_loc = sample_loc; a.slot_sample = slot_sample; a.nsel = nsel;
     const int bpe = (R + 3) / 4;
-    const size_t lds = (size_t)N * 16 + (size_t)a.nwords * 4 + 4 * 64 * 4;
+    const size_t lds = (size_t)N * 16 + (size_t)a.nwords * 4 + 4 * 64 * 4 + 16 + 4 * 64 * 16 + 4 * 64 * 8;      // + the selected samples' geometry, packed candidates
     hipStream_t st = static_cast<hipStream_t>(stream);
     static DynLds lds_attr;
     if (mode == 1 && lds > 65536) NPCD_HIP_CHECK(lds_attr.ensure(reinterpret_cast<const void*>(grid_query_kernel<false>), lds));
@@ -1293,7 +1359,7 @@ static int grid_query_compact_launch(const npcd_grid_params* g_in, const void* w
     co.counter = counter; co.capacity = capacity; co.ray_base = ray_base; co.ray_nsel = ray_nsel;
     co.ray_bits = reinterpret_cast<unsigned long long*>(ray_bits); co.nb = nb_idx; co.pts = pts;
     const int bpe = (R + 3) / 4;
-    const size_t lds = (size_t)N * 16 + (size_t)a.nwords * 4 + 4 * 64 * 4 + 4 * 64 * 8 * 4 + 4 * 64 * 4 * 4;
+    const size_t lds = (size_t)N * 16 + (size_t)a.nwords * 4 + 4 * 64 * 4 + 16 + 4 * 64 * 16 + 4 * 64 * 8 + 4 * 64 * 8 * 4 + 4 * 64 * 4 * 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
     static DynLds lds_attr;
     if (lds > 65536) NPCD_HIP_CHECK(lds_attr.ensure(reinterpret_cast<const void*>(grid_query_wave_kernel<true>), lds));

@@ -108,6 +108,60 @@ def test_grid_query_bit_exact(N, seed, level):
     np.testing.assert_array_equal(loc.cpu().numpy(), bloc)
 
 
+@pytest.mark.parametrize("level", ["fine", "scaled"])
+def test_grid_query_dense_cluster_takes_the_many_candidate_path(level):
+    """Samples with MORE than 32 in-radius candidates in their window (the packed rank selection of the query kernel holds one
+    candidate per lane of a 32-lane half; past that it falls back to the broadcast loop).  Two ingredients in one cloud: 3,000
+    points in a 0.3 cube (every 0.04 cell filled to its cap: the fine reading sees ~80 candidates per sample) and a constructed
+    cluster of 4 points in each of the 27 cells of the 0.08 grid around one cell centre, all within the radius of that centre (the
+    scaled reading sees all 108).  Dense tables (explicit positions and rays), compact lists and the oracle agree bit for bit."""
+    from npcd.hip import render as hr
+    gen = torch.Generator().manual_seed(11)
+    M, k, S = 24, 8, 48
+    cube = (torch.rand(3000, 3, generator=gen) - 0.5) * 0.3
+    c0 = torch.tensor([0.56, 0.56, 0.56])                          # centre of cell 19 of the 0.08 grid on every axis
+    offs = torch.tensor([[dx, dy, dz] for dx in (-1, 0, 1) for dy in (-1, 0, 1) for dz in (-1, 0, 1)], dtype=torch.float32)
+    cluster = (c0 + 0.043 * offs)[:, None, :] + (torch.rand(27, 4, 3, generator=gen) - 0.5) * 0.004
+    coords = torch.cat((cube, cluster.reshape(-1, 3)))[None]
+    N = coords.shape[1]
+    assert int(((cluster.reshape(-1, 3) - c0).norm(dim=-1) < 0.0799).sum()) == 108
+    R = 96
+    ro = torch.cat(((torch.rand(1, R, 2, generator=gen) - 0.5) * 0.3, torch.full((1, R, 1), -0.6)), dim=-1)
+    rd = torch.nn.functional.normalize(torch.tensor([0.0, 0.0, 1.0]) + 0.05 * torch.randn(1, R, 3, generator=gen), dim=-1)
+    rs, re = torch.full((1, R), 0.3), torch.full((1, R), 0.9)
+    x = ro[:, :, None] + orr.depth_samples(rs[..., None], re[..., None], S)[..., None] * rd[:, :, None]
+    x[0, 0, :3] = c0 + torch.tensor([[0.0, 0.0, 0.0], [0.001, -0.002, 0.0015], [-0.003, 0.001, 0.002]])      # samples at the cluster
+    x = x.numpy()
+    cfg = dict(orr.DEFAULT_GRID, grid_level=level)
+    g = ovg.VoxelGridOracle(**cfg)
+    g.set_pointset(coords.numpy(), np.array([N], dtype=np.int32))
+    ridx, rloc, rnsel, rss = g.query_dense(x, k, 2.0, M)
+    kept = coords[0][torch.from_numpy(g.kept[0][:N].astype(bool))]
+    slots = torch.from_numpy(rloc[0][ridx[0][..., 0] >= 0])                    # positions of all slots that have a neighbour
+    probe = c0 if level == "scaled" else slots[slots.norm(dim=-1).argmin()]      # fine: the slot deepest inside the cube
+    assert int(((kept - probe).norm(dim=-1) < 0.08).sum()) > 32     # the premise
+    hg = hr.HipVoxelGrid(**cfg)
+    hg.set_pointset(coords.cuda(), torch.full((1,), N, dtype=torch.int32, device="cuda"))
+    idx, loc, ss, nsel = hg.query_dense(k, 2.0, M, x=T(x).cuda())
+    np.testing.assert_array_equal(nsel.cpu().numpy(), rnsel)
+    np.testing.assert_array_equal(ss.cpu().numpy(), rss)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    np.testing.assert_array_equal(loc.cpu().numpy(), rloc)
+    assert (ridx[0, 0, 0] >= 0).all()                               # the sample at the cluster centre has k neighbours
+    # the ray forms (dense table and compact lists) on the same cloud
+    rays = (ro.cuda(), rd.cuda(), rs.cuda(), re.cuda())
+    xr = (ro[:, :, None] + orr.depth_samples(rs[..., None], re[..., None], S)[..., None] * rd[:, :, None]).numpy()
+    qidx, qloc, qnsel, _ = g.query_dense(xr, k, 2.0, M)
+    idx, loc, ss, nsel = hg.query_dense(k, 2.0, M, rays=rays, S=S)
+    np.testing.assert_array_equal(idx.cpu().numpy(), qidx)
+    np.testing.assert_array_equal(loc.cpu().numpy(), qloc)
+    counter, base, _, bits, nb, pts = hg.query_compact(k, 2.0, M, rays, S, R * M)
+    valid = (idx[..., 0] >= 0).flatten(0, 1)
+    P = int(valid.sum())
+    assert int(counter[0]) == P and P > 500
+    assert torch.equal(nb[:P], idx.flatten(0, 1)[valid]) and torch.equal(pts[:P], loc.flatten(0, 1)[valid])
+
+
 def test_grid_capacity_limits_and_batches():
     """> max_points_per_voxel points in one voxel, occupied-voxel cap, ragged counts, out-of-range points."""
     from npcd.hip import render as hr
