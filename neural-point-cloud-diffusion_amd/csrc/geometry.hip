@@ -619,17 +619,16 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
         unsigned long long cmask[4];
         int n0 = 0, n1 = 0;                                             // candidates of the lower / upper half
         unsigned long long* mycpk = cpk + wave * 64;
+        float4 cq[4];
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) cq[qi] = pts[max(cand_idx[qi], 0)];      // all four reads in flight (empty entries read point 0)
 #pragma unroll
         for (int qi = 0; qi < 4; ++qi) {
             const int jq = cand_idx[qi];
-            bool cand = false;
-            float d2 = 0.f;
-            if (jq >= 0) {
-                const float4 q = pts[jq];
-                const float dx = p[0] - q.x, dy = p[1] - q.y, dz = p[2] - q.z;
-                d2 = (dx * dx + dy * dy) + dz * dz;
-                cand = d2 < a.r2;
-            }
+            const float4 q = cq[qi];
+            const float dx = p[0] - q.x, dy = p[1] - q.y, dz = p[2] - q.z;
+            const float d2 = (dx * dx + dy * dy) + dz * dz;
+            const bool cand = jq >= 0 && d2 < a.r2;
             d2b[qi] = __float_as_uint(d2);
             key[qi] = cand ? (((unsigned long long)d2b[qi] << 32) | (uint32_t)jq) : ~0ull;
             cmask[qi] = __ballot(cand);
@@ -648,13 +647,16 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
         if (packed) {
             if (l32 < (h ? n1 : n0)) mine = mycpk[lane];                // same-wave LDS write -> read is ordered
             const unsigned long long* half = mycpk + h * 32;
-            for (int i0 = 0; i0 < nmax; i0 += 4) {                      // wave-uniform; entries past a half's count are stale
-                const int nhh = h ? n1 : n0;
+            const int nhh = h ? n1 : n0;
+            for (int i0 = 0; i0 < nmax; i0 += 4) {                      // wave-uniform
+                // four keys of the own half per trip, two broadcast 16-byte reads issued together; entries past the half's count
+                // are stale (or belong to the next region of LDS) and are masked AFTER the read -- a guarded read is a branch and
+                // an LDS round trip per key
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                const u64x2 ka = *reinterpret_cast<const u64x2*>(half + i0), kb = *reinterpret_cast<const u64x2*>(half + i0 + 2);
+                const unsigned long long ck[4] = {ka[0], ka[1], kb[0], kb[1]};
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const unsigned long long ck = (i0 + u < nhh) ? half[i0 + u] : ~0ull;     // broadcast read
-                    rank[0] += (ck < mine) ? 1 : 0;
-                }
+                for (int u = 0; u < 4; ++u) rank[0] += (i0 + u < nhh && ck[u] < mine) ? 1 : 0;
             }
         } else {
 #pragma unroll
