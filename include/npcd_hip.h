@@ -49,8 +49,11 @@ const char* npcd_last_hip_error(void);
  * autograd backward.  q/k/v are [B, n, H, d] views (typically of one interleaved [B,n,H,3d]
  * buffer, transformer.py:71-72) sharing the stride triple (sb, sn, sh); d must be 64.
  * lse [B, H, n] fp32 receives log(sum_j exp(scale * <q_i, k_j>)).
- * dtype NPCD_F32 selects the exact-fp32 inference kernel (the reference's fp32 sampling path,
- * diffusion_model.py:108-133): forward only, lse is not written (may be NULL), no backward.
+ * dtype NPCD_F32 selects the exact-fp32 kernels on the fp32 matrix instruction (the reference's fp32 sampling path,
+ * diffusion_model.py:108-133, and `--dtype float32` training through its einsum attention, transformer.py:76-81): nothing is rounded
+ * to 16 bits; lse is written when given (may be NULL for inference); strides multiples of 4 elements and 16-byte aligned pointers
+ * take the matrix-instruction form, any other layout a vector-ALU form of the forward.  npcd_attn_bwd accepts NPCD_F32 as well
+ * (two kernels, dq and dk/dv; `delta` then needs B*H*n floats and is written by the dq kernel).
  * ------------------------------------------------------------------------------------------ */
 int npcd_attn_fwd(const void* q, const void* k, const void* v, void* out, float* lse,
                   int B, int n, int H, int d,
