@@ -185,6 +185,20 @@ def test_grid_capacity_limits_and_batches():
         np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
         np.testing.assert_array_equal(nsel.cpu().numpy(), rnsel)
         np.testing.assert_array_equal(ss.cpu().numpy(), rss)
+    # the one-sample-per-trip forms of the query kernel: no cell table (more than 4 points kept per cell; a 5^3 window), and a
+    # table with a window of more than 32 cells (3 x 3 x 5)
+    for extra in (dict(max_points_per_voxel=6), dict(kernel_size=(5, 5, 5)), dict(kernel_size=(3, 3, 5))):
+        for level in ("fine", "scaled"):
+            cfg = dict(orr.DEFAULT_GRID, grid_level=level, **extra)
+            g = ovg.VoxelGridOracle(**cfg)
+            g.set_pointset(pts, counts)
+            ridx, rloc, rnsel, rss = g.query_dense(x, 8, 2.0, 10)
+            hg = hr.HipVoxelGrid(**cfg)
+            hg.set_pointset(T(pts).cuda(), T(counts).cuda())
+            idx, loc, ss, nsel = hg.query_dense(8, 2.0, 10, x=T(x).cuda())
+            np.testing.assert_array_equal(idx.cpu().numpy(), ridx, err_msg=str((extra, level)))
+            np.testing.assert_array_equal(nsel.cpu().numpy(), rnsel)
+            np.testing.assert_array_equal(loc.cpu().numpy(), rloc)
     # k < 8 and M < 8 paths
     for level in ("fine", "scaled"):
         cfg = dict(orr.DEFAULT_GRID, grid_level=level)
