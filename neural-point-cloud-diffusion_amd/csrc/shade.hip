@@ -404,19 +404,27 @@ __device__ __forceinline__ void points_pass(PointsArgs a, unsigned char* H, floa
     // ---- density head: Linear(256,256) + LeakyReLU + Linear(256,1), softplus(x - 1) ------
     layer_mfma<16, 4, NB, NPCD_POINTS_PF>(H, a.wpack + L.w[5], reinterpret_cast<const float*>(a.wpack + L.bias[5]), wave, lane, acc);
     {
+        float part[NB];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) part[cb] = 0.f;
+#pragma unroll
+        for (int oi = 0; oi < 2; ++oi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(s1 + (2 * wave + oi) * 32 + 8 * g + 4 * hh);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int cb = 0; cb < NB; ++cb) {
+                        float x = acc[oi][cb][4 * g + b];
+                        x = x > 0.f ? x : kLeaky * x;
+                        part[cb] += x * w4[b];
+                    }
+            }
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
-            float part = 0.f;
-#pragma unroll
-            for (int oi = 0; oi < 2; ++oi)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float x = acc[oi][cb][i];
-                    x = x > 0.f ? x : kLeaky * x;
-                    part += x * s1[(2 * wave + oi) * 32 + acc_row(i, hh)];
-                }
-            part += swap_half(part);
-            if (hh == 0) red[(wave * a.red_rows + cb * 32 + r) * 4 + 3] = part;
+            const float t = part[cb] + swap_half(part[cb]);
+            if (hh == 0) red[(wave * a.red_rows + cb * 32 + r) * 4 + 3] = t;
         }
     }
     NPCD_PTS(6);
@@ -453,23 +461,31 @@ __device__ __forceinline__ void points_pass(PointsArgs a, unsigned char* H, floa
         }
     }
     {
+        // (a channel's three projection weights are loaded once and applied to all NB row blocks)
+        float pc[NB][3];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) pc[cb][0] = pc[cb][1] = pc[cb][2] = 0.f;
+#pragma unroll
+        for (int oi = 0; oi < 2; ++oi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float* cp = c4 + (2 * wave + oi) * 32 + 8 * g + 4 * hh;
+                const f32x4 wr = *reinterpret_cast<const f32x4*>(cp), wg = *reinterpret_cast<const f32x4*>(cp + kHidden),
+                            wb = *reinterpret_cast<const f32x4*>(cp + 2 * kHidden);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int cb = 0; cb < NB; ++cb) {
+                        float x = acc[oi][cb][4 * g + b];
+                        x = x > 0.f ? x : kLeaky * x;
+                        pc[cb][0] += x * wr[b];
+                        pc[cb][1] += x * wg[b];
+                        pc[cb][2] += x * wb[b];
+                    }
+            }
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
-            float pr = 0.f, pg = 0.f, pb = 0.f;
-#pragma unroll
-            for (int oi = 0; oi < 2; ++oi)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    float x = acc[oi][cb][i];
-                    x = x > 0.f ? x : kLeaky * x;
-                    const int o = (2 * wave + oi) * 32 + acc_row(i, hh);
-                    pr += x * c4[o];
-                    pg += x * c4[kHidden + o];
-                    pb += x * c4[2 * kHidden + o];
-                }
-            pr += swap_half(pr);
-            pg += swap_half(pg);
-            pb += swap_half(pb);
+            const float pr = pc[cb][0] + swap_half(pc[cb][0]), pg = pc[cb][1] + swap_half(pc[cb][1]), pb = pc[cb][2] + swap_half(pc[cb][2]);
             if (hh == 0) {
                 float* q = red + (wave * a.red_rows + cb * 32 + r) * 4;
                 q[0] = pr; q[1] = pg; q[2] = pb;
