@@ -466,6 +466,7 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
     }
     int* mysel = sel + wave * 64;
     float4* myselp = selp + wave * 64;
+    const bool unit_scale = (a.g.voxel_scale[0] | a.g.voxel_scale[1] | a.g.voxel_scale[2]) == 1;      // the scaled reading
     int nsel = 0;
     for (int s0 = 0; s0 < a.S && nsel < a.M; s0 += 64) {
         const int s = s0 + lane;
@@ -476,7 +477,11 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
             sample_pos(a, ray, s, o, d, t0, t1, p);
             const FineCoord fc = fine_coord(a.g, p[0], p[1], p[2]);
             if (fc.ok) {
-                const int bit = ((fc.c[0] / a.g.voxel_scale[0]) * a.g.cdims[1] + fc.c[1] / a.g.voxel_scale[1]) * a.g.cdims[2] + fc.c[2] / a.g.voxel_scale[2];
+                int cc[3] = {fc.c[0], fc.c[1], fc.c[2]};
+                if (!unit_scale) {                     // (wave-uniform; a division by a run-time integer is ~25 instructions)
+                    cc[0] /= a.g.voxel_scale[0]; cc[1] /= a.g.voxel_scale[1]; cc[2] /= a.g.voxel_scale[2];
+                }
+                const int bit = (cc[0] * a.g.cdims[1] + cc[1]) * a.g.cdims[2] + cc[2];
                 occ = (bitmap[bit >> 5] >> (bit & 31)) & 1u;
                 cell = fc.c[0] | (fc.c[1] << 10) | (fc.c[2] << 20);
             }
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
         // candidate with all of its half, four broadcast keys per LDS read: ~3 vector instructions per candidate, where the
         // sorted-insertion form shifted an eight-entry list across lanes for every candidate (~40).  Same neighbours in the
         // same order.  (More than 32 candidates in a half -- dense clouds -- take the broadcast loop below.)
-        unsigned long long key[4];
+        unsigned long long key[4] = {~0ull, ~0ull, ~0ull, ~0ull};
         uint32_t d2b[4];
         unsigned long long cmask[4];
         int n0 = 0, n1 = 0;                                             // candidates of the lower / upper half
@@ -622,29 +627,40 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
         float4 cq[4];
 #pragma unroll
         for (int qi = 0; qi < 4; ++qi) cq[qi] = pts[max(cand_idx[qi], 0)];      // all four reads in flight (empty entries read point 0)
+        bool candf[4];
 #pragma unroll
         for (int qi = 0; qi < 4; ++qi) {
             const int jq = cand_idx[qi];
             const float4 q = cq[qi];
             const float dx = p[0] - q.x, dy = p[1] - q.y, dz = p[2] - q.z;
             const float d2 = (dx * dx + dy * dy) + dz * dz;
-            const bool cand = jq >= 0 && d2 < a.r2;
+            candf[qi] = jq >= 0 && d2 < a.r2;
             d2b[qi] = __float_as_uint(d2);
-            key[qi] = cand ? (((unsigned long long)d2b[qi] << 32) | (uint32_t)jq) : ~0ull;
-            cmask[qi] = __ballot(cand);
-            const uint32_t c0 = (uint32_t)cmask[qi], c1 = (uint32_t)(cmask[qi] >> 32);
-            // my place among the candidates of my half: those of earlier rounds + those of this round on lower lanes
-            const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(cmask[qi] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)cmask[qi], 0u));
-            const int pos = (h ? n1 + below - __popc(c0) : n0 + below);
-            if (cand && pos < 32) mycpk[h * 32 + pos] = key[qi];
-            n0 += __popc(c0);
-            n1 += __popc(c1);
+            cmask[qi] = __ballot(candf[qi]);
+            n0 += __popc((uint32_t)cmask[qi]);
+            n1 += __popc((uint32_t)(cmask[qi] >> 32));
         }
         int rank[4] = {0, 0, 0, 0};
         const int nmax = max(n0, n1);
         const bool packed = nmax <= 32;
         unsigned long long mine = ~0ull;                                // packed form: the candidate this lane ranks
-        if (packed) {
+        if (nmax > 0) {          // (most selected samples lie in the dilated shell around the cloud and have no candidate at all)
+            int b0 = 0, b1 = 0;
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                key[qi] = candf[qi] ? (((unsigned long long)d2b[qi] << 32) | (uint32_t)cand_idx[qi]) : ~0ull;
+                const uint32_t c0 = (uint32_t)cmask[qi], c1 = (uint32_t)(cmask[qi] >> 32);
+                // my place among the candidates of my half: those of earlier rounds + those of this round on lower lanes
+                const int below = (int)__builtin_amdgcn_mbcnt_hi(c1, __builtin_amdgcn_mbcnt_lo(c0, 0u));
+                const int pos = (h ? b1 + below - __popc(c0) : b0 + below);
+                if (candf[qi] && pos < 32) mycpk[h * 32 + pos] = key[qi];
+                b0 += __popc(c0);
+                b1 += __popc(c1);
+            }
+        }
+        if (nmax == 0) {
+            // nothing to rank
+        } else if (packed) {
             if (l32 < (h ? n1 : n0)) mine = mycpk[lane];                // same-wave LDS write -> read is ordered
             const unsigned long long* half = mycpk + h * 32;
             const int nhh = h ? n1 : n0;
@@ -679,16 +695,18 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
         }
         const int nh = h ? n1 : n0;
         if (COMPACT) {
-            int* row = stage_idx + (wave * 64 + slot) * 8;
-            if (live && l32 < 8 && l32 >= nh) row[l32] = -1;
-            if (packed) {
-                if (mine != ~0ull && rank[0] < 8) row[rank[0]] = gbase + (int)(uint32_t)mine;
-            } else {
+            if (nmax > 0) {          // (a slot without neighbours is never copied out of the staging rows: nothing to write)
+                int* row = stage_idx + (wave * 64 + slot) * 8;
+                if (live && l32 < 8 && l32 >= nh) row[l32] = -1;
+                if (packed) {
+                    if (mine != ~0ull && rank[0] < 8) row[rank[0]] = gbase + (int)(uint32_t)mine;
+                } else {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (key[q] != ~0ull && rank[q] < 8) row[rank[q]] = gbase + cand_idx[q];
+                    for (int q = 0; q < 4; ++q)
+                        if (key[q] != ~0ull && rank[q] < 8) row[rank[q]] = gbase + cand_idx[q];
+                }
+                if (live && l32 < 3) stage_pos[(wave * 64 + slot) * 4 + l32] = l32 == 0 ? p[0] : (l32 == 1 ? p[1] : p[2]);
             }
-            if (live && l32 < 3) stage_pos[(wave * 64 + slot) * 4 + l32] = l32 == 0 ? p[0] : (l32 == 1 ? p[1] : p[2]);
             if (n0 > 0) valid_bits |= (1ull << (2 * pair));
             if (n1 > 0) valid_bits |= (1ull << (2 * pair + 1));          // a dead upper half has no candidates
         } else {
