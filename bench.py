@@ -61,27 +61,35 @@ def synthetic_batch(global_batch, rank, world, device):
     return coords[sl].to(device), feats[sl].to(device)
 
 
-def query_roofline(S, query_ms, launches):
+def query_roofline(S, query_ms, launches, clock_ghz=None):
     """The neighbour-query kernel (grid_query_wave_kernel, csrc/geometry.hip) is neither HBM- nor MFMA-bound: its inputs are a
     6 KB cloud and a 1 MB voxel table, its work is integer / fp32 vector instructions.  Its bound is VECTOR ISSUE: a SIMD issues at
     most one vector wave-instruction per 2 cycles (MI355X_MICROARCH.md: v_fma_f32 wave64 = 2 cycles on a SIMD-32), 1,024 SIMDs.
-    Wave-instruction counts per launch come from a committed rocprofv3 --pmc pass over the same scene (profiles/r3_render_sq_pmc.json:
-    SQ_INSTS_VALU and friends; bench.py cannot collect counters); the duration is measured here with HIP events around the C call
-    (which also enqueues the 4-byte counter fill)."""
-    fp = os.path.join(ROOT, "profiles", "r3_render_sq_pmc.json")
-    if not os.path.exists(fp):
-        return {"kernel": "grid_query_wave_kernel", "avg_ms": query_ms, "launches": launches, "bound": "valu-issue", "achieved": None}
-    pj = json.load(open(fp)).get(f"S{S}", {}).get("grid_query_wave_kernel")
+    Wave-instruction counts per launch come from a committed rocprofv3 --pmc pass over the same scene (profiles/r*_render_sq_pmc.json:
+    SQ_INSTS_VALU and friends; bench.py cannot collect counters); the duration is measured here with HIP events around the C call.
+    The counter file records the sha256 of the kernel source it was taken on: when the in-tree csrc/geometry.hip differs (or the file
+    predates that record) the counts belong to another binary -- `stale_counters` says so and `achieved` / `frac` are None."""
+    import hashlib
+    base = {"kernel": "grid_query_wave_kernel", "avg_ms": query_ms, "launches": launches, "bound": "valu-issue", "achieved": None}
+    fp = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r4_render_sq_pmc.json", "r3_render_sq_pmc.json")) if os.path.exists(f)), None)
+    if fp is None:
+        return base
+    doc = json.load(open(fp))
+    pj = doc.get(f"S{S}", {}).get("grid_query_wave_kernel")
     if not pj:
-        return {"kernel": "grid_query_wave_kernel", "avg_ms": query_ms, "launches": launches, "bound": "valu-issue", "achieved": None}
-    clock_ghz = 2.4
-    peak = 1024 * clock_ghz / 2.0                                  # G vector wave-instructions / s
-    ach = pj["insts_valu"] / (query_ms * 1e-3) / 1e9
-    return {"kernel": "grid_query_wave_kernel (+ counter fill)", "bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "G wave-instr/s",
-            "frac": ach / peak, "avg_ms": query_ms, "launches": launches,
+        return base
+    src = os.path.join(ROOT, "neural-point-cloud-diffusion_amd", "csrc", "geometry.hip")
+    have = hashlib.sha256(open(src, "rb").read()).hexdigest() if os.path.exists(src) else None
+    want = doc.get("source_sha256", {}).get("geometry.hip")
+    stale = want is None or have is None or want != have
+    clock = clock_ghz or 2.4
+    peak = 1024 * clock / 2.0                                      # G vector wave-instructions / s
+    ach = None if stale else pj["insts_valu"] / (query_ms * 1e-3) / 1e9
+    return {"kernel": "grid_query_wave_kernel", "bound": "valu-issue", "achieved": ach, "peak": peak, "unit": "G wave-instr/s",
+            "frac": None if stale else ach / peak, "avg_ms": query_ms, "launches": launches, "stale_counters": stale,
             "vector_wave_instructions_per_launch": pj["insts_valu"], "all_wave_instructions_per_launch": pj.get("insts_all"),
-            "counters_source": "profiles/r3_render_sq_pmc.json (rocprofv3 --pmc, same scene / pose / depth samples)",
-            "peak_basis": "1,024 SIMDs x 2.4 GHz / 2 cycles per wave64 vector instruction"}
+            "counters_source": f"profiles/{os.path.basename(fp)} (rocprofv3 --pmc, same scene / pose / depth samples)",
+            "peak_basis": f"1,024 SIMDs x {clock:.2f} GHz ({'sclk sampled during the timed loop' if clock_ghz else 'nominal'}) / 2 cycles per wave64 vector instruction"}
 
 
 def bench_render(device, n_iters=100, burn_in=5):
@@ -127,9 +135,12 @@ def bench_render(device, n_iters=100, burn_in=5):
             from npcd.hip import render as hrender
             hrender.SHADE_EVENTS, hrender.QUERY_EVENTS = [], []
             net.renderer.count_pairs = False
-            for _ in range(22):
-                net.render(c, f, extr, intr, 128)
-            torch.cuda.synchronize()
+            with ClockSampler(device.index or 0, period_s=0.002) as rclk:
+                for _ in range(22):
+                    net.render(c, f, extr, intr, 128)
+                torch.cuda.synchronize()
+            rsum = rclk.summary()
+            rclock = rsum["sclk_mhz_min_median_max"][1] / 1e3 if rsum else None
             ev, hrender.SHADE_EVENTS = hrender.SHADE_EVENTS[2:], None
             qev, hrender.QUERY_EVENTS = hrender.QUERY_EVENTS[2:], None
             shade_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev))
@@ -141,7 +152,7 @@ def bench_render(device, n_iters=100, burn_in=5):
                                              "frac": flops / (shade_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, "avg_ms": shade_ms,
                                              "algorithmic_flops_per_view": flops, "launches": len(ev),
                                              "note": "f16 operands, fp32 accumulation (same dense peak as bf16); FLOPs as executed: the linear last aggregator layer on points, not pairs"},
-                        "roofline_query": query_roofline(S, query_ms, len(qev))}
+                        "roofline_query": query_roofline(S, query_ms, len(qev), rclock)}
     r = dict(per_s[128])
     # continuity with rounds 1-2, which ran the FINE-grid reading of torch_knnquery (fewer shading points with a neighbour, i.e.
     # less work per view): the same view at grid_level "fine" (DESIGN.md section 3 has the evidence for the default)
@@ -393,6 +404,22 @@ def host_cpu_info():
     return model, os.cpu_count() or 1, affinity
 
 
+def physical_cores():
+    """Distinct (package, core) pairs of /proc/cpuinfo; None when the file does not say."""
+    cores, phys = set(), None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                key = line.split(":", 1)[0].strip().lower()
+                if key == "physical id":
+                    phys = line.split(":", 1)[1].strip()
+                elif key == "core id":
+                    cores.add((phys, line.split(":", 1)[1].strip()))
+    except OSError:
+        return None
+    return len(cores) or None
+
+
 PARITY_PARAMS = ("input_proj.weight", "time_embed.c_fc.weight", "backbone.resblocks.0.attn.c_qkv.weight", "backbone.resblocks.0.ln_1.weight",
                  "backbone.resblocks.11.mlp.c_fc.weight", "backbone.resblocks.23.attn.c_proj.weight", "backbone.resblocks.23.mlp.c_proj.bias",
                  "ln_post.weight", "output_proj.weight")
@@ -401,14 +428,19 @@ PARITY_PARAMS = ("input_proj.weight", "time_embed.c_fc.weight", "backbone.resblo
 def cpu_baseline():
     """The CPU oracle (oracle/: an fp32 PyTorch restatement of the reference, pinned by the golden fixtures; `kind: port`) timed on
     this box's host cores on a BOUNDED sample of the benchmark workload: full-width denoiser train steps (W 1024 / L 24 / H 16,
-    forward + backward + AdamW) on B = 4 of the 64 samples of a step -- one untimed warm-up step, then THREE timed steps, the
-    median scaled by 64 / 4 -- plus one 128 x 128 render with the voxel-grid semantics for the rays/s half.
+    forward + backward + AdamW) on B = 4 of the 64 samples of a step, at TWO thread counts (BASELINE.md section 3 asks for all
+    cores): 32 threads and one thread per PHYSICAL core the process may use -- per thread count one untimed warm-up step and two
+    timed steps; `value` is the FASTER configuration's best step scaled by 64 / 4, `cores` the threads that configuration used --
+    plus one 128 x 128 render with the voxel-grid semantics for the rays/s half.
     The warm-up step's loss and gradient norms are returned too: bench.py feeds the same samples, timesteps and noise through
     the GPU trainer and reports the differences (`parity_full_width`)."""
     from oracle import denoiser as od, diffusion as odf, renderer as orr
     model_name, logical, affinity = host_cpu_info()
-    threads = min(affinity, 32)                   # more threads only add contention for these op sizes
-    torch.set_num_threads(threads)
+    phys = physical_cores()
+    candidates = [min(affinity, 32)]
+    if phys and min(affinity, phys) not in candidates:
+        candidates.append(min(affinity, phys))
+    torch.set_num_threads(candidates[0])
     B = 4
     params = od.init_params(CFG["coords_dim"], CFG["feats_dim"], CFG["width"], CFG["layers"], CFG["heads"], seed=0)
     leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
@@ -430,13 +462,23 @@ def cpu_baseline():
     ref = {"loss": float(loss0.detach()), "grad_norm": {k: float(leaves[k].grad.norm()) for k in PARITY_PARAMS},
            "inputs": (params, c0, f0, t, cn, fn)}
     opt.step()
-    samples = []
-    for _ in range(3):
-        t0 = time.perf_counter()
-        fwd_bwd()
-        opt.step()
-        samples.append(time.perf_counter() - t0)
-    dt = sorted(samples)[1]
+    by_threads = {}
+    for i, th in enumerate(candidates):
+        torch.set_num_threads(th)
+        if i:
+            fwd_bwd()                             # this thread count's warm-up
+            opt.step()
+        samples = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            fwd_bwd()
+            opt.step()
+            samples.append(time.perf_counter() - t0)
+        by_threads[th] = samples
+    threads = min(by_threads, key=lambda th: min(by_threads[th]))
+    torch.set_num_threads(threads)
+    samples = by_threads[threads]
+    dt = min(samples)
     steps_per_s = (B / dt) / CFG["global_batch"]
     fp = orr.init_field_params(32, seed=0)
     coords, feats = orr.synthetic_cloud(512, 32, 1, seed=0)
@@ -449,9 +491,11 @@ def cpu_baseline():
            "cpu_model": model_name, "host_logical_cpus": logical, "affinity_cpus": affinity,
            "sample": f"oracle (fp32 PyTorch CPU restatement of the reference) on {threads} threads of '{model_name}' "
                      f"({logical} logical CPUs, {affinity} usable): full-width denoiser train step (fwd + bwd + AdamW, "
-                     f"{CFG['layers']} blocks) at B = {B} of {CFG['global_batch']}: 1 warm-up + 3 timed steps = "
-                     f"{', '.join(f'{x:.2f}' for x in samples)} s, median x {CFG['global_batch'] // B} (batch); "
+                     f"{CFG['layers']} blocks) at B = {B} of {CFG['global_batch']}: per thread count 1 warm-up + 2 timed steps "
+                     f"({'; '.join(f'{th} threads: ' + ', '.join(f'{x:.2f}' for x in v) + ' s' for th, v in by_threads.items())}), "
+                     f"best step of the faster count x {CFG['global_batch'] // B} (batch); "
                      f"render: one {res} x {res} view (grid semantics, 128 depth samples) = {dtr:.1f} s",
+           "physical_cores": phys, "timed_step_seconds_by_threads": {str(k): v for k, v in by_threads.items()},
            "timed_step_seconds": samples, "render_rays_per_s": res * res / dtr}
     return out, ref
 

@@ -1289,12 +1289,14 @@ extern "C" int npcd_grid_query(const npcd_grid_params* g_in, const void* workspa
     a.x = x; a.rays_o = rays_o; a.rays_d = rays_d; a.t0 = t0; a.t1 = t1;
     a.sample_idx = sample_idx; a.sample_loc = sample_loc; a.slot_sample = slot_sample; a.nsel = nsel;
     const int bpe = (R + 3) / 4;
-    const size_t lds = (size_t)N * 16 + (size_t)a.nwords * 4 + 4 * 64 * 4 + 16 + 4 * 64 * 16 + 4 * 64 * 8;      // + the selected samples' geometry, packed candidates
+    // grid_query_kernel (mode 1): the cloud, the bitmap words and [4][64] selected sample ids -- nothing else
+    const size_t lds = (size_t)N * 16 + (size_t)a.nwords * 4 + 4 * 64 * 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
     static DynLds lds_attr;
     if (mode == 1 && lds > 65536) NPCD_HIP_CHECK(lds_attr.ensure(reinterpret_cast<const void*>(grid_query_kernel<false>), lds));
     if (mode == 0) {
-        const size_t lds2 = lds + 4 * 64 * 8 * 4 + 4 * 64 * 4 * 4;
+        // grid_query_wave_kernel: + the selected samples' geometry, the packed candidates and the per-ray staging rows
+        const size_t lds2 = lds + 16 + 4 * 64 * 16 + 4 * 64 * 8 + 4 * 64 * 8 * 4 + 4 * 64 * 4 * 4;
         static DynLds lds2_attr;
         if (lds2 > 65536) NPCD_HIP_CHECK(lds2_attr.ensure(reinterpret_cast<const void*>(grid_query_wave_kernel<false>), lds2));
         hipLaunchKernelGGL(grid_query_wave_kernel<false>, dim3(B * bpe), dim3(256), lds2, st, a, CompactOut{}, bpe);

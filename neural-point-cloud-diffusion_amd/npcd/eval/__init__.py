@@ -29,6 +29,7 @@ def evaluate_pointnerf(pointnerf, samples: Iterable[Dict[str, torch.Tensor]], ev
     reference's dataloader).  Returns {'psnr': mean over all views, 'runtime_model_in_msec': mean over the timed calls (NaN-free),
     'views': per-view records}."""
     records: List[Dict] = []
+    levels = set()
     dev = next(pointnerf.parameters()).device
     for num, sample in enumerate(samples):
         sample = {k: v.to(dev) for k, v in sample.items()}
@@ -41,10 +42,12 @@ def evaluate_pointnerf(pointnerf, samples: Iterable[Dict[str, torch.Tensor]], ev
             torch.cuda.synchronize()
             dt = time.time() - t0
             timed = eval_batch_size == 1 and num >= burn_in_samples
+            levels.add(pred.get("grid_level"))
             imgs = unflatten_pred(pred["channels"].contiguous()[0])
             for j, img in enumerate(imgs):
                 records.append({"sample": num, "view": v0 + j, "psnr": psnr(img, sample["images"][0, v0 + j]),
                                 "runtime_model_in_msec": 1000 * dt if timed else float("nan")})
     times = [r["runtime_model_in_msec"] for r in records if not math.isnan(r["runtime_model_in_msec"])]
     return {"psnr": sum(r["psnr"] for r in records) / max(1, len(records)),
-            "runtime_model_in_msec": sum(times) / len(times) if times else float("nan"), "views": records}
+            "runtime_model_in_msec": sum(times) / len(times) if times else float("nan"), "views": records,
+            "grid_level": sorted(str(l) for l in levels)}

@@ -278,4 +278,5 @@ def render_train(renderer, kp_pos, kp_feat, extr, intr, resolution: int, sample:
         out["ray_idx"] = ray_ids[None, :].expand(B * T, Rs).reshape(-1)[sel].view(B, T, n, 1)
     out["num_shading_points"] = int(nb.shape[0])
     out["num_pairs"] = (nb >= 0).sum()                                           # device scalar (no host round trip here)
+    out["grid_level"] = "brute_force" if knn_mode else getattr(renderer.field.aggregator.voxel_grid, "grid_level", None)
     return out

@@ -274,14 +274,44 @@ class DiffusionTrainer:
             # loop, generate() in any precision) or reads the weights through state_dict() first completes the gathers it depends
             # on.  In-place writes into parameters (copying EMA weights in) cannot be intercepted: call wait_params() first.
             self._fused_engine = eng
+            # The hooks hold the trainer only weakly and their handles are kept: a second trainer on the same model first
+            # close()s (or simply outlives) the first one without stacking hooks or keeping its moments / EMA / shadow alive.
+            import weakref
+            me = weakref.ref(self)
+
+            def _fwd_hook(module, args):
+                tr = me()
+                if tr is not None:
+                    tr._await_params_for_forward(module, args)
+
+            def _sd_hook(module, prefix, keep_vars):
+                tr = me()
+                if tr is not None:
+                    tr.wait_params()
+
+            self._hook_handles = []
             if denoiser is not None:
-                denoiser.register_forward_pre_hook(self._await_params_for_forward)
-            diffusion.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self.wait_params())
+                self._hook_handles.append(denoiser.register_forward_pre_hook(_fwd_hook))
+                self._hook_handles.append(denoiser.register_state_dict_pre_hook(_sd_hook))      # denoiser.state_dict() read directly
+            self._hook_handles.append(diffusion.register_state_dict_pre_hook(_sd_hook))
         else:
             # reference path (CPU tests / ablation): torch AdamW over ONE flat "parameter"
             self.master = nn.Parameter(self.flat.flat, requires_grad=True)
             self.master.grad = self.flat.grad
             self.optimizer = torch.optim.AdamW([self.master], lr=lr, weight_decay=weight_decay, fused=self.flat.flat.is_cuda)
+
+    def close(self):
+        """Detach this trainer from the model: complete pending parameter gathers, remove its forward / state_dict hooks and the
+        fused engine it installed.  Call before building another DiffusionTrainer on the same model."""
+        self.wait_params()
+        for h in getattr(self, "_hook_handles", []):
+            h.remove()
+        self._hook_handles = []
+        denoiser = getattr(self.model, "denoiser", None)
+        eng = getattr(self, "_fused_engine", None)
+        if denoiser is not None and eng is not None and getattr(denoiser.backbone, "fused_engine", None) is eng:
+            denoiser.backbone.fused_engine = None
+        self._fused_engine = None
 
     def ema_state_dict(self, gathered: bool = False):
         """state_dict of the EMA model: same keys as the running model (utils/ema.py:80), buffers copied.  Collective with a

@@ -98,9 +98,17 @@ def gen_timestep(ref):
          dim1024=ref.transformer.timestep_embedding(t, 1024), dim7=ref.transformer.timestep_embedding(t, 7))
 
 
-def gen_denoiser(ref):
-    for tag, (F, W, L, H, N, B) in {"f32_w64": (32, 64, 2, 1, 32, 2), "f128_w64": (128, 64, 1, 1, 16, 2)}.items():
-        torch.manual_seed(7 + F)
+DENOISER_CASES = {"f32_w64": (32, 64, 2, 1, 32, 2), "f128_w64": (128, 64, 1, 1, 16, 2),
+                  # round 4: a MULTI-HEAD case whose token count is 128 j + 1 (N = 128 -> n = 129): the edge-token path, the
+                  # column-sum by-products and the head interleave of c_qkv all run inside the fused node
+                  "f32_w128_h2": (32, 128, 2, 2, 128, 2)}
+
+
+def gen_denoiser(ref, only=None):
+    for tag, (F, W, L, H, N, B) in DENOISER_CASES.items():
+        if only and tag not in only:
+            continue
+        torch.manual_seed(7 + F + (W if H > 1 else 0))
         net = ref.transformer.NPCDTransformer(coords_dim=3, feats_dim=F, width=W, layers=L, heads=H,
                                               use_flash_attn=False)
         with torch.no_grad():                      # the reference zero-inits output_proj
@@ -120,7 +128,7 @@ def gen_denoiser(ref):
         ec, ef = net(coords, feats, t)
         ((ec * gc).sum() + (ef * gf).sum()).backward()
         arrays = {"coords": coords, "feats": feats, "t": t, "gc": gc, "gf": gf, "eps_coords": ec,
-                  "eps_feats": ef, "heads": H}
+                  "eps_feats": ef, "heads": H, "width": W, "layers": L}
         for k, v in net.state_dict().items():
             arrays["w:" + k] = v
         for k, v in net.named_parameters():
@@ -338,10 +346,15 @@ def gen_render_options(ref, ref_root):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only-denoiser", nargs="*", default=None,
+                    help="write only these denoiser_<tag>.npz fixtures (leaves every other fixture file untouched)")
     args = ap.parse_args()
     torch.set_num_threads(4)
     ref = import_reference(args.ref)
     print("writing fixtures to", HERE)
+    if args.only_denoiser is not None:
+        gen_denoiser(ref, only=args.only_denoiser)
+        return
     gen_attention(ref)
     gen_timestep(ref)
     gen_denoiser(ref)

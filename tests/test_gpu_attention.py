@@ -289,13 +289,14 @@ def test_attention_fp32_backward_kernel_ragged_lengths(n, H, B):
     assert torch.equal(grads[0], grads[1])
 
 
-@pytest.mark.parametrize("tag", ["f32_w64", "f128_w64"])
+@pytest.mark.parametrize("tag", ["f32_w64", "f128_w64", "f32_w128_h2"])
 def test_denoiser_matches_reference_golden(golden, tag):
     from npcd.models.diffusion import NPCDTransformer
     g = golden("denoiser_" + tag)
     T = torch.from_numpy
     F_ = g["feats"].shape[1]
-    net = NPCDTransformer(coords_dim=3, feats_dim=F_, width=64, layers=2 if tag == "f32_w64" else 1, heads=int(g["heads"]))
+    net = NPCDTransformer(coords_dim=3, feats_dim=F_, width=int(g.get("width", 64)), layers=int(g.get("layers", 2 if tag == "f32_w64" else 1)),
+                          heads=int(g["heads"]))
     net.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith("w:")})
     net = net.cuda()
     with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -311,7 +312,7 @@ def test_denoiser_matches_reference_golden(golden, tag):
     assert worst < 5e-2, f"worst param-grad rel-L2 {worst:.3e}"
 
 
-@pytest.mark.parametrize("tag", ["f32_w64", "f128_w64"])
+@pytest.mark.parametrize("tag", ["f32_w64", "f128_w64", "f32_w128_h2"])
 def test_denoiser_fp32_training_matches_reference_golden(golden, tag):
     """`--dtype float32` (train_diffusion.py:78 choice, no autocast): the whole denoiser forward + backward in fp32 with the fp32
     attention kernels (forward, dq, dk/dv on the fp32 matrix instruction) against the reference's own fp32 outputs and parameter
@@ -320,7 +321,8 @@ def test_denoiser_fp32_training_matches_reference_golden(golden, tag):
     g = golden("denoiser_" + tag)
     T = torch.from_numpy
     F_ = g["feats"].shape[1]
-    net = NPCDTransformer(coords_dim=3, feats_dim=F_, width=64, layers=2 if tag == "f32_w64" else 1, heads=int(g["heads"]))
+    net = NPCDTransformer(coords_dim=3, feats_dim=F_, width=int(g.get("width", 64)), layers=int(g.get("layers", 2 if tag == "f32_w64" else 1)),
+                          heads=int(g["heads"]))
     net.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith("w:")})
     net = net.cuda()
     ec, ef = net(T(g["coords"]).cuda(), T(g["feats"]).cuda(), T(g["t"]).cuda())

@@ -141,7 +141,7 @@ def test_fused_backbone_matches_module_path():
     assert rel(ta.ema, tb.ema) < 1e-4
 
 
-@pytest.mark.parametrize("tag", ["f32_w64", "f128_w64"])
+@pytest.mark.parametrize("tag", ["f32_w64", "f128_w64", "f32_w128_h2"])
 @pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
 def test_fused_engine_matches_reference_golden_directly(golden, tag, half):
     """The BENCHMARKED code path (_BackboneFn: one autograd node, hand-written backward, flat buffers, 16-bit shadow) against
@@ -156,7 +156,8 @@ def test_fused_engine_matches_reference_golden_directly(golden, tag, half):
     g = golden("denoiser_" + tag)
     T = torch.from_numpy
     F_ = g["feats"].shape[1]
-    net = NPCDTransformer(coords_dim=3, feats_dim=F_, width=64, layers=2 if tag == "f32_w64" else 1, heads=int(g["heads"]))
+    net = NPCDTransformer(coords_dim=3, feats_dim=F_, width=int(g.get("width", 64)), layers=int(g.get("layers", 2 if tag == "f32_w64" else 1)),
+                          heads=int(g["heads"]))
     net.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith("w:")})
     net = net.cuda()
     flat = FlatBuffers(net)
@@ -476,3 +477,58 @@ def test_small_wgrad_matches_the_fp32_product(T, J, K):
     assert ((out.double() - ref).abs() <= 1e-5 * mag + 1e-30).all()
     assert torch.equal(out, ew.small_wgrad(dy, x))                                      # fixed summation order
     assert ew.small_wgrad(dy.float(), x) is None and ew.small_wgrad(dy, x[:, :48].contiguous()) is None   # declined, caller falls back
+
+
+def test_full_width_two_blocks_elementwise_gradients_vs_oracle():
+    """Engine-level parity at the BENCHMARK width: W 1024 / H 16 / n = 513 (N = 512 points + the time token) / L 2 / B 2 on the
+    fused engine under bf16 autocast against the CPU oracle (oracle/denoiser.py, pinned to the reference by the denoiser_*.npz
+    fixtures) on the same weights and inputs -- ELEMENTWISE rel-L2 of the eps prediction and of named parameter gradients (a
+    head permutation, a wrong column-sum by-product or a mis-handled edge token would pass a comparison of gradient NORMS).
+    Non-trivial biases and LayerNorm affines.  Bars: eps 2e-2, every checked gradient 5e-2 (bf16 GEMM operands and attention
+    against fp32)."""
+    from oracle import denoiser as od
+    from npcd.models.diffusion import NPCDTransformer
+    from npcd.train import DiffusionTrainer
+    from npcd.models.diffusion import DiffusionModel
+    W, H, L, N, Fd, B = 1024, 16, 2, 512, 128, 2
+    params = od.init_params(3, Fd, W, L, H, seed=3)
+    g = torch.Generator().manual_seed(17)
+    for k in params:                                   # the synthetic init has zero biases and unit LayerNorms: perturb them
+        if k.endswith(".bias"):
+            params[k] = params[k] + torch.randn(params[k].shape, generator=g) * 0.05
+        elif ".ln_" in k or k.startswith("ln_"):
+            params[k] = params[k] + torch.randn(params[k].shape, generator=g) * 0.1
+    coords, feats = torch.randn(B, 3, N, generator=g), torch.rand(B, Fd, N, generator=g) * 2 - 1
+    t = torch.tensor([11, 873])
+    gc, gf = torch.randn(B, 3, N, generator=g), torch.randn(B, Fd, N, generator=g)
+    torch.set_num_threads(min(16, torch.get_num_threads() or 1))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    ec_r, ef_r = od.denoiser_forward(leaves, coords, feats, t, H)
+    ((ec_r * gc).sum() + (ef_r * gf).sum()).backward()
+
+    model = DiffusionModel(3, Fd, N, W, L, H, True)
+    model.denoiser.load_state_dict(params)
+    model = model.cuda().train()
+    tr = DiffusionTrainer(model, dtype=torch.bfloat16)
+    assert tr.native and model.denoiser.backbone.fused_engine is not None
+    tr.flat.zero_grad()
+    tr.reducer.start_step()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        ec, ef = model.denoiser(coords.cuda(), feats.cuda(), t.cuda())
+        loss = (ec.float() * gc.cuda()).sum() + (ef.float() * gf.cuda()).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert rel(ec, ec_r.detach()) < 2e-2 and rel(ef, ef_r.detach()) < 2e-2
+    named = dict(model.denoiser.named_parameters())
+    checked = ["input_proj.weight", "time_embed.c_fc.weight", "ln_pre.weight",
+               "backbone.resblocks.0.ln_1.weight", "backbone.resblocks.0.ln_1.bias",
+               "backbone.resblocks.0.attn.c_qkv.weight", "backbone.resblocks.0.attn.c_qkv.bias",
+               "backbone.resblocks.0.attn.c_proj.weight", "backbone.resblocks.0.attn.c_proj.bias",
+               "backbone.resblocks.0.ln_2.weight", "backbone.resblocks.0.mlp.c_fc.weight", "backbone.resblocks.0.mlp.c_fc.bias",
+               "backbone.resblocks.0.mlp.c_proj.weight", "backbone.resblocks.0.mlp.c_proj.bias",
+               "backbone.resblocks.1.attn.c_qkv.weight", "backbone.resblocks.1.attn.c_qkv.bias",
+               "backbone.resblocks.1.mlp.c_fc.bias", "backbone.resblocks.1.mlp.c_proj.weight",
+               "ln_post.weight", "output_proj.weight"]
+    errs = {k: rel(named[k].grad, leaves[k].grad) for k in checked}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    assert worst[1] < 5e-2, errs

@@ -35,7 +35,7 @@ def test_timestep_embedding(golden):
         close(od.timestep_embedding(t, dim), g[f"dim{dim}"], 1e-6)
 
 
-@pytest.mark.parametrize("tag", ["f32_w64", "f128_w64"])
+@pytest.mark.parametrize("tag", ["f32_w64", "f128_w64", "f32_w128_h2"])
 def test_denoiser_forward_backward(golden, tag):
     g = golden("denoiser_" + tag)
     p = {k[2:]: T(v).clone().requires_grad_(True) for k, v in g.items() if k.startswith("w:")}

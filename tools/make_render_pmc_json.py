@@ -50,7 +50,10 @@ for S in (128, 64):
         if gui and d1.get(k):
             dd = d1[k][3:] if len(d1[k]) > 3 else d1[k]
             d["duration_us_under_pmc"] = sum(dd) / len(dd) / 1e3
-            d["clock_ghz"] = gui / 8 / (sum(dd) / len(dd))
+            # GRBM_GUI_ACTIVE / profiler duration is a clock only for long dispatches (MI355X_MICROARCH.md, DVFS give-back: reads
+            # high below ~0.3 ms; the round-3 file carried 2.7-7 "GHz" for the 5-60 us kernels): not reported for short ones
+            if d["duration_us_under_pmc"] >= 50.0:
+                d["clock_ghz"] = gui / 8 / (sum(dd) / len(dd))
         if gui and m.get("SQ_VALU_MFMA_BUSY_CYCLES"):
             d["mfma_busy"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8 * 1024)
         if m.get("SQ_INSTS_MFMA"):
@@ -64,10 +67,15 @@ for S in (128, 64):
     res[f"S{S}"] = per
 res["note"] = ("rocprofv3 --pmc, tools/run_render_profile.sh: one 128 x 128 view per call of the bench scene (512-point ellipsoid cloud, pose (30, 20), k = 8, "
                "M = 50), means per launch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (ratios unit-free)")
+# which kernel sources these counters belong to: bench.py flags the file as stale when the in-tree sources differ
+import hashlib
+csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neural-point-cloud-diffusion_amd", "csrc")
+res["source_sha256"] = {f: hashlib.sha256(open(os.path.join(csrc, f), "rb").read()).hexdigest()
+                        for f in ("geometry.hip", "shade.hip", "shade_common.h", "common.h") if os.path.exists(os.path.join(csrc, f))}
 json.dump(res, open(out_all, "w"), indent=1)
-json.dump({S: {k: v for k, v in per.items() if k.startswith("shade_")} for S, per in res.items() if S != "note"} | {"note": res["note"]}, open(out_shade, "w"), indent=1)
+json.dump({S: {k: v for k, v in per.items() if k.startswith("shade_")} for S, per in res.items() if S.startswith("S") and isinstance(per, dict) and S[1:].isdigit()} | {"note": res["note"], "source_sha256": res["source_sha256"]}, open(out_shade, "w"), indent=1)
 for S, per in res.items():
-    if S == "note":
+    if not (S.startswith("S") and S[1:].isdigit()):
         continue
     for k, v in per.items():
         print(S, k, {x: (round(y, 3) if isinstance(y, float) else y) for x, y in v.items() if x not in ("counters_mean_per_launch", "wave_cycle_split")},

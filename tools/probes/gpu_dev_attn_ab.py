@@ -9,7 +9,10 @@ for _ in range(rounds):
         env = dict(os.environ)
         if l != "default":
             env["NPCD_HIP_LIB"] = l
-        out = subprocess.run([sys.executable, os.path.join(R, "tools", "gpu_dev_attn_time.py"), "40", n], env=env, capture_output=True, text=True).stdout
+        r = subprocess.run([sys.executable, os.path.join(R, "tools", "probes", "gpu_dev_attn_time.py"), "40", n], env=env, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.exit(f"child failed for {l} (rc {r.returncode}):\n{r.stderr[-2000:]}")
+        out = r.stdout
         for m in re.finditer(r"^(\w+): median ([\d.]+) us", out, re.M):
             res[l].setdefault(m.group(1), []).append(float(m.group(2)))
 for l in libs:
