@@ -45,7 +45,10 @@ def build_trainer(device, per_rank_batch):
     model = DiffusionModel(CFG["coords_dim"], CFG["feats_dim"], CFG["num_points"], CFG["width"], CFG["layers"], CFG["heads"], True)
     torch.nn.init.normal_(model.denoiser.output_proj.weight, std=0.02)    # non-zero so grads are non-trivial
     model = model.to(device).train()
-    trainer = DiffusionTrainer(model, lr=7e-5, weight_decay=0.01, ema_decay=0.9999, dtype=torch.bfloat16)
+    # NPCD_BENCH_NO_SHARD=1: plain bucketed all-reduce instead of reduce-scatter + sharded optimizer + all-gather;
+    # NPCD_COMM_BF16=1 (read by the trainer): gradient buckets travel as bf16.  A/B switches for the first multi-GPU runs.
+    shard = False if os.environ.get("NPCD_BENCH_NO_SHARD") else None
+    trainer = DiffusionTrainer(model, lr=7e-5, weight_decay=0.01, ema_decay=0.9999, dtype=torch.bfloat16, shard_optimizer=shard)
     # the number below is only valid for the native path: fused AdamW/EMA kernel, bf16 shadow, hand-written backbone node
     assert trainer.native, "DiffusionTrainer fell back to the torch optimizer: libnpcd_hip.so path not engaged"
     assert model.denoiser.backbone.fused_engine is not None, "fused HIP backbone (FusedBackboneEngine) not engaged"
@@ -577,6 +580,8 @@ def main():
     ap.add_argument("--no-proxy", action="store_true", help="skip the one-GPU strong-scaling proxy (per-GPU batch 64/32/16/8)")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the BASELINE configs[4] step (2048 points x 256-d, per-GPU batch 32)")
     ap.add_argument("--no-sampler", action="store_true", help="skip the DDPM reverse-step timing (SURVEY 8(f) rank 1)")
+    ap.add_argument("--rccl-algo", default=None, help="NCCL_ALGO for RCCL (e.g. Ring, Tree); default: RCCL's own choice")
+    ap.add_argument("--rccl-proto", default=None, help="NCCL_PROTO for RCCL (e.g. Simple, LL, LL128); default: RCCL's own choice")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -591,6 +596,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if args.rccl_algo:
+        os.environ["NCCL_ALGO"] = args.rccl_algo            # (read by RCCL at communicator creation)
+    if args.rccl_proto:
+        os.environ["NCCL_PROTO"] = args.rccl_proto
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if dryrun:
@@ -733,6 +742,17 @@ def main():
         "tuned_gemm_file": "profiles/tunableop_gfx950.csv" if use_tuned else None,
         "clock": clocks.summary(),
     }
+    if world > 1:
+        # what went over the wire in the last step, and proof that the ranks still hold the same model
+        trainer.wait_params()
+        chk = torch.stack([trainer.flat.flat.double().sum(), trainer.flat.flat.double().abs().sum()])
+        allc = [torch.empty_like(chk) for _ in range(world)]
+        dist.all_gather(allc, chk)
+        comm = trainer.comm_stats()
+        comm["parameters_identical_across_ranks"] = bool(all(torch.equal(allc[0], c) for c in allc))
+        comm["backend"] = dist.get_backend()
+        comm["rccl_env"] = {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS") if k in os.environ}
+        result["comm"] = comm
     if world == 1 and not args.no_proxy:
         try:
             result["strong_scaling_proxy"] = strong_scaling_proxy(trainer, coords, feats)

@@ -179,7 +179,12 @@ class GradReducer:
             if left > 0:
                 self._launch(b)
                 self._left[b] = 0
+        self.pending_at_finish = 0      # collectives still running when the backward ended (bookkeeping: the exposed ones)
         for (h, post), b in zip(self.handles, self.launched):
+            try:
+                self.pending_at_finish += 0 if h.is_completed() else 1
+            except (RuntimeError, AttributeError):
+                pass
             h.wait()
             if post is not None:
                 post()
@@ -299,6 +304,23 @@ class DiffusionTrainer:
             self.master = nn.Parameter(self.flat.flat, requires_grad=True)
             self.master.grad = self.flat.grad
             self.optimizer = torch.optim.AdamW([self.master], lr=lr, weight_decay=weight_decay, fused=self.flat.flat.is_cuda)
+
+    def comm_stats(self):
+        """Communication bookkeeping of the LAST step of this rank (bench.py puts it into the line for n_gpus > 1, DESIGN.md
+        section 6): bytes handed to the gradient collectives, bytes of the parameter all-gather, number of collectives, and how many
+        gradient collectives were still running when the backward had finished (the exposed ones)."""
+        red = self.reducer
+        grad_elem = 2 if red.comm_dtype is not None else 4
+        shard = bool(red.shard)
+        gather = sum((e - s) // red.world * 4 for s, e in red.buckets) if shard else 0
+        return {"mode": ("reduce_scatter+sharded_adamw+all_gather" if shard else "all_reduce") if red.active else "none",
+                "world": red.world, "buckets": len(red.buckets), "bucket_bytes_fp32": [(e - s) * 4 for s, e in red.buckets],
+                "gradient_wire_dtype": "bf16" if grad_elem == 2 else "fp32",
+                "gradient_bytes_handed_to_collectives": int(red.wire_bytes),
+                "parameter_all_gather_send_bytes": int(gather),
+                "collectives_per_step": len(getattr(red, "launched", [])) * (2 if shard else 1),
+                "gradient_collectives_pending_when_backward_ended": int(getattr(red, "pending_at_finish", 0)),
+                "lazy_parameter_gather": bool(shard and getattr(self, "lazy_gather", False))}
 
     def close(self):
         """Detach this trainer from the model: complete pending parameter gathers, remove its forward / state_dict hooks and the

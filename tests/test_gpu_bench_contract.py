@@ -49,6 +49,32 @@ def test_bench_multi_rank_code_path_dry_run():
     assert "rays_per_s_all_gpus" in d["render"]
 
 
+@pytest.mark.parametrize("mode", ["bf16_wire", "all_reduce"])
+def test_bench_multi_rank_dry_run_other_comm_modes(mode):
+    """The same two-rank dry run through bench.py with the gradient buckets on the wire as bf16 (NPCD_COMM_BF16=1) and with the
+    plain all-reduce + unsharded optimizer (NPCD_BENCH_NO_SHARD=1): after the run every rank must hold bit-identical parameters
+    (`comm.parameters_identical_across_ranks`, computed from an all-gather of parameter checksums inside bench.py) and the line
+    must say what went over the wire."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, NPCD_BENCH_DRYRUN_ONE_GPU="1")
+    env["NPCD_COMM_BF16" if mode == "bf16_wire" else "NPCD_BENCH_NO_SHARD"] = "1"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-render"], capture_output=True, text=True, env=env, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    c = d["comm"]
+    assert c["parameters_identical_across_ranks"] is True
+    n_bytes = sum(c["bucket_bytes_fp32"])
+    if mode == "bf16_wire":
+        assert c["mode"].startswith("reduce_scatter") and c["gradient_wire_dtype"] == "bf16"
+        assert c["gradient_bytes_handed_to_collectives"] == n_bytes // 2 and c["parameter_all_gather_send_bytes"] == n_bytes // 2
+    else:
+        assert c["mode"] == "all_reduce" and d["native_path"]["sharded_optimizer"] is False
+        assert c["gradient_bytes_handed_to_collectives"] == n_bytes and c["parameter_all_gather_send_bytes"] == 0
+
+
 def test_smoke_entry():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py"), "smoke"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])

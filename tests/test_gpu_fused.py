@@ -532,3 +532,31 @@ def test_full_width_two_blocks_elementwise_gradients_vs_oracle():
     errs = {k: rel(named[k].grad, leaves[k].grad) for k in checked}
     worst = max(errs.items(), key=lambda kv: kv[1])
     assert worst[1] < 5e-2, errs
+
+
+def test_trainer_close_removes_its_hooks_and_engine():
+    """A second DiffusionTrainer on the same model must not stack forward / state_dict hooks on top of the first one's:
+    close() removes them and the fused engine; the hooks hold the trainer only weakly."""
+    import gc
+    import weakref
+    from npcd.train import DiffusionTrainer
+    a, _ = _models()
+    den = a.denoiser
+    n_fwd, n_sd_model, n_sd_den = len(den._forward_pre_hooks), len(a._state_dict_pre_hooks), len(den._state_dict_pre_hooks)
+    t1 = DiffusionTrainer(a, fused=True)
+    assert len(den._forward_pre_hooks) == n_fwd + 1 and len(a._state_dict_pre_hooks) == n_sd_model + 1
+    assert len(den._state_dict_pre_hooks) == n_sd_den + 1
+    t1.close()
+    assert len(den._forward_pre_hooks) == n_fwd and len(a._state_dict_pre_hooks) == n_sd_model and len(den._state_dict_pre_hooks) == n_sd_den
+    assert den.backbone.fused_engine is None
+    t2 = DiffusionTrainer(a, fused=True)
+    assert len(den._forward_pre_hooks) == n_fwd + 1 and den.backbone.fused_engine is not None
+    g = torch.Generator().manual_seed(2)
+    c0, f0 = torch.randn(2, 3, 48, generator=g).cuda(), torch.randn(2, 32, 48, generator=g).cuda()
+    loss, _ = t2.step(c0, f0)
+    assert torch.isfinite(loss)
+    # a trainer that is dropped WITHOUT close() is collectable (the hooks do not keep it alive) and its hooks turn into no-ops
+    r = weakref.ref(t2)
+    del t2
+    gc.collect()
+    a.state_dict()

@@ -483,9 +483,10 @@ def test_disparity_space_sampling_and_fixed_limits_on_the_grid_path():
     assert orr.psnr(orr.unflatten_image(wide["channels"].cpu()), orr.unflatten_image(base["channels"].cpu())) > 20.0
 
 
-@pytest.mark.parametrize("res,B,views", [(32, 2, 2), (128, 1, 1)])
-def test_render_vs_oracle_grid(res, B, views, shade_form):
-    """Full pipeline (incl. BASELINE cfg 3: 128x128, k=8) vs the oracle with voxel-grid semantics."""
+@pytest.mark.parametrize("res,B,views,S", [(32, 2, 2, 128), (128, 1, 1, 128), (128, 1, 1, 64)])
+def test_render_vs_oracle_grid(res, B, views, S, shade_form):
+    """Full pipeline vs the oracle with voxel-grid semantics: 128 depth samples per ray is the reference's code
+    (pointnerf.py:184), (128, 1, 1, 64) is BASELINE.json configs[2] as written (128x128, k=8, 64 samples/ray)."""
     coords, feats, extr, intr = _scene(res, views, 512, 32, seed=1, B=B)
     if B > 1:
         coords[1] = coords[1].flip(-1) * 1.3              # a different cloud per batch element
@@ -495,9 +496,11 @@ def test_render_vs_oracle_grid(res, B, views, shade_form):
             p[kname] = p[kname] * 8 + 1.0                 # raise densities so the object is opaque-ish
     m = _model(32, 512, p)
     m.renderer.count_pairs = True
+    m.renderer.depth_resolution = S
     with torch.no_grad():
         out = m.render(coords.cuda(), feats.cuda(), extr.cuda(), intr.cuda(), res)
-    ref = orr.render(p, coords, feats, extr, intr, res=res, mode="grid", return_aux=True)
+    assert out["grid_level"] == m.voxel_grid.grid_level
+    ref = orr.render(p, coords, feats, extr, intr, res=res, S=S, mode="grid", return_aux=True)
     assert out["num_shading_points"] == ref["aux"]["P"] and out["num_pairs"] == ref["aux"]["Q"]
     assert float(ref["mask"].max()) > 0.5
     for key in ("mask", "depth", "channels"):

@@ -131,3 +131,7 @@ def test_trainer_bookkeeping_cpu():
     sd = tr.ema_state_dict()
     for (n, _), e in zip(b.named_parameters(), ema):
         assert torch.allclose(sd[n], e, atol=1e-6)
+    c = tr.comm_stats()                               # single process: nothing on the wire
+    assert c["mode"] == "none" and c["world"] == 1 and c["gradient_bytes_handed_to_collectives"] == 0
+    tr.close()                                        # idempotent, also on the torch-optimizer path
+    tr.close()
