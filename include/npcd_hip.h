@@ -345,6 +345,25 @@ int npcd_cast_f32_dt(const float* src, void* dst, int64_t numel, int dtype, void
 int npcd_wgrad_slices(int T, int N, int K);
 int npcd_wgrad(const void* dy, const void* x, float* out, float* workspace, int T, int N, int K, int dtype, void* stream);
 
+/* Linear layers of the residual block as own NT products with fused epilogues (csrc/gemm_nt.hip): 16-bit `dtype` operands
+ * (NPCD_BF16 / NPCD_F16), fp32 accumulation, 16-bit outputs; x [M, K], w [N, K] row-major (the nn.Linear weight as stored), any
+ * M >= 1, N % 1024 == 0, K % 64 == 0, M * N and M * K below 2^31, pointers 16-byte aligned; NPCD_ERR_UNSUPPORTED otherwise (the
+ * caller then uses the library).  Replace, in the reference, F.linear of transformer.py:67 / :107-115 / :118-137 and the autograd
+ * nodes behind them:
+ *   npcd_linear_fwd:        y = x w^T + bias                                   (bias [N] 16 bit, may be NULL)
+ *   npcd_linear_gelu_fwd:   h = x w^T + bias (rounded to 16 bit), g = gelu_erf(h)   -- mlp.c_fc followed by nn.GELU() (:131)
+ *   npcd_linear_dgelu_bwd:  dh = round16(dy wt^T) * gelu_erf'(h)               -- the data gradient of mlp.c_proj (wt = its weight
+ *                           TRANSPOSED, [N = 4 W, K = W] row-major, npcd_transpose_16) followed by the GELU backward; also writes
+ *                           part [npcd_linear_dgelu_rows(M)][N] fp32 column partial sums of dh (the c_fc bias gradient), to be
+ *                           finished by npcd_colsum_finalize(part, npcd_linear_dgelu_rows(M), N, ...)
+ * A data gradient dx = dy W is npcd_linear_fwd(dy, W^T, NULL, ...). */
+int npcd_linear_fwd(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int dtype, void* stream);
+int npcd_linear_gelu_fwd(const void* x, const void* w, const void* bias, void* h, void* g, int M, int N, int K, int dtype, void* stream);
+int npcd_linear_dgelu_rows(int M);
+int npcd_linear_dgelu_bwd(const void* dy, const void* wt, const void* h, void* dh, float* part, int M, int N, int K, int dtype, void* stream);
+/* out [C, R] = in [R, C]^T for 16-bit elements (the transposed shadow of the Linear weights that the data gradients read) */
+int npcd_transpose_16(const void* in, void* out, int R, int C, void* stream);
+
 /* out[i] = part[0 * numel + i] + ... + part[(S - 1) * numel + i], fp32, added in slice order (S = 2, 4 or 8; numel % 4 == 0;
  * 16-byte aligned): the sum of the row-split weight-gradient partials of the fused backbone (replaces torch.sum(part, dim=0)
  * there; the reference's nn.Linear weight gradient, summed over token slices). */

@@ -35,6 +35,7 @@ SOURCES = {
     "shade_rows.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "elementwise.hip": [],
     "gemm.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
+    "gemm_nt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "pairs.hip": ["-ffp-contract=off"],
     "pairs_mlp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
 }

@@ -92,6 +92,11 @@ SIGNATURES = {
     "npcd_wgrad_slices": (c_int, [c_int, c_int, c_int]),
     "npcd_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "npcd_sum_slices": (c_int, [_P, _P, c_int, c_int64, _P]),
+    "npcd_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "npcd_linear_gelu_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "npcd_linear_dgelu_rows": (c_int, [c_int]),
+    "npcd_linear_dgelu_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "npcd_transpose_16": (c_int, [_P, _P, c_int, c_int, _P]),
     "npcd_small_wgrad_blocks": (c_int, [c_int]),
     "npcd_small_wgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P]),
     "npcd_q_sample": (c_int, [_P] * 6 + [c_int, c_int64, _P]),

@@ -1,0 +1,79 @@
+"""Wrappers of the own NT GEMMs with fused epilogues (csrc/gemm_nt.hip): the Linear layers of the residual block
+(reference transformer.py:67, :107-115, :118-137) and their data gradients."""
+import torch
+
+from . import check, dtype_code, lib, ptr, require_gpu, stream_ptr
+
+_f32 = torch.float32
+
+# When set to a dict {"fwd": [], "gelu_fwd": [], "dgelu_bwd": []}, each launch is bracketed by HIP events on the launch stream
+KERNEL_EVENTS = None
+
+
+def _timed(tag, fn):
+    if KERNEL_EVENTS is None or tag not in KERNEL_EVENTS:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn()
+    e1.record()
+    KERNEL_EVENTS[tag].append((e0, e1))
+    return rc
+
+
+def supported(M: int, N: int, K: int) -> bool:
+    return M >= 1 and N % 1024 == 0 and K % 64 == 0 and M * N < 2 ** 31 and M * K < 2 ** 31
+
+
+def _check_operands(x, w):
+    require_gpu(x, w)
+    if x.dtype != w.dtype or x.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError(f"npcd linear: 16-bit operands of one type expected, got {x.dtype} / {w.dtype}")
+    if not (x.is_contiguous() and w.is_contiguous()) or x.shape[1] != w.shape[1]:
+        raise RuntimeError("npcd linear: x [M, K] and w [N, K] must be contiguous row-major with the same K")
+
+
+def linear_fwd(x, w, bias=None, out=None):
+    """y [M, N] = x [M, K] @ w [N, K]^T (+ bias [N], 16 bit)."""
+    _check_operands(x, w)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device) if out is None else out
+    check(_timed("fwd", lambda: lib().npcd_linear_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), M, N, K, dtype_code(x), stream_ptr())), "npcd_linear_fwd")
+    return y
+
+
+def linear_gelu_fwd(x, w, bias):
+    """h = x @ w^T + bias (rounded to 16 bit), g = gelu_erf(h): (h, g)."""
+    _check_operands(x, w)
+    M, K = x.shape
+    N = w.shape[0]
+    h = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    g = torch.empty_like(h)
+    check(_timed("gelu_fwd", lambda: lib().npcd_linear_gelu_fwd(ptr(x), ptr(w), ptr(bias), ptr(h), ptr(g), M, N, K, dtype_code(x), stream_ptr())),
+          "npcd_linear_gelu_fwd")
+    return h, g
+
+
+def linear_dgelu_bwd(dy, wt, h):
+    """dh = round16(dy @ wt^T) * gelu_erf'(h) and the fp32 column partial sums of dh: (dh, part, rows) -- wt [N, K] is the
+    TRANSPOSED weight of the layer after the GELU; finish the bias gradient with npcd_colsum_finalize(part, rows, N, ...)."""
+    _check_operands(dy, wt)
+    M, K = dy.shape
+    N = wt.shape[0]
+    L = lib()
+    rows = L.npcd_linear_dgelu_rows(M)
+    dh = torch.empty((M, N), dtype=dy.dtype, device=dy.device)
+    part = torch.empty((rows + L.npcd_colsum_scratch_rows(), N), dtype=_f32, device=dy.device)
+    check(_timed("dgelu_bwd", lambda: L.npcd_linear_dgelu_bwd(ptr(dy), ptr(wt), ptr(h), ptr(dh), ptr(part), M, N, K, dtype_code(dy), stream_ptr())),
+          "npcd_linear_dgelu_bwd")
+    return dh, part, rows
+
+
+def transpose16(w, out=None):
+    """[R, C] 16-bit -> [C, R]."""
+    require_gpu(w)
+    R, C = w.shape
+    o = torch.empty((C, R), dtype=w.dtype, device=w.device) if out is None else out
+    check(lib().npcd_transpose_16(ptr(w), ptr(o), R, C, stream_ptr()), "npcd_transpose_16")
+    return o
