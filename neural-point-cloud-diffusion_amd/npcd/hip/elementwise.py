@@ -37,16 +37,16 @@ class ColsumBatch:
     def __init__(self):
         self.jobs = []
 
-    def add(self, part, nblk, N, out):
-        self.jobs.append((part, nblk, N, out))
+    def add(self, part, nblk, N, out, accumulate=False):
+        self.jobs.append((part, nblk, N, out, accumulate))
 
     def flush(self):
         L, s = lib(), stream_ptr()
         for i in range(0, len(self.jobs), MAX_JOBS):
             chunk = self.jobs[i:i + MAX_JOBS]
             arr = (ColsumJob * len(chunk))()
-            for a, (part, nblk, N, out) in zip(arr, chunk):
-                a.part, a.out, a.nblk, a.N, a.accumulate, a.reserved = part.data_ptr(), out.data_ptr(), nblk, N, 0, 0
+            for a, (part, nblk, N, out, acc) in zip(arr, chunk):
+                a.part, a.out, a.nblk, a.N, a.accumulate, a.reserved = part.data_ptr(), out.data_ptr(), nblk, N, int(acc), 0
             check(L.npcd_colsum_finalize_batch(ctypes.cast(arr, ctypes.c_void_p), len(chunk), s), "npcd_colsum_finalize_batch")
         self.jobs = []
 
@@ -103,12 +103,16 @@ def gelu_fwd(h):
     return g
 
 
-def gelu_bwd(dg, h, dbias_out, batch=None):
-    """dh = dg * gelu'(h) (bf16); dbias_out[N] (fp32) = column sum of dh."""
+def gelu_bwd(dg, h, dbias_out, batch=None, out=None, part_rows=None):
+    """dh = dg * gelu'(h) (bf16); dbias_out[N] (fp32) = column sum of dh.  `part_rows`: a [>= npcd_colsum_blocks(T), N] fp32 view that
+    receives the partial rows instead (the caller finishes the sum; dbias_out is then ignored): returns (dh, rows written)."""
     T, N = h.shape
     L = lib()
     nblk = L.npcd_colsum_blocks(T)
-    dh = torch.empty_like(h)
+    dh = torch.empty_like(h) if out is None else out
+    if part_rows is not None:
+        check(_timed("gelu_bwd", lambda: L.npcd_gelu_bwd_dt(ptr(dg), ptr(h), ptr(dh), ptr(part_rows), T, N, dtype_code(h), stream_ptr())), "npcd_gelu_bwd")
+        return dh, nblk
     part = torch.empty((nblk + L.npcd_colsum_scratch_rows(), N), dtype=_f32, device=h.device)
     check(_timed("gelu_bwd", lambda: L.npcd_gelu_bwd_dt(ptr(dg), ptr(h), ptr(dh), ptr(part), T, N, dtype_code(h), stream_ptr())), "npcd_gelu_bwd")
     _finish(batch, part, nblk, N, dbias_out)

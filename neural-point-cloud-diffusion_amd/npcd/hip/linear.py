@@ -55,16 +55,17 @@ def linear_gelu_fwd(x, w, bias):
     return h, g
 
 
-def linear_dgelu_bwd(dy, wt, h):
+def linear_dgelu_bwd(dy, wt, h, out=None, extra_part_rows=0):
     """dh = round16(dy @ wt^T) * gelu_erf'(h) and the fp32 column partial sums of dh: (dh, part, rows) -- wt [N, K] is the
-    TRANSPOSED weight of the layer after the GELU; finish the bias gradient with npcd_colsum_finalize(part, rows, N, ...)."""
+    TRANSPOSED weight of the layer after the GELU; finish the bias gradient with npcd_colsum_finalize(part, rows, N, ...).
+    `extra_part_rows`: room behind the kernel's `rows` partial rows for a caller that adds partial rows of other token ranges."""
     _check_operands(dy, wt)
     M, K = dy.shape
     N = wt.shape[0]
     L = lib()
     rows = L.npcd_linear_dgelu_rows(M)
-    dh = torch.empty((M, N), dtype=dy.dtype, device=dy.device)
-    part = torch.empty((rows + L.npcd_colsum_scratch_rows(), N), dtype=_f32, device=dy.device)
+    dh = torch.empty((M, N), dtype=dy.dtype, device=dy.device) if out is None else out
+    part = torch.empty((rows + extra_part_rows + L.npcd_colsum_scratch_rows(), N), dtype=_f32, device=dy.device)
     check(_timed("dgelu_bwd", lambda: L.npcd_linear_dgelu_bwd(ptr(dy), ptr(wt), ptr(h), ptr(dh), ptr(part), M, N, K, dtype_code(dy), stream_ptr())),
           "npcd_linear_dgelu_bwd")
     return dh, part, rows

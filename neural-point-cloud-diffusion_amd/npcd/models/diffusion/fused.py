@@ -18,6 +18,7 @@ import torch
 
 from ...hip import attention as hattn
 from ...hip import elementwise as ew
+from ...hip import linear as hlin
 
 _bf16, _f32 = torch.bfloat16, torch.float32
 _BLOCK_PARAMS = ("ln_1.weight", "ln_1.bias", "attn.c_qkv.weight", "attn.c_qkv.bias", "attn.c_proj.weight", "attn.c_proj.bias",
@@ -42,6 +43,10 @@ _SUM_KERNEL = not os.environ.get("NPCD_NO_SUM_KERNEL")          # the weight-gra
 # opt-in: the weight gradients on the own split-T kernel (csrc/gemm.hip: at parity with the library's row-split form -- both are
 # bound by the L2 -> LDS stream of a 256 x 256 tile -- bitwise reproducible, no library call)
 _OWN_WGRAD = bool(os.environ.get("NPCD_OWN_WGRAD"))
+# opt-in: the data gradient of mlp.c_proj as the own NT product with the GELU backward and the c_fc bias-gradient column sums in its
+# epilogue (csrc/gemm_nt.hip, docs/experiments.md R4.1) on the full 256-row tiles of the token range; the remainder rows keep the
+# library product + the separate kernel.  Reads a TRANSPOSED 16-bit copy of the weight, refreshed per backward.
+_OWN_DGELU = bool(os.environ.get("NPCD_OWN_DGELU"))
 
 
 def _split_gemm(fn, T):
@@ -277,10 +282,24 @@ class _BackboneFn(torch.autograd.Function):
                 ctx.saved[bi] = None
                 sums = ew.ColsumBatch()            # this block's 8 bias / LN-affine column sums: one finalize
                 # ---- MLP branch: x3 = x2 + c_proj(gelu(c_fc(ln_2(x2)))) ------------------------------
-                dg = _dgrad(dxb, e["mlp_c_proj_weight_16"])
-                _wgrad_maybe_async(dxb, g, e["mlp_c_proj_weight_g"])
-                dh = ew.gelu_bwd(dg, h, e["mlp_c_fc_bias_g"], batch=sums)
-                del dg, g, h
+                Tm = T - T % 256
+                if _OWN_DGELU and Tm > 0 and hlin.supported(Tm, 4 * W, W):
+                    wT = hlin.transpose16(e["mlp_c_proj_weight_16"])
+                    dh = torch.empty_like(h)
+                    extra = ew.lib().npcd_colsum_blocks(T - Tm) if Tm < T else 0
+                    _, part, rows = hlin.linear_dgelu_bwd(dxb[:Tm], wT, h[:Tm], out=dh[:Tm], extra_part_rows=extra)
+                    if Tm < T:       # remainder rows: library product + the separate kernel, partial rows behind the own kernel's
+                        dg = torch.mm(dxb[Tm:], e["mlp_c_proj_weight_16"])
+                        ew.gelu_bwd(dg, h[Tm:], None, out=dh[Tm:], part_rows=part[rows:])
+                        del dg
+                    sums.add(part, rows + extra, 4 * W, e["mlp_c_fc_bias_g"])
+                    _wgrad_maybe_async(dxb, g, e["mlp_c_proj_weight_g"])
+                    del g, h
+                else:
+                    dg = _dgrad(dxb, e["mlp_c_proj_weight_16"])
+                    _wgrad_maybe_async(dxb, g, e["mlp_c_proj_weight_g"])
+                    dh = ew.gelu_bwd(dg, h, e["mlp_c_fc_bias_g"], batch=sums)
+                    del dg, g, h
                 dy2 = _dgrad(dh, e["mlp_c_fc_weight_16"])
                 _wgrad_maybe_async(dh, y2, e["mlp_c_fc_weight_g"])
                 del dh, y2

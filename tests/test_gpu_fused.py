@@ -479,7 +479,8 @@ def test_small_wgrad_matches_the_fp32_product(T, J, K):
     assert ew.small_wgrad(dy.float(), x) is None and ew.small_wgrad(dy, x[:, :48].contiguous()) is None   # declined, caller falls back
 
 
-def test_full_width_two_blocks_elementwise_gradients_vs_oracle():
+@pytest.mark.parametrize("own_dgelu", [False, True])
+def test_full_width_two_blocks_elementwise_gradients_vs_oracle(own_dgelu, monkeypatch):
     """Engine-level parity at the BENCHMARK width: W 1024 / H 16 / n = 513 (N = 512 points + the time token) / L 2 / B 2 on the
     fused engine under bf16 autocast against the CPU oracle (oracle/denoiser.py, pinned to the reference by the denoiser_*.npz
     fixtures) on the same weights and inputs -- ELEMENTWISE rel-L2 of the eps prediction and of named parameter gradients (a
@@ -490,6 +491,10 @@ def test_full_width_two_blocks_elementwise_gradients_vs_oracle():
     from npcd.models.diffusion import NPCDTransformer
     from npcd.train import DiffusionTrainer
     from npcd.models.diffusion import DiffusionModel
+    import npcd.models.diffusion.fused as fused
+    # own_dgelu: the opt-in data gradient of mlp.c_proj on the own NT GEMM with the GELU backward + bias column sums in its epilogue
+    # (csrc/gemm_nt.hip); T = 1026 = 4 full 256-row tiles + 2 remainder rows, so both of its row ranges run
+    monkeypatch.setattr(fused, "_OWN_DGELU", own_dgelu)
     W, H, L, N, Fd, B = 1024, 16, 2, 512, 128, 2
     params = od.init_params(3, Fd, W, L, H, seed=3)
     g = torch.Generator().manual_seed(17)
