@@ -428,7 +428,6 @@ struct CompactOut {
     // area and its count in ray_cnt; compact_ordered_kernel turns the counts into bases by a prefix sum IN RAY ORDER and moves the
     // rows -- no atomics, the lists are bit-identical from run to run
     int32_t* ray_cnt;     // [B*R] or nullptr (atomic form)
-    int32_t* blk_sum;     // [ceil(B*R / 64)] sums of ray_cnt over groups of 64 rays (zeroed before the query kernel)
     int32_t* st_nb;       // [B*R][M][k]
     float* st_pts;        // [B*R][M][3]
 };
@@ -738,7 +737,6 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
         }
         if (lane == 0) {
             co.ray_cnt[ray] = cnt;
-            if (cnt > 0) atomicAdd(&co.blk_sum[ray >> 6], cnt);
             co.ray_nsel[ray] = nsel;
             co.ray_bits[ray] = valid_bits;
         }
@@ -779,9 +777,8 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
 }
 
 // Ordered compaction (second launch of npcd_grid_query_compact_ordered).  Workgroup j owns the 64 rays [64 j, 64 j + 64).  Its
-// base is the sum of the group sums before it: the query kernel has added every ray's count to blk_sum[ray / 64] (integer
-// atomics: the SUM does not depend on their order), so a workgroup reads at most nrays / 64 integers, no flags / spinning between
-// workgroups.  A wave scan over the own 64 counts gives every ray its base; then one thread per OUTPUT row finds its ray (the
+// base is the sum of the counts of all rays before it, which it adds up itself (integers: no order dependence; no flags / spinning
+// between workgroups, no atomics, nothing to zero beforehand).  A wave scan over the own 64 counts gives every ray its base; then one thread per OUTPUT row finds its ray (the
 // last one whose base is <= the row: binary search over the 64 bases in LDS) and moves the row -- all loads of a thread are
 // independent of other rows.  Rows past `capacity` are not written and raise the overflow flag (the host retries with larger
 // lists), the total goes to counter[0].
@@ -791,8 +788,13 @@ __global__ __launch_bounds__(256) void compact_ordered_kernel(CompactOut co, int
     __shared__ int scan[kOrdRays + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int first = blockIdx.x * kOrdRays;
+    // (round 4: the counts themselves, 16 bytes per thread and trip -- at most 64 KB from L2 for the last workgroup of a 128 x 128
+    // view -- instead of per-group sums that the query kernel accumulated with atomics into a buffer a fill launch had to zero)
     int acc = 0;
-    for (int i = tid; i < (int)blockIdx.x; i += 256) acc += co.blk_sum[i];
+    for (int i = tid * 4; i < first; i += 1024) {
+        const int4 c = *reinterpret_cast<const int4*>(co.ray_cnt + i);
+        acc += (c.x + c.y) + (c.z + c.w);
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if (lane == 0) red[wave] = acc;
@@ -1389,12 +1391,10 @@ static int grid_query_compact_launch(const npcd_grid_params* g_in, const void* w
         // staging: group sums, [B R] counts (each padded to 16 bytes), [B R][M][k] indices, [B R][M][3] positions
         const int64_t nrays = (int64_t)B * R, nblk = (nrays + kOrdRays - 1) / kOrdRays;
         unsigned char* w = static_cast<unsigned char*>(order_ws);
-        co.blk_sum = reinterpret_cast<int32_t*>(w);
-        w += (nblk * 4 + 15) / 16 * 16;
+        w += (nblk * 4 + 15) / 16 * 16;                 // (the group sums of rounds 1-3: unused, the layout of the workspace is unchanged)
         co.ray_cnt = reinterpret_cast<int32_t*>(w);
         co.st_nb = reinterpret_cast<int32_t*>(w + (nrays * 4 + 15) / 16 * 16);
         co.st_pts = reinterpret_cast<float*>(co.st_nb + nrays * M * k);
-        NPCD_HIP_CHECK(hipMemsetAsync(co.blk_sum, 0, nblk * sizeof(int32_t), st));
         hipLaunchKernelGGL(grid_query_wave_kernel<true>, dim3(B * bpe), dim3(256), lds, st, a, co, bpe);
         hipLaunchKernelGGL(compact_ordered_kernel, dim3((unsigned)nblk), dim3(256), 0, st, co, (int)nrays, M, k);
     } else {

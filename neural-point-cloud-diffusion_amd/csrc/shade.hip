@@ -524,6 +524,7 @@ __global__ __launch_bounds__(256, 2) void shade_points_kernel(ShadeArgs a) {
     unsigned char* H = dsmem;
     float* red = reinterpret_cast<float*>(dsmem + MAXNB * 32 * kRowBytes);  // [4 waves][128 rows][4]
     const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0 && a.tile_counter) *a.tile_counter = 0;      // the pair kernel of this call is done: its ticket word is free again
     const PointsArgs pa{a.wpack, a.G, a.sigma, a.rgb, a.dir_bias, a.point_ray, a.feat_dim, 32 * MAXNB};
     const int P = min(*a.n_points, a.max_points);
     const int nblk = (P + 31) >> 5, q = nblk / (int)gridDim.x, rem = nblk % (int)gridDim.x;
@@ -641,6 +642,23 @@ extern "C" int npcd_shade_pack_weights(const float* const* weights_host, const f
     return NPCD_OK;
 }
 
+// Tile tickets of the pair kernel: library-owned words (zero at load), one per call in flight, handed out round-robin; the point
+// kernel of the same call -- behind the pair kernel in stream order -- sets its word back to zero.  (Rounds 1-3: a word of the
+// caller's workspace, zeroed by a fill launch per call: 4.5 us of a 390-us view.)  64 calls may be in flight on different streams.
+namespace npcd { __device__ int32_t g_tile_tickets[64]; }
+static int32_t* tile_ticket_slot() {
+    static std::atomic<unsigned> next{0};
+    static std::atomic<int32_t*> base[DynLds::kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= DynLds::kMaxDevices) return nullptr;
+    int32_t* b = base[dev].load(std::memory_order_acquire);
+    if (!b) {
+        if (hipGetSymbolAddress(reinterpret_cast<void**>(&b), HIP_SYMBOL(npcd::g_tile_tickets)) != hipSuccess) return nullptr;
+        base[dev].store(b, std::memory_order_release);
+    }
+    return b + (next.fetch_add(1) & 63u);
+}
+
 static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int hidden, const int32_t* nb_idx, const float* pts,
                                const float* kp_pos, const float* kp_feat, const int32_t* n_points_dev, int max_points, int k,
                                float* sigma, float* rgb, void* workspace, const float* dir_bias, const int32_t* point_ray, void* stream) {
@@ -661,11 +679,7 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
     a.dir_bias = dir_bias; a.point_ray = point_ray;
     hipStream_t st = static_cast<hipStream_t>(stream);
     static const bool static_tiles = getenv("NPCD_SHADE_STATIC_TILES") != nullptr;
-    if (!static_tiles) {
-        a.tile_counter = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(workspace) + (int64_t)(max_points + kRows) * kHidden * 2 +
-                                                    shade_rows_workspace_bytes(max_points));
-        NPCD_HIP_CHECK(hipMemsetAsync(a.tile_counter, 0, sizeof(int32_t), st));
-    }
+    if (!static_tiles) a.tile_counter = tile_ticket_slot();      // (nullptr: tiles strided over the grid)
     const int ldsA = kRows * kRowBytes + kRows * 4 + 32 * 4 + 16;   // activations, row weights, per-point packed-row ranges, next tile
     const int ldsB = kRows * (kRowBytes + 4 * 4 * 4);
     static DynLds lds_a32, lds_a128, lds_b, lds_bd;

@@ -51,8 +51,8 @@ for S in (128, 64):
             dd = d1[k][3:] if len(d1[k]) > 3 else d1[k]
             d["duration_us_under_pmc"] = sum(dd) / len(dd) / 1e3
             # GRBM_GUI_ACTIVE / profiler duration is a clock only for long dispatches (MI355X_MICROARCH.md, DVFS give-back: reads
-            # high below ~0.3 ms; the round-3 file carried 2.7-7 "GHz" for the 5-60 us kernels): not reported for short ones
-            if d["duration_us_under_pmc"] >= 50.0:
+            # high below ~0.3 ms; the round-3 file carried 2.7-7 "GHz" for the 5-60 us kernels, 2.7 still at 54 us): not reported for short ones
+            if d["duration_us_under_pmc"] >= 100.0:
                 d["clock_ghz"] = gui / 8 / (sum(dd) / len(dd))
         if gui and m.get("SQ_VALU_MFMA_BUSY_CYCLES"):
             d["mfma_busy"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (gui / 8 * 1024)
