@@ -292,6 +292,28 @@ class ClockSampler:
         return out
 
 
+def bench_sample_and_render(device, clouds=4):
+    """The generate -> render loop of the reference's DiffusionEvaluation (npcd/eval/diffusion_evaluation.py:146-183; FID/KID itself
+    needs the Inception assets, which are not in this environment): `clouds` point clouds from the full 1000-step sampler at the
+    benchmark's model size (bf16 autocast, the forward-only fused backbone), each rendered at 128 x 128 from the 251 bundled SRN-cars
+    test poses, 8 poses per render call.  Random-init weights: the clouds are noise-shaped, the work per cloud is the real one."""
+    from npcd.eval import load_test_poses, sample_and_render
+    from npcd.models import NPCD
+    torch.manual_seed(0)
+    net = NPCD(n_obj=1, coords_dim=3, feats_dim=32, num_points=CFG["num_points"], use_view_dir=False, width=CFG["width"], layers=CFG["layers"],
+               heads=CFG["heads"]).to(device).eval()
+    with torch.no_grad():          # a plausible normaliser: clouds inside the unit cube, so that the rays hit something
+        net.diffusion.coords_normalization.min.fill_(-2.5); net.diffusion.coords_normalization.max.fill_(2.5)
+        net.diffusion.coords_normalization.scale.fill_(0.2)
+        net.diffusion.feats_normalization.min.fill_(-1.0); net.diffusion.feats_normalization.max.fill_(1.0)
+    poses, intr = load_test_poses("srncars")
+    r = sample_and_render(net, poses, intr, num_samples=clouds, generate_batch_size=clouds, render_batch_size=8, resolution=128,
+                          dtype=torch.bfloat16)
+    r["note"] = ("reference protocol: generate_batch_size clouds per sampler call, 251 poses per cloud, render_batch_size 8; the sampler's denoiser "
+                 "under bf16 autocast (opt-in of DiffusionModel.generate; the reference samples in fp32); feats_dim 32 (the PointNeRF latent width)")
+    return r
+
+
 def bench_sampler(device, batch=16, steps=8, graph_steps=100):
     """one DDPM reverse step (denoiser forward + posterior update, diffusion_model.py:108-133 /
     gaussian_diffusion.py p_sample) at the benchmark's model size.  Lead figure: the reference's numerics (generate() runs the
@@ -792,6 +814,11 @@ def main():
             result["sampler_reverse_step"] = bench_sampler(device)
         except Exception as e:                      # noqa: BLE001
             result["sampler_reverse_step"] = {"error": f"{type(e).__name__}: {e}"}
+    if world == 1 and not args.no_sampler and not args.no_render:
+        try:
+            result["sample_and_render"] = bench_sample_and_render(device)
+        except Exception as e:                      # noqa: BLE001
+            result["sample_and_render"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

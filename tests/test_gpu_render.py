@@ -789,3 +789,30 @@ def test_grid_build_is_skipped_for_an_unchanged_cloud_and_redone_after_a_write()
     with torch.no_grad():
         d2 = m2.render(c.clone(), f, e, k, 32)
     assert torch.equal(d["channels"], d2["channels"]) and not torch.equal(a["channels"], d["channels"])
+
+
+def test_generate_then_render_loop_of_the_diffusion_evaluation():
+    """npcd.eval.sample_and_render (reference diffusion_evaluation.py:146-183) on a small NPCD model with a short diffusion chain: the
+    bundled 251 SRN-cars test poses load, every generated cloud is rendered from every pose, images are 8-bit quantised values in
+    [0, 1] and identical to a direct PointNeRF.render of the same cloud."""
+    from npcd.eval import load_test_poses, sample_and_render, unflatten_pred
+    from npcd.models import NPCD
+    from npcd.models.diffusion.gaussian_diffusion import GaussianDiffusion
+    poses, intr = load_test_poses("srncars")
+    assert poses.shape == (251, 4, 4) and intr.shape == (251, 3, 3)
+    torch.manual_seed(0)
+    net = NPCD(n_obj=1, coords_dim=3, feats_dim=32, num_points=512, use_view_dir=False, width=64, layers=1, heads=1).cuda().eval()
+    net.diffusion.diffusion_process = GaussianDiffusion(num_timesteps=8).cuda()          # a short chain: the loop is what is tested
+    with torch.no_grad():                                                              # clip ranges / scales of a "trained" normaliser
+        net.diffusion.coords_normalization.min.fill_(-2.5); net.diffusion.coords_normalization.max.fill_(2.5)
+        net.diffusion.coords_normalization.scale.fill_(0.25)
+        net.diffusion.feats_normalization.min.fill_(-1.0); net.diffusion.feats_normalization.max.fill_(1.0)
+    got = []
+    sub = slice(0, 251, 50)                                                            # 6 of the poses keep the test short
+    res = sample_and_render(net, poses[sub], intr[sub], num_samples=3, generate_batch_size=2, render_batch_size=4, resolution=32,
+                            feed=lambda im: got.append(im.cpu()))
+    assert res["clouds"] == 3 and res["poses_per_cloud"] == 6 and len(got) == 3 and got[0].shape == (6, 3, 32, 32)
+    for im in got:
+        assert float(im.min()) >= 0.0 and float(im.max()) <= 1.0
+        assert torch.equal(torch.round(im * 255), im * 255) or float((torch.round(im * 255) - im * 255).abs().max()) < 1e-4
+    assert res["views_per_s"] > 0 and res["generate_seconds"] > 0
