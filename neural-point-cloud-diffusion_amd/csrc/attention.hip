@@ -629,14 +629,19 @@ __device__ __forceinline__ void fwd_flush(const FragAddr& fa, f32x16& o0, f32x16
     o0 = TR::mfma32(tr_vec<TR>(vt[1][0]), __builtin_bit_cast(V8, pw[1]), o0);
     o1 = TR::mfma32(tr_vec<TR>(vt[1][1]), __builtin_bit_cast(V8, pw[1]), o1);
 }
+constexpr int kRowxFloats = 68;        // O[64], m, l, pad (272 B: records stay 16-byte aligned)
+__host__ __device__ inline bool rowx_mode(int n) { return NPCD_SEED_TAIL && n > 256 && ((n - 1) & 255) == 0; }
+template <class TR, int SLOT, int RING, bool LEAN> __device__ __forceinline__ void rowx_tile(unsigned char* smem, float c, int lane_in, int wave, float* rec);
 template <class TR, int SLOT>
 __device__ __forceinline__ void fwd_step(unsigned char* smem, const FragAddr& fa, const DmaLane& dl, const typename TR::elem* kb,
                                          const typename TR::elem* vb, int64_t sn, int t, int nt, int n, int wave, int lane,
-                                         const typename TR::vec8 (&qf)[4], f32x16& o0, f32x16& o1, float& m, float& l, float c, u32x4 (&pw)[2]) {
+                                         const typename TR::vec8 (&qf)[4], f32x16& o0, f32x16& o1, float& m, float& l, float c, u32x4 (&pw)[2],
+                                         int xt, float* xrec) {
     constexpr int PREV = (SLOT + 2) % 3;
     fwd_stage<TR, SLOT, 0, PREV, 1, true>(fa, qf, o0, o1, m, l, c, pw);
     kv_mid<typename TR::elem, SLOT>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
     fwd_stage<TR, SLOT, 1, SLOT, 0, true>(fa, qf, o0, o1, m, l, c, pw);
+    if (xt >= 0 && t == xt) rowx_tile<TR, SLOT, 3, true>(smem, c, lane, wave, xrec);      // (wave-uniform) this wave's share of the last query row
 }
 // the ragged last key tile (fewer than 64 keys): simple, masked, not pipelined
 template <class TR, int SLOT>
@@ -649,11 +654,15 @@ __device__ __forceinline__ void fwd_tail(const FragAddr& fa, const typename TR::
 #ifndef NPCD_FWD_WAVES
 #define NPCD_FWD_WAVES 2
 #endif
-template <class TR>
+// ROWX (opt-in, NPCD_ATTN_ROWX32=1): see `rowx` below.  Measured at cfg-D: 142-145 us against 128-130 us without it (same process,
+// same box, event-bracketed) -- the fifth workgroup it removes is cheap (one active wave, no matrix work) while the row's
+// vector work lands on eight busy waves and the merge is one more launch; as a template parameter so that the default
+// instantiation keeps its 166 registers (three waves per SIMD: 128 against 148 us at two).
+template <class TR, bool ROWX>
 __global__ __launch_bounds__(256, NPCD_FWD_WAVES) void attn_fwd_kernel(AttnParams p) {
     using E = typename TR::elem;
     using V8 = typename TR::vec8;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 16384];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 16384 + 1024 + 256];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // A sequence of 64 j + 1 tokens (the denoiser's: 512 points + the timestep token) would end in a key tile with ONE key.
@@ -662,7 +671,11 @@ __global__ __launch_bounds__(256, NPCD_FWD_WAVES) void attn_fwd_kernel(AttnParam
     // below covers nk = n - 1 keys, all in full tiles.
     const bool seeded = NPCD_SEED_TAIL && (p.n & 63) == 1 && p.n > 64;          // kernel-uniform
     const int n = p.n, nk = seeded ? n - 1 : n, nt = (nk + 63) >> 6, nfull = nk >> 6;
-    const int nqt = (n + 127) >> 7;
+    // ROWX: 256 j + 1 tokens with scratch (round 4; the 64-row form had it): no FIFTH workgroup for the single last query row -- at
+    // n = 513 it holds a slot for a whole pass over K / V, 1,024 of the 5,120 workgroups of a launch -- the first nt waves of the
+    // (batch, head) split that row's keys instead (rowx_tile, one resident key tile each), attn_fwd_rowx_merge_kernel combines them
+    const bool rowx = ROWX && p.rowx != nullptr && rowx_mode(p.n);               // kernel-uniform
+    const int nqt = rowx ? nk >> 7 : (n + 127) >> 7;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int qt = bid % nqt, bh = bid / nqt, h = bh % p.H, b = bh / p.H;
     const E* qb = static_cast<const E*>(p.q) + b * p.sb + h * p.sh;
@@ -673,6 +686,8 @@ __global__ __launch_bounds__(256, NPCD_FWD_WAVES) void attn_fwd_kernel(AttnParam
     const int qrow = q0 + r;
     const float c = p.scale_log2;
     const DmaLane dl = dma_lane<E>(p.sn, lane);
+    const int xt = (ROWX && rowx && qt * 4 + wave < nt) ? qt * 4 + wave : -1;   // the key tile this wave takes for the last query row
+    float* xrec = (ROWX && xt >= 0) ? p.rowx + ((int64_t)bh * nt + xt) * kRowxFloats : nullptr;
 
     // Q fragments stay unscaled (scores are scaled in fp32 after the MFMA, identically in fwd and bwd, so
     // that P recomputed in the backward matches the forward's LSE even for very large logits)
@@ -704,6 +719,8 @@ __global__ __launch_bounds__(256, NPCD_FWD_WAVES) void attn_fwd_kernel(AttnParam
         l = 0.5f;                                     // P = 1; the two half-wave partial sums are added at the end
         outer_seed<TR>(vx0, vx1, 1.f, lane, o0, o1);
     }
+    if (rowx && wave == 0)       // the last query row -> LDS (128 B, lanes 32..63 repeat lanes 0..31): lands with the first tiles
+        dma4_issue(qb + (int64_t)(n - 1) * p.sn, (uint32_t)((lane & 31) * 4), __builtin_amdgcn_readfirstlane(lds_addr(smem) + 3 * 16384 + 1024));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -718,10 +735,11 @@ __global__ __launch_bounds__(256, NPCD_FWD_WAVES) void attn_fwd_kernel(AttnParam
         fwd_stage<TR, 0, 0, 2, 1, false>(fa, qf, o0, o1, m, l, c, pw);
         kv_mid<E, 0>(smem, kb, vb, p.sn, 0, nt, nk, wave, lane, dl);
         fwd_stage<TR, 0, 1, 0, 0, true>(fa, qf, o0, o1, m, l, c, pw);
+        if (ROWX && xt == 0) rowx_tile<TR, 0, 3, true>(smem, c, lane, wave, xrec);
         for (int t = 1; t < nfull; t += 3) {
-            fwd_step<TR, 1>(smem, fa, dl, kb, vb, p.sn, t, nt, nk, wave, lane, qf, o0, o1, m, l, c, pw);
-            if (t + 1 < nfull) fwd_step<TR, 2>(smem, fa, dl, kb, vb, p.sn, t + 1, nt, nk, wave, lane, qf, o0, o1, m, l, c, pw);
-            if (t + 2 < nfull) fwd_step<TR, 0>(smem, fa, dl, kb, vb, p.sn, t + 2, nt, nk, wave, lane, qf, o0, o1, m, l, c, pw);
+            fwd_step<TR, 1>(smem, fa, dl, kb, vb, p.sn, t, nt, nk, wave, lane, qf, o0, o1, m, l, c, pw, xt, xrec);
+            if (t + 1 < nfull) fwd_step<TR, 2>(smem, fa, dl, kb, vb, p.sn, t + 1, nt, nk, wave, lane, qf, o0, o1, m, l, c, pw, xt, xrec);
+            if (t + 2 < nfull) fwd_step<TR, 0>(smem, fa, dl, kb, vb, p.sn, t + 2, nt, nk, wave, lane, qf, o0, o1, m, l, c, pw, xt, xrec);
         }
         const int last = (nfull - 1) % 3;
         if (last == 0) fwd_flush<TR, 0, 1>(fa, o0, o1, pw);
@@ -904,8 +922,6 @@ __device__ __forceinline__ void fwd64_flush(const FragAddr& fa, QBlk& A, QBlk& B
 // sum_j p_j v_j over its 32 keys.  ~250 instructions per wave per item, 2 registers of state.  The wave's partial state
 // (m, l, O[64]) goes to scratch; attn_fwd_rowx_merge_kernel combines the partials of a (batch, head), adds the pair (x, x) and writes
 // the row and its LSE.
-constexpr int kRowxFloats = 68;        // O[64], m, l, pad (272 B: records stay 16-byte aligned)
-__host__ __device__ inline bool rowx_mode(int n) { return NPCD_SEED_TAIL && n > 256 && ((n - 1) & 255) == 0; }
 
 // wave-wide max / sum on the vector ALU (no LDS crossbar): four DPP row rotations inside the 16-lane rows, then v_permlane16_swap
 // and v_permlane32_swap across them; every lane ends with the result
@@ -922,7 +938,8 @@ __device__ __forceinline__ float wave_reduce64(float x, Op op) {
 }
 __device__ __forceinline__ float wave_max64(float x) { return wave_reduce64(x, [](float a, float b) { return fmaxf(a, b); }); }
 __device__ __forceinline__ float wave_sum64(float x) { return wave_reduce64(x, [](float a, float b) { return a + b; }); }
-template <class TR, int SLOT, int RING = 3>
+// LEAN: half-size batches of LDS reads (the 32-row forward has ~70 registers free between two stages, the 64-row one ~100)
+template <class TR, int SLOT, int RING, bool LEAN>
 __device__ __forceinline__ void rowx_tile(unsigned char* smem, float c, int lane_in, int wave, float* rec) {
     // Everything lane-dependent in here is derived from an OPAQUE copy of the lane number: otherwise the compiler hoists the ~100
     // loop-invariant LDS addresses of the three ring-slot instances out of the tile loop and spills them (82 spilled registers,
@@ -936,6 +953,24 @@ __device__ __forceinline__ void rowx_tile(unsigned char* smem, float c, int lane
     // every lane reads the same address), two 16-byte chunks at a time so that the main loop's state stays in registers
     const uint32_t krow = base + lane * 128, ksw = (uint32_t)tile_swz(lane) << 4;
     float s0 = 0.f, s1 = 0.f;
+    if constexpr (LEAN) {
+#pragma unroll
+        for (int c2 = 0; c2 < 8; c2 += 2) {
+            u32x4 kv[2], qv[2];
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) kv[ch] = lds_b128_issue<KT>(krow + (((uint32_t)(c2 + ch) << 4) ^ ksw));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qv[0]) : "v"(qxa), "n"(c2 * 16) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(qv[1]) : "v"(qxa), "n"(c2 * 16 + 16) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kv[0]), "+v"(kv[1]), "+v"(qv[0]), "+v"(qv[1])::"memory");
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                s0 = TR::dot2(kv[ch][0], qv[ch][0], s0);
+                s1 = TR::dot2(kv[ch][1], qv[ch][1], s1);
+                s0 = TR::dot2(kv[ch][2], qv[ch][2], s0);
+                s1 = TR::dot2(kv[ch][3], qv[ch][3], s1);
+            }
+        }
+    } else {
 #pragma unroll
     for (int c4 = 0; c4 < 8; c4 += 4) {                   // (between two stages ~100 registers are free: 32 of them here)
         u32x4 kv[4], qv[4];
@@ -954,6 +989,7 @@ __device__ __forceinline__ void rowx_tile(unsigned char* smem, float c, int lane
             s1 = TR::dot2(kv[ch][3], qv[ch][3], s1);
         }
     }
+    }
     const float sc = (s0 + s1) * c;                       // exp2 domain
     const float m = wave_max64(sc);
     const float pj = __builtin_amdgcn_exp2f(sc - m);
@@ -965,12 +1001,13 @@ __device__ __forceinline__ void rowx_tile(unsigned char* smem, float c, int lane
     const int dp = lane & 31, par = lane >> 5;
     const uint32_t vrow = base + par * 128 + (dp & 3) * 4, vch = (uint32_t)(dp >> 2) << 4, prow = scr + par * 4;
     float o0 = 0.f, o1 = 0.f;
+    constexpr int VB = LEAN ? 4 : 16;
 #pragma unroll
-    for (int i0 = 0; i0 < 32; i0 += 16) {
+    for (int i0 = 0; i0 < 32; i0 += VB) {
         uint32_t vv[16];
         float pp[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < VB; ++i) {
             const int ii = i0 + i;
             const uint32_t swz = (uint32_t)((((ii & 1) << 2) | ((ii >> 1) & 3)) << 4);       // tile_swz(2 ii + parity) << 4
             const uint32_t va = vrow + (vch ^ swz);
@@ -984,13 +1021,17 @@ __device__ __forceinline__ void rowx_tile(unsigned char* smem, float c, int lane
 #undef NPCD_RX
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)"
+        if constexpr (LEAN)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(pp[0]), "+v"(pp[1]), "+v"(pp[2]), "+v"(pp[3])::"memory");
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(vv[0]), "+v"(vv[1]), "+v"(vv[2]), "+v"(vv[3]), "+v"(vv[4]), "+v"(vv[5]), "+v"(vv[6]), "+v"(vv[7]), "+v"(pp[0]), "+v"(pp[1]),
                        "+v"(pp[2]), "+v"(pp[3]), "+v"(pp[4]), "+v"(pp[5]), "+v"(pp[6]), "+v"(pp[7])::"memory");
-        asm volatile("" : "+v"(vv[8]), "+v"(vv[9]), "+v"(vv[10]), "+v"(vv[11]), "+v"(vv[12]), "+v"(vv[13]), "+v"(vv[14]), "+v"(vv[15]), "+v"(pp[8]), "+v"(pp[9]),
-                       "+v"(pp[10]), "+v"(pp[11]), "+v"(pp[12]), "+v"(pp[13]), "+v"(pp[14]), "+v"(pp[15]));
+        if constexpr (!LEAN)
+            asm volatile("" : "+v"(vv[8]), "+v"(vv[9]), "+v"(vv[10]), "+v"(vv[11]), "+v"(vv[12]), "+v"(vv[13]), "+v"(vv[14]), "+v"(vv[15]), "+v"(pp[8]), "+v"(pp[9]),
+                           "+v"(pp[10]), "+v"(pp[11]), "+v"(pp[12]), "+v"(pp[13]), "+v"(pp[14]), "+v"(pp[15]));
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < VB; ++i) {
             o0 = __builtin_fmaf(pp[i], TR::lo(vv[i]), o0);
             o1 = __builtin_fmaf(pp[i], TR::hi(vv[i]), o1);
         }
@@ -1034,7 +1075,7 @@ __device__ __forceinline__ void fwd64_step(unsigned char* smem, const FragAddr& 
     kv_mid<typename TR::elem, SLOT>(smem, kb, vb, sn, t, nt, n, wave, lane, dl);
 #endif
     fwd64_stage<TR, SLOT, 1, SLOT, 0, true>(fa, qA, qB, A, B, pwA, pwB, c);
-    if (t == xt) rowx_tile<TR, SLOT>(smem, c, lane, wave, xrec);      // (wave-uniform) this wave's share of the last query row
+    if (t == xt) rowx_tile<TR, SLOT, 3, false>(smem, c, lane, wave, xrec);      // (wave-uniform) this wave's share of the last query row
 }
 // one 32-key half of the ragged last key tile for one block: masked, exact maximum, not pipelined
 template <class TR, int SLOT, int KB>
@@ -1163,7 +1204,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(AttnParams p) {
         fwd64_stage<TR, 0, 0, 2, 1, false>(fa, qA, qB, A, B, pwA, pwB, c);
         kv_mid<E, 0>(smem, kb, vb, p.sn, 0, nt, nk, wave, lane, dl);
         fwd64_stage<TR, 0, 1, 0, 0, true>(fa, qA, qB, A, B, pwA, pwB, c);
-        if (xt == 0) rowx_tile<TR, 0>(smem, c, lane, wave, xrec);
+        if (xt == 0) rowx_tile<TR, 0, 3, false>(smem, c, lane, wave, xrec);
         NPCD_TS_TILE(0);
         for (int t = 1; t < nfull; t += 3) {
             fwd64_step<TR, 1>(smem, fa, dl, kb, vb, p.sn, t, nt, nk, wave, lane, qA, qB, A, B, pwA, pwB, xt, c, xrec);
@@ -2808,7 +2849,8 @@ static bool fwd_rows32(int n) {
 }
 extern "C" int64_t npcd_attn_fwd_workspace_floats(int B, int n, int H) {
     if (B <= 0 || n <= 0 || H <= 0) return -1;
-    return (rowx_mode(n) && !fwd_rows32(n)) ? (int64_t)B * H * ((n - 1) / 64) * kRowxFloats : 0;
+    static const bool rowx32 = getenv("NPCD_ATTN_ROWX32") != nullptr;     // (opt-in: the 32-row form without its fifth workgroup; slower, see attn_fwd_kernel)
+    return (rowx_mode(n) && (rowx32 || !fwd_rows32(n))) ? (int64_t)B * H * ((n - 1) / 64) * kRowxFloats : 0;
 }
 
 static int attn_fwd_launch(const void* q, const void* k, const void* v, void* out, float* lse, float* workspace, int B, int n, int H, int d,
@@ -2853,9 +2895,20 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* ou
     // on long sequences (n = 2049: 597-614 against 640-653 us), 32 rows per wave on short ones, where a workgroup's start-up and
     // wind-down dominate and its finer grid fills the chip better (n = 513: 113 against 117 us).  NPCD_ATTN_FWD=32 / 64 forces one.
     if (fwd_rows32(n)) {
-        const int grid = B * H * ceil_div(n, 128);
-        if (dtype == NPCD_BF16) hipLaunchKernelGGL(attn_fwd_kernel<BF16>, dim3(grid), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL(attn_fwd_kernel<F16>, dim3(grid), dim3(256), 0, st, p);
+        static const bool rowx32 = getenv("NPCD_ATTN_ROWX32") != nullptr;
+        p.rowx = (workspace && rowx32 && rowx_mode(n)) ? workspace : nullptr;
+        const int grid = B * H * (p.rowx ? (n - 1) / 128 : ceil_div(n, 128));
+        if (p.rowx) {
+            if (dtype == NPCD_BF16) hipLaunchKernelGGL((attn_fwd_kernel<BF16, true>), dim3(grid), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((attn_fwd_kernel<F16, true>), dim3(grid), dim3(256), 0, st, p);
+        } else {
+            if (dtype == NPCD_BF16) hipLaunchKernelGGL((attn_fwd_kernel<BF16, false>), dim3(grid), dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((attn_fwd_kernel<F16, false>), dim3(grid), dim3(256), 0, st, p);
+        }
+        if (p.rowx) {
+            if (dtype == NPCD_BF16) hipLaunchKernelGGL(attn_fwd_rowx_merge_kernel<__bf16>, dim3(B * H), dim3(64), 0, st, p, (n - 1) / 64);
+            else hipLaunchKernelGGL(attn_fwd_rowx_merge_kernel<_Float16>, dim3(B * H), dim3(64), 0, st, p, (n - 1) / 64);
+        }
     } else {
         p.rowx = (workspace && rowx_mode(n)) ? workspace : nullptr;
         const int grid = B * H * (p.rowx ? (n - 1) / 256 : ceil_div(n, 256));

@@ -453,3 +453,16 @@ def test_single_pass_backward_matches_oracle_and_two_pass(n, monkeypatch):
     assert rel_l2(g_one, g_two.float().cpu()) < 1.5e-2
     monkeypatch.setattr(hattn, "BWD_MODE", "fused")
     check(qkv, H, gout, f"fused n={n}")
+
+
+def test_opt_in_forward_without_the_fifth_workgroup_still_matches():
+    """NPCD_ATTN_ROWX32=1 (round 4, opt-in because it measured slower): the 32-row forward of 256 j + 1-token sequences without a workgroup
+    for the single last query row -- eight waves of the (batch, head) split that row's keys, a merge kernel combines them.  The switch
+    is read once per process, so the golden + ragged-length tests run again in a child process with it set."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NPCD_ATTN_ROWX32="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "golden or ragged"], capture_output=True, text=True,
+                         env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
