@@ -699,8 +699,8 @@ def main():
             if os.path.exists(fp):
                 return nm, json.load(open(fp))
         return None, {}
-    tname, tjson = newest("r3_attention_hbm_traffic_pmc.json", "r2_attention_hbm_traffic_pmc.json", "r1_attention_hbm_traffic_pmc.json")
-    sname, sjson = newest("r3_attention_sq_pmc.json", "r2_attention_sq_pmc.json")
+    tname, tjson = newest("r4_attention_hbm_traffic_pmc.json", "r3_attention_hbm_traffic_pmc.json", "r2_attention_hbm_traffic_pmc.json", "r1_attention_hbm_traffic_pmc.json")
+    sname, sjson = newest("r4_attention_sq_pmc.json", "r3_attention_sq_pmc.json", "r2_attention_sq_pmc.json")
     traffic = None
     # sequences of 128 j + 1 tokens: the last token's three gradient rows are finished by a small third kernel, launched (and
     # timed here) with the dK/dV pass
