@@ -53,6 +53,22 @@ __device__ __forceinline__ u32x4 l_rd128(uint32_t addr) {
 
 enum { LIN_PLAIN = 0, LIN_GELU = 1, LIN_DGELU = 2 };
 
+#ifdef NPCD_LIN_TL
+// DIAGNOSTIC build only (tools/probes/gpu_dev_lin_timeline.py): s_memtime stamps of ONE K-step (global step NPCD_LIN_TL of workgroup 0)
+// of waves 0 and 4, read back with npcd_lin_debug_read.  Instrumentation costs ~10 % of the wave's cycles.
+__device__ long long g_lin_tl[2][32];
+#define NPCD_LTS(i)                                                           \
+    do {                                                                      \
+        if (tl_on) {                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                \
+            tl[(i)] = __builtin_amdgcn_s_memtime();                           \
+            __builtin_amdgcn_sched_barrier(0);                                \
+        }                                                                     \
+    } while (0)
+#else
+#define NPCD_LTS(i) do { } while (0)
+#endif
+
 struct LinParams {
     const void* x;        // [M, K]
     const void* w;        // [N, K]
@@ -253,6 +269,11 @@ __global__ __launch_bounds__(512, 2) void lin_kernel(LinParams p) {
     asm volatile("" ::: "memory");
 
     dma_on = 0;                                          // a round of 8 pieces starts BEHIND a step's barrier and ends in the next step's sub-steps
+#ifdef NPCD_LIN_TL
+    long long tl[19];
+    for (int i = 0; i < 19; ++i) tl[i] = 0;
+    int gstep = 0;
+#endif
     u32x4 fx0[4] = {}, fw0[2] = {}, fx1[4] = {}, fw1[2] = {};
     uint32_t ox = 0, ow = kLBuf;                         // LDS offsets of the buffers being read: half-stages 2 g and 2 g + 1
     NPCD_L_ISSUE(fx0, fw0, ox, ow, 0);
@@ -261,36 +282,63 @@ __global__ __launch_bounds__(512, 2) void lin_kernel(LinParams p) {
         lin_tile(p, tile, tm, tn);
         const int m0 = tm * 256, n0 = tn * 256;
         for (int kt = 0; kt < nk; ++kt) {
+#ifdef NPCD_LIN_TL
+            const bool tl_on = blockIdx.x == 0 && (wave == 0 || wave == 4) && gstep == NPCD_LIN_TL;
+            ++gstep;
+#endif
             // (the 8 pieces requested in this step were freed by the previous step: P3 behind its barrier, P0 / P1 / P2 here)
             // sub-step 0
+            NPCD_LTS(0);
             NPCD_L_WAIT();
+            NPCD_LTS(1);
             NPCD_L_ISSUE(fx1, fw1, ox, ow, 1);
+            NPCD_LTS(2);
             NPCD_L_MMA(fx0, fw0);
+            NPCD_LTS(3);
             if (!ldw) NPCD_L_DMA(0, NPCD_LIN_X0);
             // sub-step 1
+            NPCD_LTS(4);
             NPCD_L_WAIT();
+            NPCD_LTS(5);
             NPCD_L_ISSUE(fx0, fw0, ox, ow, 2);
+            NPCD_LTS(6);
             NPCD_L_MMA(fx1, fw1);
+            NPCD_LTS(7);
             if (!ldw) NPCD_L_DMA(NPCD_LIN_X0, NPCD_LIN_X0 + NPCD_LIN_X1);
             // sub-step 2
+            NPCD_LTS(8);
             NPCD_L_WAIT();
+            NPCD_LTS(9);
             NPCD_L_ISSUE(fx1, fw1, ox, ow, 3);
+            NPCD_LTS(10);
             NPCD_L_MMA(fx0, fw0);
+            NPCD_LTS(11);
             if (!ldw) NPCD_L_DMA(NPCD_LIN_X0 + NPCD_LIN_X1, 8);
             // sub-step 3: this wave has read everything of the step; the next step's two half-stages must have landed for everybody
             // (an x loader's half-stage requested last may stay in flight: it belongs to the step after the next)
+            NPCD_LTS(12);
             NPCD_L_WAIT();
+            NPCD_LTS(13);
             if (!ldw && tail_real) NPCD_L_VMWAIT(8);
             else NPCD_L_VMWAIT(0);
+            NPCD_LTS(14);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            NPCD_LTS(15);
             // the two buffers just read are free: half-stages 2 g + 5 (w, now) and 2 g + 6 (x, during the next step) go into them
             dma_on = 1;
             if (ldw) NPCD_L_DMA(0, 8);
+            NPCD_LTS(16);
             ox = ox >= 3 * kLBuf ? ox - 3 * kLBuf : ox + 2 * kLBuf;
             ow = ow >= 3 * kLBuf ? ow - 3 * kLBuf : ow + 2 * kLBuf;
             NPCD_L_ISSUE(fx0, fw0, ox, ow, 0);           // first fragments of the next step (possibly the next tile's)
+            NPCD_LTS(17);
             NPCD_L_MMA(fx1, fw1);
+            NPCD_LTS(18);
+#ifdef NPCD_LIN_TL
+            if (tl_on && lane == 0)
+                for (int i = 0; i < 19; ++i) g_lin_tl[wave >> 2][i] = tl[i];
+#endif
         }
         // ---- epilogue of the tile: lane = output row, register quads = 4 consecutive output columns
         if (NPCD_LIN_DIAG == 3 && acc[0][0][0] != 12345.678f) {
@@ -471,6 +519,11 @@ extern "C" int npcd_linear_dgelu_bwd(const void* dy, const void* wt, const void*
                                      void* stream) {
     return lin_common(LIN_DGELU, dy, wt, nullptr, dh, nullptr, h, part, M, N, K, dtype, stream);
 }
+#ifdef NPCD_LIN_TL
+extern "C" int npcd_lin_debug_read(long long* out, int count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(npcd::g_lin_tl), sizeof(long long) * count);
+}
+#endif
 extern "C" int npcd_transpose_16(const void* in, void* out, int R, int C, void* stream) {
     if (!in || !out || R <= 0 || C <= 0) return NPCD_ERR_ARG;
     hipLaunchKernelGGL(transpose16_kernel<uint16_t>, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream),
