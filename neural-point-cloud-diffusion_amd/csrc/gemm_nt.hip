@@ -6,19 +6,26 @@
 // dx = dy . W (here: an NT product against the TRANSPOSED 16-bit shadow of W, npcd_transpose_16) followed by the GELU backward.
 // Called from the hand-written forward / backward of the fused backbone (npcd/models/diffusion/fused.py).
 //
-// Why an own kernel (docs/experiments.md R4.1): the library's products run at 1.2-1.3 PF/s at T = 32,832 but leave the GELU pair as
-// two separate HBM passes per block (86 + 154 us of a 3.45-ms block), and fall to 0.34-0.9 PF/s at the T = 4,104 of an 8-GPU rank.
+// Why an own kernel, and where it stands (docs/experiments.md R4.1): the library's products run at 1.2-1.3 PF/s at T = 32,768 but leave the
+// GELU pair as two separate HBM passes per block (86 + 154 us of a 3.45-ms block).  This family reaches 0.85-0.9 x the tuned library on
+// the bare products (c_fc 259 against 211-237 us) and 384 against 420-440 us for the data gradient of mlp.c_proj WITH the GELU backward
+// and the bias-gradient sums in its epilogue -- parity inside the step, hence an opt-in of the backbone (NPCD_OWN_DGELU=1).  The wall
+// both stand at: a 256 x 256 bf16 tile asks the CU for 32 bytes per clock of LDS fill (one 1-KB request per ~32 cycles is what its
+// vector-memory path takes) AND for all of its matrix pipe; pipe busy 0.51 here, 0.62 in the library's stream-K kernel.
 //
 // Structure (one workgroup = 8 waves = one 256 x 256 output tile, PERSISTENT over a static list of tiles):
-//   * both operands are K-contiguous, so a K-step of 64 is 256 + 256 rows of 128 bytes: one 64-KB stage, filled by LDS-DMA
-//     (global_load_lds_dwordx4, 1 KiB per wave instruction = 8 rows; the XOR swizzle of the 16-byte chunk index is applied to the
-//     SOURCE address, the LDS image stays lane-linear) and read back with ds_read_b128 (conflict-free row reads, common.h);
-//   * two stages (128 KB): stage g + 2 is requested when every wave has read stage g; the stream of stages runs across tile
-//     boundaries, so the first two K-steps of the NEXT tile are in flight while the epilogue of the current one runs;
+//   * both operands are K-contiguous, so a K-step of 64 is 256 + 256 rows of 128 bytes, moved as two 32-KB HALF-stages (x rows, w rows)
+//     by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction = 8 rows; the XOR swizzle of the 16-byte chunk index is applied
+//     to the SOURCE address, the LDS image stays lane-linear) and read back with ds_read_b128 (conflict-free row reads, common.h);
+//   * a ring of FIVE half-stage buffers = the CU's 160 KB: the x stream runs two steps ahead, the w stream one, the request queue
+//     never runs empty at a barrier, and the stream runs across tile boundaries (the next tile's first steps land during the epilogue);
+//   * loader roles: waves 4..7 request the w half-stage (8 pieces each, right behind the step's barrier), waves 0..3 the x half-stage
+//     (behind the matrix instructions of the next step's sub-steps): a request blocks its wave for 115-170 cycles, and this way one
+//     wave of every SIMD issues matrix instructions meanwhile;
 //   * wave (wm, wn) owns rows [128 wm, +128) x columns [64 wn, +64): 8 accumulators of 32 x 32 (v_mfma_f32_32x32x16), oriented
 //     with the OUTPUT COLUMN on the accumulator row (registers) and the output row on the lane: a lane then holds runs of four
 //     consecutive columns of one output row, two runs are joined by v_permlane32_swap into 16-byte stores, the bias is the same for
-//     all lanes of a register;
+//     all lanes of a register (no LDS transpose: there is no LDS left);
 //   * tile order: 8 (row) x 4 (column) super-tiles, one per XCD and round (workgroups b, b + 8, ... share an XCD and its L2), so
 //     that the 32 tiles an XCD works on at a time read 8 + 4 operand panels instead of 32 + 32.
 #include <type_traits>
