@@ -63,7 +63,7 @@ __device__ __forceinline__ void layer_mfma(const unsigned char* H, const unsigne
     if constexpr (PF > 1) {
         // weight fragments PF k-steps ahead through a ring of 4 register pairs (the one-step form below leaves the loop at the
         // latency of an L2 hit per k-step when few row blocks share a fragment)
-        static_assert(PF <= 3 && KSTEPS % 4 == 0, "ring of four");
+        static_assert(PF <= 3, "ring of four");
         f16x8 ra[4], rb[4];
 #pragma unroll
         for (int d = 0; d < PF; ++d) { ra[d] = w0[d * 64]; rb[d] = w1[d * 64]; }
@@ -107,43 +107,120 @@ __device__ __forceinline__ void layer_mfma(const unsigned char* H, const unsigne
     }
 }
 
-// epilogue: optional LeakyReLU, convert to fp16, write back in place (4 consecutive channels = 8 bytes)
+// ---- the same layer as a PINNED software pipeline (pair kernel) --------------------------------------------------------------
+// In the form above the machine scheduler sinks every weight load down to its first use (register pressure), whatever the source
+// order says: the listing shows `global_load ... s_waitcnt vmcnt(1) ... v_mfma`, i.e. one L2 round trip per k-step that only the
+// second wave of the SIMD can hide.  Here the order is fixed with scheduling fences: per k-step  [weight fragments of step s + PF |
+// activation fragments of step s + 1] fence [the step's 2 NB matrix instructions] fence.  The bias values (the C operand of the
+// first step) and the first PF weight fragments of a layer are requested by layer_prefetch(), which the caller issues BEFORE the
+// previous layer's epilogue, so that they travel during the barrier and the LDS write-back.
+// Weights and biases come through a raw BUFFER resource over the pack: address = scalar offset (layer, wave, group of four k-steps)
+// + per-lane constant (lane * 16) + 12-bit immediate -- no vector address arithmetic at all (as `global_load` the compiler
+// re-associated base + lane offset into 64-bit vector addresses and two v_add_co per 4-KB window).
+struct WRing { f16x8 a[4], b[4]; };
+typedef __amdgpu_buffer_rsrc_t wrsrc_t;
+__device__ __forceinline__ wrsrc_t pack_rsrc(const unsigned char* wpack, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(wpack), 0, (int)bytes, 0x00020000);
+}
+template <int KSTEPS>
+__device__ __forceinline__ f16x8 wfrag_load(wrsrc_t rs, int w_off, int wave, int oi, int lane, int step) {
+    const int so = w_off + (2 * wave + oi) * (KSTEPS * kFragBytes) + (step >> 2) * (4 * kFragBytes);
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + (step & 3) * kFragBytes, so, 0));
+}
+template <int KSTEPS, int PF>
+__device__ __forceinline__ void layer_prefetch(wrsrc_t rs, int w_off, int b_off, int wave, int lane, WRing& ring, f32x16 (&init)[2]) {
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int oi = 0; oi < 2; ++oi)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {       // bias of out channel (2 wave + oi) * 32 + 8 g + 4 hh + b
+            const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hh * 16 + g * 32, b_off + (2 * wave + oi) * 128, 0));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) init[oi][4 * g + b] = b4[b];
+        }
+#pragma unroll
+    for (int d = 0; d < PF && d < KSTEPS; ++d) {
+        ring.a[d] = wfrag_load<KSTEPS>(rs, w_off, wave, 0, lane, d);
+        ring.b[d] = wfrag_load<KSTEPS>(rs, w_off, wave, 1, lane, d);
+    }
+}
+template <int KSTEPS, int NB, int PF>
+__device__ __forceinline__ void layer_mfma_pipe(const unsigned char* H, wrsrc_t rs, int w_off, int wave, int lane, WRing& ring,
+                                                const f32x16 (&init)[2], f32x16 (&acc)[2][4]) {
+    static_assert(PF >= 1 && PF <= 3, "ring of four");
+    const int r = lane & 31, hh = lane >> 5;
+    const unsigned char* hb = H + r * kRowBytes + hh * 16;
+    f16x8 bc[NB], bn[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) bc[cb] = *reinterpret_cast<const f16x8*>(hb + cb * 32 * kRowBytes);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        if (s + PF < KSTEPS) {
+            ring.a[(s + PF) & 3] = wfrag_load<KSTEPS>(rs, w_off, wave, 0, lane, s + PF);
+            ring.b[(s + PF) & 3] = wfrag_load<KSTEPS>(rs, w_off, wave, 1, lane, s + PF);
+        }
+        if (s + 1 < KSTEPS) {
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) bn[cb] = *reinterpret_cast<const f16x8*>(hb + cb * 32 * kRowBytes + (s + 1) * 32);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            acc[0][cb] = F16::mfma32(ring.a[s & 3], bc[cb], s == 0 ? init[0] : acc[0][cb]);
+            acc[1][cb] = F16::mfma32(ring.b[s & 3], bc[cb], s == 0 ? init[1] : acc[1][cb]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) bc[cb] = bn[cb];
+    }
+}
+
+// epilogue: optional LeakyReLU, convert to fp16, write back in place.  A lane holds runs of 4 consecutive channels (8 bytes) of one
+// row, lanes l and l + 32 the two halves of an 8-channel chunk: one v_permlane32_swap per dword joins them, so that every lane
+// writes whole 16-byte chunks (ds_write_b128: 16 rows per pass, 4 banks apart = all 64 banks; as 8-byte writes rows r and r + 16
+// of a 32-lane pass met in the same banks -- the 2-way conflicts of profiles/r3_shade_sq_pmc.json).
 template <bool ACT, int NB = 4>
 __device__ __forceinline__ void layer_store(unsigned char* H, int wave, int lane, const f32x16 (&acc)[2][4]) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     const int r = lane & 31, hh = lane >> 5;
-    unsigned char* sb = H + r * kRowBytes + hh * 8 + wave * 128;      // row (cb*32 + r), channels (2 wave + oi)*32 + 8 g + 4 hh ..
+    unsigned char* sb = H + r * kRowBytes + hh * 16 + wave * 128;     // row (cb*32 + r), channels (2 wave + oi)*32 + 16 gp + 8 hh ..
 #pragma unroll
     for (int oi = 0; oi < 2; ++oi)
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                u32x2 v;
+            for (int gp = 0; gp < 2; ++gp) {
+                uint32_t v[2][2];        // [g - 2 gp][dword]: channels 8 g + 4 hh + {0,1 | 2,3}
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    float x0 = acc[oi][cb][4 * g + 2 * b], x1 = acc[oi][cb][4 * g + 2 * b + 1];
+                for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int e = 4 * (2 * gp + gg) + 2 * b;
+                        float x0 = acc[oi][cb][e], x1 = acc[oi][cb][e + 1];
 #ifdef NPCD_SHADE_LEAKY_F32
-                    if (ACT) {                       // LeakyReLU(0.01): max(x, 0.01 x)
-                        x0 = fmaxf(x0, kLeaky * x0);
-                        x1 = fmaxf(x1, kLeaky * x1);
-                    }
-                    const f32x2 f = {x0, x1};
-                    v[b] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2));
+                        if (ACT) {                       // LeakyReLU(0.01): max(x, 0.01 x)
+                            x0 = fmaxf(x0, kLeaky * x0);
+                            x1 = fmaxf(x1, kLeaky * x1);
+                        }
+                        const f32x2 f = {x0, x1};
+                        v[gg][b] = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2));
 #else
-                    // LeakyReLU on the converted pair: max(h, 0.01 h) in packed fp16 -- 1.5 vector instructions per value instead of
-                    // 2.5 (the negative side is rounded twice: to fp16, and after the scaling)
-                    const f32x2 f = {x0, x1};
-                    f16x2 h = __builtin_convertvector(f, f16x2);
-                    if (ACT) {
-                        const f16x2 sc = {(_Float16)kLeaky, (_Float16)kLeaky};
-                        h = __builtin_elementwise_max(h, h * sc);
-                    }
-                    v[b] = __builtin_bit_cast(uint32_t, h);
+                        // LeakyReLU on the converted pair: max(h, 0.01 h) in packed fp16 -- 1.5 vector instructions per value instead
+                        // of 2.5 (the negative side is rounded twice: to fp16, and after the scaling)
+                        const f32x2 f = {x0, x1};
+                        f16x2 h = __builtin_convertvector(f, f16x2);
+                        if (ACT) {
+                            const f16x2 sc = {(_Float16)kLeaky, (_Float16)kLeaky};
+                            h = __builtin_elementwise_max(h, h * sc);
+                        }
+                        v[gg][b] = __builtin_bit_cast(uint32_t, h);
 #endif
-                }
-                *reinterpret_cast<u32x2*>(sb + cb * 32 * kRowBytes + (oi * 4 + g) * 16) = v;
+                    }
+                // lower lanes keep chunk 2 gp (their half + the upper lanes' half), upper lanes chunk 2 gp + 1
+                const auto s0 = __builtin_amdgcn_permlane32_swap(v[0][0], v[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(v[0][1], v[1][1], false, false);
+                *reinterpret_cast<u32x4*>(sb + cb * 32 * kRowBytes + oi * 64 + gp * 32) = u32x4{s0[0], s1[0], s0[1], s1[1]};
             }
 }
 
@@ -152,25 +229,35 @@ __device__ __forceinline__ void layer_store(unsigned char* H, int wave, int lane
 // ============================================================================================
 #ifdef NPCD_SHADE_TL
 __device__ long long g_shade_tl[64];
-#define NPCD_STS(i) do { if (tl_on && tile == tl_tile) tl[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ long long g_shade_span[512 * 4];          // per workgroup: begin / end (100-MHz real time), tiles done, clocks
+#define NPCD_STS(i) do { if (tl_on) tl[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define NPCD_STS(i) do { } while (0)
 #endif
-// the four non-linear aggregator layers of one tile, activations in place in LDS (two barriers per layer)
 #ifdef NPCD_SHADE_TL
 #define NPCD_TL_PARAMS , long long* tl, bool tl_hit
-#define NPCD_TL_ARGS , tl, tl_on && tile == tl_tile
+#define NPCD_TL_ARGS , tl, tl_on
 #define NPCD_STL(i) do { if (tl_hit) tl[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define NPCD_TL_PARAMS
 #define NPCD_TL_ARGS
 #define NPCD_STL(i) do { } while (0)
 #endif
+#ifndef NPCD_PAIRS_PF
+#define NPCD_PAIRS_PF 2          // weight fragments in flight ahead of the matrix instructions (k-steps); 3 measured the same
+#endif
+struct PairPack { wrsrc_t rs; int w1, b0; };          // buffer resource of the weight pack, offsets of A1 and of the first bias
+// the four non-linear aggregator layers of one tile, activations in place in LDS (two barriers per layer)
 template <int FEAT, int NB>
-__device__ __forceinline__ void pair_layers(unsigned char* H, const ShadeArgs& a, const ShadeLayout& L, int wave, int lane NPCD_TL_PARAMS) {
-    constexpr int K0 = FEAT + kEncBlock;
+__device__ __forceinline__ void pair_layers(unsigned char* H, const PairPack& pk, int wave, int lane NPCD_TL_PARAMS) {
+    constexpr int K0 = FEAT + kEncBlock, PF = NPCD_PAIRS_PF;
+    constexpr int kLayerBytes = 8 * (kHidden / 16) * kFragBytes;
     f32x16 acc[2][4];
-    layer_mfma<K0 / 16, K0 / 16, NB>(H, a.wpack + L.w[0], reinterpret_cast<const float*>(a.wpack + L.bias[0]), wave, lane, acc);
+    WRing ring;
+    f32x16 init[2];
+    layer_prefetch<K0 / 16, PF>(pk.rs, 0, pk.b0, wave, lane, ring, init);
+    layer_mfma_pipe<K0 / 16, NB, PF>(H, pk.rs, 0, wave, lane, ring, init, acc);
+    layer_prefetch<kHidden / 16, PF>(pk.rs, pk.w1, pk.b0 + kHidden * 4, wave, lane, ring, init);
     NPCD_STL(3);
     __syncthreads();
     NPCD_STL(4);
@@ -180,10 +267,11 @@ __device__ __forceinline__ void pair_layers(unsigned char* H, const ShadeArgs& a
     NPCD_STL(6);
 #pragma unroll 1
     for (int l = 1; l < 4; ++l) {
-        // (offsets in closed form: indexing L.w[l] / L.bias[l] with the loop counter put the whole layout struct into scratch
-        // memory and a scratch load in front of every layer's first weight and bias loads)
-        const int64_t w_off = L.w[1] + (int64_t)(l - 1) * (8 * (kHidden / 16) * kFragBytes), b_off = L.bias[0] + (int64_t)l * (kHidden * 4);
-        layer_mfma<kHidden / 16, kHidden / 16, NB>(H, a.wpack + w_off, reinterpret_cast<const float*>(a.wpack + b_off), wave, lane, acc);
+        // (offsets in closed form: indexing the layout's tables with the loop counter put the whole struct into scratch memory)
+        const int w_off = pk.w1 + (l - 1) * kLayerBytes, b_off = pk.b0 + l * (kHidden * 4);
+        layer_mfma_pipe<kHidden / 16, NB, PF>(H, pk.rs, w_off, wave, lane, ring, init, acc);
+        // the next layer's bias and first fragments travel during the barrier and the write-back (after the last layer: not needed)
+        if (l < 3) layer_prefetch<kHidden / 16, PF>(pk.rs, w_off + kLayerBytes, b_off + kHidden * 4, wave, lane, ring, init);
         if (l == 1) NPCD_STL(7);
         __syncthreads();
         if (l == 1) NPCD_STL(8);
@@ -194,6 +282,40 @@ __device__ __forceinline__ void pair_layers(unsigned char* H, const ShadeArgs& a
     }
 }
 
+// What a thread needs to build its input row of a tile: requested one tile AHEAD (the neighbour indices while the previous tile's
+// layers run, the gathered data while its aggregation runs), so that the prologue starts from registers instead of two dependent
+// trips to memory.
+// (the thread index made opaque per phase: otherwise every lane-dependent address of the prologue, the gathers and the aggregation is
+// hoisted out of the tile loop and held in registers across the layers, which have none to spare)
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+template <int FEAT>
+struct PairInputs {
+    int gi, gi_other;                  // neighbour index of this thread's candidate, and of the candidate 64 rows away (for the counts)
+    float pt[3], kp[3];                // shading point, neighbour position
+    f32x4 feat[FEAT / 8];              // this half's FEAT / 2 neighbour features
+};
+template <int FEAT>
+__device__ __forceinline__ void pair_load_indices(const ShadeArgs& a, int tile, int P, int tid, PairInputs<FEAT>& in) {
+    tid = opaque(tid);
+    const int row = tid & 127, slot = row & 7;
+    const int p = tile * 16 + (row >> 3), po = tile * 16 + ((row ^ 64) >> 3);
+    in.gi = -1;
+    in.gi_other = -1;
+    if (p < P && slot < a.k) in.gi = a.nb_idx[(int64_t)p * a.k + slot];
+    if (po < P && slot < a.k) in.gi_other = a.nb_idx[(int64_t)po * a.k + slot];
+}
+template <int FEAT>
+__device__ __forceinline__ void pair_load_data(const ShadeArgs& a, int tile, int tid, PairInputs<FEAT>& in) {
+    // (unconditional, with clamped indices: loads under `if (gi >= 0)` would keep the previous tile's values alive across the layers)
+    const int row = opaque(tid) & 127, half = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int p = min(tile * 16 + (row >> 3), a.max_points - 1), g = max(in.gi, 0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { in.pt[c] = a.pts[(int64_t)p * 3 + c]; in.kp[c] = a.kp_pos[(int64_t)g * 3 + c]; }
+    const float* fp = a.kp_feat + (int64_t)g * FEAT + half * (FEAT / 2);
+#pragma unroll
+    for (int c4 = 0; c4 < FEAT / 8; ++c4) in.feat[c4] = *reinterpret_cast<const f32x4*>(fp + c4 * 4);
+}
+
 template <int FEAT>
 __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
@@ -201,23 +323,36 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
     float* wrow = reinterpret_cast<float*>(dsmem + kRows * kRowBytes);  // [128] inverse distances of the packed rows
     int* pstart = reinterpret_cast<int*>(wrow + kRows);                 // [16] first packed row of each point of the tile
     int* pcount = pstart + 16;                                          // [16] its number of valid neighbours
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // (the wave number as a SCALAR: the weight / bias addresses of the layer loops are scalar offset + per-lane constant)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const ShadeLayout L = shade_layout(FEAT);
+    const PairPack pk = {pack_rsrc(a.wpack, L.total), (int)L.w[1], (int)L.bias[0]};
     // the count comes from device memory (the compact query's counter); that counter keeps counting past the capacity of the
     // lists when they overflow (the host then retries with larger buffers), so it is clamped to the rows that exist
     const int P = min(*a.n_points, a.max_points);
     const int ntiles = (P + 15) / 16;
 
 #ifdef NPCD_SHADE_TL
+    // stamps of EVERY tile of workgroup NPCD_SHADE_TL (wave 0), summed per interval over its tiles with four occupied row blocks:
+    // g_shade_tl[0..13] = interval sums, [14] = such tiles, [15] = all tiles, [16] = the workgroup's whole time, [17] = sum of nblk
     const bool tl_on = blockIdx.x == NPCD_SHADE_TL && wave == 0;
-    const int tl_tile = blockIdx.x + 3 * gridDim.x;
-    long long tl[16];
-    for (int i = 0; i < 16; ++i) tl[i] = 0;
+    long long tl[16], tl_sum[16];
+    for (int i = 0; i < 16; ++i) { tl[i] = 0; tl_sum[i] = 0; }
+    long long tl_n4 = 0, tl_n = 0, tl_nb = 0;
+    const long long tl_begin = __builtin_amdgcn_s_memtime();
+    const long long rt_begin = __builtin_amdgcn_s_memrealtime();
+    int span_tiles = 0;
 #endif
     // Tiles differ in cost (1-4 occupied row blocks) and a 128^2 view has ~9.1 tiles per resident workgroup: handed out through
     // a counter the kernel ends when the LAST tile ends, not when the unluckiest stride does.
     int* next_tile = pcount + 16;
-    for (int tile = blockIdx.x; tile < ntiles;) {
+    int tile = blockIdx.x;
+    PairInputs<FEAT> in;
+    if (tile < ntiles) {
+        pair_load_indices<FEAT>(a, tile, P, tid, in);
+        pair_load_data<FEAT>(a, tile, tid, in);
+    }
+    while (tile < ntiles) {
         if (tid == 0) *next_tile = a.tile_counter ? (int)gridDim.x + atomicAdd(a.tile_counter, 1) : tile + (int)gridDim.x;
         NPCD_STS(0);
         // ---- prologue: build the layer-0 input rows -------------------------------------------
@@ -226,13 +361,10 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
         // 32-row MFMA blocks are skipped (typically one in four: ~29 % of the slots are empty).
         int nblk;
         {
-            const int row = tid & 127, half = tid >> 7;  // half is wave-uniform
-            const int p = tile * 16 + (row >> 3), slot = row & 7;
-            int gi = -1, gi_other = -1;
-            if (p < P && slot < a.k) gi = a.nb_idx[(int64_t)p * a.k + slot];
-            const int po = tile * 16 + ((row ^ 64) >> 3);
-            if (po < P && slot < a.k) gi_other = a.nb_idx[(int64_t)po * a.k + slot];
-            const unsigned long long mine = __ballot(gi >= 0), other = __ballot(gi_other >= 0);
+            const int row = opaque(tid) & 127, half = __builtin_amdgcn_readfirstlane(tid >> 7);  // half is wave-uniform
+            const int slot = row & 7;
+            const int gi = in.gi;
+            const unsigned long long mine = __ballot(gi >= 0), other = __ballot(in.gi_other >= 0);
             const int n_mine = __popcll(mine), n_other = __popcll(other);
             const int before = __popcll(mine & ((1ull << lane) - 1ull)) + ((row & 64) ? n_other : 0);
             const int V = n_mine + n_other;
@@ -245,18 +377,16 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
             float rel[3] = {0.f, 0.f, 0.f};
             if (gi >= 0) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) rel[c] = a.pts[(int64_t)p * 3 + c] - a.kp_pos[(int64_t)gi * 3 + c];
+                for (int c = 0; c < 3; ++c) rel[c] = in.pt[c] - in.kp[c];
             }
             if (half == 0 && gi >= 0) wrow[prow] = 1.f / (sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]) + 1e-5f);
             constexpr int FH = FEAT / 2;
             if (gi >= 0) {
                 // features: this half converts FEAT/2 channels
-                const float* fp = a.kp_feat + (int64_t)gi * FEAT + half * FH;
 #pragma unroll
                 for (int c8 = 0; c8 < FH / 8; ++c8) {
                     f16x8 v;
-                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(fp + c8 * 8);
-                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(fp + c8 * 8 + 4);
+                    const f32x4 x0 = in.feat[2 * c8], x1 = in.feat[2 * c8 + 1];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { v[j] = (_Float16)x0[j]; v[4 + j] = (_Float16)x1[j]; }
                     *reinterpret_cast<f16x8*>(H + act_off(prow, half * (FH / 8) + c8)) = v;
@@ -284,57 +414,104 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
         NPCD_STS(1);
         __syncthreads();
         NPCD_STS(2);
+        // the next tile (written at the top of this iteration) and its neighbour indices: they arrive while the layers run
+        const int ntile = *next_tile;
+        if (ntile < ntiles) pair_load_indices<FEAT>(a, ntile, P, tid, in);
         // ---- four non-linear layers (one instantiation per number of occupied 32-row blocks; nblk is workgroup-uniform) ----
         switch (nblk) {
-            case 4: pair_layers<FEAT, 4>(H, a, L, wave, lane NPCD_TL_ARGS); break;
-            case 3: pair_layers<FEAT, 3>(H, a, L, wave, lane NPCD_TL_ARGS); break;
-            case 2: pair_layers<FEAT, 2>(H, a, L, wave, lane NPCD_TL_ARGS); break;
-            case 1: pair_layers<FEAT, 1>(H, a, L, wave, lane NPCD_TL_ARGS); break;
+            case 4: pair_layers<FEAT, 4>(H, pk, wave, lane NPCD_TL_ARGS); break;
+            case 3: pair_layers<FEAT, 3>(H, pk, wave, lane NPCD_TL_ARGS); break;
+            case 2: pair_layers<FEAT, 2>(H, pk, wave, lane NPCD_TL_ARGS); break;
+            case 1: pair_layers<FEAT, 1>(H, pk, wave, lane NPCD_TL_ARGS); break;
             default: break;                                    // no valid pair in the tile
         }
         NPCD_STS(11);
+        // ... and its gathered points / positions / features while the aggregation runs
+        // (unconditional, tile clamped: under `if (ntile < ntiles)` the previous values would have to survive the layers)
+        pair_load_data<FEAT>(a, min(ntile, ntiles - 1), tid, in);
+        __builtin_amdgcn_sched_barrier(0);
         // ---- inverse-distance aggregation over the 8 neighbour slots ------------------------
         {
-            const int pl = tid >> 4, cc = tid & 15;  // point, 16-channel chunk
+            // point, and its channels 8 cc .. + 7 and 128 + 8 cc .. + 7: the 16 lanes of a point read 16 different 16-byte chunks of
+            // a row per instruction (as chunks 2 cc, 2 cc + 1 they met pairwise in the same banks)
+            const int ta = opaque(tid), pl = ta >> 4, cc = ta & 15;
             const int p = tile * 16 + pl;
             const int r0 = pstart[pl], cnt = pcount[pl];             // the point's packed rows
+            // All eight slots at once: slot s2 >= cnt re-reads the point's last row with weight 0 (adds +0: the sums are the same
+            // bits as a loop over cnt rows), so that the 8 + 16 LDS reads are independent and in flight together -- as a loop
+            // with a run-time trip count every iteration waited for its own reads.
+            const int last = max(cnt - 1, 0);
+            float w8[8];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) w8[s2] = wrow[r0 + min(s2, last)];
+            f16x8 v0[8], v1[8];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+                const int row = r0 + min(s2, last);
+                v0[s2] = *reinterpret_cast<const f16x8*>(H + act_off(row, cc));
+                v1[s2] = *reinterpret_cast<const f16x8*>(H + act_off(row, cc + 16));
+            }
             float wsum = 0.f;
-            for (int s2 = 0; s2 < cnt; ++s2) wsum += wrow[r0 + s2];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+                w8[s2] = s2 < cnt ? w8[s2] : 0.f;
+                wsum += w8[s2];
+            }
             const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
             float out[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) out[j] = 0.f;
-            for (int s2 = 0; s2 < cnt; ++s2) {
-                const int row = r0 + s2;
-                const float ws = wrow[row] * inv;
-                const f16x8 v0 = *reinterpret_cast<const f16x8*>(H + act_off(row, 2 * cc));
-                const f16x8 v1 = *reinterpret_cast<const f16x8*>(H + act_off(row, 2 * cc + 1));
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { out[j] += ws * (float)v0[j]; out[8 + j] += ws * (float)v1[j]; }
+            for (int s2 = 0; s2 < 8; ++s2) {
+                const float ws = w8[s2] * inv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { out[j] += ws * (float)v0[s2][j]; out[8 + j] += ws * (float)v1[s2][j]; }
+            }
+            if (cnt == 0) {          // (the re-read row of a point without neighbours holds whatever the tile left there)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) out[j] = 0.f;
             }
             if (p < P) {
                 f16x8 o0, o1;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { o0[j] = (_Float16)out[j]; o1[j] = (_Float16)out[8 + j]; }
-                f16x8* gp = reinterpret_cast<f16x8*>(a.G + (int64_t)p * kHidden + cc * 16);
+                f16x8* gp = reinterpret_cast<f16x8*>(a.G + (int64_t)p * kHidden + cc * 8);
                 gp[0] = o0;
-                gp[1] = o1;
+                gp[16] = o1;
             }
         }
         NPCD_STS(12);
-        __syncthreads();
+        __syncthreads();            // the tile's rows, weights and counts are free for the next prologue
         NPCD_STS(13);
-        tile = *next_tile;          // written at the top of this iteration, several barriers ago
-        __syncthreads();            // ... and not overwritten before every thread has read it
+#ifdef NPCD_SHADE_TL
+        span_tiles += 1;
+        if (tl_on) {
+            tl_n += 1; tl_nb += nblk;
+            if (nblk == 4) {
+                tl_n4 += 1;
+                for (int i = 1; i < 14; ++i) tl_sum[i] += tl[i] - tl[i - 1];
+            }
+        }
+#endif
+        tile = ntile;
     }
 #ifdef NPCD_SHADE_TL
-    if (tl_on && lane == 0)
-        for (int i = 0; i < 16; ++i) g_shade_tl[i] = tl[i];
+    if (tl_on && lane == 0) {
+        for (int i = 0; i < 14; ++i) g_shade_tl[i] = tl_sum[i];
+        g_shade_tl[14] = tl_n4; g_shade_tl[15] = tl_n; g_shade_tl[16] = __builtin_amdgcn_s_memtime() - tl_begin; g_shade_tl[17] = tl_nb;
+    }
+    if (tid == 0 && blockIdx.x < 512) {
+        long long* sp = g_shade_span + 4 * blockIdx.x;
+        sp[0] = rt_begin; sp[1] = __builtin_amdgcn_s_memrealtime(); sp[2] = span_tiles; sp[3] = __builtin_amdgcn_s_memtime() - tl_begin;
+    }
 #endif
 }
 #ifdef NPCD_SHADE_TL
 }
 namespace npcd { int rows_debug_read(long long* out, int count); }
+extern "C" int npcd_shade_span_read(long long* out, int count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(npcd::g_shade_span), sizeof(long long) * count);
+}
 extern "C" int npcd_shade_debug_read(long long* out, int count) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(npcd::g_shade_tl), sizeof(long long) * count);
 }

@@ -12,13 +12,21 @@ extr = orr.look_at_pose(30, 20)[None, None].cuda(); intr = orr.srn_intrinsics()[
 with torch.no_grad():
     for _ in range(5): model.render(coords.cuda(), feats.cuda(), extr, intr, 128)
 torch.cuda.synchronize()
-buf = (ctypes.c_longlong * 16)()
+buf = (ctypes.c_longlong * 32)()
 L = lib(); L.npcd_shade_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
-L.npcd_shade_debug_read(ctypes.cast(buf, ctypes.c_void_p), 16)
+L.npcd_shade_debug_read(ctypes.cast(buf, ctypes.c_void_p), 32)
 names = ["tile start", "prologue done", "barrier", "L0 mfma", "barrier", "L0 store", "barrier", "L1 mfma", "barrier", "L1 store", "barrier", "L2,L3 done", "aggregation", "barrier"]
-t = list(buf); prev = t[0]
-for i, x in enumerate(t[:14]):
-    print(f"{i:2d} {names[i]:16s} +{x - prev:7d}  (={x - t[0]})"); prev = x
+t = list(buf); n4 = max(t[14], 1)
+print(f"workgroup: {t[15]} tiles ({t[14]} with 4 row blocks, mean {t[17] / max(t[15], 1):.2f} blocks), {t[16]} clocks = {t[16] / max(t[15], 1):.0f} per tile")
+print("mean clocks per interval over the 4-block tiles:  " + "  ".join(f"{names[i]} {t[i] / n4:.0f}" for i in range(1, 14)) + f"   = {sum(t[1:14]) / n4:.0f}")
+if hasattr(L, "npcd_shade_span_read"):
+    import numpy as np
+    sp = (ctypes.c_longlong * 2048)(); L.npcd_shade_span_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.npcd_shade_span_read(ctypes.cast(sp, ctypes.c_void_p), 2048)
+    sp = np.array(list(sp), dtype=np.int64).reshape(512, 4); t0 = sp[:, 0].min()
+    b, e = (sp[:, 0] - t0) / 100.0, (sp[:, 1] - t0) / 100.0          # microseconds (100-MHz counter)
+    print(f"workgroup spans (us): begin min/median/max {b.min():.1f}/{np.median(b):.1f}/{b.max():.1f}   end min/median/max {e.min():.1f}/{np.median(e):.1f}/{e.max():.1f}"
+          f"   tiles min/mean/max {sp[:, 2].min()}/{sp[:, 2].mean():.2f}/{sp[:, 2].max()}   clock {np.median(sp[:, 3] / np.maximum(sp[:, 1] - sp[:, 0], 1)) / 10:.3f} GHz")
 if hasattr(L, "npcd_shade_rows_debug_read") and not os.environ.get("NPCD_SHADE_TILES"):
     L.npcd_shade_rows_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.npcd_shade_rows_debug_read(ctypes.cast(buf, ctypes.c_void_p), 16)
