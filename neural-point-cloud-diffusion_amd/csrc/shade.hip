@@ -528,7 +528,7 @@ __device__ __forceinline__ float softplus_m1(float x) {
 }
 
 #ifndef NPCD_POINTS_PF
-#define NPCD_POINTS_PF 3
+#define NPCD_POINTS_PF 2
 #endif
 #ifdef NPCD_POINTS_TL          // DIAGNOSTIC: s_memtime stamps of the first pass of workgroup NPCD_POINTS_TL, wave 0
 __device__ long long g_points_tl[32];
@@ -536,6 +536,18 @@ __device__ long long g_points_tl[32];
 #else
 #define NPCD_PTS(i) do { } while (0)
 #endif
+// A point-level layer: the pinned pipeline of the pair kernel (published configuration), or -- with view directions, whose kernel has
+// no registers to spare for the ring and the prefetched bias -- the plain form with the weights three k-steps ahead.
+template <bool PIPE, int PF>
+__device__ __forceinline__ void point_prefetch(wrsrc_t rs, int w_off, int b_off, int wave, int lane, WRing& ring, f32x16 (&init)[2]) {
+    if constexpr (PIPE) layer_prefetch<16, PF>(rs, w_off, b_off, wave, lane, ring, init);
+}
+template <bool PIPE, int NB, int PF>
+__device__ __forceinline__ void point_layer(const unsigned char* H, const unsigned char* wpack, wrsrc_t rs, int w_off, int b_off, int wave, int lane,
+                                            WRing& ring, f32x16 (&init)[2], f32x16 (&acc)[2][4]) {
+    if constexpr (PIPE) layer_mfma_pipe<16, NB, PF>(H, rs, w_off, wave, lane, ring, init, acc);
+    else layer_mfma<16, 4, NB, 3>(H, wpack + w_off, reinterpret_cast<const float*>(wpack + b_off), wave, lane, acc);
+}
 // One pass of the point-level layers over NB 32-row blocks (rows row0 .. row0 + 32 NB of the compact lists).
 struct PointsArgs {          // what a pass needs of ShadeArgs, passed BY VALUE (a reference to the kernel argument would be a scratch copy)
     const unsigned char* wpack;
@@ -556,6 +568,15 @@ __device__ __forceinline__ void points_pass(PointsArgs a, unsigned char* H, floa
     const int lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
     const float* s1 = reinterpret_cast<const float*>(a.wpack + L.s1);
     const float* c4 = reinterpret_cast<const float*>(a.wpack + L.c4);
+    // the six matrices A4, S0, C0..C3 and their biases lie back to back in the pack; every layer's bias and first weight fragments
+    // are requested before the previous layer's epilogue (layer_prefetch / layer_mfma_pipe, as in the pair kernel)
+    constexpr bool PIPE = !DIR;
+    constexpr int PF = NPCD_POINTS_PF, kLayerBytes = 8 * (kHidden / 16) * kFragBytes;
+    const wrsrc_t rs = pack_rsrc(a.wpack, L.total);
+    const int wv = __builtin_amdgcn_readfirstlane(wave), w4 = (int)L.w[4], b4 = (int)L.bias[4];
+    WRing ring;
+    f32x16 init[2];
+    point_prefetch<PIPE, PF>(rs, w4, b4, wv, lane, ring, init);
     NPCD_PTS(0);
     // ---- load the aggregated features of 32 NB points ---------------------------------------
 #pragma unroll
@@ -570,7 +591,8 @@ __device__ __forceinline__ void points_pass(PointsArgs a, unsigned char* H, floa
     NPCD_PTS(1);
     f32x16 acc[2][4];
     // ---- last aggregator layer (linear): feat ------------------------------------------
-    layer_mfma<16, 4, NB, NPCD_POINTS_PF>(H, a.wpack + L.w[4], reinterpret_cast<const float*>(a.wpack + L.bias[4]), wave, lane, acc);
+    point_layer<PIPE, NB, PF>(H, a.wpack, rs, w4, b4, wv, lane, ring, init, acc);
+    point_prefetch<PIPE, PF>(rs, w4 + kLayerBytes, b4 + kHidden * 4, wv, lane, ring, init);
     NPCD_PTS(2);
     __syncthreads();
     NPCD_PTS(3);
@@ -579,7 +601,8 @@ __device__ __forceinline__ void points_pass(PointsArgs a, unsigned char* H, floa
     __syncthreads();
     NPCD_PTS(5);
     // ---- density head: Linear(256,256) + LeakyReLU + Linear(256,1), softplus(x - 1) ------
-    layer_mfma<16, 4, NB, NPCD_POINTS_PF>(H, a.wpack + L.w[5], reinterpret_cast<const float*>(a.wpack + L.bias[5]), wave, lane, acc);
+    point_layer<PIPE, NB, PF>(H, a.wpack, rs, w4 + kLayerBytes, b4 + kHidden * 4, wv, lane, ring, init, acc);
+    point_prefetch<PIPE, PF>(rs, w4 + 2 * kLayerBytes, b4 + 2 * kHidden * 4, wv, lane, ring, init);
     {
         float part[NB];
 #pragma unroll
@@ -609,9 +632,9 @@ __device__ __forceinline__ void points_pass(PointsArgs a, unsigned char* H, floa
     // ---- colour head: 4 x [Linear(256,256) + LeakyReLU] + Linear(256,3), sigmoid ----------
 #pragma unroll 1
     for (int l = 0; l < 4; ++l) {
-        // (closed form instead of L.w[6 + l] / L.bias[6 + l]: see pair_layers)
-        const int64_t w_off = L.w[6] + (int64_t)l * (8 * (kHidden / 16) * kFragBytes), b_off = L.bias[6] + (int64_t)l * (kHidden * 4);
-        layer_mfma<16, 4, NB, NPCD_POINTS_PF>(H, a.wpack + w_off, reinterpret_cast<const float*>(a.wpack + b_off), wave, lane, acc);
+        const int w_off = w4 + (2 + l) * kLayerBytes, b_off = b4 + (2 + l) * (kHidden * 4);
+        point_layer<PIPE, NB, PF>(H, a.wpack, rs, w_off, b_off, wv, lane, ring, init, acc);
+        if (l < 3) point_prefetch<PIPE, PF>(rs, w_off + kLayerBytes, b_off + kHidden * 4, wv, lane, ring, init);
         if (DIR && l == 0) {       // + the view-direction part of the first colour layer (per ray, fp32)
 #pragma unroll
             for (int cb = 0; cb < NB; ++cb) {
