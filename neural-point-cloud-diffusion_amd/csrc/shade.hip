@@ -46,11 +46,11 @@ __device__ __forceinline__ void layer_mfma(const unsigned char* H, const unsigne
     const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int oi = 0; oi < 2; ++oi) {
-        const float* bp = bias + (2 * wave + oi) * 32 + 4 * hh;
+        const float* bp = bias + (2 * wave + oi) * 32;
         f32x16 init;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + 8 * g);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bp + acc_group_off(g, hh));
 #pragma unroll
             for (int b = 0; b < 4; ++b) init[4 * g + b] = b4[b];
         }
@@ -133,8 +133,8 @@ __device__ __forceinline__ void layer_prefetch(wrsrc_t rs, int w_off, int b_off,
 #pragma unroll
     for (int oi = 0; oi < 2; ++oi)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {       // bias of out channel (2 wave + oi) * 32 + 8 g + 4 hh + b
-            const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hh * 16 + g * 32, b_off + (2 * wave + oi) * 128, 0));
+        for (int g = 0; g < 4; ++g) {       // bias of out channel (2 wave + oi) * 32 + acc_group_off(g, hh) + b
+            const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hh * 32 + (g >> 1) * 64 + (g & 1) * 16, b_off + (2 * wave + oi) * 128, 0));
 #pragma unroll
             for (int b = 0; b < 4; ++b) init[oi][4 * g + b] = b4[b];
         }
@@ -175,23 +175,23 @@ __device__ __forceinline__ void layer_mfma_pipe(const unsigned char* H, wrsrc_t 
     }
 }
 
-// epilogue: optional LeakyReLU, convert to fp16, write back in place.  A lane holds runs of 4 consecutive channels (8 bytes) of one
-// row, lanes l and l + 32 the two halves of an 8-channel chunk: one v_permlane32_swap per dword joins them, so that every lane
-// writes whole 16-byte chunks (ds_write_b128: 16 rows per pass, 4 banks apart = all 64 banks; as 8-byte writes rows r and r + 16
-// of a 32-lane pass met in the same banks -- the 2-way conflicts of profiles/r3_shade_sq_pmc.json).
+// epilogue: optional LeakyReLU, convert to fp16, write back in place.  With the rows of the matrices permuted in the pack
+// (acc_channel, shade_common.h) the register groups 2 q, 2 q + 1 of a lane are 8 consecutive channels of its row: every lane writes
+// whole 16-byte chunks (ds_write_b128: 16 rows per pass, 4 banks apart = all 64 banks; as 8-byte writes rows r and r + 16 of a
+// 32-lane pass met in the same banks -- the 2-way conflicts of profiles/r3_shade_sq_pmc.json).
 template <bool ACT, int NB = 4>
 __device__ __forceinline__ void layer_store(unsigned char* H, int wave, int lane, const f32x16 (&acc)[2][4]) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     const int r = lane & 31, hh = lane >> 5;
-    unsigned char* sb = H + r * kRowBytes + hh * 16 + wave * 128;     // row (cb*32 + r), channels (2 wave + oi)*32 + 16 gp + 8 hh ..
+    unsigned char* sb = H + r * kRowBytes + hh * 16 + wave * 128;     // row (cb*32 + r), channels (2 wave + oi)*32 + 16 gp + 8 hh .. + 7
 #pragma unroll
     for (int oi = 0; oi < 2; ++oi)
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb)
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
-                uint32_t v[2][2];        // [g - 2 gp][dword]: channels 8 g + 4 hh + {0,1 | 2,3}
+                uint32_t v[2][2];        // [g - 2 gp][dword]: channels 16 gp + 8 hh + 4 (g - 2 gp) + {0,1 | 2,3}
 #pragma unroll
                 for (int gg = 0; gg < 2; ++gg)
 #pragma unroll
@@ -217,10 +217,7 @@ __device__ __forceinline__ void layer_store(unsigned char* H, int wave, int lane
                         v[gg][b] = __builtin_bit_cast(uint32_t, h);
 #endif
                     }
-                // lower lanes keep chunk 2 gp (their half + the upper lanes' half), upper lanes chunk 2 gp + 1
-                const auto s0 = __builtin_amdgcn_permlane32_swap(v[0][0], v[1][0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(v[0][1], v[1][1], false, false);
-                *reinterpret_cast<u32x4*>(sb + cb * 32 * kRowBytes + oi * 64 + gp * 32) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                *reinterpret_cast<u32x4*>(sb + cb * 32 * kRowBytes + oi * 64 + gp * 32) = u32x4{v[0][0], v[0][1], v[1][0], v[1][1]};
             }
 }
 
@@ -611,7 +608,7 @@ __device__ __forceinline__ void points_pass(PointsArgs a, unsigned char* H, floa
         for (int oi = 0; oi < 2; ++oi)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(s1 + (2 * wave + oi) * 32 + 8 * g + 4 * hh);
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(s1 + (2 * wave + oi) * 32 + acc_group_off(g, hh));
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
 #pragma unroll
@@ -639,12 +636,12 @@ __device__ __forceinline__ void points_pass(PointsArgs a, unsigned char* H, floa
 #pragma unroll
             for (int cb = 0; cb < NB; ++cb) {
                 const int p = row0 + cb * 32 + r;
-                const float* db = a.dir_bias + (int64_t)(p < P ? a.point_ray[p] : 0) * kHidden + 4 * hh;
+                const float* db = a.dir_bias + (int64_t)(p < P ? a.point_ray[p] : 0) * kHidden;
 #pragma unroll
                 for (int oi = 0; oi < 2; ++oi)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(db + (2 * wave + oi) * 32 + 8 * g);
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(db + (2 * wave + oi) * 32 + acc_group_off(g, hh));
 #pragma unroll
                         for (int b = 0; b < 4; ++b) acc[oi][cb][4 * g + b] += v[b];
                     }
@@ -669,7 +666,7 @@ __device__ __forceinline__ void points_pass(PointsArgs a, unsigned char* H, floa
         for (int oi = 0; oi < 2; ++oi)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float* cp = c4 + (2 * wave + oi) * 32 + 8 * g + 4 * hh;
+                const float* cp = c4 + (2 * wave + oi) * 32 + acc_group_off(g, hh);
                 const f32x4 wr = *reinterpret_cast<const f32x4*>(cp), wg = *reinterpret_cast<const f32x4*>(cp + kHidden),
                             wb = *reinterpret_cast<const f32x4*>(cp + 2 * kHidden);
 #pragma unroll
@@ -767,7 +764,7 @@ extern "C" int64_t npcd_shade_workspace_bytes(int max_points, int hidden) {
     return (int64_t)(max_points + kRows) * kHidden * 2 + shade_rows_workspace_bytes(max_points) + 16;      // + the tile counter
 }
 
-// fragment order: [out block ob][k-step s][lane][8]  with  element = W[ob*32 + (lane&31)][16 s + 8 (lane>>5) + j]
+// fragment order: [out block ob][k-step s][lane][8]  with  element = W[ob*32 + acc_channel(lane&31)][16 s + 8 (lane>>5) + j]
 static void pack_matrix(const float* W, int out_dim, int in_dim, int k_padded, unsigned char* dst) {
     _Float16* d = reinterpret_cast<_Float16*>(dst);
     const int ksteps = k_padded / 16;
@@ -775,7 +772,7 @@ static void pack_matrix(const float* W, int out_dim, int in_dim, int k_padded, u
         for (int s = 0; s < ksteps; ++s)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j) {
-                    const int o = ob * 32 + (lane & 31), c = 16 * s + 8 * (lane >> 5) + j;
+                    const int o = ob * 32 + acc_channel(lane & 31), c = 16 * s + 8 * (lane >> 5) + j;
                     const float v = c < in_dim ? W[(int64_t)o * in_dim + c] : 0.f;
                     d[(((int64_t)ob * ksteps + s) * 64 + lane) * 8 + j] = (_Float16)v;
                 }

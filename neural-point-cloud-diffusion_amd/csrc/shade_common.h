@@ -13,6 +13,17 @@ constexpr int kRowBytes = kHidden * 2 + 16; // 528: rows padded by one 16-byte c
 constexpr int kFragBytes = 1024;       // one 32(out) x 16(in) fp16 weight fragment
 constexpr float kLeaky = 0.01f;
 
+// Output channel (within a 32-row block) of accumulator row m = 8 g + 4 hh + b of a 32 x 32 tile (g = register group, hh = lane half,
+// b = register of the group).  The matrices' rows are PERMUTED in the pack so that the register groups g = 2 q and 2 q + 1 of a lane
+// are 8 CONSECUTIVE channels -- a whole 16-byte chunk of the activation row, written back without cross-lane traffic (in the natural
+// order m = channel, lanes l and l + 32 held the halves of a chunk: one v_permlane32_swap per dword, 32 per wave and layer).
+__host__ __device__ inline int acc_channel(int m) {
+    const int g = m >> 3, hh = (m >> 2) & 1, b = m & 3;
+    return 16 * (g >> 1) + 8 * hh + 4 * (g & 1) + b;
+}
+// float offset of register group g of lane half hh inside a 32-channel block of a per-channel vector (bias, head weights)
+__host__ __device__ inline int acc_group_off(int g, int hh) { return 16 * (g >> 1) + 8 * hh + 4 * (g & 1); }
+
 struct ShadeLayout {
     int k0;          // padded input width of layer 0
     int64_t w[10];   // byte offsets of the packed matrices: A0..A3, A4, S0, C0..C3
