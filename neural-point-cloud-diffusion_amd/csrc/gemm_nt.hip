@@ -450,6 +450,210 @@ __global__ __launch_bounds__(512, 2) void lin_kernel(LinParams p) {
 #undef NPCD_L_VMWAIT
 }
 
+// ============================================================================================================================
+// Small-M form: 128 x 128 tiles.  At the token counts of a rank of the 4- / 8-GPU job (T = 8,208 / 4,104) the
+// N = 1,024 products of a block have 64-68 tiles of 256 x 256 on 256 CUs; with 128 x 128 tiles they have 264 / 520.  One workgroup
+// per tile (8 waves on four 64 x 64 wave tiles), K-steps of 64 through three LDS stages filled global -> registers -> LDS, one barrier
+// per K-step (LDS-DMA is not used here: with one wave per SIMD -- 264 workgroups on 256 CUs -- its 115-170 blocked issue cycles per
+// instruction, R4.1, would exceed the step's 512 matrix cycles).  The LAST row tile takes up to 160 rows (M mod 128 <= 32: the 8 / 16 /
+// 32 rows of the time-step tokens would otherwise be a second round of 8 workgroups on a full chip): its upper waves carry a third
+// row block.  Bound: LDS traffic -- per K-step and CU 64 KB of fragment reads + 32 KB of stage writes against 512 matrix cycles.
+struct Lin128Params {
+    const void* x; const void* w; const void* bias; void* y;
+    int M, N, K, tiles_m, tiles_n;
+    int tall;             // rows of the last row tile (128 < tall <= 160), or 0: all row tiles have <= 128 rows
+};
+constexpr int kL128Rows = 160;                                   // x rows of a stage (the tall tile's)
+constexpr int kL128Stage = (kL128Rows + 128) * 128;              // bytes: x rows [160][64] + w rows [128][64]
+constexpr int kL128Lds = 3 * kL128Stage;                         // 110,592 B: one workgroup (eight waves) per CU
+
+template <class TR, int MB1>          // MB1 = row blocks of the upper waves (wm = 1): 2, or 3 in the tall last row tile
+__device__ __forceinline__ void lin128_tile(const Lin128Params& p, unsigned char* smem, int tm, int tn) {
+    using E = typename TR::elem;
+    constexpr int XL = MB1 == 3 ? 3 : 2;                           // 16-byte loads per thread and stage for the x rows (rows lrow + 64 i)
+    constexpr int MB = MB1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // EIGHT waves on a tile of four 64 x 64 wave tiles: waves w and w + 4 share a wave tile and split every K-step's four sub-steps
+    // (kg = 0: sub-steps 0, 1; kg = 1: 2, 3), their partial accumulators meet through LDS at the end.  Two waves per SIMD from ONE
+    // workgroup per CU (264 workgroups on 256 CUs): as four waves the loop ran at the latency of its own LDS reads and load waits
+    // (1,450 clocks per K-step without any stage traffic against 512 of matrix instructions).
+    const int kg = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
+    const int nk = p.K >> 6, m0 = tm * 128, n0 = tn * 128;
+    const E* X = static_cast<const E*>(p.x);
+    const E* W = static_cast<const E*>(p.w);
+    // ---- global -> register staging: thread t takes 16-byte chunk (t & 7) of rows (t >> 3) + 64 i
+    const int lrow = tid >> 3, lchunk = tid & 7;
+    const E* xs[XL];
+    const E* ws[2];
+#pragma unroll
+    for (int i = 0; i < XL; ++i) xs[i] = X + (int64_t)min(m0 + lrow + 64 * i, p.M - 1) * p.K + lchunk * 8;     // rows past M re-read the last one
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ws[i] = W + (int64_t)(n0 + lrow + 64 * i) * p.K + lchunk * 8;
+    const uint32_t lds0 = l_lds_addr(smem);
+    const uint32_t st_off = (uint32_t)tile_off(lrow, lchunk);                  // (rows r and r + 64 i share the swizzle: it repeats every 8 rows)
+    const bool x2_ok = MB1 == 3 && lrow < kL128Rows - 128;                       // the tall tile's third group: rows 128 .. 159 only
+    // two register sets: stage s is requested at the top of step s - 2 and written to LDS at the top of step s - 1 (its buffer, s & 1,
+    // was last read in step s - 2): two K-steps of flight time
+    u32x4 gx[2][XL], gw[2][2];
+    auto g_load = [&](int set, int kt) {
+#pragma unroll
+        for (int i = 0; i < XL; ++i) gx[set][i] = *reinterpret_cast<const u32x4*>(xs[i] + kt * 64);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) gw[set][i] = *reinterpret_cast<const u32x4*>(ws[i] + kt * 64);
+    };
+    auto s_store = [&](int set, int buf) {
+        unsigned char* b = smem + buf * kL128Stage;
+#pragma unroll
+        for (int i = 0; i < XL; ++i)
+            if (i < 2 || x2_ok) *reinterpret_cast<u32x4*>(b + st_off + i * 64 * 128) = gx[set][i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(b + kL128Rows * 128 + st_off + i * 64 * 128) = gw[set][i];
+    };
+    // ---- fragment addresses: MFMA operand lane (r, h) reads row r, 16-byte chunk 2 s + h of K-sub-step s = 2 kg + j
+    const int r = lane & 31, h = lane >> 5;
+    const int mb_mine = (MB1 == 3 && wm == 0) ? 2 : MB1;
+    const int xrow0 = 64 * wm;                                                  // tall tile: rows [0, 64) | [64, 160)
+    uint32_t xa[2], wa[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t c = (uint32_t)(((2 * (2 * kg + j) + h) ^ tile_swz(r)) << 4);
+        xa[j] = (xrow0 + r) * 128 + c;
+        wa[j] = kL128Rows * 128 + (64 * wn + r) * 128 + c;
+    }
+    f32x16 acc[2][MB];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) acc[ni][mi] = f32x16{0};
+
+#ifndef NPCD_L128_DIAG
+#define NPCD_L128_DIAG 0          // DIAGNOSTIC builds (wrong results, timing only): 1 no global loads in the loop, 2 no matrix instructions, 3 no stage writes
+#endif
+    // Pipeline over THREE LDS stages.  Stage u: global -> registers in step u - 3, registers -> LDS (buffer u % 3) in step u - 2,
+    // complete behind that step's barrier, its fragments are read during the matrix instructions of step u - 1, multiplied in
+    // step u.  One barrier per step; a wave's LDS reads always run one step ahead of its matrix instructions.
+    u32x4 fx[2][2][MB], fw[2][2][2];                    // [parity of the step][sub-step j][block]
+    auto f_read = [&](int par, uint32_t bo) {
+        const unsigned char* sb = smem + bo;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi)
+                if (mi < mb_mine) fx[par][j][mi] = *reinterpret_cast<const u32x4*>(sb + xa[j] + mi * 4096);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) fw[par][j][ni] = *reinterpret_cast<const u32x4*>(sb + wa[j] + ni * 4096);
+        }
+    };
+    auto k_mma = [&](int par) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MB; ++mi)
+                    if (mi < mb_mine) {
+                        if (NPCD_L128_DIAG != 2) acc[ni][mi] = TR::mfma32(__builtin_bit_cast(typename TR::vec8, fw[par][j][ni]), __builtin_bit_cast(typename TR::vec8, fx[par][j][mi]), acc[ni][mi]);
+                        else acc[ni][mi][0] += __uint_as_float(fw[par][j][ni][0] ^ fx[par][j][mi][3]);
+                    }
+    };
+    // prologue: stages 0 and 1 in LDS, stage 2 in registers (set 0), the fragments of step 0 read
+    g_load(0, 0);
+    if (nk > 1) g_load(1, 1);
+    s_store(0, 0);
+    if (nk > 2) g_load(0, 2);
+    if (nk > 1) s_store(1, 1);
+    __syncthreads();
+    f_read(0, 0);
+    uint32_t b_cur = 0;                                  // byte offset of the buffer of the step being multiplied
+    auto nxt = [](uint32_t b) { return b == 2 * kL128Stage ? 0u : b + (uint32_t)kL128Stage; };
+    // steps in pairs: the register set of a stage (its parity) and the fragment set of a step are compile-time choices
+    for (int kt = 0; kt < nk; kt += 2) {
+        const uint32_t b1 = nxt(b_cur), b2 = nxt(b1);
+        // (the request for stage kt + 3 goes out BEFORE the wait for stage kt + 2: the wait then leaves the newest loads in flight)
+        if (NPCD_L128_DIAG != 1 && kt + 3 < nk) g_load(1, kt + 3);
+        if (NPCD_L128_DIAG != 3 && kt + 2 < nk) s_store(0, (int)(b2 / kL128Stage));
+        if (kt + 1 < nk) f_read(1, b1);
+        k_mma(0);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            if (NPCD_L128_DIAG != 1 && kt + 4 < nk) g_load(0, kt + 4);
+            if (NPCD_L128_DIAG != 3 && kt + 3 < nk) s_store(1, (int)(b_cur / kL128Stage));      // buffer (kt + 3) % 3 = the one of step kt
+            if (kt + 2 < nk) f_read(0, b2);
+            k_mma(1);
+            __syncthreads();
+        }
+        b_cur = b2;
+    }
+    // ---- the two halves of every K-step meet: the upper waves hand their partial accumulators over through LDS (one column block
+    // at a time: <= 40 KB), the lower waves add them and write the tile
+    {
+        float* red = reinterpret_cast<float*>(smem) + ((wave & 3) * (MB * 16) * 64 + lane) * 1;      // [wave tile][register][lane]
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            if (kg == 1) {
+#pragma unroll
+                for (int mi = 0; mi < MB; ++mi)
+                    if (mi < mb_mine)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) red[(mi * 16 + e) * 64] = acc[ni][mi][e];
+            }
+            __syncthreads();
+            if (kg == 0) {
+#pragma unroll
+                for (int mi = 0; mi < MB; ++mi)
+                    if (mi < mb_mine)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[ni][mi][e] += red[(mi * 16 + e) * 64];
+            }
+            __syncthreads();
+        }
+    }
+    if (kg == 1) return;
+    // ---- epilogue: lane = output row, register quads = 4 consecutive output columns; lanes l and l + 32 joined into 16-byte stores
+    const E* bias = static_cast<const E*>(p.bias);
+    E* Y = static_cast<E*>(p.y);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int nb = n0 + 64 * wn + 32 * ni;
+        float bq[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (bias) lin_unpack4<TR>(*reinterpret_cast<const u32x2*>(bias + nb + 8 * q + 4 * h), bq[q]);
+            else bq[q][0] = bq[q][1] = bq[q][2] = bq[q][3] = 0.f;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) {
+            if (mi >= mb_mine) continue;
+            const int m = m0 + xrow0 + 32 * mi + r;
+            const bool ok = m < p.M;
+            const int64_t rowoff = (int64_t)(ok ? m : 0) * p.N + nb + 8 * h;
+#pragma unroll
+            for (int qp = 0; qp < 2; ++qp) {
+                float v[2][4];
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[e][j] = acc[ni][mi][4 * (2 * qp + e) + j] + bq[2 * qp + e][j];
+                const uint32_t a0 = lin_pack2<E>(v[0][0], v[0][1]), a1 = lin_pack2<E>(v[0][2], v[0][3]);
+                const uint32_t b0 = lin_pack2<E>(v[1][0], v[1][1]), b1 = lin_pack2<E>(v[1][2], v[1][3]);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                if (ok) *reinterpret_cast<u32x4*>(Y + rowoff + 16 * qp) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+            }
+        }
+    }
+}
+
+template <class TR>
+__global__ __launch_bounds__(512, 2) void lin128_kernel(Lin128Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int l = xcd_remap(blockIdx.x, gridDim.x);                 // an XCD's workgroups are consecutive: they share x row panels in its L2
+    const int tn = l % p.tiles_n, tm = l / p.tiles_n;
+    if (p.tall && tm == p.tiles_m - 1) lin128_tile<TR, 3>(p, smem, tm, tn);      // (workgroup-uniform)
+    else lin128_tile<TR, 2>(p, smem, tm, tn);
+}
+
 // 16-bit matrix transpose (weights: [R, C] -> [C, R]), 64 x 64 tiles through LDS
 template <class E>
 __global__ __launch_bounds__(256) void transpose16_kernel(const E* __restrict__ in, E* __restrict__ out, int R, int C) {
@@ -525,6 +729,32 @@ extern "C" int npcd_linear_dgelu_rows(int M) { return M <= 0 ? -1 : 2 * ((M + 25
 extern "C" int npcd_linear_dgelu_bwd(const void* dy, const void* wt, const void* h, void* dh, float* part, int M, int N, int K, int dtype,
                                      void* stream) {
     return lin_common(LIN_DGELU, dy, wt, nullptr, dh, nullptr, h, part, M, N, K, dtype, stream);
+}
+extern "C" int npcd_linear128_fwd(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int dtype, void* stream) {
+    if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0) return NPCD_ERR_ARG;
+    if (N % 128 || K % 64 || (dtype != NPCD_BF16 && dtype != NPCD_F16)) return NPCD_ERR_UNSUPPORTED;
+    if ((int64_t)M * N >= (int64_t)1 << 31 || (int64_t)M * K >= (int64_t)1 << 31) return NPCD_ERR_UNSUPPORTED;
+    for (const void* q : {x, w, bias, (const void*)y})
+        if (reinterpret_cast<uintptr_t>(q) & 15) return NPCD_ERR_ARG;
+    Lin128Params p{};
+    p.x = x; p.w = w; p.bias = bias; p.y = y;
+    p.M = M; p.N = N; p.K = K;
+    const int rem = M % 128;
+    p.tall = (M > 128 && rem >= 1 && rem <= 32) ? 128 + rem : 0;       // the left-over rows ride on the last full row tile
+    p.tiles_m = p.tall ? M / 128 : (M + 127) / 128;
+    p.tiles_n = N / 128;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static DynLds lds_b, lds_h;
+    const int grid = p.tiles_m * p.tiles_n;
+    if (dtype == NPCD_BF16) {
+        NPCD_HIP_CHECK(lds_b.ensure(reinterpret_cast<const void*>(lin128_kernel<BF16>), kL128Lds));
+        hipLaunchKernelGGL(lin128_kernel<BF16>, dim3(grid), dim3(512), kL128Lds, st, p);
+    } else {
+        NPCD_HIP_CHECK(lds_h.ensure(reinterpret_cast<const void*>(lin128_kernel<F16>), kL128Lds));
+        hipLaunchKernelGGL(lin128_kernel<F16>, dim3(grid), dim3(512), kL128Lds, st, p);
+    }
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
 }
 #ifdef NPCD_LIN_TL
 extern "C" int npcd_lin_debug_read(long long* out, int count) {

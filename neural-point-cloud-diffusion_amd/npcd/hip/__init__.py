@@ -93,6 +93,7 @@ SIGNATURES = {
     "npcd_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "npcd_sum_slices": (c_int, [_P, _P, c_int, c_int64, _P]),
     "npcd_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "npcd_linear128_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "npcd_linear_gelu_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "npcd_linear_dgelu_rows": (c_int, [c_int]),
     "npcd_linear_dgelu_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

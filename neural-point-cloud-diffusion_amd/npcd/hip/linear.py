@@ -43,6 +43,20 @@ def linear_fwd(x, w, bias=None, out=None):
     return y
 
 
+def supported128(M: int, N: int, K: int) -> bool:
+    return M >= 1 and N % 128 == 0 and K % 64 == 0 and M * N < 2 ** 31 and M * K < 2 ** 31
+
+
+def linear128_fwd(x, w, bias=None, out=None):
+    """y [M, N] = x [M, K] @ w [N, K]^T (+ bias) on 128 x 128 tiles: the form for a few thousand rows (one rank of the 4- / 8-GPU job)."""
+    _check_operands(x, w)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), dtype=x.dtype, device=x.device) if out is None else out
+    check(_timed("fwd128", lambda: lib().npcd_linear128_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), M, N, K, dtype_code(x), stream_ptr())), "npcd_linear128_fwd")
+    return y
+
+
 def linear_gelu_fwd(x, w, bias):
     """h = x @ w^T + bias (rounded to 16 bit), g = gelu_erf(h): (h, g)."""
     _check_operands(x, w)

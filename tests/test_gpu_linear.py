@@ -40,6 +40,42 @@ def test_linear_fwd_matches_fp32_reference(M, N, K, dtype):
     assert torch.equal(y, hl.linear_fwd(x, w, b))
 
 
+# the 128 x 128 form: the token counts of one rank of the 8- / 4- / 2-GPU job (left-over rows 8 / 16 / 32 ride on the last row tile),
+# one row, exactly one tile, a ragged end above 32 rows (an own row tile), N of one tile, both K extremes
+SHAPES128 = [(4104, 1024, 1024), (8208, 1024, 1024), (4104, 1024, 4096), (4104, 1024, 3072), (16416, 1024, 1024), (1, 128, 64), (128, 128, 64),
+             (129, 256, 128), (160, 128, 192), (161, 384, 64), (300, 1024, 256), (4104, 4096, 1024)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES128)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_linear128_fwd_matches_fp32_reference(M, N, K, dtype):
+    from npcd.hip import linear as hl
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    x = (torch.randn(M, K, generator=g) * 1.5).to(dtype).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype).cuda()
+    b = (torch.randn(N, generator=g) * 0.5).to(dtype).cuda()
+    ref = x.float() @ w.float().t() + b.float()
+    y = torch.full((M + 1, N), 7.0, dtype=dtype, device="cuda")             # (+ a guard row behind the output)
+    hl.linear128_fwd(x, w, b, out=y[:M])
+    assert torch.isfinite(y).all() and bool((y[M] == 7.0).all())
+    assert rel(y[:M], ref) < (4e-3 if dtype == torch.bfloat16 else 6e-4)
+    ulp = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+    assert float(((y[:M].float() - ref).abs() / ref.abs().clamp_min(1.0)).max()) < 1.01 * ulp
+    assert rel(hl.linear128_fwd(x, w, None), x.float() @ w.float().t()) < (4e-3 if dtype == torch.bfloat16 else 6e-4)
+    assert torch.equal(y[:M], hl.linear128_fwd(x, w, b))                    # bitwise reproducible
+
+
+def test_linear128_catches_a_transposed_or_permuted_output():
+    from npcd.hip import linear as hl
+    M, N, K = 300, 1024, 256
+    x = torch.zeros(M, K)
+    for m in range(M):
+        x[m, (7 * m + 3) % K] = 1.0
+    w = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125) / 16.0           # exact in bf16
+    y = hl.linear128_fwd(x.bfloat16().cuda(), w.bfloat16().cuda(), None)
+    assert torch.equal(y.float().cpu(), (x @ w.t()).bfloat16().float())
+
+
 def test_linear_catches_a_transposed_or_permuted_output():
     """A = I-style check with ASYMMETRIC operands (a swapped row / column map or a wrong column run order would pass a random
     tolerance test only by luck): x selects single rows of w."""
