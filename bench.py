@@ -634,7 +634,7 @@ def main():
 
     # hipBLASLt / rocBLAS solution choices recorded once with PyTorch TunableOp (tools/tune_gemms.py) for the GEMM shapes
     # of this step; loaded with tuning DISABLED (shapes not in the file use the library default).  NPCD_NO_TUNED_GEMM=1 skips it.
-    tuned = os.path.join(ROOT, "profiles", "tunableop_gfx950.csv")
+    tuned = os.environ.get("NPCD_TUNED_CSV") or os.path.join(ROOT, "profiles", "tunableop_gfx950.csv")      # (the variable: A/B of tuning recipes)
     use_tuned = os.path.exists(tuned) and not os.environ.get("NPCD_NO_TUNED_GEMM")
     if use_tuned:
         import torch.cuda.tunable as tun

@@ -6,8 +6,14 @@ sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-di
 import torch
 import torch.cuda.tunable as tun
 import bench
-out = os.path.join(R, "gpurun_out", "tunableop_gfx950.csv")
-tun.enable(True); tun.tuning_enable(True); tun.set_max_tuning_duration(40); tun.set_max_tuning_iterations(30)
+out = os.path.join(R, "gpurun_out", os.environ.get("NPCD_TUNE_OUT", "tunableop_gfx950.csv"))
+# NPCD_TUNE_ROTATE=<MB>: candidates are timed on operands rotated through a buffer of that size (cold caches, as in the step, where a
+# product's inputs were just written by another kernel and its weights were last read a layer ago) instead of the same hot buffers
+rot = int(os.environ.get("NPCD_TUNE_ROTATE", "0"))
+tun.enable(True); tun.tuning_enable(True)
+tun.set_max_tuning_duration(int(os.environ.get("NPCD_TUNE_MS", "40"))); tun.set_max_tuning_iterations(int(os.environ.get("NPCD_TUNE_ITERS", "30")))
+if rot and hasattr(tun, "set_rotating_buffer_size"):
+    tun.set_rotating_buffer_size(rot)
 tun.set_filename(out)
 dev = torch.device("cuda", 0)
 for B in (64, 32, 16, 8):                       # per-GPU batches of the 1/2/4/8-GPU strong-scaling runs
