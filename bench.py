@@ -196,9 +196,20 @@ def bench_stage1(device, n_iters=20, burn_in=3, mlp_dtype=None):
     sample = {"images": torch.rand(B, T, 3, res, res, device=device), "intrinsics": intr, "extrinsics": extr,
               "obj_idx": torch.arange(B, device=device)}
     tr = PointNeRFTrainer(net, mlp_dtype=mlp_dtype)
+    # the rays are redrawn every step, so the shading points P and (point, neighbour) pairs Q of a step vary: recorded per step
+    # (device scalars, read after the loop) to tell a data-dependent spread from host round trips
+    import npcd.models.pointnerf.train_path as tpath
+    counts, orig_render = [], tpath.render_train
+
+    def counted(*a, **k):
+        out = orig_render(*a, **k)
+        counts.append((out["num_shading_points"], out["num_pairs"]))
+        return out
+    tpath.render_train = counted
     for _ in range(burn_in):
         tr.step(sample)
     torch.cuda.synchronize()
+    counts.clear()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_iters + 1)]
     t0 = time.perf_counter()
     marks[0].record()
@@ -207,8 +218,20 @@ def bench_stage1(device, n_iters=20, burn_in=3, mlp_dtype=None):
         marks[i + 1].record()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n_iters
-    per_it = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n_iters))
-    return {"steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "ms_per_step_min_median_max": [per_it[0], per_it[n_iters // 2], per_it[-1]],
+    tpath.render_train = orig_render
+    raw = [marks[i].elapsed_time(marks[i + 1]) for i in range(n_iters)]
+    per_it = sorted(raw)
+    spread = {}
+    if len(counts) == n_iters:
+        import numpy as np
+        q = np.array([float(c[1]) for c in counts])
+        ms = np.array(raw)
+        a, b = np.polyfit(q, ms, 1)
+        spread = {"pairs_min_median_max": [float(q.min()), float(np.median(q)), float(q.max())],
+                  "shading_points_min_median_max": [float(min(c[0] for c in counts)), float(np.median([c[0] for c in counts])), float(max(c[0] for c in counts))],
+                  "corr_ms_vs_pairs": float(np.corrcoef(ms, q)[0, 1]), "fit_ms": {"fixed": float(b), "per_million_pairs": float(a * 1e6), "residual_std": float(np.std(ms - (a * q + b)))},
+                  "note": "the step's random rays decide its pairs: the per-iteration spread follows the pair count, not host round trips"}
+    return {"steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "ms_per_step_min_median_max": [per_it[0], per_it[n_iters // 2], per_it[-1]], "per_iteration_spread": spread,
             "timed_iterations": n_iters, "objects": B, "views_per_object": T, "rays_per_view": net.pointnerf.renderer.ray_subsamples,
             "loss": float(loss), "differentiable_part": tr.describe()}
 
