@@ -363,8 +363,8 @@ int npcd_linear_dgelu_rows(int M);
 int npcd_linear_dgelu_bwd(const void* dy, const void* wt, const void* h, void* dh, float* part, int M, int N, int K, int dtype, void* stream);
 /* The same product y = x w^T + bias on 128 x 128 tiles (csrc/gemm_nt.hip, lin128_kernel): the form for the token counts of ONE RANK
  * of the strong-scaling job (T = 4,104 / 8,208 per rank at 8 / 4 GPUs), where the N = 1,024 products of a block are 64-68 tiles of
- * 256 x 256 on 256 CUs.  Any M >= 1 (left-over rows M mod 128 <= 32 ride on the last row tile), N % 128 == 0, K % 64 == 0; the
- * other conditions of npcd_linear_fwd. */
+ * 256 x 256 on 256 CUs.  Any M >= 1 (left-over rows M mod 128 <= 32 ride on the last row tile), N % 128 == 0, K % 64 == 0, M * K and
+ * N * K below 2^30 elements (32-bit byte offsets), M * N below 2^31; 16-byte aligned pointers. */
 int npcd_linear128_fwd(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int dtype, void* stream);
 /* out [C, R] = in [R, C]^T for 16-bit elements (the transposed shadow of the Linear weights that the data gradients read) */
 int npcd_transpose_16(const void* in, void* out, int R, int C, void* stream);

@@ -458,6 +458,9 @@ __global__ __launch_bounds__(512, 2) void lin_kernel(LinParams p) {
 // instruction, R4.1, would exceed the step's 512 matrix cycles).  The LAST row tile takes up to 160 rows (M mod 128 <= 32: the 8 / 16 /
 // 32 rows of the time-step tokens would otherwise be a second round of 8 workgroups on a full chip): its upper waves carry a third
 // row block.  Bound: LDS traffic -- per K-step and CU 64 KB of fragment reads + 32 KB of stage writes against 512 matrix cycles.
+#ifdef NPCD_L128_TL
+__device__ long long g_l128_tl[2][12];
+#endif
 struct Lin128Params {
     const void* x; const void* w; const void* bias; void* y;
     int M, N, K, tiles_m, tiles_n;
@@ -484,12 +487,15 @@ __device__ __forceinline__ void lin128_tile(const Lin128Params& p, unsigned char
     const E* W = static_cast<const E*>(p.w);
     // ---- global -> register staging: thread t takes 16-byte chunk (t & 7) of rows (t >> 3) + 64 i
     const int lrow = tid >> 3, lchunk = tid & 7;
-    const E* xs[XL];
-    const E* ws[2];
+    // (raw buffer loads: per-thread byte offset + a scalar offset per K-step -- as 64-bit `global_load` addresses the compiler rebuilt
+    // them in front of every load IN the destination registers of the loads still in flight, i.e. waited for those first)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<E*>(X), 0, (int)min((int64_t)p.M * p.K * 2, (int64_t)0x7fffffff), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<E*>(W), 0, (int)min((int64_t)p.N * p.K * 2, (int64_t)0x7fffffff), 0x00020000);
+    int xo[XL], wo[2];
 #pragma unroll
-    for (int i = 0; i < XL; ++i) xs[i] = X + (int64_t)min(m0 + lrow + 64 * i, p.M - 1) * p.K + lchunk * 8;     // rows past M re-read the last one
+    for (int i = 0; i < XL; ++i) xo[i] = (min(m0 + lrow + 64 * i, p.M - 1) * p.K + lchunk * 8) * 2;     // rows past M re-read the last one
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ws[i] = W + (int64_t)(n0 + lrow + 64 * i) * p.K + lchunk * 8;
+    for (int i = 0; i < 2; ++i) wo[i] = ((n0 + lrow + 64 * i) * p.K + lchunk * 8) * 2;
     const uint32_t lds0 = l_lds_addr(smem);
     const uint32_t st_off = (uint32_t)tile_off(lrow, lchunk);                  // (rows r and r + 64 i share the swizzle: it repeats every 8 rows)
     const bool x2_ok = MB1 == 3 && lrow < kL128Rows - 128;                       // the tall tile's third group: rows 128 .. 159 only
@@ -498,9 +504,9 @@ __device__ __forceinline__ void lin128_tile(const Lin128Params& p, unsigned char
     u32x4 gx[2][XL], gw[2][2];
     auto g_load = [&](int set, int kt) {
 #pragma unroll
-        for (int i = 0; i < XL; ++i) gx[set][i] = *reinterpret_cast<const u32x4*>(xs[i] + kt * 64);
+        for (int i = 0; i < XL; ++i) gx[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo[i], kt * 128, 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) gw[set][i] = *reinterpret_cast<const u32x4*>(ws[i] + kt * 64);
+        for (int i = 0; i < 2; ++i) gw[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rw, wo[i], kt * 128, 0);
     };
     auto s_store = [&](int set, int buf) {
         unsigned char* b = smem + buf * kL128Stage;
@@ -512,8 +518,11 @@ __device__ __forceinline__ void lin128_tile(const Lin128Params& p, unsigned char
     };
     // ---- fragment addresses: MFMA operand lane (r, h) reads row r, 16-byte chunk 2 s + h of K-sub-step s = 2 kg + j
     const int r = lane & 31, h = lane >> 5;
-    const int mb_mine = (MB1 == 3 && wm == 0) ? 2 : MB1;
-    const int xrow0 = 64 * wm;                                                  // tall tile: rows [0, 64) | [64, 160)
+    // tall tile: BOTH wave rows carry three blocks, rows [0, 96) and [64, 160) -- the lower waves' third block repeats rows the upper
+    // ones own and is never stored: a wave-uniform `if (block < mine)` around every matrix instruction cut the loop into single-instruction
+    // basic blocks
+    const int mb_store = (MB1 == 3 && wm == 0) ? 2 : MB1;
+    const int xrow0 = 64 * wm;
     uint32_t xa[2], wa[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -540,7 +549,7 @@ __device__ __forceinline__ void lin128_tile(const Lin128Params& p, unsigned char
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
             for (int mi = 0; mi < MB; ++mi)
-                if (mi < mb_mine) fx[par][j][mi] = *reinterpret_cast<const u32x4*>(sb + xa[j] + mi * 4096);
+                fx[par][j][mi] = *reinterpret_cast<const u32x4*>(sb + xa[j] + mi * 4096);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) fw[par][j][ni] = *reinterpret_cast<const u32x4*>(sb + wa[j] + ni * 4096);
         }
@@ -551,11 +560,10 @@ __device__ __forceinline__ void lin128_tile(const Lin128Params& p, unsigned char
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < MB; ++mi)
-                    if (mi < mb_mine) {
-                        if (NPCD_L128_DIAG != 2) acc[ni][mi] = TR::mfma32(__builtin_bit_cast(typename TR::vec8, fw[par][j][ni]), __builtin_bit_cast(typename TR::vec8, fx[par][j][mi]), acc[ni][mi]);
-                        else acc[ni][mi][0] += __uint_as_float(fw[par][j][ni][0] ^ fx[par][j][mi][3]);
-                    }
+                for (int mi = 0; mi < MB; ++mi) {
+                    if (NPCD_L128_DIAG != 2) acc[ni][mi] = TR::mfma32(__builtin_bit_cast(typename TR::vec8, fw[par][j][ni]), __builtin_bit_cast(typename TR::vec8, fx[par][j][mi]), acc[ni][mi]);
+                    else acc[ni][mi][0] += __uint_as_float(fw[par][j][ni][0] ^ fx[par][j][mi][3]);
+                }
     };
     // prologue: stages 0 and 1 in LDS, stage 2 in registers (set 0), the fragments of step 0 read
     g_load(0, 0);
@@ -567,24 +575,62 @@ __device__ __forceinline__ void lin128_tile(const Lin128Params& p, unsigned char
     f_read(0, 0);
     uint32_t b_cur = 0;                                  // byte offset of the buffer of the step being multiplied
     auto nxt = [](uint32_t b) { return b == 2 * kL128Stage ? 0u : b + (uint32_t)kL128Stage; };
-    // steps in pairs: the register set of a stage (its parity) and the fragment set of a step are compile-time choices
-    for (int kt = 0; kt < nk; kt += 2) {
+    // steps in pairs: the register set of a stage (its parity) and the fragment set of a step are compile-time choices.  The steady
+    // state (four more stages exist) runs without conditions; the last two pairs take the guarded form.
+#ifdef NPCD_L128_TL
+    // DIAGNOSTIC build: s_memtime stamps of the step pair kt = NPCD_L128_TL of workgroup 0, waves 0 and 4 (npcd_lin128_debug_read)
+    long long tl[12];
+    for (int i = 0; i < 12; ++i) tl[i] = 0;
+#define NPCD_L8S(i) do { if (tl_on) { __builtin_amdgcn_sched_barrier(0); tl[(i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define NPCD_L8S(i) do { } while (0)
+#endif
+    auto step_pair = [&](int kt, auto guarded) {
+        constexpr bool G = decltype(guarded)::value;
+#ifdef NPCD_L128_TL
+        const bool tl_on = blockIdx.x == 0 && (wave == 0 || wave == 4) && kt == NPCD_L128_TL;
+#endif
         const uint32_t b1 = nxt(b_cur), b2 = nxt(b1);
         // (the request for stage kt + 3 goes out BEFORE the wait for stage kt + 2: the wait then leaves the newest loads in flight)
-        if (NPCD_L128_DIAG != 1 && kt + 3 < nk) g_load(1, kt + 3);
-        if (NPCD_L128_DIAG != 3 && kt + 2 < nk) s_store(0, (int)(b2 / kL128Stage));
-        if (kt + 1 < nk) f_read(1, b1);
+        // order inside a step (pinned: left alone the compiler moved the matrix instructions BELOW the barrier, behind a full
+        // `lgkmcnt(0)` drain of the stage writes and the next step's fragment reads): requests, fragment reads of the next step,
+        // matrix instructions, and only then the wait for the stage in flight + its LDS writes -- they run under the matrix pipe
+        NPCD_L8S(0);
+        if (NPCD_L128_DIAG != 1 && (!G || kt + 3 < nk)) g_load(1, kt + 3);
+        NPCD_L8S(1);
+        if (!G || kt + 1 < nk) f_read(1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        NPCD_L8S(2);
         k_mma(0);
+        __builtin_amdgcn_sched_barrier(0);
+        NPCD_L8S(3);
+        if (NPCD_L128_DIAG != 3 && (!G || kt + 2 < nk)) s_store(0, (int)(b2 / kL128Stage));
+        NPCD_L8S(4);
         __syncthreads();
-        if (kt + 1 < nk) {
-            if (NPCD_L128_DIAG != 1 && kt + 4 < nk) g_load(0, kt + 4);
-            if (NPCD_L128_DIAG != 3 && kt + 3 < nk) s_store(1, (int)(b_cur / kL128Stage));      // buffer (kt + 3) % 3 = the one of step kt
-            if (kt + 2 < nk) f_read(0, b2);
+        NPCD_L8S(5);
+        if (!G || kt + 1 < nk) {
+            if (NPCD_L128_DIAG != 1 && (!G || kt + 4 < nk)) g_load(0, kt + 4);
+            NPCD_L8S(6);
+            if (!G || kt + 2 < nk) f_read(0, b2);
+            __builtin_amdgcn_sched_barrier(0);
+            NPCD_L8S(7);
             k_mma(1);
+            __builtin_amdgcn_sched_barrier(0);
+            NPCD_L8S(8);
+            if (NPCD_L128_DIAG != 3 && (!G || kt + 3 < nk)) s_store(1, (int)(b_cur / kL128Stage));      // buffer (kt + 3) % 3 = the one of step kt
+            NPCD_L8S(9);
             __syncthreads();
+            NPCD_L8S(10);
         }
+#ifdef NPCD_L128_TL
+        if (tl_on && lane == 0)
+            for (int i = 0; i < 12; ++i) g_l128_tl[wave >> 2][i] = tl[i];
+#endif
         b_cur = b2;
-    }
+    };
+    int kt = 0;
+    for (; kt + 4 < nk; kt += 2) step_pair(kt, std::false_type{});
+    for (; kt < nk; kt += 2) step_pair(kt, std::true_type{});
     // ---- the two halves of every K-step meet: the upper waves hand their partial accumulators over through LDS (one column block
     // at a time: <= 40 KB), the lower waves add them and write the tile
     {
@@ -594,17 +640,15 @@ __device__ __forceinline__ void lin128_tile(const Lin128Params& p, unsigned char
             if (kg == 1) {
 #pragma unroll
                 for (int mi = 0; mi < MB; ++mi)
-                    if (mi < mb_mine)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) red[(mi * 16 + e) * 64] = acc[ni][mi][e];
+                    for (int e = 0; e < 16; ++e) red[(mi * 16 + e) * 64] = acc[ni][mi][e];
             }
             __syncthreads();
             if (kg == 0) {
 #pragma unroll
                 for (int mi = 0; mi < MB; ++mi)
-                    if (mi < mb_mine)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[ni][mi][e] += red[(mi * 16 + e) * 64];
+                    for (int e = 0; e < 16; ++e) acc[ni][mi][e] += red[(mi * 16 + e) * 64];
             }
             __syncthreads();
         }
@@ -624,7 +668,7 @@ __device__ __forceinline__ void lin128_tile(const Lin128Params& p, unsigned char
         }
 #pragma unroll
         for (int mi = 0; mi < MB; ++mi) {
-            if (mi >= mb_mine) continue;
+            if (mi >= mb_store) continue;                 // (wave-uniform; the tall tile's lower waves do not own their third block)
             const int m = m0 + xrow0 + 32 * mi + r;
             const bool ok = m < p.M;
             const int64_t rowoff = (int64_t)(ok ? m : 0) * p.N + nb + 8 * h;
@@ -733,7 +777,8 @@ extern "C" int npcd_linear_dgelu_bwd(const void* dy, const void* wt, const void*
 extern "C" int npcd_linear128_fwd(const void* x, const void* w, const void* bias, void* y, int M, int N, int K, int dtype, void* stream) {
     if (!x || !w || !y || M <= 0 || N <= 0 || K <= 0) return NPCD_ERR_ARG;
     if (N % 128 || K % 64 || (dtype != NPCD_BF16 && dtype != NPCD_F16)) return NPCD_ERR_UNSUPPORTED;
-    if ((int64_t)M * N >= (int64_t)1 << 31 || (int64_t)M * K >= (int64_t)1 << 31) return NPCD_ERR_UNSUPPORTED;
+    // (operands are addressed through 32-bit byte offsets of a buffer resource: below 2 GB each)
+    if ((int64_t)M * N >= (int64_t)1 << 31 || (int64_t)M * K >= (int64_t)1 << 30 || (int64_t)N * K >= (int64_t)1 << 30) return NPCD_ERR_UNSUPPORTED;
     for (const void* q : {x, w, bias, (const void*)y})
         if (reinterpret_cast<uintptr_t>(q) & 15) return NPCD_ERR_ARG;
     Lin128Params p{};
@@ -756,6 +801,11 @@ extern "C" int npcd_linear128_fwd(const void* x, const void* w, const void* bias
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }
+#ifdef NPCD_L128_TL
+extern "C" int npcd_lin128_debug_read(long long* out, int count) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(npcd::g_l128_tl), sizeof(long long) * count);
+}
+#endif
 #ifdef NPCD_LIN_TL
 extern "C" int npcd_lin_debug_read(long long* out, int count) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(npcd::g_lin_tl), sizeof(long long) * count);

@@ -44,7 +44,7 @@ def linear_fwd(x, w, bias=None, out=None):
 
 
 def supported128(M: int, N: int, K: int) -> bool:
-    return M >= 1 and N % 128 == 0 and K % 64 == 0 and M * N < 2 ** 31 and M * K < 2 ** 31
+    return M >= 1 and N % 128 == 0 and K % 64 == 0 and M * N < 2 ** 31 and M * K < 2 ** 30 and N * K < 2 ** 30
 
 
 def linear128_fwd(x, w, bias=None, out=None):
