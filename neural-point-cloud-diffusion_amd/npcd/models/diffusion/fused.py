@@ -38,6 +38,9 @@ import os
 
 _SPLIT = 0 if os.environ.get("NPCD_NO_GEMM_SPLIT") else 256       # (the env switches exist for A/B measurements)
 _SPLIT_MIN = int(os.environ.get("NPCD_GEMM_SPLIT_MIN", "16000"))
+# the left-over rows go BEHIND the large call: they then find the weights in L2 / MALL (82.08 against 82.32 ms per step, two
+# alternating rounds, tools/run_split_order_ab.sh; NPCD_GEMM_SPLIT_SMALL_FIRST=1 restores the old order)
+_SPLIT_BIG_FIRST = not os.environ.get("NPCD_GEMM_SPLIT_SMALL_FIRST")
 _ATTN_COLSUM = not os.environ.get("NPCD_NO_ATTN_COLSUM")      # c_qkv bias gradient from the attention backward itself (A/B switch)
 _SUM_KERNEL = not os.environ.get("NPCD_NO_SUM_KERNEL")          # the weight-gradient partials summed by csrc/elementwise.hip (A/B switch)
 # opt-in: the weight gradients on the own split-T kernel (csrc/gemm.hip: at parity with the library's row-split form -- both are
@@ -56,6 +59,10 @@ def _split_gemm(fn, T):
     Tm = T - T % _SPLIT if (_SPLIT and T >= _SPLIT_MIN) else T
     if Tm == 0 or Tm == T:
         fn(slice(0, T))
+        return
+    if _SPLIT_BIG_FIRST:
+        fn(slice(0, Tm))
+        fn(slice(Tm, T))
         return
     fn(slice(Tm, T))
     fn(slice(0, Tm))
