@@ -1,6 +1,7 @@
 #!/bin/bash
 # dev tool (GPU box): the full GPU suite, smoke, the default bench line and a rocprofv3 kernel-stats pass of the same command;
-# results under gpurun_out/final/ (copy bench.json / kernel_stats.csv into profiles/ afterwards)
+# results under gpurun_out/final/ (bench.json -> profiles/<tag>_bench.json; its kernel_stats.csv covers ALL bench legs -- the
+# timed region's per-kernel averages come from tools/run_stats.sh)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
 cd $R
 timeout 2400 python -m pytest tests -q -m gpu -x > $O/gpu_tests.log 2>&1; echo "pytest rc=$?" >> $O/gpu_tests.log; tail -3 $O/gpu_tests.log
