@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Benchmark of the NPCD hot path on MI355X (contract: see the repo-level task description).
 
-    python bench.py --gpus N --steps K --warmup W          (N = 1)
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (any N: for N > 1 without WORLD_SIZE it starts its own ranks
+                                                            as a torch.distributed.run child process)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one denoiser training step of BASELINE.json configs[1]: zero_grad + forward (bf16
 autocast) + backward + AdamW + EMA on 512 points x 128-d latents, width 1024 / 24 layers / 16 heads,
@@ -206,19 +207,21 @@ def bench_stage1(device, n_iters=20, burn_in=3, mlp_dtype=None):
         counts.append((out["num_shading_points"], out["num_pairs"]))
         return out
     tpath.render_train = counted
-    for _ in range(burn_in):
-        tr.step(sample)
-    torch.cuda.synchronize()
-    counts.clear()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_iters + 1)]
-    t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(n_iters):
-        loss, _ = tr.step(sample)
-        marks[i + 1].record()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / n_iters
-    tpath.render_train = orig_render
+    try:
+        for _ in range(burn_in):
+            tr.step(sample)
+        torch.cuda.synchronize()
+        counts.clear()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n_iters + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(n_iters):
+            loss, _ = tr.step(sample)
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_iters
+    finally:
+        tpath.render_train = orig_render      # a failing leg must not leave the counter installed for the later legs
     raw = [marks[i].elapsed_time(marks[i + 1]) for i in range(n_iters)]
     per_it = sorted(raw)
     spread = {}
@@ -616,6 +619,37 @@ def strong_scaling_proxy(trainer, coords, feats, steps=8, warmup=3):
     return out
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process and relay its output: stdout
+    lines pass through unchanged (exactly one JSON line, printed by rank 0), stderr is inherited.  Called BEFORE any GPU call
+    of this process; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on these hosts (RCCL needs it across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: no WORLD_SIZE in the environment, starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    try:
+        for line in child.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        return child.wait()
+    except BaseException:
+        child.terminate()
+        try:
+            child.wait(timeout=30)
+        except Exception:           # noqa: BLE001
+            child.kill()
+        raise
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -630,11 +664,16 @@ def main():
     ap.add_argument("--rccl-proto", default=None, help="NCCL_PROTO for RCCL (e.g. Simple, LL, LL128); default: RCCL's own choice")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (a CHILD process, never an exec; nothing in this
+        # process has touched the GPU yet), relay rank 0's JSON line and leave with the launcher's return code
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         f"(or unset WORLD_SIZE and bench.py starts its own ranks)")
     # NPCD_BENCH_DRYRUN_ONE_GPU=1 (tests only): all ranks share cuda:0 and talk through gloo, so that the multi-rank code path
     # of this script can be exercised on a one-GPU box (RCCL refuses two ranks on one device)
     dryrun = bool(os.environ.get("NPCD_BENCH_DRYRUN_ONE_GPU"))
@@ -785,18 +824,29 @@ def main():
         "roofline": roofline,
         "roofline_hbm": hbm,
         "loss": float(loss),
-        "tuned_gemm_file": "profiles/tunableop_gfx950.csv" if use_tuned else None,
+        "tuned_gemm_file": (os.path.relpath(tuned, ROOT) if os.path.abspath(tuned).startswith(ROOT + os.sep) else tuned) if use_tuned else None,
         "clock": clocks.summary(),
     }
     if world > 1:
         # what went over the wire in the last step, and proof that the ranks still hold the same model
         trainer.wait_params()
-        chk = torch.stack([trainer.flat.flat.double().sum(), trainer.flat.flat.double().abs().sum()])
-        allc = [torch.empty_like(chk) for _ in range(world)]
-        dist.all_gather(allc, chk)
+        # elementwise: rank 0's flat parameter buffer is broadcast and every rank reports max |p - p_rank0| (0.0 = bit-identical
+        # up to the sign of zero); the maximum over ranks goes into the line
+        p0 = trainer.flat.flat.detach().clone()
+        dist.broadcast(p0, src=0)
+        dev_max = (trainer.flat.flat.detach() - p0).abs().max().reshape(1).double()
+        dev_max = torch.nan_to_num(dev_max, nan=float("inf"))
+        dist.all_reduce(dev_max, op=dist.ReduceOp.MAX)
+        del p0
         comm = trainer.comm_stats()
-        comm["parameters_identical_across_ranks"] = bool(all(torch.equal(allc[0], c) for c in allc))
-        comm["backend"] = dist.get_backend()
+        comm["max_abs_parameter_difference_to_rank0"] = float(dev_max)
+        comm["parameters_identical_across_ranks"] = bool(float(dev_max) == 0.0)
+        comm["backend"] = dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else " (one-GPU dry run)")
+        comm["world_size_seen_by_backend"] = dist.get_world_size()
+        seen = torch.ones(1, device=device)
+        dist.all_reduce(seen)                       # every rank of the communicator adds 1: counts the ranks the collective reached
+        comm["ranks_counted_by_all_reduce"] = int(seen.item())
+        comm["launched_by"] = os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run" or "external launcher"
         comm["rccl_env"] = {k: os.environ[k] for k in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS") if k in os.environ}
         result["comm"] = comm
     if world == 1 and not args.no_proxy:

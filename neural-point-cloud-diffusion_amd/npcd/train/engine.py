@@ -279,26 +279,20 @@ class DiffusionTrainer:
             # loop, generate() in any precision) or reads the weights through state_dict() first completes the gathers it depends
             # on.  In-place writes into parameters (copying EMA weights in) cannot be intercepted: call wait_params() first.
             self._fused_engine = eng
-            # The hooks hold the trainer only weakly and their handles are kept: a second trainer on the same model first
-            # close()s (or simply outlives) the first one without stacking hooks or keeping its moments / EMA / shadow alive.
-            import weakref
-            me = weakref.ref(self)
-
-            def _fwd_hook(module, args):
-                tr = me()
-                if tr is not None:
-                    tr._await_params_for_forward(module, args)
-
-            def _sd_hook(module, prefix, keep_vars):
-                tr = me()
-                if tr is not None:
-                    tr.wait_params()
-
+            # The hooks hold the trainer STRONGLY (the model keeps its trainer alive): as long as a lazily gathered parameter can
+            # still be in flight, every forward and every state_dict() of the model completes it first -- a dropped trainer
+            # reference can never turn the waits into no-ops and let a checkpoint read half-gathered weights.  A trainer leaves the
+            # model only through close(); building another DiffusionTrainer on the same model close()s the attached one first
+            # (no stacked hooks, its moments / EMA / shadow are released with it).
+            prev = diffusion.__dict__.get("_npcd_trainer")
+            if prev is not None and prev is not self:
+                prev.close()
             self._hook_handles = []
             if denoiser is not None:
-                self._hook_handles.append(denoiser.register_forward_pre_hook(_fwd_hook))
-                self._hook_handles.append(denoiser.register_state_dict_pre_hook(_sd_hook))      # denoiser.state_dict() read directly
-            self._hook_handles.append(diffusion.register_state_dict_pre_hook(_sd_hook))
+                self._hook_handles.append(denoiser.register_forward_pre_hook(lambda m, a: self._await_params_for_forward(m, a)))
+                self._hook_handles.append(denoiser.register_state_dict_pre_hook(lambda m, prefix, keep: self.wait_params()))   # denoiser.state_dict() read directly
+            self._hook_handles.append(diffusion.register_state_dict_pre_hook(lambda m, prefix, keep: self.wait_params()))
+            diffusion.__dict__["_npcd_trainer"] = self
         else:
             # reference path (CPU tests / ablation): torch AdamW over ONE flat "parameter"
             self.master = nn.Parameter(self.flat.flat, requires_grad=True)
@@ -333,7 +327,11 @@ class DiffusionTrainer:
         eng = getattr(self, "_fused_engine", None)
         if denoiser is not None and eng is not None and getattr(denoiser.backbone, "fused_engine", None) is eng:
             denoiser.backbone.fused_engine = None
+        if eng is not None:
+            eng.wait_range = None                 # (a caller that still holds the engine no longer reaches this trainer)
         self._fused_engine = None
+        if self.model.__dict__.get("_npcd_trainer") is self:
+            del self.model.__dict__["_npcd_trainer"]
 
     def ema_state_dict(self, gathered: bool = False):
         """state_dict of the EMA model: same keys as the running model (utils/ema.py:80), buffers copied.  Collective with a

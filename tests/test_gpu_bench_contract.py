@@ -49,6 +49,25 @@ def test_bench_multi_rank_code_path_dry_run():
     assert "rays_per_s_all_gpus" in d["render"]
 
 
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the shape of the driver's N = 1 command at N > 1): the
+    script starts torch.distributed.run as a child process before touching the GPU, relays exactly one JSON line and returns the
+    launcher's exit code.  Two ranks share cuda:0 over gloo (NPCD_BENCH_DRYRUN_ONE_GPU)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["NPCD_BENCH_DRYRUN_ONE_GPU"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-render"], capture_output=True, text=True, env=env, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["per_gpu_batch"] == 32 and d["steps"] == 2 and d["warmup"] == 1
+    c = d["comm"]
+    assert c["world_size_seen_by_backend"] == 2 and c["ranks_counted_by_all_reduce"] == 2 and c["backend"].startswith("gloo")
+    assert c["parameters_identical_across_ranks"] is True and c["max_abs_parameter_difference_to_rank0"] == 0.0
+    assert "starting 2 ranks" in out.stderr
+
+
 @pytest.mark.parametrize("mode", ["bf16_wire", "all_reduce"])
 def test_bench_multi_rank_dry_run_other_comm_modes(mode):
     """The same two-rank dry run through bench.py with the gradient buckets on the wire as bf16 (NPCD_COMM_BF16=1) and with the

@@ -76,6 +76,20 @@ def _worker(rank, world, port, out):
         assert not tr._pending
         torch.cuda.synchronize()
         assert float(loss2) == res[True][2], "custom compute_loss + apply_gradients loop differs from step()"
+        # a trainer DROPPED without close(): the model's hooks hold it strongly, so a later state_dict() still completes
+        # the gathers of its last step instead of reading half-gathered parameters
+        import gc
+        tr.step(c0[sl], f0[sl], t=t[sl], coords_noise=cn[sl], feats_noise=fn[sl])
+        model_only, pend = tr.model, tr._pending
+        assert pend
+        del tr
+        gc.collect()
+        sd_dropped = model_only.state_dict()
+        assert not pend, "state_dict() after dropping the trainer left parameter gathers pending"
+        both = [torch.empty_like(sd_dropped["denoiser.ln_post.weight"]) for _ in range(world)]
+        dist.all_gather(both, sd_dropped["denoiser.ln_post.weight"].contiguous())
+        assert torch.equal(both[0], both[1])
+        model_only.__dict__["_npcd_trainer"].close()
         tr2 = DiffusionTrainer(_build(), bucket_bytes=256 << 10, shard_optimizer=False)
         for _ in range(2):
             tr2.step(c0[sl], f0[sl], t=t[sl], coords_noise=cn[sl], feats_noise=fn[sl])

@@ -541,7 +541,7 @@ def test_full_width_two_blocks_elementwise_gradients_vs_oracle(own_dgelu, monkey
 
 def test_trainer_close_removes_its_hooks_and_engine():
     """A second DiffusionTrainer on the same model must not stack forward / state_dict hooks on top of the first one's:
-    close() removes them and the fused engine; the hooks hold the trainer only weakly."""
+    close() removes them and the fused engine; the hooks hold the trainer strongly and a new trainer closes the attached one."""
     import gc
     import weakref
     from npcd.train import DiffusionTrainer
@@ -560,8 +560,27 @@ def test_trainer_close_removes_its_hooks_and_engine():
     c0, f0 = torch.randn(2, 3, 48, generator=g).cuda(), torch.randn(2, 32, 48, generator=g).cuda()
     loss, _ = t2.step(c0, f0)
     assert torch.isfinite(loss)
-    # a trainer that is dropped WITHOUT close() is collectable (the hooks do not keep it alive) and its hooks turn into no-ops
+    # a trainer whose last outside reference is dropped WITHOUT close() stays attached (the model's hooks hold it strongly, ADVICE
+    # r4): its waits keep working for every later forward / state_dict(), nothing is left half-gathered
     r = weakref.ref(t2)
     del t2
     gc.collect()
+    assert r() is not None and a.__dict__["_npcd_trainer"] is r()
+    waits = []
+    orig = r().wait_params
+    r().wait_params = lambda *x, **k: (waits.append(x), orig(*x, **k))[1]
     a.state_dict()
+    assert waits, "state_dict() of a model with an attached trainer must complete the parameter gathers first"
+    del r().wait_params
+    # a third trainer on the same model detaches the second one by itself: hooks do not stack, the old one becomes collectable
+    eng2 = den.backbone.fused_engine
+    t3 = DiffusionTrainer(a, fused=True)
+    assert len(den._forward_pre_hooks) == n_fwd + 1 and len(a._state_dict_pre_hooks) == n_sd_model + 1
+    assert den.backbone.fused_engine is not eng2 and eng2.wait_range is None and a.__dict__["_npcd_trainer"] is t3
+    del eng2
+    gc.collect()
+    assert r() is None, "a replaced trainer must not be kept alive by the model"
+    loss, _ = t3.step(c0, f0)
+    assert torch.isfinite(loss)
+    t3.close()
+    assert "_npcd_trainer" not in a.__dict__ and den.backbone.fused_engine is None

@@ -137,3 +137,19 @@ def test_row_split_linear_matches_plain_linear():
             x.grad = w.grad = b.grad = None
     finally:
         _RowSplitLinear.SLICE = old
+
+
+def test_bench_without_launcher_starts_ranks_as_a_child_and_returns_their_exit_code():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: bench.py must start torch.distributed.run itself (a child process, before
+    any GPU call).  Without a GPU the ranks die at torch.cuda.set_device; what is checked here is the launcher: the command
+    line it announces, that nothing but rank output reaches stdout, and that the child's failure is the script's exit code."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = ""          # (also on a GPU box: the ranks must not get as far as the benchmark)
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert "starting 2 ranks" in out.stderr and "--nproc-per-node 2" in out.stderr and "--master-addr 127.0.0.1" in out.stderr
+    assert out.returncode != 0                                   # no GPU -> the ranks fail -> so does bench.py, loudly
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
