@@ -390,12 +390,15 @@ def bench_sampler(device, batch=16, steps=8, graph_steps=100):
     return out
 
 
-def bench_cfg5(device, steps=6, warmup=2):
+def bench_cfg5(device, steps=20, warmup=2, round_steps=5):
     """BASELINE configs[4] as ONE rank of its 8-GPU job computes it (no communication): 2048 points x 256-d latents, 8-layer
     denoiser (width 1024 / 16 heads: BASELINE leaves W / H open, SURVEY 8(d) takes the yaml's), sequence 2049, per-GPU batch
     32 of the global 256 -- the training step with the attention forward on the bf16 kernel and on the fp8 (e4m3, block-scaled
     MFMA) kernel (backward: bf16 kernels both ways).  tests/test_gpu_fused.py::test_stress_config_step_at_per_gpu_batch_32_...
-    holds the parity bars of both modes against the fp32 oracle."""
+    holds the parity bars of both modes against the fp32 oracle.
+    The two legs are INTERLEAVED (rounds of `round_steps` steps, bf16 / fp8 / bf16 / ...; `steps` timed steps per leg) on two
+    trainers with identical weights: clock and thermal drift of the box lands on both legs alike (with the legs
+    run one after the other the same bf16 dK/dV kernel read 1.51 ms in one leg and 1.11 ms in the other)."""
     from npcd.hip import attention as hattn
     from npcd.models.diffusion import DiffusionModel
     from npcd.train import DiffusionTrainer
@@ -406,10 +409,13 @@ def bench_cfg5(device, steps=6, warmup=2):
     n = N + 1
     flops = 3 * B * (L * (24 * n * W * W + 4 * n * n * W) + 2 * N * 2 * (3 + F_) * W + 16 * W * W)
     out = {"config": f"{N} points x {F_}-d latents, {L} layers, width {W}, {H} heads (seq {n}), per-GPU batch {B} of the global 256, "
-                     f"bf16 autocast, one rank's step without communication", "timed_steps": steps, "algorithmic_flops_per_step": flops}
+                     f"bf16 autocast, one rank's step without communication", "timed_steps": steps,
+           "schedule": f"legs interleaved in rounds of {round_steps} steps", "algorithmic_flops_per_step": flops}
     saved = hattn.FWD_FP8
+    modes = ("bf16", "fp8")
     try:
-        for mode in ("bf16", "fp8"):
+        trainers, secs, events, loss = {}, {m: [] for m in modes}, {m: {k: [] for k in hattn.KERNEL_TAGS} for m in modes}, {}
+        for mode in modes:
             hattn.FWD_FP8 = mode == "fp8"
             torch.manual_seed(0)
             m = DiffusionModel(3, F_, N, W, L, H, True)
@@ -419,21 +425,33 @@ def bench_cfg5(device, steps=6, warmup=2):
             torch.manual_seed(3)
             for _ in range(warmup):
                 tr.step(c, f)
-            torch.cuda.synchronize()
-            hattn.KERNEL_EVENTS = {k: [] for k in hattn.KERNEL_TAGS}
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                loss, _ = tr.step(c, f)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / steps
-            ev, hattn.KERNEL_EVENTS = hattn.KERNEL_EVENTS, None
-            kms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in ev.items() if v}
-            U = 2 * B * H * n * n * 64
-            out[f"attention_forward_{mode}"] = {"ms_per_step": dt * 1e3, "step_tflops": flops / dt / 1e12, "loss": float(loss),
+            trainers[mode] = tr
+        torch.cuda.synchronize()
+        for _ in range((steps + round_steps - 1) // round_steps):
+            for mode in modes:
+                hattn.FWD_FP8 = mode == "fp8"
+                hattn.KERNEL_EVENTS = events[mode]
+                t0 = time.perf_counter()
+                for _ in range(round_steps):
+                    loss[mode], _ = trainers[mode].step(c, f)
+                torch.cuda.synchronize()
+                secs[mode].append((time.perf_counter() - t0) / round_steps)
+                hattn.KERNEL_EVENTS = None
+        U = 2 * B * H * n * n * 64
+        for mode in modes:
+            dt = sum(secs[mode]) / len(secs[mode])
+            kms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in events[mode].items() if v}
+            out[f"attention_forward_{mode}"] = {"ms_per_step": dt * 1e3, "ms_per_step_by_round": [x * 1e3 for x in secs[mode]],
+                                                "step_tflops": flops / dt / 1e12, "loss": float(loss[mode]),
                                                 "attention_kernel_ms": kms,
                                                 "attention_fwd_tflops": 2 * U / (kms["fwd"] * 1e-3) / 1e12 if "fwd" in kms else None}
-            del tr, m
-            torch.cuda.empty_cache()
+        out["attention_forward_fp8"]["status"] = ("opt-in (NPCD_ATTN_FP8=1), measured slower than or equal to the bf16 forward in the step at head_dim 64; "
+                                                  "forward only, backward on the bf16 kernels; output rel-L2 5e-2 against 2e-3 (DESIGN.md section 8)")
+        out["fp8_over_bf16_step_time"] = out["attention_forward_fp8"]["ms_per_step"] / out["attention_forward_bf16"]["ms_per_step"]
+        for tr in trainers.values():
+            tr.close()
+        del trainers
+        torch.cuda.empty_cache()
     finally:
         hattn.FWD_FP8, hattn.KERNEL_EVENTS = saved, None
     return out
@@ -480,18 +498,18 @@ PARITY_PARAMS = ("input_proj.weight", "time_embed.c_fc.weight", "backbone.resblo
 def cpu_baseline():
     """The CPU oracle (oracle/: an fp32 PyTorch restatement of the reference, pinned by the golden fixtures; `kind: port`) timed on
     this box's host cores on a BOUNDED sample of the benchmark workload: full-width denoiser train steps (W 1024 / L 24 / H 16,
-    forward + backward + AdamW) on B = 4 of the 64 samples of a step, at TWO thread counts (BASELINE.md section 3 asks for all
-    cores): 32 threads and one thread per PHYSICAL core the process may use -- per thread count one untimed warm-up step and two
-    timed steps; `value` is the FASTER configuration's best step scaled by 64 / 4, `cores` the threads that configuration used --
-    plus one 128 x 128 render with the voxel-grid semantics for the rays/s half.
+    forward + backward + AdamW) on B = 4 of the 64 samples of a step, at ONE thread count chosen once: 32 threads (or every usable
+    CPU when there are fewer; NPCD_CPU_BASELINE_THREADS overrides).  Round 4 timed 32 threads AND one thread per physical core on
+    the pool's 2 x 64-core EPYC 9575F hosts: 4.0-6.2 s against 14.5-17.7 s per step (profiles/r4_bench.json
+    `cpu_baseline.timed_step_seconds_by_threads`, DESIGN.md section 7 for why) -- the slower count only doubled the bench's wall
+    time.  One untimed warm-up step and three timed steps; `value` is the best step scaled by 64 / 4, `cores` the threads used
+    -- plus one 128 x 128 render with the voxel-grid semantics for the rays/s half.
     The warm-up step's loss and gradient norms are returned too: bench.py feeds the same samples, timesteps and noise through
     the GPU trainer and reports the differences (`parity_full_width`)."""
     from oracle import denoiser as od, diffusion as odf, renderer as orr
     model_name, logical, affinity = host_cpu_info()
     phys = physical_cores()
-    candidates = [min(affinity, 32)]
-    if phys and min(affinity, phys) not in candidates:
-        candidates.append(min(affinity, phys))
+    candidates = [max(1, min(affinity, int(os.environ.get("NPCD_CPU_BASELINE_THREADS", "32"))))]
     torch.set_num_threads(candidates[0])
     B = 4
     params = od.init_params(CFG["coords_dim"], CFG["feats_dim"], CFG["width"], CFG["layers"], CFG["heads"], seed=0)
@@ -521,7 +539,7 @@ def cpu_baseline():
             fwd_bwd()                             # this thread count's warm-up
             opt.step()
         samples = []
-        for _ in range(2):
+        for _ in range(3):
             t0 = time.perf_counter()
             fwd_bwd()
             opt.step()
@@ -543,9 +561,9 @@ def cpu_baseline():
            "cpu_model": model_name, "host_logical_cpus": logical, "affinity_cpus": affinity,
            "sample": f"oracle (fp32 PyTorch CPU restatement of the reference) on {threads} threads of '{model_name}' "
                      f"({logical} logical CPUs, {affinity} usable): full-width denoiser train step (fwd + bwd + AdamW, "
-                     f"{CFG['layers']} blocks) at B = {B} of {CFG['global_batch']}: per thread count 1 warm-up + 2 timed steps "
+                     f"{CFG['layers']} blocks) at B = {B} of {CFG['global_batch']}: 1 warm-up + 3 timed steps "
                      f"({'; '.join(f'{th} threads: ' + ', '.join(f'{x:.2f}' for x in v) + ' s' for th, v in by_threads.items())}), "
-                     f"best step of the faster count x {CFG['global_batch'] // B} (batch); "
+                     f"best step x {CFG['global_batch'] // B} (batch); "
                      f"render: one {res} x {res} view (grid semantics, 128 depth samples) = {dtr:.1f} s",
            "physical_cores": phys, "timed_step_seconds_by_threads": {str(k): v for k, v in by_threads.items()},
            "timed_step_seconds": samples, "render_rays_per_s": res * res / dtr}
@@ -756,24 +774,38 @@ def main():
     knames = {"fwd": "attn_fwd_kernel", "dq": "attn_bwd_dq_kernel", "dkdv": "attn_bwd_dkdv_kernel", "bwd": "attn_bwd_kernel"}
     # HBM traffic and MFMA-busy: rocprofv3 PMC passes on these exact kernels and this shape (tools/make_traffic_json.py,
     # tools/pmc_summary.py); bench.py itself cannot collect PMC counters
-    def newest(*names):
+    def newest(*names, sources=()):
+        """The newest committed counter file of the given names + whether it is STALE: the file records the sha256 of the kernel
+        sources it was taken on (`_meta.source_sha256`, tools/source_hashes.py); when a source differs in the tree -- or the file
+        predates that record -- its numbers belong to another binary and are reported as such, not as this build's."""
+        import hashlib
         for nm in names:
             fp = os.path.join(ROOT, "profiles", nm)
             if os.path.exists(fp):
-                return nm, json.load(open(fp))
-        return None, {}
-    tname, tjson = newest("r4_attention_hbm_traffic_pmc.json", "r3_attention_hbm_traffic_pmc.json", "r2_attention_hbm_traffic_pmc.json", "r1_attention_hbm_traffic_pmc.json")
-    sname, sjson = newest("r4_attention_sq_pmc.json", "r3_attention_sq_pmc.json", "r2_attention_sq_pmc.json")
+                doc = json.load(open(fp))
+                want = doc.get("_meta", {}).get("source_sha256", {})
+                stale = not want
+                for f in sources:
+                    src = os.path.join(ROOT, "neural-point-cloud-diffusion_amd", "csrc", f)
+                    have = hashlib.sha256(open(src, "rb").read()).hexdigest() if os.path.exists(src) else None
+                    stale = stale or want.get(f) != have
+                return nm, doc, stale
+        return None, {}, True
+    attn_src = ("attention.hip", "common.h")
+    tname, tjson, tstale = newest("r5_attention_hbm_traffic_pmc.json", "r4_attention_hbm_traffic_pmc.json", "r3_attention_hbm_traffic_pmc.json", sources=attn_src)
+    sname, sjson, sstale = newest("r5_attention_sq_pmc.json", "r4_attention_sq_pmc.json", "r3_attention_sq_pmc.json", sources=attn_src)
     traffic = None
     # sequences of 128 j + 1 tokens: the last token's three gradient rows are finished by a small third kernel, launched (and
     # timed here) with the dK/dV pass
     edge = "dkdv" in bwd_tags and (n & 127) == 1 and n > 128
-    if per == 64 and tjson and all(knames[k] in tjson for k in bwd_tags):
+    if per == 64 and tjson and not tstale and all(knames[k] in tjson for k in bwd_tags):
         traffic = sum(tjson[knames[k]]["hbm_bytes"] for k in bwd_tags) + (tjson.get("attn_bwd_edge_kernel", {}).get("hbm_bytes", 0) if edge else 0)
     roofline = {
         "kernel": " + ".join(knames[k] for k in bwd_tags) + (" + attn_bwd_edge_kernel" if edge else "") + " (one attention backward)",
         "bound": "mfma", "achieved": bwd_tf, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": bwd_tf / PEAK_BF16_TFLOPS,
         "traffic": traffic, "traffic_source": f"profiles/{tname} (rocprofv3 --pmc, bytes per launch, summed over the kernels)" if traffic else None,
+        "stale_counters": {"traffic": bool(tstale), "mfma_busy": bool(sstale),
+                           "note": "true = the committed counter file was taken on other kernel sources than this tree's (or records none): not reported"},
         "basis": "ALGORITHMIC FLOPs, SURVEY 8(d): backward = 5 products = 5 U, U = 2 B H n^2 d; recomputed products are not credited; "
                  "the timed kernels also produce the c_qkv bias gradient (column sums of dq / dk / dv from their row stores, ~6 us of avg_ms, "
                  "instead of a separate 46 us pass over dqkv)",
@@ -785,8 +817,9 @@ def main():
         "forward_plus_backward": {"achieved": all_tf, "frac": all_tf / PEAK_BF16_TFLOPS, "algorithmic_flops": 7 * U, "avg_ms": bwd_ms + kern_ms["fwd"]},
         "per_kernel_ms": kern_ms,
         "per_kernel_tflops_executed": {k: tf(executed[k], kern_ms[k]) for k in kern_ms},
-        "mfma_busy": {k: sjson[knames[k]] for k in kern_ms if knames[k] in sjson} or None,
-        "mfma_busy_source": f"profiles/{sname} (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES etc., rocprofv3 --pmc on the same kernels)" if sjson else None,
+        "mfma_busy": None if sstale else ({k: sjson[knames[k]] for k in kern_ms if knames[k] in sjson} or None),
+        "mfma_busy_source": (f"profiles/{sname} (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES etc., rocprofv3 --pmc on the same kernels; taken on "
+                             f"another box than this run: a property of the kernels, not of this run's clock)") if sjson and not sstale else None,
     }
 
     # the HBM-bound kernels of the step (residual stream fp32, activations bf16; T tokens x W / 4W columns), priced at their
@@ -800,11 +833,11 @@ def main():
         dom = max(ew_ms, key=lambda k: ew_ms[k] * len(ew_events[k]))
         gbs = {k: ew_bytes[k] / (ew_ms[k] * 1e-3) / 1e9 for k in ew_ms}
         hname = {"add_ln_fwd": "add_ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel", "gelu_fwd": "gelu_fwd_kernel", "gelu_bwd": "colsum_kernel<true>"}[dom]
-        hfile, hjson = newest("r2_elementwise_hbm_traffic_pmc.json", "r1_elementwise_hbm_traffic_pmc.json")
-        htraffic = hjson.get(hname, {}).get("hbm_bytes") if per == 64 else None   # PMC-measured bytes per launch at exactly this shape
+        hfile, hjson, hstale = newest("r5_elementwise_hbm_traffic_pmc.json", "r2_elementwise_hbm_traffic_pmc.json", sources=("elementwise.hip", "common.h"))
+        htraffic = hjson.get(hname, {}).get("hbm_bytes") if per == 64 and not hstale else None   # PMC-measured bytes per launch at exactly this shape
         hbm = {"kernel": hname,
                "bound": "hbm", "achieved": gbs[dom], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs[dom] / PEAK_HBM_GBS,
-               "traffic": htraffic, "traffic_source": f"profiles/{hfile}" if htraffic else None,
+               "traffic": htraffic, "traffic_source": f"profiles/{hfile}" if htraffic else None, "stale_counters": bool(hstale),
                "algorithmic_bytes_per_launch": ew_bytes[dom], "avg_ms": ew_ms[dom], "launches": len(ew_events[dom]),
                "all_elementwise_kernels_ms": ew_ms, "all_elementwise_kernels_gbs": gbs}
 

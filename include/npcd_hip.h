@@ -191,7 +191,9 @@ int npcd_grid_query(const npcd_grid_params* g, const void* workspace, const floa
  * dense [ray, slot] arrays, no host round trip.  Per ray: ray_base (row of its first valid slot in the
  * compact lists), ray_nsel, ray_bits (bit j = slot j has >= 1 neighbour).  Compact rows (slot order
  * within a ray, ray order unspecified): nb_idx [capacity,k] int32, pts [capacity,3] fp32.
- * counter[0] = number of compact rows P, counter[1] != 0 if capacity was too small. */
+ * counter [4] int32 (ABI 8; two words before): counter[0] = number of compact rows P, counter[1] != 0 if capacity was too small,
+ * counter[2] = 0 (the range-guard word the caller may pass to npcd_shade_points as `status`: zeroed by this call so that the
+ * guard costs no launch of its own), counter[3] = 0 (reserved). */
 int npcd_grid_query_compact(const npcd_grid_params* g, const void* workspace, const float* points,
                             int B, int N, int R, int S, int M, int k, float r,
                             const float* rays_o, const float* rays_d, const float* t0, const float* t1,
@@ -202,7 +204,8 @@ int npcd_grid_query_compact(const npcd_grid_params* g, const void* workspace, co
  * (npcd_grid_query_order_ws_bytes(B, R, M, k) bytes of device scratch, 16-byte aligned, uninitialised), a second launch turns the
  * counts into ray_base by a prefix sum and moves the rows.  No atomics: ray_base / nb_idx / pts are bit-identical from run to run
  * (torch_knnquery.VoxelGrid.query returns its rows in ray order as well: aggregator.py:63-73 indexes them by the ray mask).
- * Rows past `capacity` are not written and counter[1] is raised; counter needs no initialisation. */
+ * Rows past `capacity` are not written and counter[1] is raised; counter [4] needs no initialisation.  More than 32,768 rays per
+ * call: one more small launch adds the counts up per 1,024 rays first (same bits; keeps the prefix sums linear in the rays). */
 int64_t npcd_grid_query_order_ws_bytes(int B, int R, int M, int k);
 int npcd_grid_query_compact_ordered(const npcd_grid_params* g, const void* workspace, const float* points,
                                     int B, int N, int R, int S, int M, int k, float r,
@@ -234,7 +237,14 @@ int npcd_ray_gen_subset(const float* extr, const float* intr, int V, int res, fl
  *   -> sigma [P] fp32, rgb [P,3] fp32.  n_points_dev: device int32 holding P (so that P may be
  *   produced on the device without a host round trip); max_points = rows allocated in every
  *   per-point array: it bounds the launch and the kernels clamp the device-side count to it.
+ * Range guard (ABI 8).  The kernels carry activations between layers as fp16 (fp32 accumulation); the reference runs these MLPs in
+ * fp32 (eval_pointnerf.py has no autocast).  `status` (device int32, may be NULL) is OR-ed with NPCD_SHADE_NONFINITE_PAIRS when an
+ * aggregated feature row, and with NPCD_SHADE_NONFINITE_HEADS when a head's final pre-activation, is inf / NaN -- which is where
+ * every fp16 overflow (|x| >= 65,520) of an earlier layer ends up.  The library never clears the word: zero it, render, read it
+ * with the point count.  A set bit means the pixels of this call are not the reference's; use the fp32-class path instead.
  * ------------------------------------------------------------------------------------------ */
+#define NPCD_SHADE_NONFINITE_PAIRS 1
+#define NPCD_SHADE_NONFINITE_HEADS 2
 int64_t npcd_shade_wpack_bytes(int feat_dim, int n_freqs, int hidden);
 int64_t npcd_shade_workspace_bytes(int max_points, int hidden);
 int npcd_shade_pack_weights(const float* const* weights_host, const float* const* biases_host,
@@ -242,7 +252,7 @@ int npcd_shade_pack_weights(const float* const* weights_host, const float* const
 int npcd_shade_points(const void* wpack, int feat_dim, int n_freqs, int hidden,
                       const int32_t* nb_idx, const float* pts, const float* kp_pos, const float* kp_feat,
                       const int32_t* n_points_dev, int max_points, int k,
-                      float* sigma, float* rgb, void* workspace, void* stream);
+                      float* sigma, float* rgb, void* workspace, int32_t* status, void* stream);
 
 /* The same with the reference's use_view_dir option (models/npcd.py:8 -> fields/mlp.py:30-36,67-70): the first colour layer sees
  * [feat | enc(ray direction)].  Its direction part is the same for every shading point of a ray, so the caller passes it per RAY:
@@ -251,7 +261,8 @@ int npcd_shade_points(const void* wpack, int feat_dim, int n_freqs, int hidden,
 int npcd_shade_points_dir(const void* wpack, int feat_dim, int n_freqs, int hidden,
                           const int32_t* nb_idx, const float* pts, const float* kp_pos, const float* kp_feat,
                           const int32_t* n_points_dev, int max_points, int k,
-                          float* sigma, float* rgb, void* workspace, const float* dir_bias, const int32_t* point_ray, void* stream);
+                          float* sigma, float* rgb, void* workspace, const float* dir_bias, const int32_t* point_ray,
+                          int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Ray marching (renderer.py:96-110,120-185, volume_renderer.py:23-39) on the dense slot layout:

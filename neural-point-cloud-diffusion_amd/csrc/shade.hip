@@ -475,6 +475,13 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
                 f16x8* gp = reinterpret_cast<f16x8*>(a.G + (int64_t)p * kHidden + cc * 8);
                 gp[0] = o0;
                 gp[16] = o1;
+                // range guard: an fp16 overflow in any of the four layers makes every channel of the pair's row inf / NaN in the next
+                // one and from there the aggregated row (a slot >= cnt re-reads the point's own last row with weight 0: 0 x inf is
+                // NaN, still not finite).  One sum of magnitudes per thread says whether all 16 values are finite.
+                float mag = 0.f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) mag += __builtin_fabsf(out[j]);
+                if (a.status && not_finite_bits(mag)) atomicOr(a.status, kShadeNonfinitePairs);
             }
         }
         NPCD_STS(12);
@@ -552,6 +559,7 @@ struct PointsArgs {          // what a pass needs of ShadeArgs, passed BY VALUE 
     float *sigma, *rgb;
     const float* dir_bias;
     const int32_t* point_ray;
+    int32_t* status;
     int feat_dim;
     int red_rows;    // rows per wave plane of the reduction buffer (32 x the kernel's largest pass)
 };
@@ -700,6 +708,10 @@ __device__ __forceinline__ void points_pass(PointsArgs a, unsigned char* H, floa
                 const f32x4 v = *reinterpret_cast<const f32x4*>(red + (w * a.red_rows + tid) * 4);
                 t += v;
             }
+            // range guard: the heads' hidden activations are fp16 between layers; an overflow there arrives here as inf / NaN in the
+            // final pre-activation -- where sigmoid(+inf) = 1 would hide it
+            if (a.status && not_finite_bits(__builtin_fabsf(t[0]) + __builtin_fabsf(t[1]) + __builtin_fabsf(t[2]) + __builtin_fabsf(t[3])))
+                atomicOr(a.status, kShadeNonfiniteHeads);
             a.sigma[p] = softplus_m1(t[3] + s1[kHidden]);
 #pragma unroll
             for (int c = 0; c < 3; ++c) a.rgb[(int64_t)p * 3 + c] = 1.f / (1.f + expf(-(t[c] + c4[3 * kHidden + c])));
@@ -722,7 +734,7 @@ __global__ __launch_bounds__(256, 2) void shade_points_kernel(ShadeArgs a) {
     float* red = reinterpret_cast<float*>(dsmem + MAXNB * 32 * kRowBytes);  // [4 waves][128 rows][4]
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0 && a.tile_counter) *a.tile_counter = 0;      // the pair kernel of this call is done: its ticket word is free again
-    const PointsArgs pa{a.wpack, a.G, a.sigma, a.rgb, a.dir_bias, a.point_ray, a.feat_dim, 32 * MAXNB};
+    const PointsArgs pa{a.wpack, a.G, a.sigma, a.rgb, a.dir_bias, a.point_ray, a.status, a.feat_dim, 32 * MAXNB};
     const int P = min(*a.n_points, a.max_points);
     const int nblk = (P + 31) >> 5, q = nblk / (int)gridDim.x, rem = nblk % (int)gridDim.x;
     int b = (int)blockIdx.x * q + min((int)blockIdx.x, rem);
@@ -858,7 +870,8 @@ static int32_t* tile_ticket_slot() {
 
 static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int hidden, const int32_t* nb_idx, const float* pts,
                                const float* kp_pos, const float* kp_feat, const int32_t* n_points_dev, int max_points, int k,
-                               float* sigma, float* rgb, void* workspace, const float* dir_bias, const int32_t* point_ray, void* stream) {
+                               float* sigma, float* rgb, void* workspace, const float* dir_bias, const int32_t* point_ray, int32_t* status,
+                               void* stream) {
     int rc = shade_check(feat_dim, n_freqs, hidden);
     if (rc != NPCD_OK) return rc;
     if (!wpack || !nb_idx || !pts || !kp_pos || !kp_feat || !n_points_dev || !sigma || !rgb || !workspace) return NPCD_ERR_ARG;
@@ -874,6 +887,7 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
     a.G = static_cast<_Float16*>(workspace);
     a.sigma = sigma; a.rgb = rgb;
     a.dir_bias = dir_bias; a.point_ray = point_ray;
+    a.status = status;
     hipStream_t st = static_cast<hipStream_t>(stream);
     static const bool static_tiles = getenv("NPCD_SHADE_STATIC_TILES") != nullptr;
     if (!static_tiles) a.tile_counter = tile_ticket_slot();      // (nullptr: tiles strided over the grid)
@@ -905,15 +919,15 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
 
 extern "C" int npcd_shade_points(const void* wpack, int feat_dim, int n_freqs, int hidden, const int32_t* nb_idx, const float* pts,
                                  const float* kp_pos, const float* kp_feat, const int32_t* n_points_dev, int max_points, int k,
-                                 float* sigma, float* rgb, void* workspace, void* stream) {
+                                 float* sigma, float* rgb, void* workspace, int32_t* status, void* stream) {
     return shade_points_launch(wpack, feat_dim, n_freqs, hidden, nb_idx, pts, kp_pos, kp_feat, n_points_dev, max_points, k, sigma, rgb,
-                               workspace, nullptr, nullptr, stream);
+                               workspace, nullptr, nullptr, status, stream);
 }
 extern "C" int npcd_shade_points_dir(const void* wpack, int feat_dim, int n_freqs, int hidden, const int32_t* nb_idx, const float* pts,
                                      const float* kp_pos, const float* kp_feat, const int32_t* n_points_dev, int max_points, int k,
                                      float* sigma, float* rgb, void* workspace, const float* dir_bias, const int32_t* point_ray,
-                                     void* stream) {
+                                     int32_t* status, void* stream) {
     if (!dir_bias || !point_ray) return NPCD_ERR_ARG;
     return shade_points_launch(wpack, feat_dim, n_freqs, hidden, nb_idx, pts, kp_pos, kp_feat, n_points_dev, max_points, k, sigma, rgb,
-                               workspace, dir_bias, point_ray, stream);
+                               workspace, dir_bias, point_ray, status, stream);
 }

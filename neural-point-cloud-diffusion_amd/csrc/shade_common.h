@@ -70,7 +70,17 @@ struct ShadeArgs {
     // pair kernel: next tile to hand out (zeroed before the launch; nullptr = tiles strided over the grid).  A workgroup takes
     // tile blockIdx.x first and then whatever the counter says: which workgroup computes a tile changes nothing about its result
     int32_t* tile_counter;
+    // range guard (ABI 8): the activations travel between layers as fp16; a trained field whose pre-activations leave the fp16 range
+    // (|x| >= 65,520 -> inf, then inf - inf -> NaN) would otherwise render NaN pixels without a word.  Every non-finite value reaches
+    // the end of its kernel (an inf in one layer makes the whole row non-finite in the next), so the check sits where the values
+    // leave: the pair kernel ORs NPCD_SHADE_NONFINITE_PAIRS into *status when an aggregated feature row is not finite, the point
+    // kernel NPCD_SHADE_NONFINITE_HEADS when a head's final pre-activation is not.  Never cleared by the kernels; nullptr = no guard.
+    int32_t* status;
 };
+// (the bits of *status; include/npcd_hip.h repeats them for callers)
+constexpr int kShadeNonfinitePairs = 1, kShadeNonfiniteHeads = 2;
+// inf or NaN, decided on the bits: the shading sources are compiled with -fno-honor-nans, under which `!(x < big)` may become `x >= big`
+__device__ __forceinline__ bool not_finite_bits(float x) { return (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u; }
 
 // ---- positional-encoding column q (0..63) of the [x_rel(3) | per coord: sin f0..9, cos f0..9 | 0] block
 __device__ __forceinline__ float enc_value(int q, const float rel[3]) {

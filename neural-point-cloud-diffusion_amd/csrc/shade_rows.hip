@@ -544,9 +544,15 @@ __global__ __launch_bounds__(256, 1) void shade_rows_kernel(ShadeArgs a, RowsWs 
                 pp[it] = ptp[32 * pm + 2 * it + g];
                 rowv[it] = *reinterpret_cast<const u32x4*>(gst + (2 * it + g) * kRowBytes + 16 * n);
             }
+            uint32_t bad = 0;        // range guard (shade_common.h): an fp16 exponent field of all ones in any stored aggregated value
 #pragma unroll
             for (int it = 0; it < 16; ++it)
-                if (32 * pm + 2 * it + g < npts && pp[it] >= 0) *reinterpret_cast<u32x4*>(a.G + (int64_t)pp[it] * kHidden + 8 * n) = rowv[it];
+                if (32 * pm + 2 * it + g < npts && pp[it] >= 0) {
+                    *reinterpret_cast<u32x4*>(a.G + (int64_t)pp[it] * kHidden + 8 * n) = rowv[it];
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) bad |= (rowv[it][c4] & 0x7c007c00u) + 0x04000400u;     // 0x7c00 + 0x0400 sets bit 15
+                }
+            if (a.status && (bad & 0x80008000u)) atomicOr(a.status, kShadeNonfinitePairs);
         }
         NPCD_RTL(8);
     }

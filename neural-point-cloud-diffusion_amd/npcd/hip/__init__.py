@@ -64,8 +64,8 @@ SIGNATURES = {
     "npcd_shade_wpack_bytes": (c_int64, [c_int, c_int, c_int]),
     "npcd_shade_workspace_bytes": (c_int64, [c_int, c_int]),
     "npcd_shade_pack_weights": (c_int, [POINTER(_P), POINTER(_P), c_int, c_int, c_int, _P]),
-    "npcd_shade_points": (c_int, [_P, c_int, c_int, c_int] + [_P] * 5 + [c_int, c_int] + [_P] * 3 + [_P]),
-    "npcd_shade_points_dir": (c_int, [_P, c_int, c_int, c_int] + [_P] * 5 + [c_int, c_int] + [_P] * 3 + [_P, _P] + [_P]),
+    "npcd_shade_points": (c_int, [_P, c_int, c_int, c_int] + [_P] * 5 + [c_int, c_int] + [_P] * 3 + [_P] + [_P]),
+    "npcd_shade_points_dir": (c_int, [_P, c_int, c_int, c_int] + [_P] * 5 + [c_int, c_int] + [_P] * 3 + [_P, _P] + [_P] + [_P]),
     "npcd_ray_march_ws_floats": (c_int64, [c_int]),
     "npcd_ray_gen_ws_floats": (c_int64, [c_int, c_int, c_int]),
     "npcd_ray_march": (c_int, [_P] * 8 + [c_int, c_int, c_int] + [_P] * 4 + [_P]),

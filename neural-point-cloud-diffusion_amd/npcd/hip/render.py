@@ -154,7 +154,7 @@ class HipVoxelGrid:
         return idx, loc, ss, nsel
 
     def query_compact(self, k: int, r: float, M: int, rays, S: int, capacity: int, points: Optional[torch.Tensor] = None):
-        """Fused-render form (npcd_grid_query_compact): returns counter [2] int32 (P, overflow flag),
+        """Fused-render form (npcd_grid_query_compact): returns counter [4] int32 (P, overflow flag, shading status word = 0, 0),
         ray_base [B*R] int32, ray_nsel [B*R] int32, ray_bits [B*R] int64 (valid-slot masks),
         nb [capacity,k] int32, pts [capacity,3] fp32 -- all on the device, no host round trip."""
         pts_t = self.points if points is None else points.detach().to(_f32).contiguous()
@@ -162,7 +162,7 @@ class HipVoxelGrid:
         o, d, t0, t1 = (t.to(_f32).contiguous() for t in rays)
         R = o.shape[1]
         dev = pts_t.device
-        counter = torch.empty(2, dtype=_i32, device=dev)
+        counter = torch.empty(4, dtype=_i32, device=dev)
         ray_base = torch.empty(B * R, dtype=_i32, device=dev)
         ray_nsel = torch.empty(B * R, dtype=_i32, device=dev)
         ray_bits = torch.empty(B * R, dtype=torch.int64, device=dev)
@@ -223,15 +223,22 @@ def pack_field_weights(state: dict, feat_dim: int, device, n_freqs: int = 10, hi
 # When set to a list, the two shading kernels of every shade_points() call (shade_pairs_kernel + shade_points_kernel, one C call)
 # are bracketed by HIP events recorded on the launch stream (bench.py: per-kernel roofline of the renderer's dominant kernels).
 SHADE_EVENTS = None
+SHADE_NONFINITE_PAIRS, SHADE_NONFINITE_HEADS = 1, 2          # bits of the range-guard word (include/npcd_hip.h)
 
 
 def shade_points(wpack: torch.Tensor, feat_dim: int, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch.Tensor,
                  kp_feat: torch.Tensor, n_points: Optional[torch.Tensor] = None, n_freqs: int = 10, hidden: int = 256,
-                 dir_bias: Optional[torch.Tensor] = None, point_ray: Optional[torch.Tensor] = None):
+                 dir_bias: Optional[torch.Tensor] = None, point_ray: Optional[torch.Tensor] = None,
+                 status: Optional[torch.Tensor] = None):
     """nb_idx [P,k] int32 (global indices, -1 pad), pts [P,3], kp_pos [B*N,3], kp_feat [B*N,F] -> sigma [P], rgb [P,3].
     use_view_dir (fields/mlp.py:67-70): dir_bias [n_rays, hidden] fp32 = the direction part of the first colour layer's
-    pre-activation per ray, point_ray [P] int32 = the ray of every compact point (npcd_shade_points_dir)."""
+    pre-activation per ray, point_ray [P] int32 = the ray of every compact point (npcd_shade_points_dir).
+    status: optional device int32 word (zeroed by the caller) that the kernels OR with SHADE_NONFINITE_PAIRS / _HEADS when an
+    fp16 activation left its range (include/npcd_hip.h, range guard)."""
     require_gpu(wpack, nb_idx, pts, kp_pos, kp_feat)
+    if status is not None:
+        require_gpu(status)
+        assert status.dtype == _i32 and status.numel() >= 1
     if (dir_bias is None) != (point_ray is None):
         raise ValueError("dir_bias and point_ray go together")
     P, k = nb_idx.shape
@@ -253,7 +260,7 @@ def shade_points(wpack: torch.Tensor, feat_dim: int, nb_idx: torch.Tensor, pts: 
         ev[0].record()
     if dir_bias is None:
         check(L.npcd_shade_points(ptr(wpack), feat_dim, n_freqs, hidden, ptr(nb_idx), ptr(pts), ptr(kp_pos), ptr(kp_feat),
-                                  ptr(n_points), P, k, ptr(sigma), ptr(rgb), ptr(work), stream_ptr()), "npcd_shade_points")
+                                  ptr(n_points), P, k, ptr(sigma), ptr(rgb), ptr(work), ptr(status), stream_ptr()), "npcd_shade_points")
     else:
         require_gpu(dir_bias, point_ray)
         dir_bias = dir_bias.to(_f32).contiguous()
@@ -261,7 +268,7 @@ def shade_points(wpack: torch.Tensor, feat_dim: int, nb_idx: torch.Tensor, pts: 
         assert dir_bias.shape[1] == hidden and point_ray.shape[0] == P
         check(L.npcd_shade_points_dir(ptr(wpack), feat_dim, n_freqs, hidden, ptr(nb_idx), ptr(pts), ptr(kp_pos), ptr(kp_feat),
                                       ptr(n_points), P, k, ptr(sigma), ptr(rgb), ptr(work), ptr(dir_bias), ptr(point_ray),
-                                      stream_ptr()), "npcd_shade_points_dir")
+                                      ptr(status), stream_ptr()), "npcd_shade_points_dir")
     if ev is not None:
         ev[1].record()
         SHADE_EVENTS.append(ev)

@@ -290,8 +290,14 @@ class _BackboneFn(torch.autograd.Function):
                 sums = ew.ColsumBatch()            # this block's 8 bias / LN-affine column sums: one finalize
                 # ---- MLP branch: x3 = x2 + c_proj(gelu(c_fc(ln_2(x2)))) ------------------------------
                 Tm = T - T % 256
-                if _OWN_DGELU and Tm > 0 and hlin.supported(Tm, 4 * W, W):
-                    wT = hlin.transpose16(e["mlp_c_proj_weight_16"])
+                w2 = e["mlp_c_proj_weight_16"]
+                # (the own launch only for what npcd_linear_dgelu_bwd takes -- contiguous 16-bit operands of one type; anything else
+                # goes through the library product + gelu_bwd below instead of raising, like NPCD_ERR_UNSUPPORTED would, ADVICE r4.
+                # The transposed copy of the weight is made per backward: it changes with every optimizer step and each backward
+                # uses it once, so a cached copy would have to be refreshed as often -- 8 MB and ~5 us per block either way.)
+                if (_OWN_DGELU and Tm > 0 and hlin.supported(Tm, 4 * W, W) and dxb.is_contiguous() and h.is_contiguous()
+                        and w2.is_contiguous() and dxb.dtype == w2.dtype == h.dtype and dxb.dtype in (torch.bfloat16, torch.float16)):
+                    wT = hlin.transpose16(w2)
                     dh = torch.empty_like(h)
                     extra = ew.lib().npcd_colsum_blocks(T - Tm) if Tm < T else 0
                     _, part, rows = hlin.linear_dgelu_bwd(dxb[:Tm], wT, h[:Tm], out=dh[:Tm], extra_part_rows=extra)

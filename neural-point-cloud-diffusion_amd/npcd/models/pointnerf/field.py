@@ -143,9 +143,9 @@ class Field(nn.Module):
         w = self.channel_net[0].weight[:, self.hid_dim:]
         return (encode_dir(rays_d.float(), self.dir_freqs) @ w.detach().float().t()).contiguous()
 
-    def shade(self, nb_idx, pts, kp_pos, kp_feat, dir_bias=None, point_ray=None):
+    def shade(self, nb_idx, pts, kp_pos, kp_feat, dir_bias=None, point_ray=None, status=None):
         """compact shading points -> sigma [P] (softplus(x-1) applied), rgb [P,3] (sigmoid applied).  With use_dir: dir_bias
         [n_rays, hid] (Field.dir_bias) and point_ray [P] int32, the ray of every compact point."""
         return hr.shade_points(self.packed_weights(pts.device), self.aggregator.in_dim, nb_idx, pts,
                                kp_pos.reshape(-1, 3), kp_feat.reshape(-1, kp_feat.shape[-1]),
-                               n_freqs=self.aggregator.n_freqs, hidden=self.hid_dim, dir_bias=dir_bias, point_ray=point_ray)
+                               n_freqs=self.aggregator.n_freqs, hidden=self.hid_dim, dir_bias=dir_bias, point_ray=point_ray, status=status)

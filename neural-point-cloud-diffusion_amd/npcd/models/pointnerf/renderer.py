@@ -21,6 +21,11 @@ class VolumeRenderer(nn.Module):
         self.sync_free_points = 1 << 23    # ... unless the worst case is at most this many points (eight 128^2 views: 6.6 M):
         #                                    then the buffers take the worst case (44 B of lists + 512 B of workspace per point)
         self.count_pairs = False           # also report the number of (point, neighbour) pairs (an extra reduction + sync, ~8 % of a view)
+        # fp16 range guard of the fused shading kernels (include/npcd_hip.h): the kernels raise bits in a device word when an
+        # activation left the fp16 range (the reference shades in fp32).  The word comes back as out["shading_status"] -- a host
+        # int where the call reads the point count from the device anyway, a device scalar on the sync-free path -- and
+        # `check_shading_status` turns a raised bit into a FloatingPointError ("raise"), a RuntimeWarning ("warn") or nothing.
+        self.range_guard = "warn"
 
     def limits(self, t0: torch.Tensor, t1: torch.Tensor):
         """Box limits from the ray kernel, or the fixed (near, far) of `ray_limits` for every ray (renderer.py:36-47)."""
@@ -77,15 +82,15 @@ class VolumeRenderer(nn.Module):
                                                     right=True) - 1).clamp_(min=0).to(torch.int32)
                 sigma, rgb = hr.shade_points(field.packed_weights(kp_pos.device), agg.in_dim, nb, pts, kp_pos.reshape(-1, 3),
                                              kp_feat.reshape(-1, kp_feat.shape[-1]), n_points=counter[:1], n_freqs=agg.n_freqs,
-                                             hidden=field.hid_dim, dir_bias=dir_bias, point_ray=point_ray)
+                                             hidden=field.hid_dim, dir_bias=dir_bias, point_ray=point_ray, status=counter[2:3])
                 mask, depth, chan = hr.ray_march_compact(sigma, rgb, ray_bits, pts, ray_base, o.view(-1, 3), d.view(-1, 3), t1.reshape(-1),
                                                          M, self.white_back)
                 if sync_free:
                     # buffers sized for the worst case cannot overflow: nothing to check, the call returns without a host
                     # round trip (the point count stays a device scalar) and the next call's launches overlap this one
-                    P = counter[0]
+                    P, shading_status = counter[0], counter[2]
                     break
-                P, overflow = counter.tolist()
+                P, overflow, shading_status, _ = counter.tolist()      # (the range-guard word rides on the read of the point count)
                 if not overflow:
                     break
                 capacity = worst
@@ -108,10 +113,12 @@ class VolumeRenderer(nn.Module):
             nb = idx.view(Nr, M, agg.k)[valid]                            # compact, row-major over [ray, slot]
             pts = loc.view(Nr, M, 3)[valid]
             point_ray = torch.nonzero(valid)[:, 0].to(torch.int32)        # the ray of every compact point
-            sigma, rgb = field.shade(nb, pts, kp_pos, kp_feat, dir_bias, None if dir_bias is None else point_ray)
+            status = torch.zeros(1, dtype=torch.int32, device=nb.device)
+            sigma, rgb = field.shade(nb, pts, kp_pos, kp_feat, dir_bias, None if dir_bias is None else point_ray, status=status)
             march = (valid, loc.view(Nr, M, 3), base, o.view(-1, 3), d.view(-1, 3), t1.reshape(-1), self.white_back)
             mask, depth, chan = hr.ray_march(sigma, rgb, *march)
             P, n_pairs = int(nb.shape[0]), int((nb >= 0).sum())
+            shading_status = int(status)
             if return_kp_weights:
                 kp_weights = self._kp_weights(sigma, rgb, march, nb, pts, point_ray, kp_pos).view(B, T, R, kp_pos.shape[1])
         out = AttrDict(mask=mask.view(B, T, R, 1), depth=depth.view(B, T, R, 1))
@@ -121,10 +128,29 @@ class VolumeRenderer(nn.Module):
             out["kp_weights"] = kp_weights
         out["num_shading_points"] = P
         out["num_pairs"] = n_pairs
+        out["shading_status"] = shading_status
+        if not torch.is_tensor(shading_status):
+            self.check_shading_status(shading_status)
         # which neighbour search produced this render: the reading of the (absent) torch_knnquery source, or
         # the reference's in-repo brute-force branch -- so that evaluation logs and saved renders say what they were made with
         out["grid_level"] = "brute_force" if knn_mode else getattr(grid, "grid_level", None)
         return out
+
+    def check_shading_status(self, status) -> int:
+        """The range-guard word of a render (out["shading_status"]: int, or a device scalar after a sync-free call -- reading it
+        here waits for that call).  Non-zero: an fp16 activation of the fused shading MLPs overflowed, the pixels are not the
+        reference's (fp32) pixels.  Acts as `range_guard` says and returns the word."""
+        status = int(status)
+        if status and self.range_guard != "off":
+            where = [n for bit, n in ((hr.SHADE_NONFINITE_PAIRS, "per-pair aggregator layers"), (hr.SHADE_NONFINITE_HEADS, "density / colour heads"))
+                     if status & bit]
+            msg = ("fused fp16 shading left the fp16 range (|activation| >= 65,520 -> inf / NaN) in the " + " and the ".join(where) +
+                   ": these pixels differ from the reference's fp32 shading; render with mlp_dtype=torch.float32")
+            if self.range_guard == "raise":
+                raise FloatingPointError(msg)
+            import warnings
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
+        return status
 
     @staticmethod
     def _kp_weights(sigma, rgb, march, nb, pts, point_ray, kp_pos):

@@ -571,7 +571,7 @@ def test_trainer_close_removes_its_hooks_and_engine():
     r().wait_params = lambda *x, **k: (waits.append(x), orig(*x, **k))[1]
     a.state_dict()
     assert waits, "state_dict() of a model with an attached trainer must complete the parameter gathers first"
-    del r().wait_params
+    del r().wait_params, orig
     # a third trainer on the same model detaches the second one by itself: hooks do not stack, the old one becomes collectable
     eng2 = den.backbone.fused_engine
     t3 = DiffusionTrainer(a, fused=True)

@@ -265,6 +265,116 @@ def test_shading_large_weights(F_, shade_form):
     assert float(es) < 5e-3 and float(er) < 5e-3, (float(es), float(er))
 
 
+def _overflow_case(which, F_=32):
+    """weights that push an inter-layer activation past the fp16 range: `pairs` scales the second aggregator layer, `heads` the first
+    colour layer (whose output is rounded to fp16 for the next one); `last_heads` scales the LAST colour hidden layer only -- its
+    output stays in the fp32 accumulators, which must not raise the guard"""
+    p = orr.init_field_params(F_, seed=3)
+    key = {"pairs": "aggregator.local_field.2", "heads": "channel_net.0", "last_heads": "channel_net.6"}[which]
+    p[key + ".weight"] = p[key + ".weight"] * 3.0e5
+    coords, feats = orr.synthetic_cloud(256, F_, 1, seed=4)
+    gen = torch.Generator().manual_seed(1)
+    P = 700
+    base = coords[0][torch.randint(0, 256, (P,), generator=gen)]
+    pts = base + torch.randn(P, 3, generator=gen) * 0.02
+    dist, nb = torch.topk(torch.cdist(pts, coords[0]), 8, largest=False)
+    nb[dist >= 0.08] = -1
+    nb[::5, 2:] = -1                                  # points with fewer than 8 neighbours (the aggregation re-reads their last row)
+    keep = (nb >= 0).any(dim=1)
+    return p, coords, feats, nb[keep].int(), pts[keep]
+
+
+@pytest.mark.parametrize("which,bit", [("pairs", 1), ("heads", 2), ("last_heads", 0), (None, 0)])
+def test_shading_range_guard_raises_its_bit_when_fp16_overflows(which, bit, shade_form):
+    """the fused shading kernels round activations to fp16 between layers and used to turn an overflow into NaN
+    pixels without a word.  npcd_shade_points(status=) must raise NPCD_SHADE_NONFINITE_PAIRS / _HEADS exactly when a constructed
+    overflow happens in that kernel, and nothing for ordinary weights."""
+    from npcd.hip import render as hr
+    if which is None:
+        p = orr.init_field_params(32, seed=3)
+        _, coords, feats, nb, pts = _overflow_case("pairs")
+    else:
+        p, coords, feats, nb, pts = _overflow_case(which)
+    m = _model(32, 256, p)
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    sig, rgb = m.field.shade(nb.cuda(), pts.cuda(), coords.cuda(), feats.cuda(), status=status)
+    torch.cuda.synchronize()
+    got = int(status)
+    if which == "pairs":
+        assert got & hr.SHADE_NONFINITE_PAIRS, got          # (the point kernel then sees non-finite inputs and may add its own bit)
+        assert not bool(torch.isfinite(rgb).all() and torch.isfinite(sig).all()) or got & hr.SHADE_NONFINITE_HEADS
+    else:
+        assert got == bit, (which, got)
+    if bit == 0:
+        assert bool(torch.isfinite(sig).all()) and bool(torch.isfinite(rgb).all())
+    # the word is sticky (never cleared by the library) and optional
+    sig2, rgb2 = m.field.shade(nb.cuda(), pts.cuda(), coords.cuda(), feats.cuda(), status=status)
+    assert int(status) == got
+    sig3, _ = m.field.shade(nb.cuda(), pts.cuda(), coords.cuda(), feats.cuda())
+    assert torch.equal(torch.nan_to_num(sig3), torch.nan_to_num(sig2))
+
+
+def test_render_surfaces_the_range_guard(monkeypatch):
+    """PointNeRF.render: out["shading_status"] is 0 for ordinary weights; with overflowing weights the renderer warns (default), raises
+    (range_guard="raise"), and on the sync-free path hands the word back as a device scalar that check_shading_status() reads."""
+    res = 32
+    coords, feats, extr, intr = _scene(res, 1, 512, 32, seed=1)
+    args = (coords.cuda(), feats.cuda(), extr.cuda(), intr.cuda(), res)
+    m = _model(32, 512, orr.init_field_params(32, seed=0))
+    with torch.no_grad():
+        out = m.render(*args)
+        assert torch.is_tensor(out["shading_status"]) and int(out["shading_status"]) == 0            # sync-free path: device scalar
+        m.renderer.sync_free_points = 0                                                               # the path that reads the point count
+        out = m.render(*args)
+        assert out["shading_status"] == 0
+        p = orr.init_field_params(32, seed=0)
+        p["aggregator.local_field.2.weight"] = p["aggregator.local_field.2.weight"] * 3.0e5
+        bad = _model(32, 512, p)
+        bad.renderer.sync_free_points = 0
+        with pytest.warns(RuntimeWarning, match="fp16 range"):
+            out = bad.render(*args)
+        assert out["shading_status"] & 1
+        bad.renderer.range_guard = "raise"
+        with pytest.raises(FloatingPointError):
+            bad.render(*args)
+        bad.renderer.sync_free_points = 1 << 23
+        out = bad.render(*args)                                   # sync-free: no host read inside the call, the caller checks
+        assert torch.is_tensor(out["shading_status"])
+        with pytest.raises(FloatingPointError):
+            bad.renderer.check_shading_status(out["shading_status"])
+        for mode in (1,):                                         # the dense path (brute-force neighbour search) carries the word too
+            bad.renderer.range_guard = "off"
+            out = bad.renderer(coords.cuda(), feats.cuda(), extr.cuda(), intr.cuda(), res, False, knn_mode=mode)
+            assert out["shading_status"] & 1
+
+
+def test_ordered_compaction_above_32768_rays_uses_block_sums_and_gives_the_same_lists():
+    """More than 32,768 rays per call: a first pass adds the per-ray counts up per 1,024 rays and the compaction workgroups read block
+    sums instead of every earlier count (the one-level form is quadratic in the rays).  The bases must still be the
+    exclusive prefix sum of the counts and the rows those of the dense query, in ray order."""
+    from npcd.hip import render as hr
+    res, M, k, S, V = 112, 24, 8, 48, 3                           # 37,632 rays in one example
+    coords, feats, extr, intr = _scene(res, V, 512, 32, seed=5)
+    m = _model(32, 512, orr.init_field_params(32, seed=0))
+    agg = m.field.aggregator
+    grid = agg.voxel_grid
+    with torch.no_grad():
+        grid.set_pointset(coords.cuda(), None)
+        o, d, t0, t1 = hr.ray_gen(extr.flatten(0, 1).cuda(), intr.flatten(0, 1).cuda(), res, 1.0)
+        rays = tuple(t.reshape(1, V * res * res, *t.shape[2:]) for t in (o, d, t0, t1))
+        assert rays[0].shape[1] > 32768 and hr.COMPACT_ORDERED
+        idx, loc, _, nsel = grid.query_dense(k, agg.r, M, rays=rays, S=S)
+        cap = V * res * res * M
+        c1, base1, nsel1, bits1, nb1, pts1 = grid.query_compact(k, agg.r, M, rays, S, cap)
+    torch.cuda.synchronize()
+    valid = (idx[..., 0] >= 0).flatten(0, 1)
+    cnt = valid.sum(1)
+    P = int(cnt.sum())
+    assert c1.tolist() == [P, 0, 0, 0] and P > 20000
+    assert torch.equal(base1.long(), torch.cumsum(cnt, 0) - cnt)
+    assert torch.equal(nb1[:P], idx.flatten(0, 1)[valid]) and torch.equal(pts1[:P], loc.flatten(0, 1)[valid])
+
+
 def test_rows_form_of_the_shading_kernel(monkeypatch):
     """csrc/shade_rows.hip against the tile form on neighbour lists with everything the C interface allows: points without any
     neighbour (their sigma / rgb come from the biases alone), -1 entries before valid ones, 1..8 neighbours, a point count that is

@@ -41,5 +41,11 @@ for k, c in acc.items():
         d["wave_cycle_split"] = {"active": m.get("SQ_ACTIVE_INST_ANY", 0) / m["SQ_WAVE_CYCLES"], "issue_stalled": m.get("SQ_WAIT_INST_ANY", 0) / m["SQ_WAVE_CYCLES"],
                                  "parked": m.get("SQ_WAIT_ANY", 0) / m["SQ_WAVE_CYCLES"]}
     out[k] = d
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_hashes import source_hashes
+if any("attn" in w for w in want):
+    out["_meta"] = {"source_sha256": source_hashes("attention.hip", "common.h")}
 json.dump(out, open(sys.argv[2], "w"), indent=1)
+out.pop("_meta", None)
 print(json.dumps({k: {x: (round(y, 3) if isinstance(y, float) else y) for x, y in v.items() if x != "counters_mean_per_launch"} for k, v in out.items()}, indent=1))

@@ -5,7 +5,7 @@
 #       FETCH_SIZE / WRITE_SIZE passes at the step's shape
 #   (3) kernel stats of the bench's timed region alone + its bench line      (tools/run_stats.sh)
 # usage: tools/run_round_profiles.sh [tag]
-TAG=${1:-r3}
+TAG=${1:-r5}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${TAG}_profiles; mkdir -p $O
 bash $R/tools/run_render_profile.sh $TAG > $O/render.log 2>&1; tail -30 $O/render.log
 cp $R/gpurun_out/${TAG}_render/${TAG}_render_sq_pmc.json $R/gpurun_out/${TAG}_render/${TAG}_shade_sq_pmc.json $O/ 2>/dev/null
@@ -19,7 +19,11 @@ timeout 600 rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $O/attn_sq
 unset NPCD_B NPCD_N
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/attn_fetch -- python3 $R/tools/probes/gpu_dev_attn_time.py 10 > $O/attn_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/attn_write -- python3 $R/tools/probes/gpu_dev_attn_time.py 10 > $O/attn_write.log 2>&1
+# (2b) the elementwise kernels of the step (add + LayerNorm, LayerNorm backward, GELU, GELU backward + column sums): FETCH_SIZE / WRITE_SIZE
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/ew_fetch -- python3 $R/tools/probes/gpu_dev_ew_time.py > $O/ew_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/ew_write -- python3 $R/tools/probes/gpu_dev_ew_time.py > $O/ew_write.log 2>&1
 cd $R
+python3 tools/make_traffic_json.py ew $(ls $O/ew_fetch/*/*counter_collection.csv | head -1) $(ls $O/ew_write/*/*counter_collection.csv | head -1) $O/${TAG}_elementwise_hbm_traffic_pmc.json
 python3 tools/make_sq_pmc_json.py $(dirname $(ls $O/attn_sq/*/*counter_collection.csv | head -1)) $O/${TAG}_attention_sq_pmc.json
 python3 tools/make_sq_pmc_json.py $(dirname $(ls $O/attn_sq_n2049/*/*counter_collection.csv | head -1)) $O/${TAG}_attention_sq_pmc_n2049.json
 python3 tools/make_traffic_json.py attn $(ls $O/attn_fetch/*/*counter_collection.csv | head -1) $(ls $O/attn_write/*/*counter_collection.csv | head -1) $O/${TAG}_attention_hbm_traffic_pmc.json
