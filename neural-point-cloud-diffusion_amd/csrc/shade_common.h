@@ -79,8 +79,15 @@ struct ShadeArgs {
 };
 // (the bits of *status; include/npcd_hip.h repeats them for callers)
 constexpr int kShadeNonfinitePairs = 1, kShadeNonfiniteHeads = 2;
-// inf or NaN, decided on the bits: the shading sources are compiled with -fno-honor-nans, under which `!(x < big)` may become `x >= big`
-__device__ __forceinline__ bool not_finite_bits(float x) { return (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u; }
+// inf or NaN, decided on the bits of an OPAQUE integer: the shading sources are compiled with -fno-honor-nans, under which
+// `!(x < big)` becomes `x >= big` and even `(bits(x) & 0x7f800000) == 0x7f800000` is recognised as a floating-point class test and
+// narrowed to `|x| == inf` (seen in the listing: v_cmp_eq_f32 |v|, 0x7f800000 -- a NaN row passed).  The empty asm hides where
+// the integer came from.
+__device__ __forceinline__ bool not_finite_bits(float x) {
+    uint32_t u = __float_as_uint(x);
+    asm volatile("" : "+v"(u));
+    return (u & 0x7f800000u) == 0x7f800000u;
+}
 
 // ---- positional-encoding column q (0..63) of the [x_rel(3) | per coord: sin f0..9, cos f0..9 | 0] block
 __device__ __forceinline__ float enc_value(int q, const float rel[3]) {

@@ -68,10 +68,22 @@ def _split_gemm(fn, T):
     fn(slice(0, Tm))
 
 
+# The token counts of one rank of a 4- / 8-GPU job (8,208 / 4,104 rows): the square product of the block (attn.c_proj, N = K = 1,024:
+# 64-68 tiles of 256 x 256 for 256 CUs in the library's form) goes to the own 128 x 128-tile kernel, which measured 1.3 x the tuned
+# library there (17.6-18.1 against 23-29 us at T = 4,104; docs/experiments.md R4.7) and loses on every other shape of the block --
+# selected by shape, NPCD_NO_LIN128=1 switches it off (A/B).
+_LIN128 = not os.environ.get("NPCD_NO_LIN128")
+_LIN128_MAX_T = int(os.environ.get("NPCD_LIN128_MAX_T", "4200"))
+
+
 def _linear(bias, x, w16):
     """x [T, K] bf16, w16 [N, K] bf16, bias [N] bf16 -> x @ w16^T + bias, [T, N] bf16."""
     T = x.shape[0]
     out = torch.empty((T, w16.shape[0]), dtype=x.dtype, device=x.device)
+    N, K = w16.shape
+    if (_LIN128 and N == 1024 and K == 1024 and T <= _LIN128_MAX_T and x.is_cuda and x.is_contiguous() and w16.is_contiguous()
+            and bias.is_contiguous() and x.dtype == w16.dtype == bias.dtype and hlin.supported128(T, N, K)):
+        return hlin.linear128_fwd(x, w16, bias, out)
     wt = w16.t()
     _split_gemm(lambda r: torch.addmm(bias, x[r], wt, out=out[r]), T)
     return out

@@ -272,6 +272,9 @@ def _overflow_case(which, F_=32):
     p = orr.init_field_params(F_, seed=3)
     key = {"pairs": "aggregator.local_field.2", "heads": "channel_net.0", "last_heads": "channel_net.6"}[which]
     p[key + ".weight"] = p[key + ".weight"] * 3.0e5
+    if which != "pairs":       # (default-initialised layers shrink the activations ~0.4 x each: give the heads inputs of O(1) to overflow with)
+        for n in ("weight", "bias"):
+            p["aggregator.local_field.8." + n] = p["aggregator.local_field.8." + n] * 50.0
     coords, feats = orr.synthetic_cloud(256, F_, 1, seed=4)
     gen = torch.Generator().manual_seed(1)
     P = 700
