@@ -899,11 +899,18 @@ def main():
             r["rays_per_s_all_gpus"] = float(tt)
         result["render"] = r
         try:
-            # lead figure: the reference's numerics -- stage 1 trains in fp32 (train_pointnerf.py has no autocast): fp32 operands,
-            # library GEMMs at the fp32 matrix rate.  The bf16-operand / fp32-accumulate form with the per-pair MLP on the matrix
-            # cores (csrc/pairs_mlp.hip) is an opt-in (PointNeRFTrainer(mlp_dtype=torch.bfloat16)) and reported beside it.
+            # lead figure: the reference's numerics class -- stage 1 trains in fp32 (train_pointnerf.py has no autocast).  Default of
+            # PointNeRFTrainer since round 5: the per-pair layers on the fp32-class matrix-core kernels (two bf16 halves per operand,
+            # three products, fp32 accumulation: ~1e-5 relative per product, tests/test_gpu_train_render.py::
+            # test_fused_pair_mlp_fp32_class_mode), the point-level layers on fp32 library GEMMs.  Beside it: every Linear layer on
+            # fp32 library GEMMs (the lead until round 4), and the bf16-operand opt-in (narrower than the reference).
             s1 = bench_stage1(device)
-            s1["numerics"] = "fp32 operands and accumulation like the reference's train_pointnerf.py (PointNeRFTrainer(mlp_dtype=None))"
+            s1["numerics"] = ("fp32-class: per-pair aggregator MLP with every operand as two bf16 halves (hi + lo), three matrix instructions per product, "
+                              "fp32 accumulation, fp32 weight gradients (csrc/pairs_mlp.hip precision 1: forward 5e-6, gradients 1e-5 relative to float64 "
+                              "in the kernel test); point-level layers, losses and Adam in fp32 (PointNeRFTrainer(mlp_dtype=None))")
+            libr = bench_stage1(device, mlp_dtype="library")
+            s1["fp32_library_gemms"] = {k: libr[k] for k in ("steps_per_s", "ms_per_step", "ms_per_step_min_median_max", "loss", "differentiable_part")}
+            s1["fp32_library_gemms"]["numerics"] = "fp32 operands and accumulation on library GEMMs for every Linear layer (PointNeRFTrainer(mlp_dtype='library'))"
             opt = bench_stage1(device, mlp_dtype=torch.bfloat16)
             s1["bf16_operands_opt_in"] = {k: opt[k] for k in ("steps_per_s", "ms_per_step", "ms_per_step_min_median_max", "loss", "differentiable_part")}
             s1["bf16_operands_opt_in"]["numerics"] = ("bf16 operands, fp32 accumulation, fp32 weight gradients and optimizer: NARROWER than the "

@@ -450,17 +450,27 @@ int npcd_pair_aggregate(int backward, const float* src, const float* w, const in
  *   npcd_pair_mlp_bwd  : dG [P,256] fp32, owner [Q] int64 -> dfeat [Q,F] fp32 (gradient w.r.t. the gathered feature rows, to be
  *                        scattered with npcd_pair_input_bwd), dW[l] [256, in_l] fp32, db[l] [256] fp32 (overwritten; slabs summed
  *                        in a fixed order: bitwise reproducible).  dact: 2 x [Q,256] bf16 scratch; part: fp32 scratch of
- *                        npcd_pair_mlp_bwd_workspace_floats() elements.  F in {32, 128}. */
-int64_t npcd_pair_mlp_wpack_bytes(int feat_dim);
-int npcd_pair_mlp_pack(const float* const* weights_dev, const float* const* biases_dev, int feat_dim, void* wpack_dev, void* stream);
-int npcd_pair_mlp_fwd(const void* wpack, int feat_dim, const int64_t* nb_idx, const float* pts, const float* kp_pos,
+ *                        npcd_pair_mlp_bwd_workspace_floats() elements.  F in {32, 128}.
+ * `precision` (ABI 8) of every entry point:
+ *   NPCD_PAIR_MLP_BF16 (0): bf16 operands, fp32 accumulation -- narrower than the reference's fp32 (train_pointnerf.py has no autocast);
+ *   NPCD_PAIR_MLP_X2   (1): fp32-class -- every operand (weights, activations, gradients) as two bf16 halves hi + lo, every product
+ *                        as three matrix instructions hi*hi + hi*lo + lo*hi accumulated in fp32: ~1e-5 relative per product, fp32's
+ *                        exponent range.  All 16-bit arrays then hold TWO planes (hi, then lo): x0 [2][Q][F+64], acts [4][2][Q][256],
+ *                        dact 2 x [2][Q][256]; wpack twice the matrices.  Same calls, same outputs (G, dfeat, dW, db: fp32).
+ * Forward only (rendering with fp32-class shading): x0 = acts = wn = NULL -- nothing is saved. */
+#define NPCD_PAIR_MLP_BF16 0
+#define NPCD_PAIR_MLP_X2 1
+int64_t npcd_pair_mlp_wpack_bytes(int feat_dim, int precision);
+int npcd_pair_mlp_pack(const float* const* weights_dev, const float* const* biases_dev, int feat_dim, int precision, void* wpack_dev,
+                       void* stream);
+int npcd_pair_mlp_fwd(const void* wpack, int feat_dim, int precision, const int64_t* nb_idx, const float* pts, const float* kp_pos,
                       const float* kp_feat, const int64_t* off, int64_t n_points, int k, int64_t n_pairs, void* x0, void* acts,
                       float* wn, float* G, void* stream);
-int npcd_pair_mlp_bwd_slabs(int64_t n_pairs);
-int64_t npcd_pair_mlp_bwd_workspace_floats(int feat_dim, int64_t n_pairs);
-int npcd_pair_mlp_bwd(const void* wpack, int feat_dim, const float* dG, const int64_t* owner, const float* wn, const void* x0,
-                      const void* acts, int64_t n_pairs, void* dact, float* dfeat, float* part, float* const* dW, float* const* db,
-                      void* stream);
+int npcd_pair_mlp_bwd_slabs(int64_t n_pairs, int precision);
+int64_t npcd_pair_mlp_bwd_workspace_floats(int feat_dim, int64_t n_pairs, int precision);
+int npcd_pair_mlp_bwd(const void* wpack, int feat_dim, int precision, const float* dG, const int64_t* owner, const float* wn,
+                      const void* x0, const void* acts, int64_t n_pairs, void* dact, float* dfeat, float* part, float* const* dW,
+                      float* const* db, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,8 +13,15 @@
 //                           (a 10^6-long reduction), writes it once, and a second launch sums the slabs in a fixed order.
 //                           dA_3 = wn * dG[owner] is formed on the fly from the gradient of the aggregated features.
 //
-// Numerics: bf16 operands, fp32 accumulation, fp32 weight / bias gradients (what `PointNeRFTrainer(mlp_dtype=torch.bfloat16)`
-// computed with library GEMMs before; the reference trains this stage in fp32, which stays the trainer's default).
+// Numerics, two modes (`precision` of the entry points):
+//   0  bf16 operands, fp32 accumulation, fp32 weight / bias gradients (what `PointNeRFTrainer(mlp_dtype=torch.bfloat16)` computed
+//      with library GEMMs before): NARROWER than the reference, which trains this stage in fp32.
+//   1  "x2", the fp32-class mode (template parameter X2): every matrix operand -- weights, activations, gradients -- is carried as TWO
+//      bf16 halves  x = hi + lo,  hi = bf16(x), lo = bf16(x - hi)  (16 mantissa bits, fp32's exponent range: nothing can overflow
+//      that fp32 holds), every product as THREE matrix instructions  hi*hi + hi*lo + lo*hi  accumulated in fp32 (the lo*lo term,
+//      2^-18 relative, is dropped): ~1e-5 relative per product against fp32's 6e-8 and bf16's 4e-3, at a third of the bf16 matrix
+//      rate = 5 x the fp32 matrix instruction's.  Activations saved for the backward as the two planes (4 B per element, like fp32).
+//      The row tile of the backward is 64 instead of 128 rows (four LDS planes), the forward runs eight waves on one 128-row tile.
 // Pairs are compact and ordered by point (row q of every [Q, .] array; off[p] = first pair of point p), see csrc/pairs.hip.
 //
 // Bounds.  Forward: matrix pipe (0.41 MFLOP per pair, 2.2 kB written per pair).  Backward layer: HBM -- per 128-row tile
@@ -46,23 +53,32 @@ __host__ __device__ inline int64_t pl_bw(int feat, int l) {
     const int64_t base = pl_fw(feat, 4), l0 = (int64_t)(feat / 32) * 16 * kPFrag, ll = (int64_t)(kPH / 32) * 16 * kPFrag;
     return l == 0 ? base : base + l0 + (l - 1) * ll;
 }
-__host__ __device__ inline int64_t pl_bias(int feat, int l) { return pl_bw(feat, 4) + (int64_t)l * kPH * 4; }
-__host__ __device__ inline int64_t pl_total(int feat) { return pl_bias(feat, 4); }
+// x2: a second set of matrices (the lo halves) in the same order behind the first, the biases behind both
+__host__ __device__ inline int64_t pl_mats(int feat) { return pl_bw(feat, 4); }
+__host__ __device__ inline int64_t pl_bias(int feat, int l, bool x2 = false) { return (x2 ? 2 : 1) * pl_mats(feat) + (int64_t)l * kPH * 4; }
+__host__ __device__ inline int64_t pl_total(int feat, bool x2 = false) { return pl_bias(feat, 4, x2); }
 
 struct PackArgs {
     const float* W[4];
     const float* b[4];
     unsigned char* out;
     int feat_dim;
+    int x2;
 };
+// the two bf16 halves of a float: x ~ hi + lo
+__device__ __forceinline__ void pm_split(float x, __bf16& hi, __bf16& lo) {
+    hi = (__bf16)x;
+    lo = (__bf16)(x - (float)hi);
+}
 // one thread per packed 16-byte fragment piece (8 elements)
 __global__ __launch_bounds__(256) void pair_pack_kernel(PackArgs a) {
     const int F = a.feat_dim;
     const int in0 = a.feat_dim + 3 + 6 * kPFreqs;
     const int64_t piece = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t npieces = pl_bias(F, 0) / 16;
-    if (piece < npieces) {
-        const int64_t byte = piece * 16;
+    const int64_t npieces = pl_mats(F) / 16;
+    const int plane = piece >= npieces ? 1 : 0;                  // x2: the lo halves are a second pass over the same pieces
+    if (piece < npieces * (a.x2 ? 2 : 1)) {
+        const int64_t byte = (piece - plane * npieces) * 16;
         const bool bwd = byte >= pl_bw(F, 0);
         int l = 0;
         for (int i = 1; i < 4; ++i)
@@ -79,22 +95,26 @@ __global__ __launch_bounds__(256) void pair_pack_kernel(PackArgs a) {
             float x;
             if (!bwd) x = k < in_dim ? a.W[l][(int64_t)m * in_dim + k] : 0.f;      // A = W[out m][in k]
             else x = a.W[l][(int64_t)k * in_dim + m];                              // A = W^T[in m][out k]   (m < F <= in_dim for layer 0)
-            v[j] = (__bf16)x;
+            __bf16 hi, lo;
+            pm_split(x, hi, lo);
+            v[j] = plane ? lo : hi;
         }
-        *reinterpret_cast<bf16x8*>(a.out + byte) = v;
+        *reinterpret_cast<bf16x8*>(a.out + plane * pl_mats(F) + byte) = v;
     }
     if (piece < 4 * kPH) {
         const int l = (int)(piece / kPH), c = (int)(piece % kPH);
-        reinterpret_cast<float*>(a.out + pl_bias(F, l))[c] = a.b[l][c];
+        reinterpret_cast<float*>(a.out + pl_bias(F, l, a.x2 != 0))[c] = a.b[l][c];
     }
 }
 
 __device__ __forceinline__ int row_off(int row, int chunk) { return row * kPitchR + (chunk << 4); }
 
 // acc[oi][cb] = bias + W[(NOB*wave+oi)*32.., :] . H^T[:, cb*32..]   (activations = B operand, weights = A operand streamed from L2)
-template <int KSTEPS, int NOB, int NCB>
+// X2: the lo plane of the activations lies `hplane` bytes behind the hi plane in LDS, the lo weights `wlo` bytes behind the hi ones;
+// three matrix instructions per (fragment, fragment) pair: hi*hi + hi*lo + lo*hi.
+template <int KSTEPS, int NOB, int NCB, bool X2 = false>
 __device__ __forceinline__ void pm_layer_mfma(const unsigned char* H, int pitch, const unsigned char* wfrag, const float* bias, int wave, int lane,
-                                              f32x16 (&acc)[NOB][NCB], int nblk) {
+                                              f32x16 (&acc)[NOB][NCB], int nblk, int hplane = 0, int64_t wlo = 0) {
     const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int oi = 0; oi < NOB; ++oi) {
@@ -118,23 +138,40 @@ __device__ __forceinline__ void pm_layer_mfma(const unsigned char* H, int pitch,
 #pragma unroll
     for (int oi = 0; oi < NOB; ++oi) w[oi] = reinterpret_cast<const bf16x8*>(wfrag + (int64_t)(NOB * wave + oi) * KSTEPS * kPFrag) + lane;
     const unsigned char* hb = H + r * pitch + hh * 16;
-    bf16x8 a[NOB], nx[NOB];
+    bf16x8 a[NOB], nx[NOB], al[NOB], nxl[NOB];
 #pragma unroll
-    for (int oi = 0; oi < NOB; ++oi) a[oi] = w[oi][0];
+    for (int oi = 0; oi < NOB; ++oi) {
+        a[oi] = w[oi][0];
+        if (X2) al[oi] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(w[oi]) + wlo);
+    }
 #pragma unroll 4
     for (int s = 0; s < KSTEPS; ++s) {
 #pragma unroll
-        for (int oi = 0; oi < NOB; ++oi) nx[oi] = s + 1 < KSTEPS ? w[oi][(s + 1) * 64] : a[oi];
+        for (int oi = 0; oi < NOB; ++oi) {
+            nx[oi] = s + 1 < KSTEPS ? w[oi][(s + 1) * 64] : a[oi];
+            if (X2) nxl[oi] = s + 1 < KSTEPS ? *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(w[oi] + (s + 1) * 64) + wlo) : al[oi];
+        }
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             if (cb < nblk) {                         // wave-uniform: whole 32-row blocks past the tile's rows are skipped
                 const bf16x8 b = *reinterpret_cast<const bf16x8*>(hb + cb * 32 * pitch + s * 32);
+                if (X2) {
+                    const bf16x8 bl = *reinterpret_cast<const bf16x8*>(hb + hplane + cb * 32 * pitch + s * 32);
+#pragma unroll
+                    for (int oi = 0; oi < NOB; ++oi) {          // small terms first, the leading product last
+                        acc[oi][cb] = BF16::mfma32(al[oi], b, acc[oi][cb]);
+                        acc[oi][cb] = BF16::mfma32(a[oi], bl, acc[oi][cb]);
+                    }
+                }
 #pragma unroll
                 for (int oi = 0; oi < NOB; ++oi) acc[oi][cb] = BF16::mfma32(a[oi], b, acc[oi][cb]);
             }
         }
 #pragma unroll
-        for (int oi = 0; oi < NOB; ++oi) a[oi] = nx[oi];
+        for (int oi = 0; oi < NOB; ++oi) {
+            a[oi] = nx[oi];
+            if (X2) al[oi] = nxl[oi];
+        }
     }
 }
 
@@ -146,8 +183,9 @@ __device__ __forceinline__ uint32_t pm_pack2(float a, float b) {
 }
 
 // epilogue: optional LeakyReLU, convert to bf16, write in place: lane owns row (cb*32 + r), channels (NOB wave + oi)*32 + 8 g + 4 hh ..
-template <bool ACT, int NOB, int NCB>
-__device__ __forceinline__ void pm_layer_store(unsigned char* H, int pitch, int wave, int lane, const f32x16 (&acc)[NOB][NCB], int nblk) {
+// X2: the remainder x - hi goes to the lo plane, `hplane` bytes further
+template <bool ACT, int NOB, int NCB, bool X2 = false>
+__device__ __forceinline__ void pm_layer_store(unsigned char* H, int pitch, int wave, int lane, const f32x16 (&acc)[NOB][NCB], int nblk, int hplane = 0) {
     const int r = lane & 31, hh = lane >> 5;
     unsigned char* sb = H + r * pitch + hh * 8 + wave * (NOB * 64);
 #pragma unroll
@@ -157,7 +195,7 @@ __device__ __forceinline__ void pm_layer_store(unsigned char* H, int pitch, int 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 if (cb >= nblk) continue;
-                u32x2 v;
+                u32x2 v, vl;
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     float x0 = acc[oi][cb][4 * g + 2 * b], x1 = acc[oi][cb][4 * g + 2 * b + 1];
@@ -166,9 +204,26 @@ __device__ __forceinline__ void pm_layer_store(unsigned char* H, int pitch, int 
                         x1 = fmaxf(x1, kPSlope * x1);
                     }
                     v[b] = pm_pack2(x0, x1);
+                    if (X2) vl[b] = pm_pack2(x0 - BF16::lo(v[b]), x1 - BF16::hi(v[b]));
                 }
                 *reinterpret_cast<u32x2*>(sb + cb * 32 * pitch + (oi * 4 + g) * 16) = v;
+                if (X2) *reinterpret_cast<u32x2*>(sb + hplane + cb * 32 * pitch + (oi * 4 + g) * 16) = vl;
             }
+}
+
+// eight fp32 values -> one 16-byte chunk of the hi plane (and of the lo plane)
+template <bool X2>
+__device__ __forceinline__ void pm_put8(unsigned char* p, int hplane, const float (&x)[8]) {
+    bf16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        __bf16 hi, lo;
+        pm_split(x[j], hi, lo);
+        h[j] = hi;
+        l[j] = lo;
+    }
+    *reinterpret_cast<bf16x8*>(p) = h;
+    if (X2) *reinterpret_cast<bf16x8*>(p + hplane) = l;
 }
 
 __device__ __forceinline__ float pm_enc_value(int q, const float rel[3]) {
@@ -187,37 +242,52 @@ struct PairFwdArgs {
     const int64_t* off;        // [P] first pair row of each point
     int64_t P, Q;
     int k;
-    __bf16* x0;                // [Q, F + 64]
-    __bf16* acts;              // [4][Q][256]
-    float* wn;                 // [Q]
+    __bf16* x0;                // [Q, F + 64]            (x2: [2][Q][F + 64], hi plane then lo plane); nullptr = not saved (inference)
+    __bf16* acts;              // [4][Q][256]            (x2: [4][2][Q][256]); nullptr = not saved
+    float* wn;                 // [Q]; nullptr = not saved
     float* G;                  // [P, 256]
 };
 
 // copy the first `rows` rows of the LDS tile (width bytes each) to a row-major global array starting at row `row0`
+template <int NT>
 __device__ __forceinline__ void pm_copy_out(const unsigned char* H, int rows, int width_bytes, unsigned char* dst, int64_t row0, int tid) {
     const int cpr = width_bytes >> 4;
-    for (int c = tid; c < rows * cpr; c += 256) {
+    for (int c = tid; c < rows * cpr; c += NT) {
         const int row = c / cpr, chunk = c - row * cpr;
         *reinterpret_cast<u32x4*>(dst + (row0 + row) * width_bytes + (chunk << 4)) = *reinterpret_cast<const u32x4*>(H + row_off(row, chunk));
     }
 }
+// eight positional-encoding columns BASE .. BASE + 7 of a row
+// (`base` is a compile-time constant at every call site once the caller's loop is unrolled: the column tests of pm_enc_value fold)
+template <bool X2>
+__device__ __forceinline__ void pm_enc8(unsigned char* p, int hplane, const float rel[3], int base) {
+    float e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = pm_enc_value(base + j, rel);
+    pm_put8<X2>(p, hplane, e);
+}
 
-// tile = 16 points x 8 neighbour slots; the tile's valid pairs are packed to the front (a point's rows stay consecutive)
-template <int FEAT>
-__global__ __launch_bounds__(256, 2) void pair_mlp_fwd_kernel(PairFwdArgs a) {
-    constexpr int K0 = FEAT + kPEnc;
+// tile = 16 points x 8 neighbour slots; the tile's valid pairs are packed to the front (a point's rows stay consecutive).
+// X2 = false: 256 threads (wave = two 32-channel output blocks), two workgroups per CU.  X2 = true: the two LDS planes of a tile are
+// 135 KB, one workgroup per CU -- of 512 threads (wave = one output block), so that a SIMD still holds two waves.
+template <int FEAT, bool X2>
+__global__ __launch_bounds__(X2 ? 512 : 256, 2) void pair_mlp_fwd_kernel(PairFwdArgs a) {
+    constexpr int K0 = FEAT + kPEnc, NT = X2 ? 512 : 256, NPART = NT / 128, NOB = X2 ? 1 : 2;
+    constexpr int HP = X2 ? kPTile * kPitchR : 0;                 // byte distance hi plane -> lo plane
+    constexpr int FQ = FEAT / NPART, EC = kPEnc / NPART;          // feature / encoding columns one thread fills
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
     unsigned char* H = dsmem;
-    float* wrow = reinterpret_cast<float*>(dsmem + kPTile * kPitchR);
+    float* wrow = reinterpret_cast<float*>(dsmem + (X2 ? 2 : 1) * kPTile * kPitchR);
     int* pstart = reinterpret_cast<int*>(wrow + kPTile);
     int* pcount = pstart + 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t ntiles = (a.P + 15) / 16;
+    const int64_t wlo = X2 ? pl_mats(FEAT) : 0;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int nblk, V;
         const int64_t row0 = a.off[tile * 16];                     // first pair row of the tile
         {
-            const int row = tid & 127, half = tid >> 7;
+            const int row = tid & 127, part = __builtin_amdgcn_readfirstlane(tid >> 7);      // part is wave-uniform
             const int64_t p = tile * 16 + (row >> 3);
             const int slot = row & 7;
             int64_t gi = -1, gi_other = -1;
@@ -229,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_fwd_kernel(PairFwdArgs a) {
             const int prow = __popcll(mine & ((1ull << lane) - 1ull)) + ((row & 64) ? n_other : 0);
             V = n_mine + n_other;
             nblk = (V + 31) >> 5;
-            if (half == 0 && slot == 0) {
+            if (part == 0 && slot == 0) {
                 pstart[row >> 3] = prow;
                 pcount[row >> 3] = __popcll((mine >> (lane & ~7)) & 0xffull);
             }
@@ -238,54 +308,63 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_fwd_kernel(PairFwdArgs a) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) rel[c] = a.pts[p * 3 + c] - a.kp_pos[gi * 3 + c];
             }
-            if (half == 0 && gi >= 0) wrow[prow] = 1.f / (sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]) + 1e-5f);
-            constexpr int FH = FEAT / 2;
+            if (part == 0 && gi >= 0) wrow[prow] = 1.f / (sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]) + 1e-5f);
             if (gi >= 0) {
-                const float* fp = a.kp_feat + gi * FEAT + half * FH;
+                const float* fp = a.kp_feat + gi * FEAT + part * FQ;
 #pragma unroll
-                for (int c8 = 0; c8 < FH / 8; ++c8) {
-                    bf16x8 v;
+                for (int c8 = 0; c8 < FQ / 8; ++c8) {
                     const f32x4 x0 = *reinterpret_cast<const f32x4*>(fp + c8 * 8);
                     const f32x4 x1 = *reinterpret_cast<const f32x4*>(fp + c8 * 8 + 4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[j] = (__bf16)x0[j]; v[4 + j] = (__bf16)x1[j]; }
-                    *reinterpret_cast<bf16x8*>(H + row_off(prow, half * (FH / 8) + c8)) = v;
+                    const float x[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                    pm_put8<X2>(H + row_off(prow, part * (FQ / 8) + c8), HP, x);
                 }
+                // positional encoding: part fills EC of the 64 columns (the column numbers are compile-time inside each branch)
+                unsigned char* ep = H + row_off(prow, FEAT / 8 + part * (EC / 8));
 #pragma unroll
-                for (int c8 = 0; c8 < 4; ++c8) {
-                    bf16x8 v;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (__bf16)(half == 0 ? pm_enc_value(c8 * 8 + j, rel) : pm_enc_value(32 + c8 * 8 + j, rel));
-                    *reinterpret_cast<bf16x8*>(H + row_off(prow, FEAT / 8 + half * 4 + c8)) = v;
+                for (int c8 = 0; c8 < EC / 8; ++c8) {
+                    if (part == 0) pm_enc8<X2>(ep + c8 * 16, HP, rel, c8 * 8);
+                    else if (part == 1) pm_enc8<X2>(ep + c8 * 16, HP, rel, EC + c8 * 8);
+                    else if (part == 2) pm_enc8<X2>(ep + c8 * 16, HP, rel, (2 * EC + c8 * 8) % kPEnc);
+                    else pm_enc8<X2>(ep + c8 * 16, HP, rel, (3 * EC + c8 * 8) % kPEnc);
                 }
             }
             if (row >= V && row < 32 * nblk) {       // rows of a partly filled 32-row block: defined (zero) inputs
-                bf16x8 z;
+                const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f;
+                for (int c8 = 0; c8 < FQ / 8; ++c8) pm_put8<X2>(H + row_off(row, part * (FQ / 8) + c8), HP, z);
 #pragma unroll
-                for (int c8 = 0; c8 < FH / 8; ++c8) *reinterpret_cast<bf16x8*>(H + row_off(row, half * (FH / 8) + c8)) = z;
-#pragma unroll
-                for (int c8 = 0; c8 < 4; ++c8) *reinterpret_cast<bf16x8*>(H + row_off(row, FEAT / 8 + half * 4 + c8)) = z;
+                for (int c8 = 0; c8 < EC / 8; ++c8) pm_put8<X2>(H + row_off(row, FEAT / 8 + part * (EC / 8) + c8), HP, z);
             }
         }
         __syncthreads();
-        pm_copy_out(H, V, K0 * 2, reinterpret_cast<unsigned char*>(a.x0), row0, tid);
-        f32x16 acc[2][4];
-        pm_layer_mfma<K0 / 16, 2, 4>(H, kPitchR, a.wpack + pl_fw(FEAT, 0), reinterpret_cast<const float*>(a.wpack + pl_bias(FEAT, 0)), wave, lane, acc, nblk);
+        if (a.x0) {
+            pm_copy_out<NT>(H, V, K0 * 2, reinterpret_cast<unsigned char*>(a.x0), row0, tid);
+            if (X2) pm_copy_out<NT>(H + HP, V, K0 * 2, reinterpret_cast<unsigned char*>(a.x0 + a.Q * K0), row0, tid);
+        }
+        f32x16 acc[NOB][4];
+        pm_layer_mfma<K0 / 16, NOB, 4, X2>(H, kPitchR, a.wpack + pl_fw(FEAT, 0), reinterpret_cast<const float*>(a.wpack + pl_bias(FEAT, 0, X2)), wave, lane,
+                                           acc, nblk, HP, wlo);
         __syncthreads();
-        pm_layer_store<true, 2, 4>(H, kPitchR, wave, lane, acc, nblk);
+        pm_layer_store<true, NOB, 4, X2>(H, kPitchR, wave, lane, acc, nblk, HP);
         __syncthreads();
-        pm_copy_out(H, V, kPH * 2, reinterpret_cast<unsigned char*>(a.acts), row0, tid);
+        if (a.acts) {
+            pm_copy_out<NT>(H, V, kPH * 2, reinterpret_cast<unsigned char*>(a.acts), row0, tid);
+            if (X2) pm_copy_out<NT>(H + HP, V, kPH * 2, reinterpret_cast<unsigned char*>(a.acts + a.Q * kPH), row0, tid);
+        }
 #pragma unroll 1
         for (int l = 1; l < 4; ++l) {
-            pm_layer_mfma<kPH / 16, 2, 4>(H, kPitchR, a.wpack + pl_fw(FEAT, l), reinterpret_cast<const float*>(a.wpack + pl_bias(FEAT, l)), wave, lane, acc, nblk);
+            pm_layer_mfma<kPH / 16, NOB, 4, X2>(H, kPitchR, a.wpack + pl_fw(FEAT, l), reinterpret_cast<const float*>(a.wpack + pl_bias(FEAT, l, X2)), wave,
+                                                lane, acc, nblk, HP, wlo);
             __syncthreads();
-            pm_layer_store<true, 2, 4>(H, kPitchR, wave, lane, acc, nblk);
+            pm_layer_store<true, NOB, 4, X2>(H, kPitchR, wave, lane, acc, nblk, HP);
             __syncthreads();
-            pm_copy_out(H, V, kPH * 2, reinterpret_cast<unsigned char*>(a.acts + (int64_t)l * a.Q * kPH), row0, tid);
+            if (a.acts) {
+                __bf16* dst = a.acts + (int64_t)l * (X2 ? 2 : 1) * a.Q * kPH;
+                pm_copy_out<NT>(H, V, kPH * 2, reinterpret_cast<unsigned char*>(dst), row0, tid);
+                if (X2) pm_copy_out<NT>(H + HP, V, kPH * 2, reinterpret_cast<unsigned char*>(dst + a.Q * kPH), row0, tid);
+            }
         }
-        {   // inverse-distance weighted mean over each point's pairs
+        if (tid < 256) {   // inverse-distance weighted mean over each point's pairs
             const int pl = tid >> 4, cc = tid & 15;
             const int64_t p = tile * 16 + pl;
             const int r0 = pstart[pl], cnt = pcount[pl];
@@ -298,11 +377,18 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_fwd_kernel(PairFwdArgs a) {
             for (int s2 = 0; s2 < cnt; ++s2) {
                 const int row = r0 + s2;
                 const float ws = wrow[row] * inv;
-                if (cc == 0) a.wn[row0 + row] = ws;
+                if (cc == 0 && a.wn) a.wn[row0 + row] = ws;
                 const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(H + row_off(row, 2 * cc));
                 const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(H + row_off(row, 2 * cc + 1));
+                if (X2) {
+                    const bf16x8 l0 = *reinterpret_cast<const bf16x8*>(H + HP + row_off(row, 2 * cc));
+                    const bf16x8 l1 = *reinterpret_cast<const bf16x8*>(H + HP + row_off(row, 2 * cc + 1));
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { out[j] += ws * (float)v0[j]; out[8 + j] += ws * (float)v1[j]; }
+                    for (int j = 0; j < 8; ++j) { out[j] += ws * ((float)v0[j] + (float)l0[j]); out[8 + j] += ws * ((float)v1[j] + (float)l1[j]); }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { out[j] += ws * (float)v0[j]; out[8 + j] += ws * (float)v1[j]; }
+                }
             }
             if (p < a.P) {
                 f32x4* gp = reinterpret_cast<f32x4*>(a.G + p * kPH + cc * 16);
@@ -319,14 +405,15 @@ __global__ __launch_bounds__(256, 2) void pair_mlp_fwd_kernel(PairFwdArgs a) {
 // ============================================================================================
 struct PairBwdArgs {
     const unsigned char* wT;   // W_l^T fragments (data gradient); unused when there is no data gradient to produce
+    int64_t wlo;               // x2: byte distance to the lo halves of the same fragments
     const float* dG;           // layer 3: [P, 256] gradient of the aggregated features
     const int64_t* owner;      // layer 3: [Q]
     const float* wn;           // layer 3: [Q]
-    const __bf16* dA;          // layers 0..2: [Q, 256] gradient w.r.t. this layer's output
-    const __bf16* A;           // [Q, 256] this layer's output (sign of the LeakyReLU)
-    const __bf16* Aprev;       // [Q, KP] this layer's input
+    const __bf16* dA;          // layers 0..2: [Q, 256] gradient w.r.t. this layer's output      (x2: [2][Q][256], hi then lo)
+    const __bf16* A;           // [Q, 256] this layer's output (sign of the LeakyReLU; x2: its hi plane)
+    const __bf16* Aprev;       // [Q, KP] this layer's input                                      (x2: [2][Q][KP])
     int64_t Q;
-    __bf16* dAprev;            // layers 1..3: [Q, 256]
+    __bf16* dAprev;            // layers 1..3: [Q, 256]                                           (x2: [2][Q][256])
     float* dfeat;              // layer 0: [Q, FB*32] fp32 gradient w.r.t. the gathered features
     float* part;               // [gridDim.x][256 * KP + 256] fp32 slabs: dW_l then db_l
 };
@@ -349,14 +436,18 @@ __device__ __forceinline__ uint32_t pm_lds_addr(const unsigned char* p) {
 }
 
 // LAYER3: dA is formed from dG / owner / wn.  KP = input width of the layer (256, or F + 64 for layer 0); FB = number of 32-wide
-// input blocks whose data gradient is produced (8 for layers 1..3, F / 32 for layer 0).
-template <bool LAYER3, int KP, int FB, bool FEAT_OUT>
+// input blocks whose data gradient is produced (8 for layers 1..3, F / 32 for layer 0).  X2: row tiles of 64 (two planes of dZ and
+// two of A_{l-1} take the LDS the 128-row tile of the bf16 mode takes), three matrix instructions per fragment pair.
+template <bool LAYER3, int KP, int FB, bool FEAT_OUT, bool X2>
 __global__ __launch_bounds__(512, 2) void pair_mlp_bwd_kernel(PairBwdArgs a) {
+    constexpr int TILE = X2 ? 64 : kPTile;   // rows per tile
     constexpr int NIB = KP / 32;             // dW column blocks per wave (one 32-row output block per wave)
     constexpr int PITCH_P = (KP * 2 + 255) / 256 * 256 + 64;     // previous activations (transposed reads only): pitch = 64 mod 256 bytes
+    constexpr int ZP = TILE * kPitchR, PP = TILE * PITCH_P;      // bytes of one plane
+    constexpr int NPL = X2 ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
-    unsigned char* Z = dsmem;                               // [128][528]  dZ (bf16): row reads + transposed reads
-    unsigned char* Pt = dsmem + kPTile * kPitchR;           // [128][PITCH_P] A_{l-1}; later the staging area of dA_{l-1}
+    unsigned char* Z = dsmem;                               // [NPL][TILE][528]  dZ (bf16): row reads + transposed reads
+    unsigned char* Pt = dsmem + NPL * ZP;                   // [NPL][TILE][PITCH_P] A_{l-1}; later the staging area of dA_{l-1}
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     f32x16 dw[NIB];
@@ -373,18 +464,18 @@ __global__ __launch_bounds__(512, 2) void pair_mlp_bwd_kernel(PairBwdArgs a) {
     const uint32_t zt1 = zt0 + 8 * kPitchR;
     const uint32_t pt0 = pm_lds_addr(Pt) + (4 * th + tq) * PITCH_P + (16 * (grp & 1) + 4 * tp) * 2;
     const uint32_t pt1 = pt0 + 8 * PITCH_P;
-    const int64_t ntiles = (a.Q + kPTile - 1) / kPTile;
+    const int64_t ntiles = (a.Q + TILE - 1) / TILE;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t row0 = tile * kPTile;
+        const int64_t row0 = tile * TILE;
         // ---- load: dZ = dA * leaky'(A) -> Z, bias-gradient partials; A_{l-1} -> Pt -----------------------------------------
         // (the 128 dW accumulators stay live through this phase: a few rows in flight per thread, not all eight)
 #pragma unroll LAYER3 ? 2 : 4
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < TILE / 16; ++it) {
             const int cidx = it * 512 + tid, row = cidx >> 5, chunk = cidx & 31;       // chunk = tid & 31 for every it
             const int64_t q = row0 + row;
-            bf16x8 z;
+            float dz[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) z[j] = (__bf16)0.f;
+            for (int j = 0; j < 8; ++j) dz[j] = 0.f;
             if (q < a.Q) {
                 const bf16x8 act = *reinterpret_cast<const bf16x8*>(a.A + q * kPH + chunk * 8);
                 float g[8];
@@ -399,51 +490,72 @@ __global__ __launch_bounds__(512, 2) void pair_mlp_bwd_kernel(PairBwdArgs a) {
                     const bf16x8 gv = *reinterpret_cast<const bf16x8*>(a.dA + q * kPH + chunk * 8);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) g[j] = (float)gv[j];
+                    if (X2) {
+                        const bf16x8 gl = *reinterpret_cast<const bf16x8*>(a.dA + (a.Q + q) * kPH + chunk * 8);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) g[j] += (float)gl[j];
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    z[j] = (__bf16)(g[j] * ((float)act[j] > 0.f ? 1.f : kPSlope));
-                    db[j] += (float)z[j];                  // the bias gradient sums the rounded values the matrix products see
+                    dz[j] = g[j] * ((float)act[j] > 0.f ? 1.f : kPSlope);
+                    if (!X2) dz[j] = (float)(__bf16)dz[j];  // bf16 mode: the bias gradient sums the rounded values the matrix products see
+                    db[j] += dz[j];
                 }
             }
-            *reinterpret_cast<bf16x8*>(Z + row_off(row, chunk)) = z;
+            pm_put8<X2>(Z + row_off(row, chunk), ZP, dz);
         }
         constexpr int CPR = KP / 8;                        // 16-byte chunks per row of A_{l-1}
-        for (int c = tid; c < kPTile * CPR; c += 512) {
-            const int row = c / CPR, chunk = c - row * CPR;
-            const int64_t q = row0 + row;
-            u32x4 v = {0, 0, 0, 0};
-            if (q < a.Q) v = *reinterpret_cast<const u32x4*>(a.Aprev + q * KP + chunk * 8);
-            *reinterpret_cast<u32x4*>(Pt + row * PITCH_P + (chunk << 4)) = v;
-        }
-        __syncthreads();
-        // ---- dW[o-block = wave][all input blocks] += dZ^T A_{l-1}  (K = the tile's 128 rows) ---------------------------------
-        {
-            bf16x8 zf[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) zf[s] = pm_tr_frag(zt0, zt1, s * 16 * kPitchR);
+        for (int pl = 0; pl < NPL; ++pl)
+            for (int c = tid; c < TILE * CPR; c += 512) {
+                const int row = c / CPR, chunk = c - row * CPR;
+                const int64_t q = row0 + row;
+                u32x4 v = {0, 0, 0, 0};
+                if (q < a.Q) v = *reinterpret_cast<const u32x4*>(a.Aprev + (pl * a.Q + q) * KP + chunk * 8);
+                *reinterpret_cast<u32x4*>(Pt + pl * PP + row * PITCH_P + (chunk << 4)) = v;
+            }
+        __syncthreads();
+        // ---- dW[o-block = wave][all input blocks] += dZ^T A_{l-1}  (K = the tile's rows) -------------------------------------
+        {
+            constexpr int KS = TILE / 16;
+            bf16x8 zf[KS], zl[X2 ? KS : 1];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                zf[s] = pm_tr_frag(zt0, zt1, s * 16 * kPitchR);
+                if (X2) zl[s] = pm_tr_frag(zt0, zt1, ZP + s * 16 * kPitchR);
+            }
             pm_lds_wait();
 #pragma unroll
             for (int ib = 0; ib < NIB; ++ib) {
 #pragma unroll
-                for (int s4 = 0; s4 < 8; s4 += 4) {          // four k-steps at a time: 16 transient registers instead of 32
-                    bf16x8 pf[4];
+                for (int s4 = 0; s4 < KS; s4 += 4) {         // four k-steps at a time: 16 transient registers instead of 32
+                    bf16x8 pf[4], pfl[X2 ? 4 : 1];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) pf[s] = pm_tr_frag(pt0, pt1, (s4 + s) * 16 * PITCH_P + ib * 64);
+                    for (int s = 0; s < 4; ++s) {
+                        pf[s] = pm_tr_frag(pt0, pt1, (s4 + s) * 16 * PITCH_P + ib * 64);
+                        if (X2) pfl[s] = pm_tr_frag(pt0, pt1, PP + (s4 + s) * 16 * PITCH_P + ib * 64);
+                    }
                     pm_lds_wait();
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) dw[ib] = BF16::mfma32(zf[s4 + s], pf[s], dw[ib]);
+                    for (int s = 0; s < 4; ++s) {
+                        if (X2) {
+                            dw[ib] = BF16::mfma32(zl[s4 + s], pf[s], dw[ib]);
+                            dw[ib] = BF16::mfma32(zf[s4 + s], pfl[s], dw[ib]);
+                        }
+                        dw[ib] = BF16::mfma32(zf[s4 + s], pf[s], dw[ib]);
+                    }
                 }
             }
         }
-        // ---- dA_{l-1}^T[i-block][rows] = W^T dZ^T : wave w owns input block w (FB of them), all four 32-row blocks -----------
+        // ---- dA_{l-1}^T[i-block][rows] = W^T dZ^T : wave w owns input block w (FB of them), all 32-row blocks ---------------------
         {
             const bool mine = wave < FB;                   // wave-uniform
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {         // two 64-row halves: 32 accumulator registers at a time
+            for (int half = 0; half < TILE / 64; ++half) { // 64-row halves: 32 accumulator registers at a time
                 f32x16 acc[1][2];
-                if (mine) pm_layer_mfma<kPH / 16, 1, 2>(Z + half * 64 * kPitchR, kPitchR, a.wT, nullptr, wave, lane, acc, 2);
+                if (mine) pm_layer_mfma<kPH / 16, 1, 2, X2>(Z + half * 64 * kPitchR, kPitchR, a.wT, nullptr, wave, lane, acc, 2, ZP, a.wlo);
                 if (half == 0) __syncthreads();            // every wave is done with Pt (the dW products' operand)
                 if (mine) {
                     if (FEAT_OUT) {                        // layer 0: fp32 feature gradient rows, 4 consecutive columns per lane
@@ -457,17 +569,21 @@ __global__ __launch_bounds__(512, 2) void pair_mlp_bwd_kernel(PairBwdArgs a) {
                                         f32x4{acc[0][cb][4 * g], acc[0][cb][4 * g + 1], acc[0][cb][4 * g + 2], acc[0][cb][4 * g + 3]};
                             }
                     } else {
-                        pm_layer_store<false, 1, 2>(Pt + half * 64 * PITCH_P, PITCH_P, wave, lane, acc, 2);
+                        pm_layer_store<false, 1, 2, X2>(Pt + half * 64 * PITCH_P, PITCH_P, wave, lane, acc, 2, PP);
                     }
                 }
             }
             if (!FEAT_OUT) {
                 __syncthreads();
-                for (int c = tid; c < kPTile * 32; c += 512) {
-                    const int row = c >> 5, chunk = c & 31;
-                    const int64_t q = row0 + row;
-                    if (q < a.Q) *reinterpret_cast<u32x4*>(a.dAprev + q * kPH + chunk * 8) = *reinterpret_cast<const u32x4*>(Pt + row * PITCH_P + (chunk << 4));
-                }
+#pragma unroll
+                for (int pl = 0; pl < NPL; ++pl)
+                    for (int c = tid; c < TILE * 32; c += 512) {
+                        const int row = c >> 5, chunk = c & 31;
+                        const int64_t q = row0 + row;
+                        if (q < a.Q)
+                            *reinterpret_cast<u32x4*>(a.dAprev + (pl * a.Q + q) * kPH + chunk * 8) =
+                                *reinterpret_cast<const u32x4*>(Pt + pl * PP + row * PITCH_P + (chunk << 4));
+                    }
             }
         }
         __syncthreads();
@@ -521,15 +637,19 @@ __global__ __launch_bounds__(256) void pair_slab_sum_kernel(const float* __restr
 
 using namespace npcd;
 
-static int pm_check(int feat_dim) { return (feat_dim == 32 || feat_dim == 128) ? NPCD_OK : NPCD_ERR_UNSUPPORTED; }
-
-extern "C" int64_t npcd_pair_mlp_wpack_bytes(int feat_dim) {
-    if (pm_check(feat_dim) != NPCD_OK) return -1;
-    return pl_total(feat_dim);
+static int pm_check(int feat_dim, int precision = 0) {
+    if (precision != 0 && precision != 1) return NPCD_ERR_UNSUPPORTED;
+    return (feat_dim == 32 || feat_dim == 128) ? NPCD_OK : NPCD_ERR_UNSUPPORTED;
 }
 
-extern "C" int npcd_pair_mlp_pack(const float* const* weights_dev, const float* const* biases_dev, int feat_dim, void* wpack_dev, void* stream) {
-    int rc = pm_check(feat_dim);
+extern "C" int64_t npcd_pair_mlp_wpack_bytes(int feat_dim, int precision) {
+    if (pm_check(feat_dim, precision) != NPCD_OK) return -1;
+    return pl_total(feat_dim, precision == 1);
+}
+
+extern "C" int npcd_pair_mlp_pack(const float* const* weights_dev, const float* const* biases_dev, int feat_dim, int precision, void* wpack_dev,
+                                  void* stream) {
+    int rc = pm_check(feat_dim, precision);
     if (rc != NPCD_OK) return rc;
     if (!weights_dev || !biases_dev || !wpack_dev) return NPCD_ERR_ARG;
     PackArgs a;
@@ -540,18 +660,30 @@ extern "C" int npcd_pair_mlp_pack(const float* const* weights_dev, const float* 
     }
     a.out = static_cast<unsigned char*>(wpack_dev);
     a.feat_dim = feat_dim;
-    const int64_t pieces = pl_bias(feat_dim, 0) / 16;
+    a.x2 = precision == 1;
+    const int64_t pieces = pl_mats(feat_dim) / 16 * (a.x2 ? 2 : 1);
     hipLaunchKernelGGL(pair_pack_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }
 
-extern "C" int npcd_pair_mlp_fwd(const void* wpack, int feat_dim, const int64_t* nb_idx, const float* pts, const float* kp_pos,
+template <int FEAT, bool X2>
+static hipError_t pm_launch_fwd(const PairFwdArgs& a, int grid, hipStream_t st) {
+    constexpr int lds = (X2 ? 2 : 1) * kPTile * kPitchR + kPTile * 4 + 32 * 4;
+    static DynLds attr;
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(pair_mlp_fwd_kernel<FEAT, X2>), lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((pair_mlp_fwd_kernel<FEAT, X2>), dim3(grid), dim3(X2 ? 512 : 256), lds, st, a);
+    return hipGetLastError();
+}
+
+extern "C" int npcd_pair_mlp_fwd(const void* wpack, int feat_dim, int precision, const int64_t* nb_idx, const float* pts, const float* kp_pos,
                                  const float* kp_feat, const int64_t* off, int64_t n_points, int k, int64_t n_pairs, void* x0, void* acts,
                                  float* wn, float* G, void* stream) {
-    int rc = pm_check(feat_dim);
+    int rc = pm_check(feat_dim, precision);
     if (rc != NPCD_OK) return rc;
-    if (!wpack || !nb_idx || !pts || !kp_pos || !kp_feat || !off || !x0 || !acts || !wn || !G) return NPCD_ERR_ARG;
+    if (!wpack || !nb_idx || !pts || !kp_pos || !kp_feat || !off || !G) return NPCD_ERR_ARG;
+    if ((x0 == nullptr) != (acts == nullptr) || (x0 == nullptr) != (wn == nullptr)) return NPCD_ERR_ARG;     // saved for the backward: all or none
     if (k <= 0 || k > 8 || n_points < 0 || n_pairs < 0) return NPCD_ERR_ARG;
     if (n_points == 0) return NPCD_OK;
     PairFwdArgs a;
@@ -559,75 +691,84 @@ extern "C" int npcd_pair_mlp_fwd(const void* wpack, int feat_dim, const int64_t*
     a.nb_idx = nb_idx; a.pts = pts; a.kp_pos = kp_pos; a.kp_feat = kp_feat; a.off = off;
     a.P = n_points; a.Q = n_pairs; a.k = k;
     a.x0 = static_cast<__bf16*>(x0); a.acts = static_cast<__bf16*>(acts); a.wn = wn; a.G = G;
-    const int lds = kPTile * kPitchR + kPTile * 4 + 32 * 4;
-    static DynLds l32, l128;
-    NPCD_HIP_CHECK(l32.ensure(reinterpret_cast<const void*>(pair_mlp_fwd_kernel<32>), lds));
-    NPCD_HIP_CHECK(l128.ensure(reinterpret_cast<const void*>(pair_mlp_fwd_kernel<128>), lds));
     const int64_t tiles = (n_points + 15) / 16;
-    const int grid = (int)(tiles < 512 ? tiles : 512);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (feat_dim == 32) hipLaunchKernelGGL(pair_mlp_fwd_kernel<32>, dim3(grid), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(pair_mlp_fwd_kernel<128>, dim3(grid), dim3(256), lds, st, a);
-    NPCD_HIP_CHECK(hipGetLastError());
+    hipError_t e;
+    if (precision == 1) {
+        const int grid = (int)(tiles < 256 ? tiles : 256);          // one 512-thread workgroup per CU
+        e = feat_dim == 32 ? pm_launch_fwd<32, true>(a, grid, st) : pm_launch_fwd<128, true>(a, grid, st);
+    } else {
+        const int grid = (int)(tiles < 512 ? tiles : 512);
+        e = feat_dim == 32 ? pm_launch_fwd<32, false>(a, grid, st) : pm_launch_fwd<128, false>(a, grid, st);
+    }
+    NPCD_HIP_CHECK(e);
     return NPCD_OK;
 }
 
-extern "C" int npcd_pair_mlp_bwd_slabs(int64_t n_pairs) {
-    const int64_t tiles = (n_pairs + kPTile - 1) / kPTile;
+extern "C" int npcd_pair_mlp_bwd_slabs(int64_t n_pairs, int precision) {
+    const int rows = precision == 1 ? 64 : kPTile;
+    const int64_t tiles = (n_pairs + rows - 1) / rows;
     return (int)(tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256);
 }
 
-extern "C" int64_t npcd_pair_mlp_bwd_workspace_floats(int feat_dim, int64_t n_pairs) {
-    if (pm_check(feat_dim) != NPCD_OK) return -1;
+extern "C" int64_t npcd_pair_mlp_bwd_workspace_floats(int feat_dim, int64_t n_pairs, int precision) {
+    if (pm_check(feat_dim, precision) != NPCD_OK) return -1;
     const int kmax = feat_dim + kPEnc > kPH ? feat_dim + kPEnc : kPH;
-    return (int64_t)npcd_pair_mlp_bwd_slabs(n_pairs) * ((int64_t)kPH * kmax + kPH) + (int64_t)kPH * kmax + kPH;   // slabs + one summed slab
+    return (int64_t)npcd_pair_mlp_bwd_slabs(n_pairs, precision) * ((int64_t)kPH * kmax + kPH) + (int64_t)kPH * kmax + kPH;   // slabs + one summed slab
 }
 
-template <bool L3, int KP, int FB, bool FO>
+template <bool L3, int KP, int FB, bool FO, bool X2>
 static hipError_t pm_launch_bwd(const PairBwdArgs& a, int grid, hipStream_t st) {
-    constexpr int lds = kPTile * kPitchR + kPTile * ((KP * 2 + 255) / 256 * 256 + 64);
+    constexpr int TILE = X2 ? 64 : kPTile;
+    constexpr int lds = (X2 ? 2 : 1) * (TILE * kPitchR + TILE * ((KP * 2 + 255) / 256 * 256 + 64));
     static DynLds attr;
-    hipError_t e = attr.ensure(reinterpret_cast<const void*>(pair_mlp_bwd_kernel<L3, KP, FB, FO>), lds);
+    hipError_t e = attr.ensure(reinterpret_cast<const void*>(pair_mlp_bwd_kernel<L3, KP, FB, FO, X2>), lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((pair_mlp_bwd_kernel<L3, KP, FB, FO>), dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL((pair_mlp_bwd_kernel<L3, KP, FB, FO, X2>), dim3(grid), dim3(512), lds, st, a);
     return hipGetLastError();
 }
+template <bool X2>
+static hipError_t pm_launch_bwd_layer(const PairBwdArgs& a, int l, int feat_dim, int grid, hipStream_t st) {
+    if (l == 3) return pm_launch_bwd<true, 256, 8, false, X2>(a, grid, st);
+    if (l > 0) return pm_launch_bwd<false, 256, 8, false, X2>(a, grid, st);
+    if (feat_dim == 32) return pm_launch_bwd<false, 96, 1, true, X2>(a, grid, st);
+    return pm_launch_bwd<false, 192, 4, true, X2>(a, grid, st);
+}
 
-// dG [P,256] fp32; x0 [Q,F+64], acts [4][Q][256] bf16 (from the forward); dact: workspace 2 x [Q][256] bf16; dfeat [Q,F] fp32 out;
-// part: npcd_pair_mlp_bwd_workspace_floats(); dW[l] fp32 [256, in_l] (in_0 = F + 63), db[l] fp32 [256]: overwritten.
-extern "C" int npcd_pair_mlp_bwd(const void* wpack, int feat_dim, const float* dG, const int64_t* owner, const float* wn, const void* x0,
-                                 const void* acts, int64_t n_pairs, void* dact, float* dfeat, float* part, float* const* dW, float* const* db,
-                                 void* stream) {
-    int rc = pm_check(feat_dim);
+// dG [P,256] fp32; x0 [Q,F+64], acts [4][Q][256] bf16 (from the forward; precision 1: two planes each, see PairFwdArgs); dact: workspace
+// 2 x [Q][256] bf16 (precision 1: 2 x 2 x [Q][256]); dfeat [Q,F] fp32 out; part: npcd_pair_mlp_bwd_workspace_floats(); dW[l] fp32
+// [256, in_l] (in_0 = F + 63), db[l] fp32 [256]: overwritten.
+extern "C" int npcd_pair_mlp_bwd(const void* wpack, int feat_dim, int precision, const float* dG, const int64_t* owner, const float* wn,
+                                 const void* x0, const void* acts, int64_t n_pairs, void* dact, float* dfeat, float* part, float* const* dW,
+                                 float* const* db, void* stream) {
+    int rc = pm_check(feat_dim, precision);
     if (rc != NPCD_OK) return rc;
     if (!wpack || !dG || !owner || !wn || !x0 || !acts || !dact || !dfeat || !part || !dW || !db) return NPCD_ERR_ARG;
     for (int l = 0; l < 4; ++l)
         if (!dW[l] || !db[l]) return NPCD_ERR_ARG;
     if (n_pairs <= 0) return NPCD_ERR_ARG;
+    const bool x2 = precision == 1;
+    const int npl = x2 ? 2 : 1;
     const unsigned char* wp = static_cast<const unsigned char*>(wpack);
     const __bf16* A = static_cast<const __bf16*>(acts);
     __bf16* d0 = static_cast<__bf16*>(dact);
-    __bf16* d1 = d0 + n_pairs * kPH;
+    __bf16* d1 = d0 + (int64_t)npl * n_pairs * kPH;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int grid = npcd_pair_mlp_bwd_slabs(n_pairs);
+    const int grid = npcd_pair_mlp_bwd_slabs(n_pairs, precision);
     const int in0 = feat_dim + 3 + 6 * kPFreqs;
     for (int l = 3; l >= 0; --l) {
         PairBwdArgs a{};
         a.wT = wp + pl_bw(feat_dim, l);
+        a.wlo = x2 ? pl_mats(feat_dim) : 0;
         a.dG = dG; a.owner = owner; a.wn = wn;
-        a.A = A + (int64_t)l * n_pairs * kPH;
-        a.Aprev = l > 0 ? A + (int64_t)(l - 1) * n_pairs * kPH : static_cast<const __bf16*>(x0);
+        a.A = A + (int64_t)l * npl * n_pairs * kPH;
+        a.Aprev = l > 0 ? A + (int64_t)(l - 1) * npl * n_pairs * kPH : static_cast<const __bf16*>(x0);
         a.Q = n_pairs;
         a.dA = (l & 1) ? d1 : d0;          // written by layer l + 1
         a.dAprev = (l & 1) ? d0 : d1;
         a.dfeat = dfeat;
         a.part = part;
-        hipError_t e;
-        if (l == 3) e = pm_launch_bwd<true, 256, 8, false>(a, grid, st);
-        else if (l > 0) e = pm_launch_bwd<false, 256, 8, false>(a, grid, st);
-        else if (feat_dim == 32) e = pm_launch_bwd<false, 96, 1, true>(a, grid, st);
-        else e = pm_launch_bwd<false, 192, 4, true>(a, grid, st);
-        NPCD_HIP_CHECK(e);
+        NPCD_HIP_CHECK(x2 ? pm_launch_bwd_layer<true>(a, l, feat_dim, grid, st) : pm_launch_bwd_layer<false>(a, l, feat_dim, grid, st));
         const int KP = l > 0 ? kPH : feat_dim + kPEnc;
         const int64_t slab = (int64_t)kPH * KP + kPH;
         if (l > 0) {

@@ -421,55 +421,72 @@ def leaky_bwd_colsum(dz, z, slope):
     return dy, db
 
 
+PAIR_MLP_BF16, PAIR_MLP_X2 = 0, 1          # `precision` of the npcd_pair_mlp_* entry points (include/npcd_hip.h)
+
+
 class _PairMLP(torch.autograd.Function):
     """The four non-linear layers of the per-pair aggregator network + the inverse-distance mean over each point's pairs, forward
-    and backward on the matrix cores (csrc/pairs_mlp.hip: bf16 operands, fp32 accumulation, fp32 weight / bias gradients).
+    and backward on the matrix cores (csrc/pairs_mlp.hip).  precision PAIR_MLP_BF16: bf16 operands, fp32 accumulation (narrower than
+    the reference); PAIR_MLP_X2: fp32-class -- every operand as two bf16 halves, three matrix instructions per product, ~1e-5
+    relative; fp32 weight / bias gradients either way.
     feat [Nt, F] (differentiable), w0, b0 .. w3, b3 (differentiable), nb [P, k] int64 (-1 pad), pts [P, 3], pos [Nt, 3],
     off / owner / flat: the compact pair lists of csrc/pairs.hip  ->  G [P, 256] fp32."""
 
     @staticmethod
-    def forward(ctx, feat, w0, b0, w1, b1, w2, b2, w3, b3, nb, pts, pos, off, owner, flat):
-        G, wpack, x0, acts, wn = pair_mlp_forward_raw(feat, (w0, w1, w2, w3), (b0, b1, b2, b3), nb, pts, pos, off, flat.numel())
+    def forward(ctx, feat, w0, b0, w1, b1, w2, b2, w3, b3, nb, pts, pos, off, owner, flat, precision):
+        G, wpack, x0, acts, wn = pair_mlp_forward_raw(feat, (w0, w1, w2, w3), (b0, b1, b2, b3), nb, pts, pos, off, flat.numel(), precision)
         ctx.save_for_backward(wpack, x0, acts, wn, owner.contiguous(), flat.contiguous())
-        ctx.dims = (feat.shape[0], feat.shape[1], tuple(tuple(w.shape) for w in (w0, w1, w2, w3)))
+        ctx.dims = (feat.shape[0], feat.shape[1], tuple(tuple(w.shape) for w in (w0, w1, w2, w3)), precision)
         return G
 
     @staticmethod
     def backward(ctx, dG):
         wpack, x0, acts, wn, owner, flat = ctx.saved_tensors
-        Nt, F_, wshapes = ctx.dims
-        dfeat_tab, dW, db = pair_mlp_backward_raw(dG, wpack, x0, acts, wn, owner, flat, Nt, F_, wshapes)
-        return (dfeat_tab, dW[0], db[0], dW[1], db[1], dW[2], db[2], dW[3], db[3], None, None, None, None, None, None)
+        Nt, F_, wshapes, precision = ctx.dims
+        dfeat_tab, dW, db = pair_mlp_backward_raw(dG, wpack, x0, acts, wn, owner, flat, Nt, F_, wshapes, precision)
+        return (dfeat_tab, dW[0], db[0], dW[1], db[1], dW[2], db[2], dW[3], db[3], None, None, None, None, None, None, None)
 
 
-def pair_mlp_forward_raw(feat, weights, biases, nb, pts, pos, off, Q):
-    """npcd_pair_mlp_pack + npcd_pair_mlp_fwd -> (G [P,256] fp32, wpack, x0 [Q,F+64] bf16, acts [4,Q,256] bf16, wn [Q] fp32)."""
+def pair_mlp_pack(weights, biases, F_, precision, dev):
+    """npcd_pair_mlp_pack: the four (weight, bias) pairs -> the packed fragment buffer of the given precision."""
+    L = lib()
+    ws = [t.detach().to(_f32).contiguous() for t in weights]
+    bs = [t.detach().to(_f32).contiguous() for t in biases]
+    nbytes = L.npcd_pair_mlp_wpack_bytes(F_, precision)
+    if nbytes < 0:
+        raise RuntimeError(f"the fused pair MLP supports feat_dim in (32, 128) and precision 0 / 1; got {F_} / {precision}")
+    wpack = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    wp = (ctypes.c_void_p * 4)(*[w.data_ptr() for w in ws])
+    bp = (ctypes.c_void_p * 4)(*[b.data_ptr() for b in bs])
+    check(L.npcd_pair_mlp_pack(wp, bp, F_, precision, ptr(wpack), stream_ptr()), "npcd_pair_mlp_pack")
+    return wpack
+
+
+def pair_mlp_forward_raw(feat, weights, biases, nb, pts, pos, off, Q, precision=PAIR_MLP_BF16, save=True, wpack=None):
+    """npcd_pair_mlp_pack + npcd_pair_mlp_fwd -> (G [P,256] fp32, wpack, x0 [(2,) Q,F+64] bf16, acts [4,(2,) Q,256] bf16, wn [Q] fp32);
+    the 16-bit arrays hold two planes (hi, lo) at PAIR_MLP_X2.  save=False (rendering): nothing is kept for a backward."""
     require_gpu(feat, nb, pts, pos, off)
     L = lib()
     F_ = feat.shape[1]
     P, k = nb.shape
     dev = feat.device
-    ws = [t.detach().to(_f32).contiguous() for t in weights]
-    bs = [t.detach().to(_f32).contiguous() for t in biases]
-    nbytes = L.npcd_pair_mlp_wpack_bytes(F_)
-    if nbytes < 0:
-        raise RuntimeError(f"the fused pair MLP supports feat_dim in (32, 128); got {F_}")
-    wpack = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    wp = (ctypes.c_void_p * 4)(*[w.data_ptr() for w in ws])
-    bp = (ctypes.c_void_p * 4)(*[b.data_ptr() for b in bs])
-    check(L.npcd_pair_mlp_pack(wp, bp, F_, ptr(wpack), stream_ptr()), "npcd_pair_mlp_pack")
+    if wpack is None:
+        wpack = pair_mlp_pack(weights, biases, F_, precision, dev)
     feat_c, pts_c, pos_c = feat.detach().to(_f32).contiguous(), pts.to(_f32).contiguous(), pos.to(_f32).contiguous()
     nb_c, off_c = nb.contiguous(), off.contiguous()
-    x0 = torch.empty((max(Q, 1), F_ + 64), dtype=torch.bfloat16, device=dev)
-    acts = torch.empty((4, max(Q, 1), 256), dtype=torch.bfloat16, device=dev)
-    wn = torch.empty(max(Q, 1), dtype=_f32, device=dev)
+    planes = (2,) if precision == PAIR_MLP_X2 else ()
+    x0 = acts = wn = None
+    if save:
+        x0 = torch.empty(planes + (max(Q, 1), F_ + 64), dtype=torch.bfloat16, device=dev)
+        acts = torch.empty((4,) + planes + (max(Q, 1), 256), dtype=torch.bfloat16, device=dev)
+        wn = torch.empty(max(Q, 1), dtype=_f32, device=dev)
     G = torch.zeros((P, 256), dtype=_f32, device=dev)
-    check(L.npcd_pair_mlp_fwd(ptr(wpack), F_, ptr(nb_c), ptr(pts_c), ptr(pos_c), ptr(feat_c), ptr(off_c), P, k, Q, ptr(x0), ptr(acts),
+    check(L.npcd_pair_mlp_fwd(ptr(wpack), F_, precision, ptr(nb_c), ptr(pts_c), ptr(pos_c), ptr(feat_c), ptr(off_c), P, k, Q, ptr(x0), ptr(acts),
                               ptr(wn), ptr(G), stream_ptr()), "npcd_pair_mlp_fwd")
     return G, wpack, x0, acts, wn
 
 
-def pair_mlp_backward_raw(dG, wpack, x0, acts, wn, owner, flat, Nt, F_, wshapes):
+def pair_mlp_backward_raw(dG, wpack, x0, acts, wn, owner, flat, Nt, F_, wshapes, precision=PAIR_MLP_BF16):
     """npcd_pair_mlp_bwd + the feature scatter -> (dfeat [Nt,F], [dW_l], [db_l]) fp32."""
     dev = dG.device
     L = lib()
@@ -481,22 +498,22 @@ def pair_mlp_backward_raw(dG, wpack, x0, acts, wn, owner, flat, Nt, F_, wshapes)
         for t in dW + db:
             t.zero_()
         return dfeat_tab, dW, db
-    dact = torch.empty((2, Q, 256), dtype=torch.bfloat16, device=dev)
+    dact = torch.empty((2, 2 if precision == PAIR_MLP_X2 else 1, Q, 256), dtype=torch.bfloat16, device=dev)
     dfeat = torch.empty((Q, F_), dtype=_f32, device=dev)
-    part = torch.empty(L.npcd_pair_mlp_bwd_workspace_floats(F_, Q), dtype=_f32, device=dev)
+    part = torch.empty(L.npcd_pair_mlp_bwd_workspace_floats(F_, Q, precision), dtype=_f32, device=dev)
     dWp = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in dW])
     dbp = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in db])
     dG = dG.contiguous().to(_f32)
-    check(L.npcd_pair_mlp_bwd(ptr(wpack), F_, ptr(dG), ptr(owner), ptr(wn), ptr(x0), ptr(acts), Q, ptr(dact),
+    check(L.npcd_pair_mlp_bwd(ptr(wpack), F_, precision, ptr(dG), ptr(owner), ptr(wn), ptr(x0), ptr(acts), Q, ptr(dact),
                               ptr(dfeat), ptr(part), dWp, dbp, stream_ptr()), "npcd_pair_mlp_bwd")
     check(L.npcd_pair_input_bwd(ptr(flat), ptr(dfeat), F_, F_, Q, ptr(dfeat_tab), stream_ptr()), "npcd_pair_input_bwd")
     return dfeat_tab, dW, db
 
 
-def pair_mlp(feat, layers, nb, pts, pos, off, owner, flat):
+def pair_mlp(feat, layers, nb, pts, pos, off, owner, flat, precision=PAIR_MLP_BF16):
     """layers: the four (weight, bias) pairs of aggregator.local_field.{0,2,4,6}."""
     (w0, b0), (w1, b1), (w2, b2), (w3, b3) = layers
-    return _PairMLP.apply(feat, w0, b0, w1, b1, w2, b2, w3, b3, nb, pts, pos, off, owner, flat)
+    return _PairMLP.apply(feat, w0, b0, w1, b1, w2, b2, w3, b3, nb, pts, pos, off, owner, flat, precision)
 
 
 def pair_input(feat, flat, owner, pts, pos, n_freqs):

@@ -138,14 +138,32 @@ def _mlp(seq, x, dtype):
     return x
 
 
-def fused_pair_mlp_ok(field, mlp_dtype) -> bool:
-    """The matrix-core pair MLP (csrc/pairs_mlp.hip) covers the published network (pointnerf.py:174-179: four LeakyReLU layers
-    of width 256 + a linear one, 10 frequency bands, feature width 32 or 128) in the bf16-operand mode of the trainer."""
+def fused_pair_mlp_precision(field, mlp_dtype):
+    """Which mode of the matrix-core pair MLP (csrc/pairs_mlp.hip) runs the four non-linear per-pair layers, or None for the library
+    GEMMs.  The fused kernels cover the published network (pointnerf.py:174-179: four LeakyReLU layers of width 256 + a linear
+    one, 10 frequency bands, feature width 32 or 128).
+      mlp_dtype None / torch.float32 (the reference's numerics, train_pointnerf.py has no autocast): PAIR_MLP_X2 -- fp32-class,
+          every operand as two bf16 halves, ~1e-5 relative per product (round 5; before: fp32 library GEMMs with every [Q, 256]
+          activation round-tripping HBM, still selectable with mlp_dtype="library" or NPCD_STAGE1_LIBRARY_FP32=1);
+      mlp_dtype torch.bfloat16: PAIR_MLP_BF16 -- bf16 operands, narrower than the reference (opt-in)."""
     agg = field.aggregator
     lf = agg.local_field
-    return (mlp_dtype == torch.bfloat16 and not os.environ.get("NPCD_NO_FUSED_PAIR_MLP") and agg.in_dim in (32, 128) and agg.n_freqs == 10
-            and len(lf) == 9 and all(isinstance(lf[i], torch.nn.Linear) and lf[i].out_features == 256 for i in (0, 2, 4, 6, 8))
-            and all(isinstance(lf[i], torch.nn.LeakyReLU) and lf[i].negative_slope == 0.01 for i in (1, 3, 5, 7)))
+    if isinstance(mlp_dtype, str) or os.environ.get("NPCD_NO_FUSED_PAIR_MLP"):
+        return None
+    covered = (agg.in_dim in (32, 128) and agg.n_freqs == 10
+               and len(lf) == 9 and all(isinstance(lf[i], torch.nn.Linear) and lf[i].out_features == 256 for i in (0, 2, 4, 6, 8))
+               and all(isinstance(lf[i], torch.nn.LeakyReLU) and lf[i].negative_slope == 0.01 for i in (1, 3, 5, 7)))
+    if not covered:
+        return None
+    if mlp_dtype == torch.bfloat16:
+        return hr.PAIR_MLP_BF16
+    if mlp_dtype in (None, torch.float32) and not os.environ.get("NPCD_STAGE1_LIBRARY_FP32"):
+        return hr.PAIR_MLP_X2
+    return None
+
+
+def fused_pair_mlp_ok(field, mlp_dtype) -> bool:
+    return fused_pair_mlp_precision(field, mlp_dtype) is not None
 
 
 def shade_autograd(field, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch.Tensor, kp_feat: torch.Tensor,
@@ -164,25 +182,31 @@ def shade_autograd(field, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch
     # the reference trains stage 1 in fp32; `field.train_mlp_dtype = torch.bfloat16` (PointNeRFTrainer(mlp_dtype=...)) is an
     # opt-in that runs the Linear layers of the three MLPs under autocast (MFMA instead of fp32 matrix instructions)
     mlp_dtype = getattr(field, "train_mlp_dtype", None)
-    if fused_pair_mlp_ok(field, mlp_dtype):
-        # bf16 mode: the four non-linear per-pair layers and the weighted mean run as ONE forward launch and one backward launch
-        # per layer on the matrix cores (csrc/pairs_mlp.hip); the network's last, linear layer commutes with the mean (the
-        # normalised weights of a point sum to one and every compact point has a pair) and runs on the points
+    precision = fused_pair_mlp_precision(field, mlp_dtype)
+    lib_dtype = None if (mlp_dtype is None or isinstance(mlp_dtype, str) or mlp_dtype == torch.float32) else mlp_dtype     # operand type of the library layers
+    if precision is not None:
+        # the four non-linear per-pair layers and the weighted mean run as ONE forward launch and one backward launch per layer on
+        # the matrix cores (csrc/pairs_mlp.hip; fp32-class by default, bf16 operands as the opt-in); the network's last, linear
+        # layer commutes with the mean (the normalised weights of a point sum to one and every compact point has a pair) and runs
+        # on the points
         lf = agg.local_field
         G = hr.pair_mlp(kp_feat.reshape(-1, kp_feat.shape[-1]), [(lf[i].weight, lf[i].bias) for i in (0, 2, 4, 6)], nb_idx, pts,
-                        kp_pos.detach().reshape(-1, 3), off, owner, flat)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            agg_feat = lf[8](G).float()
+                        kp_pos.detach().reshape(-1, 3), off, owner, flat, precision)
+        if precision == hr.PAIR_MLP_BF16:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                agg_feat = lf[8](G).float()
+        else:
+            agg_feat = _mlp(torch.nn.Sequential(lf[8]), G, None).float()
     else:
         # MLP input of every pair and its inverse-distance weight: one HIP kernel forward, one backward (csrc/pairs.hip)
         x0, w = hr.pair_input(kp_feat.reshape(-1, kp_feat.shape[-1]), flat, owner, pts, kp_pos.detach().reshape(-1, 3), agg.n_freqs)
-        local = _mlp(agg.local_field, x0, mlp_dtype).float()
+        local = _mlp(agg.local_field, x0, lib_dtype).float()
         agg_feat = hr.pair_aggregate(local, w, off, cnt)         # weighted mean over each point's pairs (HIP fwd + bwd)
     chan_in = agg_feat
     if field.use_dir:
         from .field import encode_dir
         chan_in = torch.cat((agg_feat, encode_dir(point_dir, field.dir_freqs)), dim=-1)
-    shape, chan = _mlp(field.shape_net, agg_feat, mlp_dtype).float(), _mlp(field.channel_net, chan_in, mlp_dtype).float()
+    shape, chan = _mlp(field.shape_net, agg_feat, lib_dtype).float(), _mlp(field.channel_net, chan_in, lib_dtype).float()
     sigma = F.softplus(shape - 1.0)[:, 0]
     rgb = torch.sigmoid(chan)
     return sigma, rgb

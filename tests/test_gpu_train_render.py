@@ -172,10 +172,11 @@ def test_losses_match_reference_golden_and_oracle(golden):
     assert isinstance(PointNeRFLoss(net), torch.nn.Module)
 
 
-@pytest.mark.parametrize("mlp_dtype", [None, torch.bfloat16])
+@pytest.mark.parametrize("mlp_dtype", [None, "library", torch.bfloat16])
 def test_stage1_training_step_reduces_the_loss(mlp_dtype):
     """PointNeRFTrainer on a synthetic target: images rendered from a 'teacher' feature table; the student starts from zeros.
-    mlp_dtype None = the reference's fp32; torch.bfloat16 = the matrix-core pair MLP (csrc/pairs_mlp.hip), which must be engaged."""
+    mlp_dtype None = the reference's numerics on the fp32-class matrix-core pair MLP (csrc/pairs_mlp.hip precision 1), "library" = fp32
+    library GEMMs for every layer, torch.bfloat16 = the bf16-operand pair MLP; the fused kernels must be engaged where they are named."""
     from npcd.train import PointNeRFTrainer
     B, Tn, N, F_, res = 2, 2, 512, 32, 32
     coords, feats = orr.synthetic_cloud(N, F_, B, seed=8)
@@ -199,7 +200,8 @@ def test_stage1_training_step_reduces_the_loss(mlp_dtype):
         pn.feats.get_emb().weight.view(B, N, 2 * F_)[..., F_:] = -6.0                                      # small variance
     coords_before = pn.get_all_coords().clone()
     trainer = PointNeRFTrainer(net, lr=2e-3, mlp_dtype=mlp_dtype)
-    assert ("csrc/pairs_mlp.hip" in trainer.describe()) == (mlp_dtype is not None)
+    assert ("csrc/pairs_mlp.hip" in trainer.describe()) == (mlp_dtype != "library")
+    assert ("fp32-class" in trainer.describe()) == (mlp_dtype is None)
     sample = {"images": images, "intrinsics": intr, "extrinsics": extr, "obj_idx": torch.arange(B, device="cuda")}
     torch.manual_seed(0)
     losses = [float(trainer.step(sample)[0]) for _ in range(40)]
@@ -332,6 +334,98 @@ def test_pair_input_and_aggregate_kernels_vs_torch():
     (aggr * ga).sum().backward()
     assert torch.allclose(agg, aggr, atol=1e-5) and torch.allclose(g2, local.grad, atol=1e-6)
     assert float(agg[7].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("F_", [32, 128])
+def test_fused_pair_mlp_fp32_class_mode(F_):
+    """precision = PAIR_MLP_X2 of csrc/pairs_mlp.hip: every operand as two bf16 halves, three matrix instructions per product, fp32
+    accumulation.  Against a float64 restatement of the same network (npcd_pair_input's rows -> four Linear + LeakyReLU(0.01) ->
+    weighted mean):
+      forward: G to rel-L2 <= 5e-5 (bf16 mode: 2e-2; an fp32 GEMM chain sits at ~1e-6);
+      backward, layer by layer from the kernels' own stored activations (so that a LeakyReLU unit whose tiny pre-activation falls on
+      the other side of zero does not decide the comparison): every gradient to rel-L2 <= 1e-4;
+      backward end to end against float64 autograd: <= 5e-3 -- what is left are those units (slope 1 against 0.01), the same
+      effect two fp32 implementations with different summation orders show at ~3e-4.
+    Same ragged lists as the bf16 test; bitwise reproducible weight gradients."""
+    import torch.nn.functional as F
+    from npcd.hip import render as hr
+    torch.manual_seed(F_ + 1)
+    P, k, Nt = 1237, 8, 300
+    cnt = torch.randint(1, k + 1, (P,))
+    cnt[16:32] = 1
+    nb = torch.full((P, k), -1, dtype=torch.long)
+    for p in range(P):
+        nb[p, :cnt[p]] = torch.randperm(Nt)[:cnt[p]]
+    nb = nb.cuda()
+    pts = (torch.rand(P, 3) - 0.5).cuda()
+    pos = (torch.rand(Nt, 3) - 0.5).cuda()
+    feat = torch.randn(Nt, F_).cuda().requires_grad_(True)
+    dims = [F_ + 63, 256, 256, 256, 256]
+    lins = [torch.nn.Linear(dims[i], dims[i + 1]).cuda() for i in range(4)]
+    valid = nb >= 0
+    owner, col = torch.nonzero(valid, as_tuple=True)
+    flat = nb[owner, col]
+    c = valid.sum(dim=1)
+    off = torch.cumsum(c, 0) - c
+    gout = torch.randn(P, 256).cuda()
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    names = ["feat"] + [f"{n}{i}" for i in range(4) for n in ("W", "b")]
+    X2 = hr.PAIR_MLP_X2
+    layers = [(lin.weight, lin.bias) for lin in lins]
+    G = hr.pair_mlp(feat, layers, nb, pts, pos, off, owner, flat, X2)
+    (G * gout).sum().backward()
+    got = [feat.grad.clone()] + [p_.grad.clone() for lin in lins for p_ in (lin.weight, lin.bias)]
+    feat.grad = None
+    for lin in lins:
+        lin.weight.grad = lin.bias.grad = None
+    # ---- float64 restatement (the input rows and weights of the fp32 kernel npcd_pair_input, everything after in float64)
+    x0, w = hr.pair_input(feat.detach(), flat, owner, pts, pos, 10)
+    f64 = feat.detach().double().requires_grad_(True)
+    x64 = torch.cat((f64[flat], x0[:, F_:].double()), dim=1)
+    W64 = [lin.weight.detach().double().requires_grad_(True) for lin in lins]
+    b64 = [lin.bias.detach().double().requires_grad_(True) for lin in lins]
+    h = x64
+    for Wl, bl in zip(W64, b64):
+        h = F.leaky_relu(h @ Wl.t() + bl, 0.01)
+    wn64 = (w.double() / torch.zeros(P, device="cuda", dtype=torch.float64).index_add_(0, owner, w.double())[owner])
+    G64 = torch.zeros(P, 256, device="cuda", dtype=torch.float64).index_add_(0, owner, wn64[:, None] * h)
+    (G64 * gout.double()).sum().backward()
+    ref = [f64.grad] + [t.grad for pair in zip(W64, b64) for t in pair]
+    assert rel(G, G64.detach()) < 5e-5, rel(G, G64.detach())
+    errs = {n: rel(a, b) for n, a, b in zip(names, got, ref)}
+    assert max(errs.values()) < 5e-3, errs
+    # ---- layer by layer from the stored activations (hi + lo planes)
+    with torch.no_grad():
+        Q = flat.numel()
+        Gk, wpack, x0k, actk, wnk = hr.pair_mlp_forward_raw(feat, [l_.weight for l_ in lins], [l_.bias for l_ in lins], nb, pts, pos, off, Q, X2)
+        assert torch.equal(Gk, G) and x0k.shape == (2, Q, F_ + 64) and actk.shape == (4, 2, Q, 256)
+        x0s = x0k[0].double() + x0k[1].double()
+        x0p = torch.cat((x0.double(), torch.zeros(Q, 1, device="cuda", dtype=torch.float64)), dim=1)
+        assert rel(x0s, x0p) < 2e-5, rel(x0s, x0p)                   # two halves of the fp32 input rows (v_sin / v_cos included)
+        acts = [actk[l, 0].double() + actk[l, 1].double() for l in range(4)]
+        layer_in = [x0s[:, :F_ + 63]] + acts[:3]
+        for l, lin in enumerate(lins):
+            a_e = F.leaky_relu(layer_in[l] @ lin.weight.double().t() + lin.bias.double(), 0.01)
+            assert rel(acts[l], a_e) < 2e-5, (l, rel(acts[l], a_e))
+        dA = wnk.double()[:, None] * gout.double()[owner]
+        emu = {}
+        for l in (3, 2, 1, 0):
+            dZ = dA * torch.where(actk[l, 0].double() > 0, 1.0, 0.01)
+            emu[f"b{l}"] = dZ.sum(0)
+            emu[f"W{l}"] = dZ.t() @ layer_in[l]
+            dA = dZ @ lins[l].weight.double()
+        emu["feat"] = torch.zeros(Nt, F_, device="cuda", dtype=torch.float64).index_add_(0, flat, dA[:, :F_])
+    errs_k = {n: rel(a, emu[n]) for n, a in zip(names, got)}
+    assert max(errs_k.values()) < 1e-4, errs_k
+    print("x2 pair MLP: forward", rel(G, G64.detach()), "gradients vs float64 autograd", errs, "vs stored activations", errs_k)
+    # ---- bitwise reproducible
+    G2 = hr.pair_mlp(feat, layers, nb, pts, pos, off, owner, flat, X2)
+    (G2 * gout).sum().backward()
+    again = [p_.grad.clone() for lin in lins for p_ in (lin.weight, lin.bias)]
+    assert torch.equal(G, G2) and all(torch.equal(a, b) for a, b in zip(got[1:], again))
+    # ---- forward only (rendering): nothing saved, same G
+    G3, _, x3, a3, w3 = hr.pair_mlp_forward_raw(feat, [l_.weight for l_ in lins], [l_.bias for l_ in lins], nb, pts, pos, off, Q, X2, save=False)
+    assert x3 is None and a3 is None and w3 is None and torch.equal(G3, G)
 
 
 @pytest.mark.parametrize("F_", [32, 128])
