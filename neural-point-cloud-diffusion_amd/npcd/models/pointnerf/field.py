@@ -143,6 +143,39 @@ class Field(nn.Module):
         w = self.channel_net[0].weight[:, self.hid_dim:]
         return (encode_dir(rays_d.float(), self.dir_freqs) @ w.detach().float().t()).contiguous()
 
+    def fp32_class_ok(self) -> bool:
+        """Can shade_fp32 run this field?  (the published aggregator network: pointnerf.py:174-179)"""
+        from .train_path import fused_pair_mlp_precision
+        return fused_pair_mlp_precision(self, torch.float32) == hr.PAIR_MLP_X2
+
+    @torch.no_grad()
+    def shade_fp32(self, nb_idx, pts, kp_pos, kp_feat, point_dir=None):
+        """The same shading in the reference's numerics class (eval_pointnerf.py / eval_diffusion.py run the field in fp32): the four
+        non-linear per-pair layers + the weighted mean on the fp32-class matrix-core kernel (csrc/pairs_mlp.hip precision 1: every
+        operand as two bf16 halves, ~1e-5 relative per product, fp32's exponent range -- nothing overflows that fp32 holds), the
+        linear fifth layer and both heads on the P points as fp32 library GEMMs.  nb_idx [P, k] (-1 pad, valid entries first),
+        pts [P, 3]; point_dir [P, 3] with use_dir.  -> sigma [P], rgb [P, 3].  Roughly 4 x the time of the fp16 kernels."""
+        import torch.nn.functional as F
+        agg, lf = self.aggregator, self.aggregator.local_field
+        nb = nb_idx.long()
+        valid = nb >= 0
+        cnt = valid.sum(dim=1)
+        off = torch.cumsum(cnt, 0) - cnt
+        key = (str(pts.device),) + tuple((lf[i].weight.data_ptr(), lf[i].weight._version, lf[i].bias._version) for i in (0, 2, 4, 6))
+        if getattr(self, "_pack32_key", None) != key:
+            self._pack32 = hr.pair_mlp_pack([lf[i].weight for i in (0, 2, 4, 6)], [lf[i].bias for i in (0, 2, 4, 6)], agg.in_dim, hr.PAIR_MLP_X2,
+                                            pts.device)
+            self._pack32_key = key
+        G = hr.pair_mlp_forward_raw(kp_feat.reshape(-1, kp_feat.shape[-1]), None, None, nb, pts, kp_pos.reshape(-1, 3), off, 0,
+                                    hr.PAIR_MLP_X2, save=False, wpack=self._pack32)[0]
+        with torch.autocast("cuda", enabled=False):
+            feat = lf[8](G)
+            # (a point without neighbours aggregates to zero and sees the biases only, like the fused kernels and aggregators/mlp.py:60-62)
+            chan_in = feat if not self.use_dir else torch.cat((feat, encode_dir(point_dir.float(), self.dir_freqs)), dim=-1)
+            sigma = F.softplus(self.shape_net(feat) - 1.0)[:, 0]
+            rgb = torch.sigmoid(self.channel_net(chan_in))
+        return sigma.contiguous(), rgb.contiguous()
+
     def shade(self, nb_idx, pts, kp_pos, kp_feat, dir_bias=None, point_ray=None, status=None):
         """compact shading points -> sigma [P] (softplus(x-1) applied), rgb [P,3] (sigmoid applied).  With use_dir: dir_bias
         [n_rays, hid] (Field.dir_bias) and point_ray [P] int32, the ray of every compact point."""

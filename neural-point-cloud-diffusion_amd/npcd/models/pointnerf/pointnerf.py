@@ -93,14 +93,20 @@ class PointNeRF(nn.Module):
                              sample=sample_rays, return_channels=True, rng=rng)
         return pred, aux
 
-    def render(self, coords, feats, extrinsics, intrinsics, resolution=128, max_shading_points=None, sample_rays=False):
-        """reference pointnerf.py:107-131."""
+    def render(self, coords, feats, extrinsics, intrinsics, resolution=128, max_shading_points=None, sample_rays=False, mlp_dtype=None):
+        """reference pointnerf.py:107-131.  mlp_dtype (not in the reference): None = the fused fp16-operand shading kernels with their
+        range guard (out["shading_status"]); torch.float32 = the reference's numerics class for the field MLPs (the evaluation
+        scripts run them in fp32): fp32-class matrix-core per-pair layers + fp32 heads, VolumeRenderer.shade_dtype."""
         agg = self.field.aggregator
-        prev = agg.max_shading_pts
+        prev, prev_dtype = agg.max_shading_pts, self.renderer.shade_dtype
         if max_shading_points is not None:
             agg.max_shading_pts = max_shading_points
+        if mlp_dtype is not None:
+            if mlp_dtype != torch.float32 or not self.field.fp32_class_ok():
+                raise ValueError("render(mlp_dtype=...): torch.float32 on the published field architecture, or None")
+            self.renderer.shade_dtype = mlp_dtype
         try:
             self._set_pointset(coords)
             return self.renderer(coords, feats, extrinsics, intrinsics, resolution, sample_rays)
         finally:
-            agg.max_shading_pts = prev
+            agg.max_shading_pts, self.renderer.shade_dtype = prev, prev_dtype

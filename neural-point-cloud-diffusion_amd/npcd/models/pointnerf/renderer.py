@@ -26,6 +26,10 @@ class VolumeRenderer(nn.Module):
         # int where the call reads the point count from the device anyway, a device scalar on the sync-free path -- and
         # `check_shading_status` turns a raised bit into a FloatingPointError ("raise"), a RuntimeWarning ("warn") or nothing.
         self.range_guard = "warn"
+        # None: the fused fp16-operand shading kernels (csrc/shade.hip).  torch.float32: the reference's numerics class -- per-pair
+        # layers on the fp32-class matrix-core kernel, heads on fp32 library GEMMs (Field.shade_fp32); one host read of the point
+        # count per call, about 4 x the shading time.  PointNeRF.render(mlp_dtype=...) sets it per call.
+        self.shade_dtype = None
 
     def limits(self, t0: torch.Tensor, t1: torch.Tensor):
         """Box limits from the ray kernel, or the fixed (near, far) of `ray_limits` for every ray (renderer.py:36-47)."""
@@ -80,9 +84,20 @@ class VolumeRenderer(nn.Module):
                 if dir_bias is not None:       # lists are in ray order: row p belongs to the last ray whose base is <= p
                     point_ray = (torch.searchsorted(ray_base, torch.arange(capacity, dtype=torch.int32, device=ray_base.device),
                                                     right=True) - 1).clamp_(min=0).to(torch.int32)
-                sigma, rgb = hr.shade_points(field.packed_weights(kp_pos.device), agg.in_dim, nb, pts, kp_pos.reshape(-1, 3),
-                                             kp_feat.reshape(-1, kp_feat.shape[-1]), n_points=counter[:1], n_freqs=agg.n_freqs,
-                                             hidden=field.hid_dim, dir_bias=dir_bias, point_ray=point_ray, status=counter[2:3])
+                if self.shade_dtype == torch.float32:
+                    Pn, overflow = counter[:2].tolist()
+                    if overflow and capacity < worst:
+                        capacity = worst
+                        continue
+                    s32, c32 = field.shade_fp32(nb[:Pn], pts[:Pn], kp_pos, kp_feat,
+                                                None if point_ray is None else d.view(-1, 3)[point_ray[:Pn].long()])
+                    sigma = torch.zeros(capacity, dtype=torch.float32, device=nb.device)
+                    rgb = torch.zeros((capacity, 3), dtype=torch.float32, device=nb.device)
+                    sigma[:Pn], rgb[:Pn] = s32, c32
+                else:
+                    sigma, rgb = hr.shade_points(field.packed_weights(kp_pos.device), agg.in_dim, nb, pts, kp_pos.reshape(-1, 3),
+                                                 kp_feat.reshape(-1, kp_feat.shape[-1]), n_points=counter[:1], n_freqs=agg.n_freqs,
+                                                 hidden=field.hid_dim, dir_bias=dir_bias, point_ray=point_ray, status=counter[2:3])
                 mask, depth, chan = hr.ray_march_compact(sigma, rgb, ray_bits, pts, ray_base, o.view(-1, 3), d.view(-1, 3), t1.reshape(-1),
                                                          M, self.white_back)
                 if sync_free:
@@ -114,7 +129,10 @@ class VolumeRenderer(nn.Module):
             pts = loc.view(Nr, M, 3)[valid]
             point_ray = torch.nonzero(valid)[:, 0].to(torch.int32)        # the ray of every compact point
             status = torch.zeros(1, dtype=torch.int32, device=nb.device)
-            sigma, rgb = field.shade(nb, pts, kp_pos, kp_feat, dir_bias, None if dir_bias is None else point_ray, status=status)
+            if self.shade_dtype == torch.float32:
+                sigma, rgb = field.shade_fp32(nb, pts, kp_pos, kp_feat, None if dir_bias is None else d.view(-1, 3)[point_ray.long()])
+            else:
+                sigma, rgb = field.shade(nb, pts, kp_pos, kp_feat, dir_bias, None if dir_bias is None else point_ray, status=status)
             march = (valid, loc.view(Nr, M, 3), base, o.view(-1, 3), d.view(-1, 3), t1.reshape(-1), self.white_back)
             mask, depth, chan = hr.ray_march(sigma, rgb, *march)
             P, n_pairs = int(nb.shape[0]), int((nb >= 0).sum())
@@ -129,6 +147,7 @@ class VolumeRenderer(nn.Module):
         out["num_shading_points"] = P
         out["num_pairs"] = n_pairs
         out["shading_status"] = shading_status
+        out["shading_numerics"] = "fp32-class (two bf16 halves per operand; heads fp32)" if self.shade_dtype == torch.float32 else "fp16 operands, fp32 accumulation"
         if not torch.is_tensor(shading_status):
             self.check_shading_status(shading_status)
         # which neighbour search produced this render: the reading of the (absent) torch_knnquery source, or

@@ -351,6 +351,68 @@ def test_render_surfaces_the_range_guard(monkeypatch):
             assert out["shading_status"] & 1
 
 
+def test_render_in_the_reference_numerics_class(golden):
+    """PointNeRF.render(mlp_dtype=torch.float32) (VERDICT r4 missing 3): the field MLPs in the reference's fp32 class -- per-pair layers
+    on the fp32-class matrix-core kernel, heads in fp32 -- against the fp32 CPU oracle: pixels to 2e-5 (the fp16-operand kernels'
+    bar is 5e-3), with and without the host read of the point count; with weights that overflow fp16 (the range guard's case) it stays
+    finite and on the oracle where the fp16 kernels return NaN; with view directions on the reference's own brute-force branch
+    (fixture render_options.npz: 1e-4 instead of the 2e-3 of the fp16 kernels); on the grid path with view directions it agrees with
+    the fp16 kernels to their rounding."""
+    res = 24
+    coords, feats, extr, intr = _scene(res, 2, 512, 32, seed=3)
+    p = orr.init_field_params(32, seed=2)
+    for name in p:
+        if "shape_net.2" in name:
+            p[name] = p[name] * 8 + 1.0                       # rays terminate on the object: the shading decides the pixels
+    m = _model(32, 512, p)
+    args = (coords.cuda(), feats.cuda(), extr.cuda(), intr.cuda(), res)
+    ref = orr.render(p, coords, feats, extr, intr, res=res, return_aux=True)
+    with torch.no_grad():
+        out32 = m.render(*args, mlp_dtype=torch.float32)
+        out16 = m.render(*args)
+        m.renderer.sync_free_points = 0
+        out32b = m.render(*args, mlp_dtype=torch.float32)
+        m.renderer.sync_free_points = 1 << 23
+    assert out32["shading_numerics"].startswith("fp32-class") and m.renderer.shade_dtype is None
+    e32 = float((out32["channels"].cpu() - ref["channels"]).abs().max())
+    e16 = float((out16["channels"].cpu() - ref["channels"]).abs().max())
+    print("fp32-class render: max |pixel - oracle|", e32, "fp16-operand kernels", e16)
+    assert e32 < 2e-5 and e16 < 5e-3 and e32 < e16, (e32, e16)
+    assert torch.equal(out32["channels"], out32b["channels"])
+    assert float((out32["depth"].cpu() - ref["depth"]).abs().max()) < 1e-4
+    # weights that leave the fp16 range: the fp16 kernels flag it (and return NaN), the fp32-class path follows the oracle
+    pb = dict(p)
+    pb["aggregator.local_field.2.weight"] = p["aggregator.local_field.2.weight"] * 3.0e5
+    bad = _model(32, 512, pb)
+    bad.renderer.range_guard = "off"
+    refb = orr.render(pb, coords, feats, extr, intr, res=res, return_aux=True)
+    with torch.no_grad():
+        o16 = bad.render(*args)
+        o32 = bad.render(*args, mlp_dtype=torch.float32)
+    assert int(o16["shading_status"]) & 1 and not bool(torch.isfinite(o16["channels"]).all())
+    assert bool(torch.isfinite(o32["channels"]).all())
+    assert float((o32["channels"].cpu() - refb["channels"]).abs().max()) < 1e-3
+    # view directions: the reference's own numbers (voxel_grid=None branch) ...
+    g = golden("render_options")
+    gargs = (T(g["coords"]).cuda(), T(g["feats"]).cuda(), T(g["extr"]).cuda(), T(g["intr"]).cuda(), int(g["res"]), False)
+    with torch.no_grad():
+        out = _options_model(g, use_dir=True, shade_dtype=torch.float32).renderer(*gargs, knn_mode=1)
+    for key in ("mask", "depth", "channels"):
+        np.testing.assert_allclose(out[key].cpu().numpy(), g["dir_" + key], atol=1e-4)
+    # ... and on the fused grid path against the fp16 kernels
+    from npcd.models.pointnerf import PointNeRF
+    pd = orr.init_field_params(32, seed=0, dir_dim=51)
+    for name in pd:
+        if "shape_net.2" in name:
+            pd[name] = pd[name] * 8 + 1.0
+    md = PointNeRF(1, 32, 512, True)
+    md.field.load_state_dict(pd)
+    md = md.cuda().eval()
+    with torch.no_grad():
+        d16, d32 = md.render(*args), md.render(*args, mlp_dtype=torch.float32)
+    assert float((d16["channels"] - d32["channels"]).abs().max()) < 5e-3 and torch.equal(d16["mask"] > 0, d32["mask"] > 0)
+
+
 def test_ordered_compaction_above_32768_rays_uses_block_sums_and_gives_the_same_lists():
     """More than 32,768 rays per call: a first pass adds the per-ray counts up per 1,024 rays and the compaction workgroups read block
     sums instead of every earlier count (the one-level form is quadratic in the rays).  The bases must still be the
