@@ -939,16 +939,15 @@ __device__ __forceinline__ float wave_reduce64(float x, Op op) {
 __device__ __forceinline__ float wave_max64(float x) { return wave_reduce64(x, [](float a, float b) { return fmaxf(a, b); }); }
 __device__ __forceinline__ float wave_sum64(float x) { return wave_reduce64(x, [](float a, float b) { return a + b; }); }
 // LEAN: half-size batches of LDS reads (the 32-row forward has ~70 registers free between two stages, the 64-row one ~100)
-template <class TR, int SLOT, int RING, bool LEAN>
-__device__ __forceinline__ void rowx_tile(unsigned char* smem, float c, int lane_in, int wave, float* rec) {
+// rowx_core: `base` + KT / VT = the LDS byte addresses of the K / V tile, `scr` = 256 bytes of wave-private scratch (the row's P),
+// `qxa` = the 128-byte copy of the last query row; rowx_tile = the ring form of it (ring slot SLOT, scratch behind the RING slots)
+template <class TR, int KT, int VT, bool LEAN>
+__device__ __forceinline__ void rowx_core(uint32_t base, uint32_t scr, uint32_t qxa, float c, int lane_in, float* rec) {
     // Everything lane-dependent in here is derived from an OPAQUE copy of the lane number: otherwise the compiler hoists the ~100
     // loop-invariant LDS addresses of the three ring-slot instances out of the tile loop and spills them (82 spilled registers,
     // the whole kernel 20 % slower).  Ring slot and row numbers go into the instructions' immediate offsets.
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
-    constexpr int KT = SLOT * 16384, VT = SLOT * 16384 + 8192;
-    const uint32_t base = lds_addr(smem);
-    const uint32_t scr = base + RING * 16384 + wave * 256, qxa = base + RING * 16384 + 1024;
     // scores: lane j = key j of the tile; its 128-byte row against the last query row (a 128-byte LDS copy made by the prologue,
     // every lane reads the same address), two 16-byte chunks at a time so that the main loop's state stays in registers
     const uint32_t krow = base + lane * 128, ksw = (uint32_t)tile_swz(lane) << 4;
@@ -1040,6 +1039,11 @@ __device__ __forceinline__ void rowx_tile(unsigned char* smem, float c, int lane
     o1 = half_sum(o1);
     if (lane < 32) *reinterpret_cast<float2*>(rec + 2 * dp) = make_float2(o0, o1);
     if (lane == 0) *reinterpret_cast<float2*>(rec + 64) = make_float2(m, l);
+}
+template <class TR, int SLOT, int RING, bool LEAN>
+__device__ __forceinline__ void rowx_tile(unsigned char* smem, float c, int lane_in, int wave, float* rec) {
+    const uint32_t base = lds_addr(smem);
+    rowx_core<TR, SLOT * 16384, SLOT * 16384 + 8192, LEAN>(base, base + RING * 16384 + wave * 256, base + RING * 16384 + 1024, c, lane_in, rec);
 }
 // one 64-thread block per (batch, head): combine the nw partial states, add the pair (x, x), write the row and its LSE
 template <class E>
@@ -1251,6 +1255,147 @@ __global__ __launch_bounds__(256, 2) void attn_fwd64_kernel(AttnParams p) {
     if (tl_on && lane == 0)
         for (int i = 0; i < 40; ++i) g_timeline[i] = tl[i];
 #endif
+}
+
+// ============================================================================================
+// forward, third form: K and V of a (batch, head) RESIDENT in LDS (sequences of 513 tokens: the denoiser's)
+// ============================================================================================
+// What the stage-loop probe says (tools/probes/attn_shape_probe.hip, round 5): the pipelined stage of the kernels above runs at
+// 408 cycles per 32 x 32 score block and SIMD with three waves per SIMD, 499 with two, 780 with one -- 1.0 / 0.88 / 0.70 PFLOP/s --
+// while the forward at n = 513 delivers 0.59-0.65: more than 40 % of its time is NOT the loop.  It is the shape of the launch:
+// five workgroups per (batch, head), each streaming all of K / V through a ring for 128 (or one!) query rows, a prologue and an
+// epilogue per eight tiles, a barrier + DMA wait per tile, 6.67 rounds of workgroups on the chip.
+// Here ONE workgroup of eight waves owns a whole (batch, head): its 512 keys x (K, V) = 128 KB are requested by LDS-DMA up front, tile
+// after tile, and stay; a wave owns 64 query rows (the two-block stage of the 64-row form: every fragment read feeds two matrix
+// instructions) and walks the eight tiles as they land -- one counted wait + barrier per tile, nothing to refill, no ring; the
+// 513th key seeds the softmax state as before; the 513th QUERY row is split over the eight waves (wave w takes the keys of tile w:
+// rowx_core) and merged by wave 0 through LDS -- no fifth workgroup, no scratch in HBM, no second launch.  K / V are read from HBM
+// exactly once per (batch, head); 1,024 workgroups = four rounds of one per CU (two waves per SIMD).
+// LDS: [0, 16 KB) the last query row, the eight partial records of its softmax, per-wave scratch; [16 KB + 16 KB t) tile t (K | V).
+// The fragment addresses point ONE TILE BELOW the current tile and are advanced by 16 KB per tile, so that every stage is the same
+// instantiation (ring slot 1, previous slot 0) and every offset fits the instructions' 16-bit immediate.
+constexpr int kResMisc = 16384, kResRecOff = 256, kResScrOff = 4096, kResTiles = 8;
+constexpr int kResLds = kResMisc + kResTiles * 16384;
+__host__ __device__ inline bool fwd_res_shape(int n) { return n == 64 * kResTiles + 1; }
+
+template <class E>
+__device__ __forceinline__ void rowx_merge_lds(const AttnParams& p, int b, int h, const float* rec, int nw, int d) {
+    const int x = p.n - 1;
+    const E* qx = static_cast<const E*>(p.q) + b * p.sb + (int64_t)x * p.sn + h * p.sh;
+    const E* kx = static_cast<const E*>(p.k) + b * p.sb + (int64_t)x * p.sn + h * p.sh;
+    const E* vx = static_cast<const E*>(p.v) + b * p.sb + (int64_t)x * p.sn + h * p.sh;
+    const float sxx = wave_sum64((float)qx[d] * (float)kx[d]) * p.scale_log2;
+    float M = sxx;
+    for (int w = 0; w < nw; ++w) M = fmaxf(M, rec[w * kRowxFloats + 64]);
+    const float pxx = __builtin_amdgcn_exp2f(sxx - M);
+    float L = pxx, O = pxx * (float)vx[d];
+    for (int w = 0; w < nw; ++w) {
+        const float a = __builtin_amdgcn_exp2f(rec[w * kRowxFloats + 64] - M);
+        L += a * rec[w * kRowxFloats + 65];
+        O += a * rec[w * kRowxFloats + d];
+    }
+    E* orow = static_cast<E*>(p.o_w) + b * p.osb + (int64_t)x * p.osn + h * p.osh;
+    orow[d] = (E)(O / L);
+    if (d == 0) p.lse[(int64_t)(b * p.H + h) * p.n + x] = M * kLn2 + logf(L);
+}
+
+template <int N> struct ResWait { static __device__ __forceinline__ void at(int t) { if (t == N) vm_wait<2 * (6 - N)>(); else ResWait<N + 1>::at(t); } };
+template <> struct ResWait<7> { static __device__ __forceinline__ void at(int) {} };
+
+template <class TR>
+__global__ __launch_bounds__(512, 2) void attn_fwd_res_kernel(AttnParams p) {
+    using E = typename TR::elem;
+    using V8 = typename TR::vec8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char rsmem[];
+    unsigned char* tiles = rsmem + kResMisc;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = p.n, nk = n - 1;
+    const int bh = xcd_remap(blockIdx.x, gridDim.x), h = bh % p.H, b = bh / p.H;
+    const E* qb = static_cast<const E*>(p.q) + b * p.sb + h * p.sh;
+    const E* kb = static_cast<const E*>(p.k) + b * p.sb + h * p.sh;
+    const E* vb = static_cast<const E*>(p.v) + b * p.sb + h * p.sh;
+    const int q0 = wave * 64;
+    const float c = p.scale_log2;
+    const DmaLane dl = dma_lane<E>(p.sn, lane);
+    // ---- prologue: the wave's query rows and the seed rows (oldest), the last query row -> LDS, then ALL tiles ------------------
+    u32x4 qrawA[4], qrawB[4], keraw[4];
+    row_bcast_issue(qb + (int64_t)(q0 + r) * p.sn, hh, qrawA);             // (one row per lane, not a broadcast)
+    row_bcast_issue(qb + (int64_t)(q0 + 32 + r) * p.sn, hh, qrawB);
+    row_bcast_issue(kb + (int64_t)nk * p.sn, hh, keraw);
+    uint32_t vx0 = gload_u16(vb + (int64_t)nk * p.sn + r), vx1 = gload_u16(vb + (int64_t)nk * p.sn + 32 + r);
+    // (every wave issues the 128-byte copy of the last query row -- same bytes, same place -- so that all waves count the same DMAs)
+    dma4_issue(qb + (int64_t)nk * p.sn, (uint32_t)((lane & 31) * 4), __builtin_amdgcn_readfirstlane(lds_addr(rsmem)));
+    {
+        // wave w: rows 16 (w & 3) .. + 15 of every K (w < 4) or V (w >= 4) tile = two 1-KiB pieces per tile
+        const bool second = wave >= 4;
+        const int w4 = wave & 3;
+        const char* sbase = reinterpret_cast<const char*>((second ? vb : kb) + (int64_t)(w4 * 16) * p.sn);
+        const uint32_t dst0 = lds_addr(tiles) + (second ? 8192 : 0) + w4 * 2048;
+#pragma unroll
+        for (int t = 0; t < kResTiles; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                dma16_issue(sbase + ((int64_t)t * 64 + i * 8) * p.sn * (int64_t)sizeof(E), dl.off[i & 1], __builtin_amdgcn_readfirstlane(dst0 + t * 16384 + i * 1024));
+    }
+    vm_wait<2 * kResTiles + 1>();                     // the register loads have landed; the DMAs may all still be in flight
+    V8 qA[4], qB[4], ke[4];
+    arrived4(qrawA, qA);
+    arrived4(qrawB, qB);
+    arrived4(keraw, ke);
+    NPCD_ARRIVED(vx0);
+    NPCD_ARRIVED(vx1);
+    QBlk A, B;
+    A.o0 = A.o1 = B.o0 = B.o1 = f32x16{0};
+    A.m = mfma_dot<TR>(ke, qA) * c;                   // the 513th key seeds the state (see attn_fwd_kernel): m = its score, l = 1, O = its value row
+    B.m = mfma_dot<TR>(ke, qB) * c;
+    A.l = B.l = 0.5f;                                 // (the two half-wave partial sums are added at the end)
+    outer_seed<TR>(vx0, vx1, 1.f, lane, A.o0, A.o1);
+    outer_seed<TR>(vx0, vx1, 1.f, lane, B.o0, B.o1);
+    vm_wait<2 * (kResTiles - 1)>();                   // this wave's pieces of tile 0 and the last query row
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    FragAddr fa = frag_addr(rsmem, lane);             // one tile below tile 0
+    u32x4 pwA[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}}, pwB[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
+    const uint32_t scr = lds_addr(rsmem) + kResScrOff + wave * 256, qxa = lds_addr(rsmem);
+    float* rec = reinterpret_cast<float*>(rsmem + kResRecOff) + wave * kRowxFloats;
+    // tile 0 (peeled: its first stage has no predecessor)
+    fwd64_stage<TR, 1, 0, 0, 1, false>(fa, qA, qB, A, B, pwA, pwB, c);
+    vm_wait<2 * (kResTiles - 2)>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    fwd64_stage<TR, 1, 1, 1, 0, true>(fa, qA, qB, A, B, pwA, pwB, c);
+    if (wave == 0) rowx_core<TR, 0, 8192, false>(lds_addr(tiles), scr, qxa, c, lane, rec);
+#pragma unroll 1
+    for (int t = 1; t < kResTiles; ++t) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) fa.row[s2] += 16384;
+#pragma unroll
+        for (int db = 0; db < 2; ++db) { fa.tr[db][0] += 16384; fa.tr[db][1] += 16384; }
+        fwd64_stage<TR, 1, 0, 0, 1, true>(fa, qA, qB, A, B, pwA, pwB, c);
+        if (t + 1 < kResTiles) {                      // tile t + 1: this wave's pieces have landed -> barrier -> everybody's have
+            ResWait<1>::at(t);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        fwd64_stage<TR, 1, 1, 1, 0, true>(fa, qA, qB, A, B, pwA, pwB, c);
+        if (t == wave) rowx_core<TR, 0, 8192, false>(lds_addr(tiles) + t * 16384, scr, qxa, c, lane, rec);      // (wave-uniform)
+    }
+    fwd64_flush<TR, 1, 1>(fa, A, B, pwA, pwB);
+    A.l = half_sum(A.l);
+    B.l = half_sum(B.l);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // the partial record of the last query row is written
+    __builtin_amdgcn_s_barrier();     // every wave has left the tiles: 4 KiB of them per wave stage the output rows
+    asm volatile("" ::: "memory");
+    E* orow0 = static_cast<E*>(p.o_w) + b * p.osb + (int64_t)q0 * p.osn + h * p.osh;
+    store_rows_staged<TR>(tiles + wave * 4096, orow0, p.osn, 64, A.o0, A.o1, 1.f / A.l, lane);
+    store_rows_staged<TR>(tiles + wave * 4096, orow0 + 32 * p.osn, p.osn, 32, B.o0, B.o1, 1.f / B.l, lane);
+    float* lrow = p.lse + (int64_t)(b * p.H + h) * n;
+    if (hh == 0) {
+        lrow[q0 + r] = A.m * kLn2 + logf(A.l);
+        lrow[q0 + 32 + r] = B.m * kLn2 + logf(B.l);
+    }
+    if (wave == kResTiles - 1) rowx_merge_lds<E>(p, b, h, reinterpret_cast<const float*>(rsmem + kResRecOff), kResTiles, lane);
 }
 
 // ============================================================================================
@@ -2845,7 +2990,7 @@ extern "C" int npcd_debug_read(long long* out, int count) {
 // which form of the forward a sequence length takes (NPCD_ATTN_FWD=32 / 64 forces one; see attn_fwd_launch)
 static bool fwd_rows32(int n) {
     const char* form = getenv("NPCD_ATTN_FWD");
-    return form ? form[0] == '3' : n < 1024;
+    return (form && form[0] != 'r') ? form[0] == '3' : n < 1024;
 }
 extern "C" int64_t npcd_attn_fwd_workspace_floats(int B, int n, int H) {
     if (B <= 0 || n <= 0 || H <= 0) return -1;
@@ -2894,6 +3039,24 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* ou
     // Two forms of the forward (measured in one process, tools/probes/gpu_dev_fwd_ab.py): 64 query rows per wave wins
     // on long sequences (n = 2049: 597-614 against 640-653 us), 32 rows per wave on short ones, where a workgroup's start-up and
     // wind-down dominate and its finer grid fills the chip better (n = 513: 113 against 117 us).  NPCD_ATTN_FWD=32 / 64 forces one.
+    // n = 513 (the denoiser's sequence), OPT-IN NPCD_ATTN_FWD=res: K / V of a (batch, head) resident in LDS, one workgroup per
+    // (batch, head) -- attn_fwd_res_kernel.  Built in round 5 as the "different body" for this shape; parity green, and SLOWER in the
+    // step: 141 against 120 us (same box, alternating bench runs): with one workgroup per CU nothing computes while a workgroup's
+    // 200 KB arrive, the four rounds of workgroups load and compute in phase, and the eight waves of a workgroup run in lockstep
+    // behind the per-tile barrier (docs/experiments.md R5.2).
+    const char* fwd_form = getenv("NPCD_ATTN_FWD");
+    if (fwd_res_shape(n) && fwd_form && fwd_form[0] == 'r') {
+        static DynLds lds_bf, lds_f;
+        if (dtype == NPCD_BF16) {
+            NPCD_HIP_CHECK(lds_bf.ensure(reinterpret_cast<const void*>(attn_fwd_res_kernel<BF16>), kResLds));
+            hipLaunchKernelGGL(attn_fwd_res_kernel<BF16>, dim3(B * H), dim3(512), kResLds, st, p);
+        } else {
+            NPCD_HIP_CHECK(lds_f.ensure(reinterpret_cast<const void*>(attn_fwd_res_kernel<F16>), kResLds));
+            hipLaunchKernelGGL(attn_fwd_res_kernel<F16>, dim3(B * H), dim3(512), kResLds, st, p);
+        }
+        NPCD_HIP_CHECK(hipGetLastError());
+        return NPCD_OK;
+    }
     if (fwd_rows32(n)) {
         static const bool rowx32 = getenv("NPCD_ATTN_ROWX32") != nullptr;
         p.rowx = (workspace && rowx32 && rowx_mode(n)) ? workspace : nullptr;

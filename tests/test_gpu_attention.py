@@ -466,3 +466,17 @@ def test_opt_in_forward_without_the_fifth_workgroup_still_matches():
     out = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "golden or ragged"], capture_output=True, text=True,
                          env=env, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
+
+
+def test_opt_in_resident_forward_still_matches():
+    """NPCD_ATTN_FWD=res (round 5, opt-in because it measured slower: 141 against 120 us in the step): the forward of 513-token sequences
+    with K / V of a (batch, head) resident in LDS -- one workgroup of eight waves per (batch, head), the 513th query row split over the
+    waves and merged through LDS.  The golden, ragged-length (513 is among them), forced-rescale and reproducibility tests run again
+    in a child process with the switch set; other lengths fall through to the ring kernels."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, NPCD_ATTN_FWD="res")
+    out = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k", "golden or ragged or rescale or reproduc or edge_token"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
