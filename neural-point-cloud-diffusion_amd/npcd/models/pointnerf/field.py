@@ -168,12 +168,26 @@ class Field(nn.Module):
             self._pack32_key = key
         G = hr.pair_mlp_forward_raw(kp_feat.reshape(-1, kp_feat.shape[-1]), None, None, nb, pts, kp_pos.reshape(-1, 3), off, 0,
                                     hr.PAIR_MLP_X2, save=False, wpack=self._pack32)[0]
+        from .train_path import x2_linear_forward
+
+        import os
+        _X2_HEADS = bool(os.environ.get("NPCD_STAGE1_X2_HEADS"))      # (opt-in, measured slower in training: train_path._X2Linear)
+
+        def mlp(seq, x):      # fp32 library GEMMs; with the switch the wide layers as three cross products of split bf16 operands
+            for m in seq:
+                if _X2_HEADS and isinstance(m, nn.Linear) and m.out_features >= 16 and m.in_features % 8 == 0 and x.shape[0] >= 4096:
+                    x = x2_linear_forward(x, m.weight, m.bias)[0]
+                else:
+                    x = m(x)
+            return x
         with torch.autocast("cuda", enabled=False):
-            feat = lf[8](G)
+            feat = mlp([lf[8]], G)
             # (a point without neighbours aggregates to zero and sees the biases only, like the fused kernels and aggregators/mlp.py:60-62)
-            chan_in = feat if not self.use_dir else torch.cat((feat, encode_dir(point_dir.float(), self.dir_freqs)), dim=-1)
-            sigma = F.softplus(self.shape_net(feat) - 1.0)[:, 0]
-            rgb = torch.sigmoid(self.channel_net(chan_in))
+            chan_in = feat
+            if self.use_dir:          # (the first colour layer then has 256 + 51 input columns and stays a plain fp32 GEMM)
+                chan_in = torch.cat((feat, encode_dir(point_dir.float(), self.dir_freqs)), dim=-1)
+            sigma = F.softplus(mlp(self.shape_net, feat) - 1.0)[:, 0]
+            rgb = torch.sigmoid(mlp(self.channel_net, chan_in))
         return sigma.contiguous(), rgb.contiguous()
 
     def shade(self, nb_idx, pts, kp_pos, kp_feat, dir_bias=None, point_ray=None, status=None):

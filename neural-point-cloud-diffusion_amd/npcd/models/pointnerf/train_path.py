@@ -116,13 +116,87 @@ class _RowSplitLinear(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
+def split2(t: torch.Tensor):
+    """fp32 -> (hi, lo) bf16 with t ~ hi + lo: 16 mantissa bits in two halves (the operand form of the fp32-class kernels)."""
+    hi = t.to(torch.bfloat16)
+    return hi, (t - hi.float()).to(torch.bfloat16)
+
+
+def x2_linear_forward(x, weight, bias):
+    """y = x W^T + b in the fp32 class on the bf16 matrix rate: x W^T ~ xh Wh^T + xl Wh^T + xh Wl^T as ONE library GEMM over a three
+    times longer contraction, [xh | xl | xh] [Wh | Wh | Wl]^T, with fp32 accumulation and output (the lo x lo term, 2^-18 relative,
+    is dropped: ~1e-5 relative per product, like csrc/pairs_mlp.hip at precision 1).  Returns (y, saved operands)."""
+    xh, xl = split2(x)
+    wh, wl = split2(weight)
+    y = torch.mm(torch.cat((xh, xl, xh), dim=1), torch.cat((wh, wh, wl), dim=1).t(), out_dtype=torch.float32)
+    return y + bias, (xh, xl, wh, wl)
+
+
+class _X2Linear(torch.autograd.Function):
+    """A Linear (+ LeakyReLU) layer of the point-level networks in the fp32-class mode of the stage-1 trainer: forward, data gradient
+    and weight gradient each as one bf16 library GEMM over the three cross products of the split operands (x2_linear_forward), fp32
+    accumulation and fp32 results; the weight gradient's long reduction (3 x ~2e5 rows into 256 x 256) is split into slices like
+    _RowSplitLinear's.  OPT-IN (NPCD_STAGE1_X2_HEADS=1): on paper 3 x the rate of fp32 library GEMMs at ~1e-5 relative; measured, the
+    step got slower (the split / concatenation passes and the library's fp32-output bf16 kernels at these shapes cost more than the
+    fp32 GEMMs they replace): 20.6-21.1 against 16.1 ms."""
+    SLICE = 16384
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, slope=None):
+        y, (xh, xl, wh, wl) = x2_linear_forward(x, weight, bias)
+        if slope is not None:
+            y = F.leaky_relu(y, slope, inplace=True)
+            ctx.save_for_backward(xh, xl, wh, wl, y)
+        else:
+            ctx.save_for_backward(xh, xl, wh, wl)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xh, xl, wh, wl = ctx.saved_tensors[:4]
+        f32 = torch.float32
+        dy = dy.to(f32).contiguous()
+        db = None
+        if ctx.slope is not None:
+            z = ctx.saved_tensors[4]
+            fused = hr.leaky_bwd_colsum(dy, z, ctx.slope) if dy.is_cuda else None
+            if fused is not None:
+                dy, db = fused
+            else:
+                dy = dy * torch.where(z > 0, 1.0, ctx.slope)
+        if db is None:
+            db = dy.sum(dim=0)
+        dh, dl = split2(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:      # dy W ~ dh Wh + dl Wh + dh Wl
+            dx = torch.mm(torch.cat((dh, dl, dh), dim=1), torch.cat((wh, wh, wl), dim=0), out_dtype=f32)
+        # dW = dy^T x ~ dh^T xh + dl^T xh + dh^T xl: per row slice one batched GEMM over [dh | dl | dh]^T [xh ; xh ; xl], fp32 partials
+        rows, c = dy.shape[0], _X2Linear.SLICE
+        S = rows // c
+        if S >= 2:
+            head = S * c
+            a = torch.cat((dh[:head].view(S, c, -1), dl[:head].view(S, c, -1), dh[:head].view(S, c, -1)), dim=1).transpose(1, 2)
+            b = torch.cat((xh[:head].view(S, c, -1), xh[:head].view(S, c, -1), xl[:head].view(S, c, -1)), dim=1)
+            dw = torch.bmm(a, b, out_dtype=f32).sum(dim=0)
+            if rows > head:
+                dw = dw + torch.mm(torch.cat((dh[head:], dl[head:], dh[head:]), dim=0).t(), torch.cat((xh[head:], xh[head:], xl[head:]), dim=0),
+                                   out_dtype=f32)
+        else:
+            dw = torch.mm(torch.cat((dh, dl, dh), dim=0).t(), torch.cat((xh, xh, xl), dim=0), out_dtype=f32)
+        return dx, dw, db, None
+
+
 def _mlp(seq, x, dtype):
     """nn.Sequential of Linear / LeakyReLU (utils/model.py:22-36).  From a few ten thousand rows on (the per-pair network, and the
     point-level layers of a training batch: ~2 x 10^5 shading points) the Linear layers run as _RowSplitLinear; below that the
     plain modules (under autocast for the bf16 opt-in).  (Round 1 had the threshold at 262,144 rows because lower values cost
     10 ms per step in the bf16 mode: that was the library's fp32-output GEMM for the heads' 1- and 3-row weight gradients, see
     _RowSplitLinear.backward; with those on the bf16-output path the point-level layers gain 1.1 ms of a 9.7 ms step.)"""
-    if x.shape[0] < _ROWSPLIT_MIN:
+    x2 = isinstance(dtype, str) and dtype == "x2"      # fp32-class: wide layers as _X2Linear, the heads' 1- / 3-row layers in plain fp32
+    if x2 and (not x.is_cuda or x.shape[0] < 4096):
+        x2, dtype = False, None
+    if not x2 and x.shape[0] < _ROWSPLIT_MIN:
         with torch.autocast("cuda", dtype=dtype or torch.bfloat16, enabled=dtype is not None):
             return seq(x)
     mods, i = list(seq), 0
@@ -130,7 +204,11 @@ def _mlp(seq, x, dtype):
         m = mods[i]
         if isinstance(m, torch.nn.Linear):
             act = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.LeakyReLU) else None
-            x = _RowSplitLinear.apply(x, m.weight, m.bias, dtype, None if act is None else act.negative_slope)
+            slope = None if act is None else act.negative_slope
+            if x2 and m.out_features >= 16 and m.in_features % 8 == 0:
+                x = _X2Linear.apply(x, m.weight, m.bias, slope)
+            else:
+                x = _RowSplitLinear.apply(x, m.weight, m.bias, None if x2 else dtype, slope)
             i += 2 if act is not None else 1
         else:
             x = m(x)
@@ -184,6 +262,10 @@ def shade_autograd(field, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch
     mlp_dtype = getattr(field, "train_mlp_dtype", None)
     precision = fused_pair_mlp_precision(field, mlp_dtype)
     lib_dtype = None if (mlp_dtype is None or isinstance(mlp_dtype, str) or mlp_dtype == torch.float32) else mlp_dtype     # operand type of the library layers
+    if precision == hr.PAIR_MLP_X2 and os.environ.get("NPCD_STAGE1_X2_HEADS"):
+        # opt-in (measured SLOWER: 20.6-21.1 against 16.1 ms per step, docs/experiments.md R5.4): the point-level layers in the same fp32
+        # class as one bf16 library GEMM over the three cross products of the split operands (_X2Linear) instead of fp32 library GEMMs
+        lib_dtype = "x2"
     if precision is not None:
         # the four non-linear per-pair layers and the weighted mean run as ONE forward launch and one backward launch per layer on
         # the matrix cores (csrc/pairs_mlp.hip; fp32-class by default, bf16 operands as the opt-in); the network's last, linear
@@ -196,7 +278,7 @@ def shade_autograd(field, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 agg_feat = lf[8](G).float()
         else:
-            agg_feat = _mlp(torch.nn.Sequential(lf[8]), G, None).float()
+            agg_feat = _mlp(torch.nn.Sequential(lf[8]), G, lib_dtype).float()
     else:
         # MLP input of every pair and its inverse-distance weight: one HIP kernel forward, one backward (csrc/pairs.hip)
         x0, w = hr.pair_input(kp_feat.reshape(-1, kp_feat.shape[-1]), flat, owner, pts, kp_pos.detach().reshape(-1, 3), agg.n_freqs)
