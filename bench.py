@@ -75,7 +75,7 @@ def query_roofline(S, query_ms, launches, clock_ghz=None):
     predates that record) the counts belong to another binary -- `stale_counters` says so and `achieved` / `frac` are None."""
     import hashlib
     base = {"kernel": "grid_query_wave_kernel", "avg_ms": query_ms, "launches": launches, "bound": "valu-issue", "achieved": None}
-    fp = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r4_render_sq_pmc.json", "r3_render_sq_pmc.json")) if os.path.exists(f)), None)
+    fp = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r5_render_sq_pmc.json", "r4_render_sq_pmc.json", "r3_render_sq_pmc.json")) if os.path.exists(f)), None)
     if fp is None:
         return base
     doc = json.load(open(fp))
