@@ -35,6 +35,11 @@ def mean_counter(path, name):
             flag = a.split("<")[1]
             return (base + "<" + flag) in k or (base + "ILb" + ("1" if flag == "true" else "0")) in k
         key = next((a for a in alg if hit(a)), None)
+        if key is None and "colsum_kernel<bool _Accum" in k:
+            # rocprofv3 (ROCm 7.2) leaves this template's arguments undemangled ("colsum_kernel<bool _Accum, bool, E, 1>") for BOTH
+            # instantiations; the probe is run with NPCD_EW_ONLY_GELU_COLSUM=1 for these passes, so that the only one in the trace
+            # is the GELU backward + column sums
+            key = "colsum_kernel<true"
         if key:
             acc[key].append(float(r["Counter_Value"]))
     return {k: sum(v[2:]) / len(v[2:]) for k, v in acc.items() if len(v) > 2}

@@ -20,8 +20,10 @@ unset NPCD_B NPCD_N
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/attn_fetch -- python3 $R/tools/probes/gpu_dev_attn_time.py 10 > $O/attn_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/attn_write -- python3 $R/tools/probes/gpu_dev_attn_time.py 10 > $O/attn_write.log 2>&1
 # (2b) the elementwise kernels of the step (add + LayerNorm, LayerNorm backward, GELU, GELU backward + column sums): FETCH_SIZE / WRITE_SIZE
+export NPCD_EW_ONLY_GELU_COLSUM=1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/ew_fetch -- python3 $R/tools/probes/gpu_dev_ew_time.py > $O/ew_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/ew_write -- python3 $R/tools/probes/gpu_dev_ew_time.py > $O/ew_write.log 2>&1
+unset NPCD_EW_ONLY_GELU_COLSUM
 cd $R
 python3 tools/make_traffic_json.py ew $(ls $O/ew_fetch/*/*counter_collection.csv | head -1) $(ls $O/ew_write/*/*counter_collection.csv | head -1) $O/${TAG}_elementwise_hbm_traffic_pmc.json
 python3 tools/make_sq_pmc_json.py $(dirname $(ls $O/attn_sq/*/*counter_collection.csv | head -1)) $O/${TAG}_attention_sq_pmc.json
