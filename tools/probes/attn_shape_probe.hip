@@ -46,8 +46,31 @@ __device__ __forceinline__ void softmax16(const float (&s)[16], float m, float c
     l += rs;
 }
 
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) { return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
+__device__ __forceinline__ void dma16(const void* sbase, unsigned voff, unsigned lds_dst) {
+    const unsigned long long v = (unsigned long long)sbase;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    const void* sb = (const void*)(((unsigned long long)hi << 32) | lo);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sb), "s"(lds_dst) : "memory");
+}
+// what the shipped kernels do once per 64-key tile (kv_mid): ring = 1: wait for the tile in flight + barrier + this wave's four 1-KiB pieces of the tile after next;
+// 2: the wait + barrier only; 3: the four pieces only (no barrier: timing only); 0: nothing (the bare stage loop)
+__device__ __forceinline__ void ring_step(int ring, int tile, const unsigned* src, unsigned char* smem, int wave, int lane) {
+    if (ring == 0) return;
+    if (ring != 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    if (ring != 2) {
+        const char* sb = reinterpret_cast<const char*>(src) + (((size_t)(blockIdx.x >> 2) * 131072 + (size_t)tile * 16384 + wave * 4096) & 0xFFFFF);
+        const unsigned dst = lds_addr_of(smem) + ((tile + 2) % 3) * 16384 + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dma16(sb + i * 1024, (unsigned)lane * 16u, __builtin_amdgcn_readfirstlane(dst + i * 1024));
+    }
+}
+
 template <int SHAPE>
-__global__ __launch_bounds__(256, 3) void stage_loop(const unsigned* __restrict__ src, float* __restrict__ out, long long* __restrict__ clk, int iters) {
+__global__ __launch_bounds__(256, 3) void stage_loop(const unsigned* __restrict__ src, float* __restrict__ out, long long* __restrict__ clk, int iters, int ring) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * 16384];
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < 3 * 16384 / 16; i += 256) reinterpret_cast<u32x4*>(smem)[i] = reinterpret_cast<const u32x4*>(src)[(blockIdx.x * 131 + i) % 65536];
@@ -92,6 +115,7 @@ __global__ __launch_bounds__(256, 3) void stage_loop(const unsigned* __restrict_
             const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1])) * c;
             if (__any(mx > m + 1e30f)) m = mx;
+            if (it & 1) ring_step(ring, it >> 1, src, smem, __builtin_amdgcn_readfirstlane(tid >> 6), lane);
         }
         float acc = l + m;
         for (int i = 0; i < 16; ++i) acc += o0[i] + o1[i];
@@ -142,6 +166,7 @@ __global__ __launch_bounds__(256, 3) void stage_loop(const unsigned* __restrict_
             softmax16(sv, m, c, l, pw, mx);
             // deferred-maximum test on the lane's own scores (the four lanes of a query only meet when it fires)
             if (__any(mx * c > m + 1e30f)) m = mx * c;
+            if (it & 1) ring_step(ring, it >> 1, src, smem, __builtin_amdgcn_readfirstlane(tid >> 6), lane);
         }
         float acc = l + m;
         for (int t = 0; t < 8; ++t) acc += o[t][0] + o[t][1] + o[t][2] + o[t][3];
@@ -153,18 +178,18 @@ __global__ __launch_bounds__(256, 3) void stage_loop(const unsigned* __restrict_
     }
 }
 
-static int g_wgs = 768;          // resident workgroups: 768 = three waves per SIMD, 512 = two, 256 = one
+static int g_wgs = 768, g_ring = 0;          // resident workgroups: 768 = three waves per SIMD, 512 = two, 256 = one
 template <int SHAPE>
 static void run(const unsigned* src, float* out, long long* clk, int iters, const char* name) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int w = 0; w < 3; ++w) stage_loop<SHAPE><<<g_wgs, 256>>>(src, out, clk, iters);
+    for (int w = 0; w < 3; ++w) stage_loop<SHAPE><<<g_wgs, 256>>>(src, out, clk, iters, g_ring);
     hipDeviceSynchronize();
     float best = 1e30f, sum = 0.f;
     const int reps = 10;
     for (int r = 0; r < reps; ++r) {
         hipEventRecord(e0);
-        stage_loop<SHAPE><<<g_wgs, 256>>>(src, out, clk, iters);
+        stage_loop<SHAPE><<<g_wgs, 256>>>(src, out, clk, iters, g_ring);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -184,6 +209,7 @@ int main(int argc, char** argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 4000;
     const bool zeros = argc > 2 && atoi(argv[2]) != 0;
     if (argc > 3) g_wgs = atoi(argv[3]);
+    if (argc > 4) g_ring = atoi(argv[4]);
     unsigned* src; float* out; long long* clk;
     hipMalloc(&src, 65536 * 16 + 3 * 16384); hipMalloc(&out, 768 * 256 * 4); hipMalloc(&clk, 2 * 768 * 8);
     std::vector<unsigned> h(65536 * 4 + 3 * 4096);
@@ -194,7 +220,7 @@ int main(int argc, char** argv) {
         x = zeros ? 0u : (one() << 16) | one();
     }
     hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice);
-    printf("stage loop, %d stages per wave, %d workgroups = %d waves per SIMD, %s operands\n", iters, g_wgs, g_wgs / 256, zeros ? "ZERO" : "random");
+    printf("stage loop, %d stages per wave, %d workgroups = %d waves per SIMD, %s operands, per-tile ring step %d (0 none, 1 wait + barrier + 4 DMA pieces, 2 wait + barrier, 3 pieces only)\n", iters, g_wgs, g_wgs / 256, zeros ? "ZERO" : "random", g_ring);
     for (int round = 0; round < 2; ++round) {
         run<0>(src, out, clk, iters, "32x32x16 (8 per stage)");
         run<1>(src, out, clk, iters, "16x16x32 (16 per stage)");
