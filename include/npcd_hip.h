@@ -472,6 +472,13 @@ int npcd_pair_mlp_bwd(const void* wpack, int feat_dim, int precision, const floa
                       const void* x0, const void* acts, int64_t n_pairs, void* dact, float* dfeat, float* part, float* const* dW,
                       float* const* db, void* stream);
 
+/* ---- fp32-class forward of the denoiser's Linear layers (sampling in the reference's numerics class, diffusion_model.py:108-133;
+ * transformer.py:67,107-115,118-137): x W^T on fp32 operands as ONE bf16 library GEMM over the three cross products of split operands,
+ * [xh | xl | xh] [Wh | Wh | Wl]^T (x = xh + xl, bf16 halves; fp32 accumulation and output): 3e-6 relative, 2.3-3.5 x the fp32 GEMM's rate.
+ * npcd_split3_bf16: the activation side in one pass: y = x [rows, K] fp32 (+ bias [K]) (-> exact-erf GELU if gelu != 0)  ->
+ * out [rows, 3 K] bf16 = [hi(y) | lo(y) | hi(y)].  K % 8 == 0, 16-byte aligned pointers.  (ABI 8) */
+int npcd_split3_bf16(const float* x, const float* bias, void* out, int64_t rows, int K, int gelu, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,7 @@ SOURCES = {
     "gemm_nt.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "pairs.hip": ["-ffp-contract=off"],
     "pairs_mlp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
+    "split.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-fno-gpu-rdc", "-ffast-math" if False else "-fno-fast-math"]

@@ -182,6 +182,18 @@ def cast_f32_bf16(src, dst):
     return dst
 
 
+def split3(x, bias=None, gelu=False):
+    """y = x [T, K] fp32 (+ bias [K]) (-> exact-erf GELU)  ->  [T, 3 K] bf16 = [hi(y) | lo(y) | hi(y)]: the activation operand of the
+    fp32-class Linear layers (csrc/split.hip: one bf16 GEMM over the three cross products of split operands)."""
+    require_gpu(x)
+    x = x.contiguous()
+    T, K = x.shape
+    out = torch.empty((T, 3 * K), dtype=torch.bfloat16, device=x.device)
+    b = None if bias is None else bias.to(torch.float32).contiguous()
+    check(lib().npcd_split3_bf16(ptr(x), ptr(b), ptr(out), T, K, 1 if gelu else 0, stream_ptr()), "npcd_split3_bf16")
+    return out
+
+
 def ddpm_reverse_step(x_t, eps, noise, t, tables, clip=None, want_x0=False):
     """Fused reverse step of the sampler.  x_t / noise fp32 [B, ...], eps fp32 or bf16 (same shape), t int64 [B], tables = the five
     fp32 device tables (sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_mean_coef1, posterior_mean_coef2,

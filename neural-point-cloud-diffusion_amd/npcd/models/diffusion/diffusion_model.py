@@ -86,9 +86,25 @@ class DiffusionModel(nn.Module):
         training-time bf16 tolerance; `use_graph` replays each reverse step from a captured HIP graph."""
         assert not self.training, "Model must be in eval mode for generation"
         device = next(self.parameters()).device
-        coords_out, feats_out = [], []
         sizes = [batch_size] * (num // batch_size) + ([num % batch_size] if num % batch_size else [])
-        ctx = torch.autocast(device.type, dtype=dtype) if dtype is not None else contextlib.nullcontext()
+        # dtype = "fp32_class": the reference's fp32 sampling with the backbone's Linear layers as split-operand bf16 GEMMs (two bf16 halves
+        # per operand, three cross products, fp32 accumulation: 3e-6 relative per product; everything else fp32) -- fused.backbone_forward_x2
+        fp32_class = isinstance(dtype, str)
+        if fp32_class and dtype != "fp32_class":
+            raise ValueError("generate(dtype=...): a torch dtype for autocast, 'fp32_class', or None")
+        backbone = getattr(self.denoiser, "backbone", None)
+        ctx = torch.autocast(device.type, dtype=dtype) if (dtype is not None and not fp32_class) else contextlib.nullcontext()
+        prev_mode = getattr(backbone, "fp32_class", False)
+        if backbone is not None:
+            backbone.fp32_class = fp32_class
+        try:
+            return self._generate(sizes, device, ctx, progress, use_graph)
+        finally:
+            if backbone is not None:
+                backbone.fp32_class = prev_mode
+
+    def _generate(self, sizes, device, ctx, progress, use_graph):
+        coords_out, feats_out = [], []
         for bs in sizes:
             c = torch.randn(bs, self.coords_dim, self.num_points, device=device)
             f = torch.randn(bs, self.feats_dim, self.num_points, device=device)

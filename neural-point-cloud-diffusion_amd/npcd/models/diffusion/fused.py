@@ -233,6 +233,63 @@ class InferenceWeights:
         return self.blocks
 
 
+class InferenceWeightsX2:
+    """The block weights of a backbone in the split-operand form of the fp32-class forward (csrc/split.hip): per Linear layer
+    [Wh | Wh | Wl] bf16 [N, 3 K] with W = Wh + Wl, the biases and LayerNorm parameters in fp32.  Rebuilt when a parameter was written
+    to or replaced since the copy was taken."""
+
+    def __init__(self, backbone):
+        self.heads = backbone.resblocks[0].attn.heads
+        self.params = [[dict(blk.named_parameters())[n] for n in _BLOCK_PARAMS] for blk in backbone.resblocks]
+        self.stamp, self.blocks = None, None
+
+    def current(self):
+        stamp = [(p._version, p.data_ptr()) for ps in self.params for p in ps]
+        if stamp != self.stamp:
+            self.blocks = []
+            for ps in self.params:
+                e = {}
+                for n, p in zip(_BLOCK_PARAMS, ps):
+                    key = n.replace(".", "_")
+                    w = p.data.to(_f32)
+                    if n.endswith("weight") and not n.startswith("ln_"):
+                        hi = w.to(_bf16)
+                        lo = (w - hi.float()).to(_bf16)
+                        e[key + "_x3"] = torch.cat((hi, hi, lo), dim=1).contiguous()
+                    else:
+                        e[key] = w.contiguous()
+                self.blocks.append(e)
+            self.stamp = stamp
+        return self.blocks
+
+
+def backbone_forward_x2(x, blocks, heads):
+    """Forward only, in the reference's fp32 class (the sampler, diffusion_model.py:108-133, runs the denoiser in fp32): residual stream,
+    LayerNorm, attention (the fp32 matrix-instruction kernels of csrc/attention.hip) and GELU in fp32; the four Linear layers of a
+    block as ONE bf16 library GEMM each over the three cross products of split operands (csrc/split.hip, npcd_split3_bf16), fp32
+    accumulation and output -- 3e-6 relative per product against float64 (an fp32 GEMM: 4e-7), at 2.3-3.5 x the fp32 GEMM's rate.
+    x [B, n, W] fp32 -> [B, n, W] fp32.  `blocks`: InferenceWeightsX2.current()."""
+    import torch.nn.functional as F
+    B, n, W = x.shape
+    T, d = B * n, W // heads
+    scale = 1.0 / math.sqrt(d)
+    f32 = _f32
+
+    def lin(a3, e, name):           # [T, 3 K] bf16 x [N, 3 K]^T -> [T, N] fp32 (bias added by the consumer)
+        return torch.mm(a3, e[name + "_weight_x3"].t(), out_dtype=f32)
+    with torch.autocast("cuda", enabled=False):
+        xs = x.reshape(T, W).contiguous()
+        for e in blocks:
+            y1 = F.layer_norm(xs, (W,), e["ln_1_weight"], e["ln_1_bias"])
+            qkv = lin(ew.split3(y1), e, "attn_c_qkv").add_(e["attn_c_qkv_bias"]).view(B, n, heads, 3 * d)
+            a, _ = hattn._fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], scale)
+            xs = xs + lin(ew.split3(a.reshape(T, W)), e, "attn_c_proj").add_(e["attn_c_proj_bias"])
+            y2 = F.layer_norm(xs, (W,), e["ln_2_weight"], e["ln_2_bias"])
+            h = lin(ew.split3(y2), e, "mlp_c_fc")
+            xs = xs + lin(ew.split3(h, bias=e["mlp_c_fc_bias"], gelu=True), e, "mlp_c_proj").add_(e["mlp_c_proj_bias"])
+    return xs.view(B, n, W)
+
+
 def backbone_forward(x, blocks, heads, dtype=_bf16):
     """Forward only (sampler, evaluation): the kernels of the training forward, nothing kept for a backward.
     x [B, n, W] fp32 -> [B, n, W] fp32.  `dtype`: the 16-bit type of the weights in `blocks`."""

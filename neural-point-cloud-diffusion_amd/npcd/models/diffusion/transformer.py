@@ -102,6 +102,8 @@ class Transformer(nn.Module):
             for _ in range(layers))
         self.fused_engine = None        # set by npcd.train.DiffusionTrainer (explicit fwd/bwd over flat buffers)
         self._infer_weights = None      # bf16 weight copies of the forward-only path (sampler), built on first use
+        self._infer_weights_x2 = None   # split-operand weight copies of the fp32-class forward-only path
+        self.fp32_class = False         # set by DiffusionModel.generate(dtype="fp32_class"): fp32 forward with split-operand GEMMs
 
     def forward(self, x):
         eng = self.fused_engine
@@ -125,6 +127,13 @@ class Transformer(nn.Module):
                 return fused.backbone_forward(x, self._infer_weights.current(), self._infer_weights.heads)
         if eng is not None and eng.wait_range is not None:
             eng.wait_range()            # module path while a trainer's parameter gathers may still be in flight (engine.py)
+        if (self.fp32_class and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and not torch.is_grad_enabled()
+                and self.width // self.resblocks[0].attn.heads == 64 and self.width % 8 == 0):
+            # sampling / evaluation in the reference's fp32 class on the bf16 matrix rate (fused.backbone_forward_x2)
+            from . import fused
+            if self._infer_weights_x2 is None:
+                self._infer_weights_x2 = fused.InferenceWeightsX2(self)
+            return fused.backbone_forward_x2(x, self._infer_weights_x2.current(), self._infer_weights_x2.heads)
         for blk in self.resblocks:
             x = blk(x)
         return x

@@ -126,8 +126,12 @@ def x2_linear_forward(x, weight, bias):
     """y = x W^T + b in the fp32 class on the bf16 matrix rate: x W^T ~ xh Wh^T + xl Wh^T + xh Wl^T as ONE library GEMM over a three
     times longer contraction, [xh | xl | xh] [Wh | Wh | Wl]^T, with fp32 accumulation and output (the lo x lo term, 2^-18 relative,
     is dropped: ~1e-5 relative per product, like csrc/pairs_mlp.hip at precision 1).  Returns (y, saved operands)."""
-    xh, xl = split2(x)
     wh, wl = split2(weight)
+    if x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 8 == 0 and not torch.is_grad_enabled():
+        # forward only (rendering): the activation side in one pass (csrc/split.hip)
+        y = torch.mm(ew.split3(x), torch.cat((wh, wh, wl), dim=1).t(), out_dtype=torch.float32)
+        return y + bias, None
+    xh, xl = split2(x)
     y = torch.mm(torch.cat((xh, xl, xh), dim=1), torch.cat((wh, wh, wl), dim=1).t(), out_dtype=torch.float32)
     return y + bias, (xh, xl, wh, wl)
 

@@ -468,6 +468,70 @@ def test_opt_in_forward_without_the_fifth_workgroup_still_matches():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
 
 
+def test_fp32_class_sampler_forward_matches_the_fp32_path():
+    """DiffusionModel.generate(dtype="fp32_class") (round 5): the reference samples in fp32 (diffusion_model.py:108-133); here the backbone's
+    Linear layers run as ONE bf16 library GEMM each over the three cross products of split operands (csrc/split.hip + fused.backbone_forward_x2),
+    everything else -- residual stream, LayerNorm, the fp32 matrix-instruction attention, exact-erf GELU -- in fp32.  Against the plain fp32 module
+    path on the same weights: the eps prediction to rel-L2 <= 2e-5 (bf16 autocast: ~5e-3) at the tiny golden width AND at the benchmark's
+    width (1024 / 16 heads, 2 blocks, sequence 513); against the float32 CPU oracle like the fp32 path; one sampling loop reproduces the fp32 loop
+    from the same seed to 1e-3; the split kernel itself against its definition."""
+    from npcd.hip import elementwise as ew
+    from npcd.models.diffusion import DiffusionModel
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    # the split kernel: [hi | lo | hi] of (x + bias) and of gelu(x + bias)
+    x = torch.randn(37, 256, device="cuda") * 3
+    b = torch.randn(256, device="cuda")
+    for gelu in (False, True):
+        y = x + b
+        if gelu:
+            y = torch.nn.functional.gelu(y)
+        got = ew.split3(x, b, gelu)
+        hi = y.bfloat16()
+        lo = (y - hi.float()).bfloat16()
+        assert got.shape == (37, 768)
+        assert rel(got[:, :256].float() + got[:, 256:512].float(), y) < 1e-5 and torch.equal(got[:, :256], got[:, 512:])
+        assert float((got[:, :256].float() - hi.float()).abs().max()) <= 1e-2 * float(y.abs().max()) and rel(got[:, 256:512].float(), lo.float()) < 2e-2
+    for (F_, N, W, L, H, B) in ((32, 48, 128, 2, 2, 3), (128, 512, 1024, 2, 16, 2)):
+        torch.manual_seed(W)
+        params = od.init_params(3, F_, W, L, H, seed=4)
+        model = DiffusionModel(3, F_, N, W, L, H, False)
+        model.denoiser.load_state_dict(params)
+        with torch.no_grad():
+            model.denoiser.output_proj.weight.normal_(0, 0.05)           # (zero-initialised in the reference: eps would not see the backbone)
+        model = model.cuda().eval()
+        c = torch.randn(B, 3, N, device="cuda")
+        f = torch.randn(B, F_, N, device="cuda")
+        t = torch.randint(0, 1000, (B,), device="cuda")
+        bb = model.denoiser.backbone
+        with torch.no_grad():
+            e32 = model.denoiser(c, f, t)
+            bb.fp32_class = True
+            ex2 = model.denoiser(c, f, t)
+            bb.fp32_class = False
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                e16 = model.denoiser(c, f, t)
+        assert bb._infer_weights_x2 is not None, "the split-operand path was not taken"
+        r_c, r_f = rel(ex2[0], e32[0]), rel(ex2[1], e32[1])
+        print(f"fp32-class denoiser forward W {W}: eps rel-L2 vs the fp32 path {r_c:.1e} / {r_f:.1e}; bf16 autocast {rel(e16[0].float(), e32[0]):.1e}")
+        assert r_c < 2e-5 and r_f < 2e-5 and rel(e16[0].float(), e32[0]) > 1e-4
+        if W == 128:
+            sd = {k: v.cpu() for k, v in model.denoiser.state_dict().items()}
+            oc, of = od.denoiser_forward(sd, c.cpu(), f.cpu(), t.cpu(), H)
+            assert rel(ex2[0].cpu(), oc) < 1e-4 and rel(ex2[1].cpu(), of) < 1e-4
+            # a shortened sampling loop: same seed, fp32 against fp32-class
+            model.diffusion_process.num_timesteps = 10
+            model.coords_normalization.min.fill_(-3); model.coords_normalization.max.fill_(3)
+            model.feats_normalization.min.fill_(-1); model.feats_normalization.max.fill_(1)
+            torch.manual_seed(3)
+            a_c, a_f = model.generate(2, batch_size=2, progress=False)
+            torch.manual_seed(3)
+            b_c, b_f = model.generate(2, batch_size=2, progress=False, dtype="fp32_class")
+            assert bb.fp32_class is False
+            assert float((torch.stack(a_c) - torch.stack(b_c)).abs().max()) < 1e-3 and float((torch.stack(a_f) - torch.stack(b_f)).abs().max()) < 1e-3
+            with pytest.raises(ValueError):
+                model.generate(1, batch_size=1, progress=False, dtype="fp64")
+
+
 def test_opt_in_resident_forward_still_matches():
     """NPCD_ATTN_FWD=res (round 5, opt-in because it measured slower: 141 against 120 us in the step): the forward of 513-token sequences
     with K / V of a (batch, head) resident in LDS -- one workgroup of eight waves per (batch, head), the 513th query row split over the
