@@ -337,7 +337,7 @@ class ClockSampler:
         return out
 
 
-def bench_sample_and_render(device, clouds=4):
+def bench_sample_and_render(device, clouds=4, fp32_class=False):
     """The generate -> render loop of the reference's DiffusionEvaluation (npcd/eval/diffusion_evaluation.py:146-183; FID/KID itself
     needs the Inception assets, which are not in this environment): `clouds` point clouds from the full 1000-step sampler at the
     benchmark's model size (bf16 autocast, the forward-only fused backbone), each rendered at 128 x 128 from the 251 bundled SRN-cars
@@ -352,6 +352,14 @@ def bench_sample_and_render(device, clouds=4):
         net.diffusion.coords_normalization.scale.fill_(0.2)
         net.diffusion.feats_normalization.min.fill_(-1.0); net.diffusion.feats_normalization.max.fill_(1.0)
     poses, intr = load_test_poses("srncars")
+    if fp32_class:
+        # the reference's numerics class end to end (--eval-loop-fp32-class; ~10 s): fp32 sampling with split-operand GEMMs in the backbone,
+        # fp32-class shading (per-pair layers as two bf16 halves per operand, heads fp32)
+        r = sample_and_render(net, poses, intr, num_samples=clouds, generate_batch_size=clouds, render_batch_size=8, resolution=128,
+                              dtype="fp32_class", use_graph=False, render_mlp_dtype=torch.float32)
+        r["note"] = ("reference protocol in the reference's numerics class: DiffusionModel.generate(dtype='fp32_class') (fp32 everywhere, the backbone's Linear layers as "
+                     "split-operand bf16 GEMMs: eps 8e-7 from the fp32 path) and PointNeRF.render(mlp_dtype=torch.float32)")
+        return r
     r = sample_and_render(net, poses, intr, num_samples=clouds, generate_batch_size=clouds, render_batch_size=8, resolution=128,
                           dtype=torch.bfloat16, use_graph=True)
     r["note"] = ("reference protocol: generate_batch_size clouds per sampler call, 251 poses per cloud, render_batch_size 8; the sampler's denoiser "
@@ -703,6 +711,7 @@ def main():
     ap.add_argument("--no-proxy", action="store_true", help="skip the one-GPU strong-scaling proxy (per-GPU batch 64/32/16/8)")
     ap.add_argument("--no-cfg5", action="store_true", help="skip the BASELINE configs[4] step (2048 points x 256-d, per-GPU batch 32)")
     ap.add_argument("--no-sampler", action="store_true", help="skip the DDPM reverse-step timing (SURVEY 8(f) rank 1)")
+    ap.add_argument("--eval-loop-fp32-class", action="store_true", help="also run the generate -> render evaluation loop in the reference's numerics class (~10 s more)")
     ap.add_argument("--rccl-algo", default=None, help="NCCL_ALGO for RCCL (e.g. Ring, Tree); default: RCCL's own choice")
     ap.add_argument("--rccl-proto", default=None, help="NCCL_PROTO for RCCL (e.g. Simple, LL, LL128); default: RCCL's own choice")
     args = ap.parse_args()
@@ -958,6 +967,11 @@ def main():
             result["sample_and_render"] = bench_sample_and_render(device)
         except Exception as e:                      # noqa: BLE001
             result["sample_and_render"] = {"error": f"{type(e).__name__}: {e}"}
+        if args.eval_loop_fp32_class:
+            try:
+                result["sample_and_render_fp32_class"] = bench_sample_and_render(device, fp32_class=True)
+            except Exception as e:                  # noqa: BLE001
+                result["sample_and_render_fp32_class"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:

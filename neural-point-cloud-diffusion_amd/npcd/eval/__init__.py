@@ -68,12 +68,13 @@ def load_test_poses(name: str = "srncars"):
 @torch.no_grad()
 def sample_and_render(model, poses: torch.Tensor, intrinsics: torch.Tensor, num_samples: int = 4, generate_batch_size: int = 4,
                       render_batch_size: int = 8, resolution: int = 128, dtype=None, use_graph: bool = False, feed=None,
-                      max_shading_points=None) -> Dict:
+                      max_shading_points=None, render_mlp_dtype=None) -> Dict:
     """The measurement loop of the reference's DiffusionEvaluation._evaluate (:146-183): `generate_batch_size` clouds at a time from
     model.diffusion.generate (:152), every cloud rendered from all poses, `render_batch_size` poses per PointNeRF.render call
     (:163-169), images clipped to [0, 1] and rounded to 8 bits (:172-173).  `feed(images [n_poses, 3, H, W] in [0, 1])`, when given,
     receives every cloud's images (the reference hands them to FID/KID as images * 2 - 1, :179; the Inception network is outside this
-    package).  `dtype`: run the sampler's denoiser under autocast (DiffusionModel.generate).  Returns timings:
+    package, SURVEY section 8).  `dtype`: run the sampler's denoiser under autocast, or "fp32_class" (DiffusionModel.generate);
+    `render_mlp_dtype=torch.float32`: shade in the reference's numerics class (PointNeRF.render).  Returns timings:
     seconds in generate / render, clouds per second, rendered views and rays per second (device-synchronised walls)."""
     model.eval()
     dev = next(model.pointnerf.parameters()).device
@@ -97,7 +98,7 @@ def sample_and_render(model, poses: torch.Tensor, intrinsics: torch.Tensor, num_
             imgs = []
             for p0 in range(0, n_poses, render_batch_size):
                 out = model.pointnerf.render(coords, feats, poses[None, p0:p0 + render_batch_size], intrinsics[None, p0:p0 + render_batch_size],
-                                             resolution=resolution, max_shading_points=max_shading_points)
+                                             resolution=resolution, max_shading_points=max_shading_points, mlp_dtype=render_mlp_dtype)
                 im = unflatten_pred(out["channels"])[0].clamp(0.0, 1.0)
                 imgs.append(torch.round(im * 255.0) / 255.0)
             images = torch.cat(imgs)
