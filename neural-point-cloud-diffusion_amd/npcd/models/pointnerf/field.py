@@ -157,6 +157,8 @@ class Field(nn.Module):
         pts [P, 3]; point_dir [P, 3] with use_dir.  -> sigma [P], rgb [P, 3].  Roughly 4 x the time of the fp16 kernels."""
         import torch.nn.functional as F
         agg, lf = self.aggregator, self.aggregator.local_field
+        if nb_idx.shape[0] == 0:          # no shading point at all (every ray misses the cloud)
+            return torch.zeros(0, dtype=torch.float32, device=pts.device), torch.zeros((0, 3), dtype=torch.float32, device=pts.device)
         nb = nb_idx.long()
         valid = nb >= 0
         cnt = valid.sum(dim=1)

@@ -380,6 +380,13 @@ def test_render_in_the_reference_numerics_class(golden):
     assert e32 < 2e-5 and e16 < 5e-3 and e32 < e16, (e32, e16)
     assert torch.equal(out32["channels"], out32b["channels"])
     assert float((out32["depth"].cpu() - ref["depth"]).abs().max()) < 1e-4
+    # no shading point at all (every ray misses the cloud: principal point far outside the image): white image, no error
+    intr_miss = intr.clone()
+    intr_miss[..., 0, 2] = 1.0e5
+    with torch.no_grad():
+        om = m.render(coords.cuda(), feats.cuda(), extr.cuda(), intr_miss.cuda(), res, mlp_dtype=torch.float32)
+        om16 = m.render(coords.cuda(), feats.cuda(), extr.cuda(), intr_miss.cuda(), res)
+    assert int(om["num_shading_points"]) == 0 and torch.equal(om["channels"], om16["channels"]) and float(om["mask"].abs().max()) == 0.0
     # weights that leave the fp16 range: the fp16 kernels flag it (and return NaN), the fp32-class path follows the oracle
     pb = dict(p)
     pb["aggregator.local_field.2.weight"] = p["aggregator.local_field.2.weight"] * 3.0e5
