@@ -478,6 +478,11 @@ int npcd_pair_mlp_bwd(const void* wpack, int feat_dim, int precision, const floa
  * npcd_split3_bf16: the activation side in one pass: y = x [rows, K] fp32 (+ bias [K]) (-> exact-erf GELU if gelu != 0)  ->
  * out [rows, 3 K] bf16 = [hi(y) | lo(y) | hi(y)].  K % 8 == 0, 16-byte aligned pointers.  (ABI 8) */
 int npcd_split3_bf16(const float* x, const float* bias, void* out, int64_t rows, int K, int gelu, void* stream);
+/* The same hand-over behind a LayerNorm (transformer.py:169-172: x = x + attn(ln_1(x)); x = x + mlp(ln_2(x))), one pass:
+ * xnew = x (+ o + bias, written when o is given);  out [rows, 3 W] = [hi | lo | hi] of LayerNorm(xnew) * gamma + beta (fp32 statistics, biased
+ * variance).  o / bias / xnew: all three or none.  W in {256, 512, 768, 1024, 2048, 4096}.  (ABI 8) */
+int npcd_add_ln_split3_bf16(const float* x, const float* o, const float* bias, const float* gamma, const float* beta, float* xnew,
+                            void* out, int64_t rows, int W, float eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -105,6 +105,7 @@ SIGNATURES = {
     "npcd_eps_mse_fwd": (c_int, [_P, _P, c_int, c_int64, _P, _P, _P, _P]),
     "npcd_eps_mse_bwd": (c_int, [_P, _P, c_int, c_int64, _P, _P, _P]),
     "npcd_split3_bf16": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P]),
+    "npcd_add_ln_split3_bf16": (c_int, [_P] * 7 + [c_int64, c_int, c_float, _P]),
     "npcd_pair_mlp_wpack_bytes": (c_int64, [c_int, c_int]),
     "npcd_pair_mlp_pack": (c_int, [POINTER(_P), POINTER(_P), c_int, c_int, _P, _P]),
     "npcd_pair_mlp_fwd": (c_int, [_P, c_int, c_int] + [_P] * 5 + [c_int64, c_int, c_int64] + [_P] * 4 + [_P]),

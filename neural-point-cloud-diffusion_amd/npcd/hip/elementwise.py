@@ -194,6 +194,25 @@ def split3(x, bias=None, gelu=False):
     return out
 
 
+def add_ln_split3(x, gamma, beta, o=None, bias=None, eps=1e-5):
+    """xnew = x (+ o + bias);  [T, 3 W] bf16 = [hi | lo | hi] of LayerNorm(xnew) * gamma + beta: (xnew or x itself, split) -- csrc/split.hip.
+    Returns None for widths the kernel does not take (the caller composes it from torch's LayerNorm and split3)."""
+    require_gpu(x)
+    T, W = x.shape
+    if W % 256 or W // 256 not in (1, 2, 3, 4, 8, 16):
+        return None
+    x = x.contiguous()
+    out = torch.empty((T, 3 * W), dtype=torch.bfloat16, device=x.device)
+    xnew = None
+    if o is not None:
+        o = o.contiguous()
+        bias = bias.to(torch.float32).contiguous()
+        xnew = torch.empty_like(x)
+    check(lib().npcd_add_ln_split3_bf16(ptr(x), ptr(o), ptr(bias), ptr(gamma.contiguous()), ptr(beta.contiguous()), ptr(xnew), ptr(out), T, W,
+                                        float(eps), stream_ptr()), "npcd_add_ln_split3_bf16")
+    return (x if xnew is None else xnew), out
+
+
 def ddpm_reverse_step(x_t, eps, noise, t, tables, clip=None, want_x0=False):
     """Fused reverse step of the sampler.  x_t / noise fp32 [B, ...], eps fp32 or bf16 (same shape), t int64 [B], tables = the five
     fp32 device tables (sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod, posterior_mean_coef1, posterior_mean_coef2,

@@ -277,16 +277,24 @@ def backbone_forward_x2(x, blocks, heads):
 
     def lin(a3, e, name):           # [T, 3 K] bf16 x [N, 3 K]^T -> [T, N] fp32 (bias added by the consumer)
         return torch.mm(a3, e[name + "_weight_x3"].t(), out_dtype=f32)
+    def ln_split(xs, e, ln, o=None, bias=None):      # (xs + o + bias, split(LayerNorm(.))): one kernel, or torch + split3 for other widths
+        r = ew.add_ln_split3(xs, e[ln + "_weight"], e[ln + "_bias"], o, bias)
+        if r is not None:
+            return r
+        if o is not None:
+            xs = xs + o + bias
+        return xs, ew.split3(F.layer_norm(xs, (W,), e[ln + "_weight"], e[ln + "_bias"]))
     with torch.autocast("cuda", enabled=False):
         xs = x.reshape(T, W).contiguous()
+        o, ob = None, None               # the previous block's mlp.c_proj output and bias: added by the next LayerNorm kernel
         for e in blocks:
-            y1 = F.layer_norm(xs, (W,), e["ln_1_weight"], e["ln_1_bias"])
-            qkv = lin(ew.split3(y1), e, "attn_c_qkv").add_(e["attn_c_qkv_bias"]).view(B, n, heads, 3 * d)
+            xs, y1 = ln_split(xs, e, "ln_1", o, ob)
+            qkv = lin(y1, e, "attn_c_qkv").add_(e["attn_c_qkv_bias"]).view(B, n, heads, 3 * d)
             a, _ = hattn._fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], scale)
-            xs = xs + lin(ew.split3(a.reshape(T, W)), e, "attn_c_proj").add_(e["attn_c_proj_bias"])
-            y2 = F.layer_norm(xs, (W,), e["ln_2_weight"], e["ln_2_bias"])
-            h = lin(ew.split3(y2), e, "mlp_c_fc")
-            xs = xs + lin(ew.split3(h, bias=e["mlp_c_fc_bias"], gelu=True), e, "mlp_c_proj").add_(e["mlp_c_proj_bias"])
+            xs, y2 = ln_split(xs, e, "ln_2", lin(ew.split3(a.reshape(T, W)), e, "attn_c_proj"), e["attn_c_proj_bias"])
+            h = lin(y2, e, "mlp_c_fc")
+            o, ob = lin(ew.split3(h, bias=e["mlp_c_fc_bias"], gelu=True), e, "mlp_c_proj"), e["mlp_c_proj_bias"]
+        xs = xs + o + ob
     return xs.view(B, n, W)
 
 

@@ -491,6 +491,18 @@ def test_fp32_class_sampler_forward_matches_the_fp32_path():
         assert got.shape == (37, 768)
         assert rel(got[:, :256].float() + got[:, 256:512].float(), y) < 1e-5 and torch.equal(got[:, :256], got[:, 512:])
         assert float((got[:, :256].float() - hi.float()).abs().max()) <= 1e-2 * float(y.abs().max()) and rel(got[:, 256:512].float(), lo.float()) < 2e-2
+    # the LayerNorm hand-over kernel: xnew = x + o + bias (bit-exact in that order), [hi | lo | hi] of LayerNorm(xnew); widths it does not take -> None
+    for W_, T_ in ((256, 5), (1024, 1027), (768, 64)):
+        x, o = torch.randn(T_, W_, device="cuda") * 2 + 0.5, torch.randn(T_, W_, device="cuda")
+        b, g, be = torch.randn(W_, device="cuda"), torch.rand(W_, device="cuda") + 0.5, torch.randn(W_, device="cuda")
+        for fused_add in (False, True):
+            xn, got = ew.add_ln_split3(x, g, be, o, b) if fused_add else ew.add_ln_split3(x, g, be)
+            want_x = x + (o + b) if fused_add else x
+            assert torch.equal(xn, want_x)
+            y = torch.nn.functional.layer_norm(want_x.double(), (W_,), g.double(), be.double())
+            assert got.shape == (T_, 3 * W_) and torch.equal(got[:, :W_], got[:, 2 * W_:])
+            assert rel(got[:, :W_].float() + got[:, W_:2 * W_].float(), y) < 1e-5
+    assert ew.add_ln_split3(torch.randn(4, 128, device="cuda"), torch.ones(128, device="cuda"), torch.zeros(128, device="cuda")) is None
     for (F_, N, W, L, H, B) in ((32, 48, 128, 2, 2, 3), (128, 512, 1024, 2, 16, 2)):
         torch.manual_seed(W)
         params = od.init_params(3, F_, W, L, H, seed=4)
