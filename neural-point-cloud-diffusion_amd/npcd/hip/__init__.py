@@ -167,5 +167,12 @@ def ptr(t):
     return c_void_p(0 if t is None else t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """torch's current HIP stream of the current device as a pointer.  (`torch.cuda.current_stream().cuda_stream` costs ~9 us of Python per
+    call -- 126 calls = 1.2 ms of a rank's 17-ms step at per-GPU batch 8, which is host-bound; the raw accessor is one C call.)"""
+    if _raw_stream is not None:
+        return c_void_p(_raw_stream(torch.cuda.current_device()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -126,9 +126,15 @@ def _wgrad(dy, x, out):
         torch.sum(part, dim=0, out=out)
 
 
-# A/B switch (measured, not the default: docs/experiments.md R3.9): the weight gradients of a block on a second HIP stream, beside
-# the HBM-bound GELU / LayerNorm backward kernels of the critical path.  NPCD_WGRAD_STREAM=1, NPCD_WGRAD_STREAM_PRIO=<priority>.
-_WGRAD_STREAM = bool(os.environ.get("NPCD_WGRAD_STREAM"))
+# The weight gradients of a block on a second HIP stream, beside the data-gradient products and the HBM-bound GELU / LayerNorm backward
+# kernels of the critical path; joined before the block's gradients are handed to the reducer.  Round 3 measured nothing at per-GPU
+# batch 64 (docs/experiments.md R3.9); round 5 at the batches of a rank of the strong-scaling job, where a product is one partial
+# round of tiles: 19.1 -> 18.6 ms per step at batch 8, 29.3 -> 28.7 at 16, 46.0 -> 45.6 at 32; at 64 it measures 84.4-84.5 against
+# 82.9-84.3 ms (R5.11) -- the default below _WGRAD_STREAM_MAX_T token rows since.  NPCD_WGRAD_STREAM=0 / 1 forces it off / on at
+# every size, NPCD_WGRAD_STREAM_PRIO=<priority> sets the side stream's priority.  Same kernels in the same order per tensor: the
+# gradients are the same bits either way (tests/test_gpu_fused.py).
+_WGRAD_STREAM = os.environ.get("NPCD_WGRAD_STREAM", "1") != "0"
+_WGRAD_STREAM_MAX_T = (1 << 62) if os.environ.get("NPCD_WGRAD_STREAM") == "1" else 20000
 _side = {}
 
 
@@ -139,20 +145,26 @@ def _side_stream(device):
     return s
 
 
-def _wgrad_maybe_async(dy, x, out):
-    if not _WGRAD_STREAM:
-        return _wgrad(dy, x, out)
-    side = _side_stream(dy.device)
+def _wgrad_side_ok(T):
+    return _WGRAD_STREAM and T <= _WGRAD_STREAM_MAX_T
+
+
+def _wgrad_fork(pending, device):
+    """The weight-gradient products of ONE block -- (dy, x, out) triples -- on the side stream, behind everything the current stream has
+    been given so far: one fork per block (per product it cost the host ~40 us of stream bookkeeping, 3.8 ms of a rank's step at
+    per-GPU batch 8, which is host-bound: tools/probes/gpu_dev_b8_hostprofile.py)."""
+    side = _side_stream(device)
     side.wait_stream(torch.cuda.current_stream())
-    dy.record_stream(side)
-    x.record_stream(side)
     with torch.cuda.stream(side):
-        _wgrad(dy, x, out)
+        for dy, x, out in pending:
+            dy.record_stream(side)
+            x.record_stream(side)
+            _wgrad(dy, x, out)
+    pending.clear()
 
 
 def _wgrad_join(device):
-    if _WGRAD_STREAM:
-        torch.cuda.current_stream().wait_stream(_side_stream(device))
+    torch.cuda.current_stream().wait_stream(_side_stream(device))
 
 
 class FusedBackboneEngine:
@@ -360,11 +372,18 @@ class _BackboneFn(torch.autograd.Function):
             dxb = dx.to(eng.dtype)
             last = eng.blocks[-1]
             last["mlp_c_proj_bias_g"].copy_(dx.sum(dim=0))
+            side, pending = _wgrad_side_ok(T), []
+
+            def ready(entry):
+                if eng.reducer is not None:
+                    for p in entry["params"]:
+                        eng.reducer.mark_ready(p)
             for bi in range(len(eng.blocks) - 1, -1, -1):
                 e = eng.blocks[bi]
                 x_cur, mean1, rstd1, y1, qkv, a, lse, x2, mean2, rstd2, y2, h, g = ctx.saved[bi]
                 ctx.saved[bi] = None
                 sums = ew.ColsumBatch()            # this block's 8 bias / LN-affine column sums: one finalize
+                wg = pending.append if side else (lambda t: _wgrad(*t))      # weight gradients: now, or queued for the side stream
                 # ---- MLP branch: x3 = x2 + c_proj(gelu(c_fc(ln_2(x2)))) ------------------------------
                 Tm = T - T % 256
                 w2 = e["mlp_c_proj_weight_16"]
@@ -383,22 +402,22 @@ class _BackboneFn(torch.autograd.Function):
                         ew.gelu_bwd(dg, h[Tm:], None, out=dh[Tm:], part_rows=part[rows:])
                         del dg
                     sums.add(part, rows + extra, 4 * W, e["mlp_c_fc_bias_g"])
-                    _wgrad_maybe_async(dxb, g, e["mlp_c_proj_weight_g"])
+                    wg((dxb, g, e["mlp_c_proj_weight_g"]))
                     del g, h
                 else:
                     dg = _dgrad(dxb, e["mlp_c_proj_weight_16"])
-                    _wgrad_maybe_async(dxb, g, e["mlp_c_proj_weight_g"])
+                    wg((dxb, g, e["mlp_c_proj_weight_g"]))
                     dh = ew.gelu_bwd(dg, h, e["mlp_c_fc_bias_g"], batch=sums)
                     del dg, g, h
                 dy2 = _dgrad(dh, e["mlp_c_fc_weight_16"])
-                _wgrad_maybe_async(dh, y2, e["mlp_c_fc_weight_g"])
+                wg((dh, y2, e["mlp_c_fc_weight_g"]))
                 del dh, y2
                 dx2, dx2b = ew.ln_bwd(dy2, x2, mean2, rstd2, e["ln_2_weight"], dx, e["ln_2_weight_g"], e["ln_2_bias_g"],
                                       e["attn_c_proj_bias_g"], batch=sums)
                 del dy2, x2, dx, dxb
                 # ---- attention branch: x2 = x + c_proj(attn(c_qkv(ln_1(x)))) ---------------------------
                 da = _dgrad(dx2b, e["attn_c_proj_weight_16"])
-                _wgrad_maybe_async(dx2b, a, e["attn_c_proj_weight_g"])
+                wg((dx2b, a, e["attn_c_proj_weight_g"]))
                 dqkv = torch.empty_like(qkv)
                 q4, g4 = qkv.view(B, n, H, 3 * d), dqkv.view(B, n, H, 3 * d)
                 # the c_qkv bias gradient (column sums of dqkv) is a by-product of the attention backward's row stores
@@ -411,16 +430,23 @@ class _BackboneFn(torch.autograd.Function):
                 else:
                     ew.colsum_bf16(dqkv, e["attn_c_qkv_bias_g"], batch=sums)
                 dy1 = _dgrad(dqkv, e["attn_c_qkv_weight_16"])
-                _wgrad_maybe_async(dqkv, y1, e["attn_c_qkv_weight_g"])
+                wg((dqkv, y1, e["attn_c_qkv_weight_g"]))
                 del dqkv, y1
                 prev_bias_g = eng.blocks[bi - 1]["mlp_c_proj_bias_g"] if bi > 0 else None
                 dx, dxb = ew.ln_bwd(dy1, x_cur, mean1, rstd1, e["ln_1_weight"], dx2, e["ln_1_weight_g"], e["ln_1_bias_g"],
                                     prev_bias_g, want_bf16=bi > 0, batch=sums)
                 del dy1, dx2
                 sums.flush()
+                if side:
+                    # the block ABOVE had this block's critical path to finish its weight gradients beside: join them, hand its
+                    # gradients on, then start this block's four products on the side stream
+                    if bi + 1 < len(eng.blocks):
+                        _wgrad_join(dx.device)
+                        ready(eng.blocks[bi + 1])
+                    _wgrad_fork(pending, dx.device)
+                else:
+                    ready(e)       # this block's gradients are final (mlp.c_proj.bias was finished by the block above / the tail)
+            if side:
                 _wgrad_join(dx.device)
-                if eng.reducer is not None:
-                    # this block's gradients are final (mlp.c_proj.bias was finished by the block above / the tail)
-                    for p in e["params"]:
-                        eng.reducer.mark_ready(p)
+                ready(eng.blocks[0])
         return dx.view(B, n, W), None

@@ -141,6 +141,40 @@ def test_fused_backbone_matches_module_path():
     assert rel(ta.ema, tb.ema) < 1e-4
 
 
+def test_weight_gradients_on_the_side_stream_are_the_same_bits():
+    """The weight-gradient products of a block run on a second HIP stream (fused._WGRAD_STREAM, the default since round 5) and are joined
+    before the block's gradients are handed on: every gradient after a backward, and the parameters after three optimizer steps, are
+    bit-identical to the single-stream order."""
+    from npcd.models.diffusion import fused
+    from npcd.train import DiffusionTrainer
+    assert fused._WGRAD_STREAM is True
+    a, b = _models()
+    ta, tb = DiffusionTrainer(a, fused=True), DiffusionTrainer(b, fused=True)
+    g = torch.Generator().manual_seed(3)
+    B, N, F_ = 5, 48, 32
+    c0, f0 = torch.randn(B, 3, N, generator=g).cuda(), torch.randn(B, F_, N, generator=g).cuda()
+    t = torch.tensor([5, 500, 990, 17, 640]).cuda()
+    cn, fn = torch.randn(B, 3, N, generator=g).cuda(), torch.randn(B, F_, N, generator=g).cuda()
+    try:
+        for tr, side in ((ta, True), (tb, False)):
+            fused._WGRAD_STREAM = side
+            tr.flat.zero_grad(); tr.reducer.start_step()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss, _, _ = tr.model.compute_loss(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
+            loss.backward()
+            torch.cuda.synchronize()
+        for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+            assert torch.equal(pa.grad, pb.grad), n
+        for tr, side in ((ta, True), (tb, False)):
+            fused._WGRAD_STREAM = side
+            for _ in range(3):
+                tr.step(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
+        torch.cuda.synchronize()
+        assert torch.equal(ta.flat.flat, tb.flat.flat)
+    finally:
+        fused._WGRAD_STREAM = True
+
+
 @pytest.mark.parametrize("tag", ["f32_w64", "f128_w64", "f32_w128_h2"])
 @pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
 def test_fused_engine_matches_reference_golden_directly(golden, tag, half):
