@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) rel[c] = in.pt[c] - in.kp[c];
             }
-            if (half == 0 && gi >= 0) wrow[prow] = 1.f / (sqrtf(rel[0] * rel[0] + rel[1] * rel[1] + rel[2] * rel[2]) + 1e-5f);
+            if (half == 0 && gi >= 0) wrow[prow] = 1.f / (sqrtf(__builtin_fmaf(rel[0], rel[0], __builtin_fmaf(rel[1], rel[1], rel[2] * rel[2]))) + 1e-5f);
             constexpr int FH = FEAT / 2;
             if (gi >= 0) {
                 // features: this half converts FEAT/2 channels
@@ -462,7 +462,10 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
             for (int s2 = 0; s2 < 8; ++s2) {
                 const float ws = w8[s2] * inv;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { out[j] += ws * (float)v0[s2][j]; out[8 + j] += ws * (float)v1[s2][j]; }
+                for (int j = 0; j < 8; ++j) {      // (explicit fused multiply-adds: the eight-wave form must round the same way)
+                    out[j] = __builtin_fmaf(ws, (float)v0[s2][j], out[j]);
+                    out[8 + j] = __builtin_fmaf(ws, (float)v1[s2][j], out[8 + j]);
+                }
             }
             if (cnt == 0) {          // (the re-read row of a point without neighbours holds whatever the tile left there)
 #pragma unroll
@@ -506,7 +509,9 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
     }
     if (tid == 0 && blockIdx.x < 512) {
         long long* sp = g_shade_span + 4 * blockIdx.x;
-        sp[0] = rt_begin; sp[1] = __builtin_amdgcn_s_memrealtime(); sp[2] = span_tiles; sp[3] = __builtin_amdgcn_s_memtime() - tl_begin;
+        // (tiles | HW_ID << 16 | XCC_ID << 48: which CU / XCD the workgroup ran on)
+        const long long hw = (long long)(unsigned)__builtin_amdgcn_s_getreg(63492), xcc = (long long)(__builtin_amdgcn_s_getreg(6164) & 15);
+        sp[0] = rt_begin; sp[1] = __builtin_amdgcn_s_memrealtime(); sp[2] = span_tiles | (hw << 16) | (xcc << 48); sp[3] = __builtin_amdgcn_s_memtime() - tl_begin;
     }
 #endif
 }
@@ -522,6 +527,280 @@ extern "C" int npcd_shade_debug_read(long long* out, int count) {
 extern "C" int npcd_shade_rows_debug_read(long long* out, int count) { return npcd::rows_debug_read(out, count); }
 namespace npcd {
 #endif
+
+// ============================================================================================
+// kernel A, eight-wave form: the same tile on 512 threads
+// ============================================================================================
+// Why (docs/experiments.md R5.12): with two workgroups of four waves a SIMD holds TWO waves, each alternating between a matrix phase
+// and a phase without matrix instructions (write-back, barriers, prologue, aggregation, the start of a layer's weight stream).  The
+// counters say a wave is issuing 27 % of its cycles and no unit is saturated (matrix pipe 0.51, LDS ~0.3, vector L1 ~0.3): the tile is
+// a dependency chain, and two chains per SIMD leave the matrix pipe idle whenever both are outside their matrix phases.  Here a wave
+// owns 32 output channels instead of 64 (accumulators 64 registers instead of 128, <= 128 registers per wave): two workgroups of
+// EIGHT waves put four chains on a SIMD.  The price: every wave reads all activation fragments of its tile, so the LDS read volume of
+// the layers doubles (~1.8 MB per tile = ~14 k clocks of the CU's LDS pipe against ~12 k of matrix pipe).  Same instructions per
+// output element in the same order: results are bit-identical to the four-wave form.
+struct WRing8 { f16x8 a[4]; };
+template <int KSTEPS>
+__device__ __forceinline__ f16x8 wfrag_load8(wrsrc_t rs, int w_off, int wave, int lane, int step) {
+    const int so = w_off + wave * (KSTEPS * kFragBytes) + (step >> 2) * (4 * kFragBytes);
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + (step & 3) * kFragBytes, so, 0));
+}
+template <int KSTEPS, int PF>
+__device__ __forceinline__ void layer_prefetch8(wrsrc_t rs, int w_off, int b_off, int wave, int lane, WRing8& ring, f32x16& init) {
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, hh * 32 + (g >> 1) * 64 + (g & 1) * 16, b_off + wave * 128, 0));
+#pragma unroll
+        for (int b = 0; b < 4; ++b) init[4 * g + b] = b4[b];
+    }
+#pragma unroll
+    for (int d = 0; d < PF && d < KSTEPS; ++d) ring.a[d] = wfrag_load8<KSTEPS>(rs, w_off, wave, lane, d);
+}
+// per k-step: [weight fragment of step s + PF] fence [NB matrix instructions] fence [activation fragments of step s + 1, into the
+// registers the matrix instructions just read: one set -- the other three waves of the SIMD cover the LDS latency]
+template <int KSTEPS, int NB, int PF>
+__device__ __forceinline__ void layer_mfma8(const unsigned char* H, wrsrc_t rs, int w_off, int wave, int lane, WRing8& ring, const f32x16& init,
+                                            f32x16 (&acc)[4]) {
+    static_assert(PF >= 1 && PF <= 3, "ring of four");
+    const int r = lane & 31, hh = lane >> 5;
+    const unsigned char* hb = H + r * kRowBytes + hh * 16;
+    f16x8 bc[NB];
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) bc[cb] = *reinterpret_cast<const f16x8*>(hb + cb * 32 * kRowBytes);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        if (s + PF < KSTEPS) ring.a[(s + PF) & 3] = wfrag_load8<KSTEPS>(rs, w_off, wave, lane, s + PF);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) acc[cb] = F16::mfma32(ring.a[s & 3], bc[cb], s == 0 ? init : acc[cb]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < KSTEPS) {
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) bc[cb] = *reinterpret_cast<const f16x8*>(hb + cb * 32 * kRowBytes + (s + 1) * 32);
+        }
+    }
+}
+template <bool ACT, int NB>
+__device__ __forceinline__ void layer_store8(unsigned char* H, int wave, int lane, const f32x16 (&acc)[4]) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const int r = lane & 31, hh = lane >> 5;
+    unsigned char* sb = H + r * kRowBytes + hh * 16 + wave * 64;      // row (cb*32 + r), channels 32 wave + 16 gp + 8 hh .. + 7
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            uint32_t v[2][2];
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int e = 4 * (2 * gp + gg) + 2 * b;
+                    const f32x2 f = {acc[cb][e], acc[cb][e + 1]};
+                    f16x2 h = __builtin_convertvector(f, f16x2);
+                    if (ACT) {
+                        const f16x2 sc = {(_Float16)kLeaky, (_Float16)kLeaky};
+                        h = __builtin_elementwise_max(h, h * sc);
+                    }
+                    v[gg][b] = __builtin_bit_cast(uint32_t, h);
+                }
+            *reinterpret_cast<u32x4*>(sb + cb * 32 * kRowBytes + gp * 32) = u32x4{v[0][0], v[0][1], v[1][0], v[1][1]};
+        }
+}
+#ifndef NPCD_PAIRS8_PF
+#define NPCD_PAIRS8_PF 2
+#endif
+template <int FEAT, int NB>
+__device__ __forceinline__ void pair_layers8(unsigned char* H, const PairPack& pk, int wave, int lane) {
+    constexpr int K0 = FEAT + kEncBlock, PF = NPCD_PAIRS8_PF;
+    constexpr int kLayerBytes = 8 * (kHidden / 16) * kFragBytes;
+    f32x16 acc[4];
+    WRing8 ring;
+    f32x16 init;
+    layer_prefetch8<K0 / 16, PF>(pk.rs, 0, pk.b0, wave, lane, ring, init);
+    layer_mfma8<K0 / 16, NB, PF>(H, pk.rs, 0, wave, lane, ring, init, acc);
+    layer_prefetch8<kHidden / 16, PF>(pk.rs, pk.w1, pk.b0 + kHidden * 4, wave, lane, ring, init);
+    __syncthreads();
+    layer_store8<true, NB>(H, wave, lane, acc);
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 1; l < 4; ++l) {
+        const int w_off = pk.w1 + (l - 1) * kLayerBytes, b_off = pk.b0 + l * (kHidden * 4);
+        layer_mfma8<kHidden / 16, NB, PF>(H, pk.rs, w_off, wave, lane, ring, init, acc);
+        if (l < 3) layer_prefetch8<kHidden / 16, PF>(pk.rs, w_off + kLayerBytes, b_off + kHidden * 4, wave, lane, ring, init);
+        __syncthreads();
+        layer_store8<true, NB>(H, wave, lane, acc);
+        __syncthreads();
+    }
+}
+template <int FEAT>
+struct PairInputs8 {
+    int gi, gi_other;
+    float pt[3], kp[3];
+    f32x4 feat[FEAT / 16];             // this quarter's FEAT / 4 neighbour features
+};
+template <int FEAT>
+__device__ __forceinline__ void pair_load_indices8(const ShadeArgs& a, int tile, int P, int tid, PairInputs8<FEAT>& in) {
+    tid = opaque(tid);
+    const int row = tid & 127, slot = row & 7;
+    const int p = tile * 16 + (row >> 3), po = tile * 16 + ((row ^ 64) >> 3);
+    in.gi = -1;
+    in.gi_other = -1;
+    if (p < P && slot < a.k) in.gi = a.nb_idx[(int64_t)p * a.k + slot];
+    if (po < P && slot < a.k) in.gi_other = a.nb_idx[(int64_t)po * a.k + slot];
+}
+template <int FEAT>
+__device__ __forceinline__ void pair_load_data8(const ShadeArgs& a, int tile, int tid, PairInputs8<FEAT>& in) {
+    const int row = opaque(tid) & 127, part = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int p = min(tile * 16 + (row >> 3), a.max_points - 1), g = max(in.gi, 0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { in.pt[c] = a.pts[(int64_t)p * 3 + c]; in.kp[c] = a.kp_pos[(int64_t)g * 3 + c]; }
+    const float* fp = a.kp_feat + (int64_t)g * FEAT + part * (FEAT / 4);
+#pragma unroll
+    for (int c4 = 0; c4 < FEAT / 16; ++c4) in.feat[c4] = *reinterpret_cast<const f32x4*>(fp + c4 * 4);
+}
+// the 16 positional-encoding columns 16 PART .. 16 PART + 15 of a row (two 16-byte chunks)
+template <int FEAT, int PART>
+__device__ __forceinline__ void enc_put16(unsigned char* H, int prow, const float (&rel)[3]) {
+#pragma unroll
+    for (int c8 = 0; c8 < 2; ++c8) {
+        f16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)enc_value(PART * 16 + c8 * 8 + j, rel);
+        *reinterpret_cast<f16x8*>(H + act_off(prow, FEAT / 8 + PART * 2 + c8)) = v;
+    }
+}
+
+template <int FEAT>
+__global__ __launch_bounds__(512, 4) void shade_pairs8_kernel(ShadeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+    unsigned char* H = dsmem;
+    float* wrow = reinterpret_cast<float*>(dsmem + kRows * kRowBytes);
+    int* pstart = reinterpret_cast<int*>(wrow + kRows);
+    int* pcount = pstart + 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const ShadeLayout L = shade_layout(FEAT);
+    const PairPack pk = {pack_rsrc(a.wpack, L.total), (int)L.w[1], (int)L.bias[0]};
+    const int P = min(*a.n_points, a.max_points);
+    const int ntiles = (P + 15) / 16;
+    int* next_tile = pcount + 16;
+    int tile = blockIdx.x;
+    PairInputs8<FEAT> in;
+    if (tile < ntiles) {
+        pair_load_indices8<FEAT>(a, tile, P, tid, in);
+        pair_load_data8<FEAT>(a, tile, tid, in);
+    }
+    while (tile < ntiles) {
+        if (tid == 0) *next_tile = a.tile_counter ? (int)gridDim.x + atomicAdd(a.tile_counter, 1) : tile + (int)gridDim.x;
+        int nblk;
+        {
+            // a wave = 64 candidates of one QUARTER of the input columns: rows (wave & 1) * 64 .., quarter wave >> 1
+            const int row = opaque(tid) & 127, part = __builtin_amdgcn_readfirstlane(tid >> 7);
+            const int slot = row & 7;
+            const int gi = in.gi;
+            const unsigned long long mine = __ballot(gi >= 0), other = __ballot(in.gi_other >= 0);
+            const int n_mine = __popcll(mine), n_other = __popcll(other);
+            const int before = __popcll(mine & ((1ull << lane) - 1ull)) + ((row & 64) ? n_other : 0);
+            const int V = n_mine + n_other;
+            nblk = (V + 31) >> 5;
+            const int prow = before;
+            if (part == 0 && slot == 0) {
+                pstart[row >> 3] = before;
+                pcount[row >> 3] = __popcll((mine >> (lane & ~7)) & 0xffull);
+            }
+            float rel[3] = {0.f, 0.f, 0.f};
+            if (gi >= 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rel[c] = in.pt[c] - in.kp[c];
+            }
+            if (part == 0 && gi >= 0) wrow[prow] = 1.f / (sqrtf(__builtin_fmaf(rel[0], rel[0], __builtin_fmaf(rel[1], rel[1], rel[2] * rel[2]))) + 1e-5f);
+            constexpr int FQ = FEAT / 4;
+            if (gi >= 0) {
+#pragma unroll
+                for (int c8 = 0; c8 < FQ / 8; ++c8) {
+                    f16x8 v;
+                    const f32x4 x0 = in.feat[2 * c8], x1 = in.feat[2 * c8 + 1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] = (_Float16)x0[j]; v[4 + j] = (_Float16)x1[j]; }
+                    *reinterpret_cast<f16x8*>(H + act_off(prow, part * (FQ / 8) + c8)) = v;
+                }
+                switch (part) {        // (wave-uniform)
+                    case 0: enc_put16<FEAT, 0>(H, prow, rel); break;
+                    case 1: enc_put16<FEAT, 1>(H, prow, rel); break;
+                    case 2: enc_put16<FEAT, 2>(H, prow, rel); break;
+                    default: enc_put16<FEAT, 3>(H, prow, rel); break;
+                }
+            }
+            if (row >= V && row < 32 * nblk) {
+                f16x8 z;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
+#pragma unroll
+                for (int c8 = 0; c8 < FQ / 8; ++c8) *reinterpret_cast<f16x8*>(H + act_off(row, part * (FQ / 8) + c8)) = z;
+#pragma unroll
+                for (int c8 = 0; c8 < 2; ++c8) *reinterpret_cast<f16x8*>(H + act_off(row, FEAT / 8 + part * 2 + c8)) = z;
+            }
+        }
+        __syncthreads();
+        const int ntile = *next_tile;
+        if (ntile < ntiles) pair_load_indices8<FEAT>(a, ntile, P, tid, in);
+        switch (nblk) {
+            case 4: pair_layers8<FEAT, 4>(H, pk, wave, lane); break;
+            case 3: pair_layers8<FEAT, 3>(H, pk, wave, lane); break;
+            case 2: pair_layers8<FEAT, 2>(H, pk, wave, lane); break;
+            case 1: pair_layers8<FEAT, 1>(H, pk, wave, lane); break;
+            default: break;
+        }
+        pair_load_data8<FEAT>(a, min(ntile, ntiles - 1), tid, in);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // point, and its channels 8 cc .. + 7: the 32 lanes of a point read the 32 chunks of a row
+            const int ta = opaque(tid), pl = ta >> 5, cc = ta & 31;
+            const int p = tile * 16 + pl;
+            const int r0 = pstart[pl], cnt = pcount[pl];
+            const int last = max(cnt - 1, 0);
+            float w8[8];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) w8[s2] = wrow[r0 + min(s2, last)];
+            f16x8 v0[8];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) v0[s2] = *reinterpret_cast<const f16x8*>(H + act_off(r0 + min(s2, last), cc));
+            float wsum = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+                w8[s2] = s2 < cnt ? w8[s2] : 0.f;
+                wsum += w8[s2];
+            }
+            const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
+            float out[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[j] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+                const float ws = w8[s2] * inv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) out[j] = __builtin_fmaf(ws, (float)v0[s2][j], out[j]);
+            }
+            if (cnt == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) out[j] = 0.f;
+            }
+            if (p < P) {
+                f16x8 o0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o0[j] = (_Float16)out[j];
+                *reinterpret_cast<f16x8*>(a.G + (int64_t)p * kHidden + cc * 8) = o0;
+                float mag = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mag += __builtin_fabsf(out[j]);
+                if (a.status && not_finite_bits(mag)) atomicOr(a.status, kShadeNonfinitePairs);
+            }
+        }
+        __syncthreads();
+        tile = ntile;
+    }
+}
 
 // ============================================================================================
 // kernel B: points.  tile = 128 points
@@ -896,6 +1175,11 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
     static DynLds lds_a32, lds_a128, lds_b, lds_bd;
     NPCD_HIP_CHECK(lds_a32.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<32>), ldsA));
     NPCD_HIP_CHECK(lds_a128.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<128>), ldsA));
+    static DynLds lds_a8_32, lds_a8_128;
+    NPCD_HIP_CHECK(lds_a8_32.ensure(reinterpret_cast<const void*>(shade_pairs8_kernel<32>), ldsA));
+    NPCD_HIP_CHECK(lds_a8_128.ensure(reinterpret_cast<const void*>(shade_pairs8_kernel<128>), ldsA));
+    const char* pairs8_env = getenv("NPCD_SHADE_PAIRS8");                 // read per call (A/B in one process)
+    const bool pairs8 = pairs8_env && pairs8_env[0] == '1';
     NPCD_HIP_CHECK(lds_b.ensure(reinterpret_cast<const void*>(shade_points_kernel<false>), ldsB));
     NPCD_HIP_CHECK(lds_bd.ensure(reinterpret_cast<const void*>(shade_points_kernel<true>), ldsB));
     // persistent-style grids: 2 workgroups per CU, tiles strided over the grid; the tile count is
@@ -909,6 +1193,9 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
     if (rows_env && rows_env[0] == '1') {
         rc = shade_rows_launch(a, static_cast<unsigned char*>(workspace) + (int64_t)(max_points + kRows) * kHidden * 2, st);
         if (rc != NPCD_OK) return rc;
+    } else if (pairs8) {
+        if (feat_dim == 32) hipLaunchKernelGGL(shade_pairs8_kernel<32>, dim3(gridA), dim3(512), ldsA, st, a);
+        else hipLaunchKernelGGL(shade_pairs8_kernel<128>, dim3(gridA), dim3(512), ldsA, st, a);
     } else if (feat_dim == 32) hipLaunchKernelGGL(shade_pairs_kernel<32>, dim3(gridA), dim3(256), ldsA, st, a);
     else hipLaunchKernelGGL(shade_pairs_kernel<128>, dim3(gridA), dim3(256), ldsA, st, a);
     if (dir_bias) hipLaunchKernelGGL(shade_points_kernel<true>, dim3(gridB), dim3(256), ldsB, st, a);

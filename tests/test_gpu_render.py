@@ -481,6 +481,40 @@ def test_rows_form_of_the_shading_kernel(monkeypatch):
     assert int(empty.sum()) > 35 and torch.equal(s_r[empty], s_t[empty]) and torch.equal(c_r[empty], c_t[empty])   # zero features in both
 
 
+@pytest.mark.parametrize("F_", [32, 128])
+def test_eight_wave_form_of_the_pair_kernel_is_the_same_bits(monkeypatch, F_):
+    """`NPCD_SHADE_PAIRS8=1` (csrc/shade.hip, shade_pairs8_kernel: the tile on 512 threads, a wave owns 32 output channels, four waves
+    per SIMD; opt-in, experiments R5.12): the same products in the same order per output element -- sigma / rgb bit-identical to
+    the four-wave form on neighbour lists with holes, neighbour-less points, 1..8 neighbours, a clamped device-side count; the
+    range guard raises the same bit."""
+    from npcd.hip import render as hr
+    torch.manual_seed(2)
+    Np, k, Ntab = 2999, 8, 512
+    p = orr.init_field_params(F_, seed=0)
+    wp = hr.pack_field_weights(p, F_, "cuda")
+    nb = torch.randint(0, Ntab, (Np, k), dtype=torch.int32, device="cuda")
+    nb[torch.rand(Np, k, device="cuda") < 0.35] = -1
+    nb[5:40] = -1
+    nb[100:164, 1:] = -1                                                          # tiles with few packed rows: 1-3 row blocks
+    pts = torch.rand(Np, 3, device="cuda") - 0.5
+    kp = torch.rand(Ntab, 3, device="cuda") - 0.5
+    kf = torch.randn(Ntab, F_, device="cuda")
+    over = torch.full((1,), 7 * Np, dtype=torch.int32, device="cuda")
+    monkeypatch.delenv("NPCD_SHADE_PAIRS8", raising=False)
+    s4, c4 = hr.shade_points(wp, F_, nb, pts, kp, kf, n_points=over)
+    monkeypatch.setenv("NPCD_SHADE_PAIRS8", "1")
+    s8, c8 = hr.shade_points(wp, F_, nb, pts, kp, kf, n_points=over)
+    torch.cuda.synchronize()
+    assert torch.isfinite(s8).all() and torch.equal(s4, s8) and torch.equal(c4, c8)
+    # the range guard: weights that overflow fp16 in the pair layers
+    big = {kn: (v * 300 if kn.startswith("aggregator.local_field") and kn.endswith("weight") else v) for kn, v in p.items()}
+    wpb = hr.pack_field_weights(big, F_, "cuda")
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hr.shade_points(wpb, F_, nb, pts, kp, kf, status=status)
+    torch.cuda.synchronize()
+    assert int(status) & hr.SHADE_NONFINITE_PAIRS
+
+
 def test_ray_march_golden(golden):
     from npcd.hip import render as hr
     g = golden("raymarch")

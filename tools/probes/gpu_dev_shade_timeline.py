@@ -24,6 +24,20 @@ if hasattr(L, "npcd_shade_span_read"):
     sp = (ctypes.c_longlong * 2048)(); L.npcd_shade_span_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.npcd_shade_span_read(ctypes.cast(sp, ctypes.c_void_p), 2048)
     sp = np.array(list(sp), dtype=np.int64).reshape(512, 4); t0 = sp[:, 0].min()
+    hw, xcc = (sp[:, 2] >> 16) & 0xffffffff, (sp[:, 2] >> 48) & 15
+    sp[:, 2] &= 0xffff
+    cu, sh, se = (hw >> 8) & 15, (hw >> 12) & 1, (hw >> 13) & 7
+    where = xcc * 10000 + se * 1000 + sh * 100 + cu                  # one number per physical CU
+    print("tiles by XCD:", {int(x): int(sp[xcc == x, 2].sum()) for x in np.unique(xcc)}, " workgroups by XCD:", {int(x): int((xcc == x).sum()) for x in np.unique(xcc)})
+    per_cu = {}
+    for w, tl in zip(where, sp[:, 2]):
+        per_cu.setdefault(int(w), []).append(int(tl))
+    from collections import Counter
+    print("workgroups per CU:", dict(Counter(len(v) for v in per_cu.values())), " CUs used:", len(per_cu))
+    print("tiles per CU (sum of its workgroups) min/mean/max:", min(sum(v) for v in per_cu.values()), np.mean([sum(v) for v in per_cu.values()]), max(sum(v) for v in per_cu.values()))
+    for k in (1, 2, 3):
+        vs = [sum(v) for v in per_cu.values() if len(v) == k]
+        if vs: print(f"  CUs with {k} workgroup(s): {len(vs)}, tiles per CU mean {np.mean(vs):.2f}, per workgroup {np.mean(vs) / k:.2f}")
     b, e = (sp[:, 0] - t0) / 100.0, (sp[:, 1] - t0) / 100.0          # microseconds (100-MHz counter)
     print(f"workgroup spans (us): begin min/median/max {b.min():.1f}/{np.median(b):.1f}/{b.max():.1f}   end min/median/max {e.min():.1f}/{np.median(e):.1f}/{e.max():.1f}"
           f"   tiles min/mean/max {sp[:, 2].min()}/{sp[:, 2].mean():.2f}/{sp[:, 2].max()}   clock {np.median(sp[:, 3] / np.maximum(sp[:, 1] - sp[:, 0], 1)) / 10:.3f} GHz")
