@@ -279,6 +279,117 @@ __device__ __forceinline__ void pair_layers(unsigned char* H, const PairPack& pk
     }
 }
 
+// ---- the four layers on v_mfma_f32_16x16x32_f16 (round 5, experiments R5.13) -------------------------------------------------------
+// The shading kernels are POWER-bound on this pool, and the clock the chip holds depends on the instruction: the bare layer loop
+// (tools/probes/mfma_energy_probe.hip, random operands) runs 32x32x16 at 1.44-1.53 GHz and 16x16x32 at 1.66-1.78 GHz -- the same
+// FLOPs, the same operand bytes, half the accumulator traffic per FLOP.  Same wave tile (64 output channels x <= 128 rows, 128
+// accumulator registers as 4 channel blocks x 8 row blocks of 16 x 16), same LDS bytes: per 32 input channels 4 weight fragments
+// (one 4-KiB run of the pack) and 8 activation fragments (lane = (row l & 15, 16-byte chunk l >> 4)), in two half-steps of 4 row
+// blocks so that the fragment registers stay what they were.  Output channel of accumulator row 4 g + b of block mb:
+// 64 wave + 32 (mb >> 1) + 8 g + 4 (mb & 1) + b (the pack's row order): blocks 2 p, 2 p + 1 of a lane are 8 CONSECUTIVE channels, a
+// whole 16-byte chunk per store.  Row granularity 16: a tile computes ceil(V / 16) row blocks (the 32x32 form: 2 ceil(V / 32)).
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+struct WRing16 { f16x8 a[2][4]; };
+__device__ __forceinline__ f32x4a mfma16(f16x8 a, f16x8 b, f32x4a c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+template <int KS32>
+__device__ __forceinline__ f16x8 wfrag16(wrsrc_t rs, int w_off, int wave, int lane, int s, int mb) {
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + mb * kFragBytes, w_off + (wave * KS32 + s) * (4 * kFragBytes), 0));
+}
+template <int KS32>
+__device__ __forceinline__ void layer_prefetch16(wrsrc_t rs, int w_off, int b_off, int wave, int lane, WRing16& ring, f32x4a (&init)[4]) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)      // bias16: [wave][g][mb][4]
+        init[mb] = __builtin_bit_cast(f32x4a, __builtin_amdgcn_raw_buffer_load_b128(rs, g * 64 + mb * 16, b_off + wave * 256, 0));
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) ring.a[0][mb] = wfrag16<KS32>(rs, w_off, wave, lane, 0, mb);
+}
+template <int KS32, int NB16>
+__device__ __forceinline__ void layer_mfma16(const unsigned char* H, wrsrc_t rs, int w_off, int wave, int lane, WRing16& ring,
+                                             const f32x4a (&init)[4], f32x4a (&acc)[4][8]) {
+    constexpr int NH = NB16 > 4 ? 2 : 1;                     // half-steps per 32 input channels
+    const unsigned char* hb = H + (lane & 15) * kRowBytes + (lane >> 4) * 16;
+    f16x8 bc[4], bn[4];
+#pragma unroll
+    for (int r = 0; r < (NB16 < 4 ? NB16 : 4); ++r) bc[r] = *reinterpret_cast<const f16x8*>(hb + r * 16 * kRowBytes);
+#pragma unroll
+    for (int s = 0; s < KS32; ++s) {
+        if (s + 1 < KS32) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) ring.a[(s + 1) & 1][mb] = wfrag16<KS32>(rs, w_off, wave, lane, s + 1, mb);
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            constexpr int dummy = 0; (void)dummy;
+            const int r0 = h * 4, nr = (NB16 - r0) < 4 ? (NB16 - r0) : 4;                       // this half-step's row blocks
+            const int ns = (h + 1 < NH) ? s : s + 1, nr0 = (h + 1 < NH) ? 4 : 0;                 // the next half-step
+            const int nnr = (NB16 - nr0) < 4 ? (NB16 - nr0) : 4;
+            if (ns < KS32) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r < nnr) bn[r] = *reinterpret_cast<const f16x8*>(hb + (nr0 + r) * 16 * kRowBytes + ns * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < nr) {
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) acc[mb][r0 + r] = mfma16(ring.a[s & 1][mb], bc[r], s == 0 ? init[mb] : acc[mb][r0 + r]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bc[r] = bn[r];
+        }
+    }
+}
+template <bool ACT, int NB16>
+__device__ __forceinline__ void layer_store16(unsigned char* H, int wave, int lane, const f32x4a (&acc)[4][8]) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    unsigned char* sb = H + (lane & 15) * kRowBytes + (lane >> 4) * 16 + wave * 128;     // row rb*16 + (l & 15), chunk 8 wave + 4 p + g
+#pragma unroll
+    for (int rb = 0; rb < NB16; ++rb)
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+            uint32_t v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {       // channels 2 q, 2 q + 1 of the chunk: block 2 p + (q >> 1), registers 2 (q & 1), + 1
+                const f32x2 f = {acc[2 * p2 + (q >> 1)][rb][2 * (q & 1)], acc[2 * p2 + (q >> 1)][rb][2 * (q & 1) + 1]};
+                f16x2 h = __builtin_convertvector(f, f16x2);
+                if (ACT) {
+                    const f16x2 sc = {(_Float16)kLeaky, (_Float16)kLeaky};
+                    h = __builtin_elementwise_max(h, h * sc);
+                }
+                v[q] = __builtin_bit_cast(uint32_t, h);
+            }
+            *reinterpret_cast<u32x4*>(sb + rb * 16 * kRowBytes + p2 * 64) = u32x4{v[0], v[1], v[2], v[3]};
+        }
+}
+struct PairPack16 { wrsrc_t rs; int w[4], b[4]; };
+template <int FEAT, int NB16>
+__device__ __forceinline__ void pair_layers16(unsigned char* H, const PairPack16& pk, int wave, int lane) {
+    constexpr int K0 = FEAT + kEncBlock;
+    f32x4a acc[4][8];
+    WRing16 ring;
+    f32x4a init[4];
+    layer_prefetch16<K0 / 32>(pk.rs, pk.w[0], pk.b[0], wave, lane, ring, init);
+    layer_mfma16<K0 / 32, NB16>(H, pk.rs, pk.w[0], wave, lane, ring, init, acc);
+    layer_prefetch16<kHidden / 32>(pk.rs, pk.w[1], pk.b[1], wave, lane, ring, init);
+    __syncthreads();
+    layer_store16<true, NB16>(H, wave, lane, acc);
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 1; l < 4; ++l) {
+        // (w[1..3] / b[1..3] are equally spaced: offsets in closed form, no indexed struct access -- see pair_layers)
+        const int w_off = pk.w[1] + (l - 1) * (kHidden * kHidden * 2), b_off = pk.b[1] + (l - 1) * (kHidden * 4);
+        layer_mfma16<kHidden / 32, NB16>(H, pk.rs, w_off, wave, lane, ring, init, acc);
+        if (l < 3) layer_prefetch16<kHidden / 32>(pk.rs, w_off + kHidden * kHidden * 2, b_off + kHidden * 4, wave, lane, ring, init);
+        __syncthreads();
+        layer_store16<true, NB16>(H, wave, lane, acc);
+        __syncthreads();
+    }
+}
+
 // What a thread needs to build its input row of a tile: requested one tile AHEAD (the neighbour indices while the previous tile's
 // layers run, the gathered data while its aggregation runs), so that the prologue starts from registers instead of two dependent
 // trips to memory.
@@ -313,7 +424,7 @@ __device__ __forceinline__ void pair_load_data(const ShadeArgs& a, int tile, int
     for (int c4 = 0; c4 < FEAT / 8; ++c4) in.feat[c4] = *reinterpret_cast<const f32x4*>(fp + c4 * 4);
 }
 
-template <int FEAT>
+template <int FEAT, int FORM = 0>          // FORM 0: v_mfma_f32_32x32x16_f16 layers, 1: the 16x16x32 layers
 __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
     unsigned char* H = dsmem;
@@ -324,6 +435,8 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const ShadeLayout L = shade_layout(FEAT);
     const PairPack pk = {pack_rsrc(a.wpack, L.total), (int)L.w[1], (int)L.bias[0]};
+    const PairPack16 pk16 = {pk.rs, {(int)L.w16[0], (int)L.w16[1], (int)L.w16[2], (int)L.w16[3]},
+                             {(int)L.bias16[0], (int)L.bias16[1], (int)L.bias16[2], (int)L.bias16[3]}};
     // the count comes from device memory (the compact query's counter); that counter keeps counting past the capacity of the
     // lists when they overflow (the host then retries with larger buffers), so it is clamped to the rows that exist
     const int P = min(*a.n_points, a.max_points);
@@ -365,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
             const int n_mine = __popcll(mine), n_other = __popcll(other);
             const int before = __popcll(mine & ((1ull << lane) - 1ull)) + ((row & 64) ? n_other : 0);
             const int V = n_mine + n_other;
-            nblk = (V + 31) >> 5;
+            nblk = FORM == 1 ? (V + 15) >> 4 : (V + 31) >> 5;               // occupied row blocks (of 16 / of 32 rows)
             const int prow = before;                                        // packed row of this candidate (if valid)
             if (half == 0 && slot == 0) {
                 pstart[row >> 3] = before;
@@ -398,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
                 }
             }
             // rows V .. 32 nblk - 1 are computed (whole MFMA blocks) but never aggregated: give them defined inputs
-            if (row >= V && row < 32 * nblk) {
+            if (row >= V && row < (FORM == 1 ? 16 : 32) * nblk) {
                 f16x8 z;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) z[j] = (_Float16)0.f;
@@ -415,12 +528,26 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
         const int ntile = *next_tile;
         if (ntile < ntiles) pair_load_indices<FEAT>(a, ntile, P, tid, in);
         // ---- four non-linear layers (one instantiation per number of occupied 32-row blocks; nblk is workgroup-uniform) ----
+        if constexpr (FORM == 1) {
+            switch (nblk) {
+                case 8: pair_layers16<FEAT, 8>(H, pk16, wave, lane); break;
+                case 7: pair_layers16<FEAT, 7>(H, pk16, wave, lane); break;
+                case 6: pair_layers16<FEAT, 6>(H, pk16, wave, lane); break;
+                case 5: pair_layers16<FEAT, 5>(H, pk16, wave, lane); break;
+                case 4: pair_layers16<FEAT, 4>(H, pk16, wave, lane); break;
+                case 3: pair_layers16<FEAT, 3>(H, pk16, wave, lane); break;
+                case 2: pair_layers16<FEAT, 2>(H, pk16, wave, lane); break;
+                case 1: pair_layers16<FEAT, 1>(H, pk16, wave, lane); break;
+                default: break;
+            }
+        } else {
         switch (nblk) {
             case 4: pair_layers<FEAT, 4>(H, pk, wave, lane NPCD_TL_ARGS); break;
             case 3: pair_layers<FEAT, 3>(H, pk, wave, lane NPCD_TL_ARGS); break;
             case 2: pair_layers<FEAT, 2>(H, pk, wave, lane NPCD_TL_ARGS); break;
             case 1: pair_layers<FEAT, 1>(H, pk, wave, lane NPCD_TL_ARGS); break;
             default: break;                                    // no valid pair in the tile
+        }
         }
         NPCD_STS(11);
         // ... and its gathered points / positions / features while the aggregation runs
@@ -1069,6 +1196,29 @@ static void pack_matrix(const float* W, int out_dim, int in_dim, int k_padded, u
                 }
 }
 
+// the 16x16x32 form's order (pair_layers16): [wave][32-column step s][block mb][lane][8] with
+//   element = W[64 wave + 32 (mb >> 1) + 8 g + 4 (mb & 1) + b][32 s + 8 (lane >> 4) + j],  4 g + b = lane & 15
+static void pack_matrix16(const float* W, int in_dim, int k_padded, unsigned char* dst) {
+    _Float16* d = reinterpret_cast<_Float16*>(dst);
+    const int ks = k_padded / 32;
+    for (int w = 0; w < 4; ++w)
+        for (int s = 0; s < ks; ++s)
+            for (int mb = 0; mb < 4; ++mb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int m = lane & 15, o = 64 * w + 32 * (mb >> 1) + 8 * (m >> 2) + 4 * (mb & 1) + (m & 3), c = 32 * s + 8 * (lane >> 4) + j;
+                        const float v = c < in_dim ? W[(int64_t)o * in_dim + c] : 0.f;
+                        d[((((int64_t)w * ks + s) * 4 + mb) * 64 + lane) * 8 + j] = (_Float16)v;
+                    }
+}
+static void pack_bias16(const float* bias, unsigned char* dst) {        // [wave][g][mb][b]
+    float* d = reinterpret_cast<float*>(dst);
+    for (int w = 0; w < 4; ++w)
+        for (int g = 0; g < 4; ++g)
+            for (int mb = 0; mb < 4; ++mb)
+                for (int b = 0; b < 4; ++b) d[((w * 4 + g) * 4 + mb) * 4 + b] = bias[64 * w + 32 * (mb >> 1) + 8 * g + 4 * (mb & 1) + b];
+}
+
 // The slab stream of the rows kernel (shade_rows.hip): layers A0..A3, each as 4 quarters (output blocks 2 q, 2 q + 1) x steps of
 // two k-steps; a slab = fragments (k-step, block) = (0,0) (0,1) (1,0) (1,1).  Input column of k-slot (s, g = lane >> 5, e):
 //   hidden layers: 32 (s/2) + 8 (2 (s%2) + e/4) + 4 g + e%4   (an accumulator tile's values 8 jp .. 8 jp + 7 ARE fragment 2 mb + jp)
@@ -1121,6 +1271,10 @@ extern "C" int npcd_shade_pack_weights(const float* const* weights_host, const f
         memcpy(out + L.bias[i], biases_host[src[i]], kHidden * 4);
     }
     pack_rows_stream(weights_host, feat_dim, L.k0, out + L.rows);
+    for (int i = 0; i < 4; ++i) {
+        pack_matrix16(weights_host[i], i == 0 ? in0 : kHidden, i == 0 ? L.k0 : kHidden, out + L.w16[i]);
+        pack_bias16(biases_host[i], out + L.bias16[i]);
+    }
     float* s1 = reinterpret_cast<float*>(out + L.s1);
     memcpy(s1, weights_host[6], kHidden * 4);
     s1[kHidden] = biases_host[6][0];
@@ -1178,6 +1332,11 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
     static DynLds lds_a8_32, lds_a8_128;
     NPCD_HIP_CHECK(lds_a8_32.ensure(reinterpret_cast<const void*>(shade_pairs8_kernel<32>), ldsA));
     NPCD_HIP_CHECK(lds_a8_128.ensure(reinterpret_cast<const void*>(shade_pairs8_kernel<128>), ldsA));
+    static DynLds lds_a16_32, lds_a16_128;
+    NPCD_HIP_CHECK(lds_a16_32.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<32, 1>), ldsA));
+    NPCD_HIP_CHECK(lds_a16_128.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<128, 1>), ldsA));
+    const char* pairs16_env = getenv("NPCD_SHADE_PAIRS16");               // read per call (A/B in one process)
+    const bool pairs16 = !(pairs16_env && pairs16_env[0] == '0');         // the default since round 5 (R5.13); 0 = the 32x32x16 layers
     const char* pairs8_env = getenv("NPCD_SHADE_PAIRS8");                 // read per call (A/B in one process)
     const bool pairs8 = pairs8_env && pairs8_env[0] == '1';
     NPCD_HIP_CHECK(lds_b.ensure(reinterpret_cast<const void*>(shade_points_kernel<false>), ldsB));
@@ -1196,6 +1355,9 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
     } else if (pairs8) {
         if (feat_dim == 32) hipLaunchKernelGGL(shade_pairs8_kernel<32>, dim3(gridA), dim3(512), ldsA, st, a);
         else hipLaunchKernelGGL(shade_pairs8_kernel<128>, dim3(gridA), dim3(512), ldsA, st, a);
+    } else if (pairs16) {
+        if (feat_dim == 32) hipLaunchKernelGGL((shade_pairs_kernel<32, 1>), dim3(gridA), dim3(256), ldsA, st, a);
+        else hipLaunchKernelGGL((shade_pairs_kernel<128, 1>), dim3(gridA), dim3(256), ldsA, st, a);
     } else if (feat_dim == 32) hipLaunchKernelGGL(shade_pairs_kernel<32>, dim3(gridA), dim3(256), ldsA, st, a);
     else hipLaunchKernelGGL(shade_pairs_kernel<128>, dim3(gridA), dim3(256), ldsA, st, a);
     if (dir_bias) hipLaunchKernelGGL(shade_points_kernel<true>, dim3(gridB), dim3(256), ldsB, st, a);

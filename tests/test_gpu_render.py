@@ -501,6 +501,7 @@ def test_eight_wave_form_of_the_pair_kernel_is_the_same_bits(monkeypatch, F_):
     kf = torch.randn(Ntab, F_, device="cuda")
     over = torch.full((1,), 7 * Np, dtype=torch.int32, device="cuda")
     monkeypatch.delenv("NPCD_SHADE_PAIRS8", raising=False)
+    monkeypatch.setenv("NPCD_SHADE_PAIRS16", "0")                                  # (both are forms of the 32x32x16 layers)
     s4, c4 = hr.shade_points(wp, F_, nb, pts, kp, kf, n_points=over)
     monkeypatch.setenv("NPCD_SHADE_PAIRS8", "1")
     s8, c8 = hr.shade_points(wp, F_, nb, pts, kp, kf, n_points=over)
@@ -513,6 +514,50 @@ def test_eight_wave_form_of_the_pair_kernel_is_the_same_bits(monkeypatch, F_):
     hr.shade_points(wpb, F_, nb, pts, kp, kf, status=status)
     torch.cuda.synchronize()
     assert int(status) & hr.SHADE_NONFINITE_PAIRS
+
+
+@pytest.mark.parametrize("F_", [32, 128])
+def test_pair_layers_on_both_matrix_instruction_shapes(monkeypatch, F_):
+    """The per-pair layers run on v_mfma_f32_16x16x32_f16 by default (round 5, experiments R5.13: the kernel is power-bound and the chip
+    holds a higher clock under that instruction; row blocks of 16 instead of 32); `NPCD_SHADE_PAIRS16=0` selects the 32x32x16 layers
+    the kernel had before.  Same inputs, same fp16 activations between layers: the two agree to fp16 rounding of a few values (3e-3 of
+    max(1, |value|); in practice bit for bit) on lists with holes, neighbour-less points, every number of occupied row blocks, a clamped
+    device-side count; both are bitwise repeatable and raise the range-guard bit on overflowing weights."""
+    from npcd.hip import render as hr
+    torch.manual_seed(3)
+    Np, k, Ntab = 3001, 8, 512
+    p = orr.init_field_params(F_, seed=0)
+    for kname in p:
+        if kname.endswith("weight"):
+            p[kname] = p[kname] * 1.5
+    wp = hr.pack_field_weights(p, F_, "cuda")
+    nb = torch.randint(0, Ntab, (Np, k), dtype=torch.int32, device="cuda")
+    nb[torch.rand(Np, k, device="cuda") < 0.35] = -1
+    nb[5:40] = -1
+    for i, keep in enumerate((1, 2, 3, 4, 5, 6, 7)):                               # tiles of 16 points with 16 * keep packed rows
+        nb[160 + 16 * i:176 + 16 * i, keep:] = -1
+        nb[160 + 16 * i:176 + 16 * i, :keep] = torch.randint(0, Ntab, (16, keep), dtype=torch.int32, device="cuda")
+    pts = torch.rand(Np, 3, device="cuda") - 0.5
+    kp = torch.rand(Ntab, 3, device="cuda") - 0.5
+    kf = torch.randn(Ntab, F_, device="cuda")
+    over = torch.full((1,), 7 * Np, dtype=torch.int32, device="cuda")
+    monkeypatch.setenv("NPCD_SHADE_PAIRS16", "0")
+    s32, c32 = hr.shade_points(wp, F_, nb, pts, kp, kf, n_points=over)
+    monkeypatch.delenv("NPCD_SHADE_PAIRS16")
+    s16, c16 = hr.shade_points(wp, F_, nb, pts, kp, kf, n_points=over)
+    s16b, c16b = hr.shade_points(wp, F_, nb, pts, kp, kf)
+    torch.cuda.synchronize()
+    assert torch.isfinite(s16).all() and torch.isfinite(c16).all()
+    assert float(((s16 - s32).abs() / s32.abs().clamp_min(1.0)).max()) < 3e-3 and float((c16 - c32).abs().max()) < 3e-3
+    assert torch.equal(s16, s16b) and torch.equal(c16, c16b)
+    big = {kn: (v * 300 if kn.startswith("aggregator.local_field") and kn.endswith("weight") else v) for kn, v in p.items()}
+    wpb = hr.pack_field_weights(big, F_, "cuda")
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NPCD_SHADE_PAIRS16", mode)
+        status = torch.zeros(1, dtype=torch.int32, device="cuda")
+        hr.shade_points(wpb, F_, nb, pts, kp, kf, status=status)
+        torch.cuda.synchronize()
+        assert int(status) & hr.SHADE_NONFINITE_PAIRS, mode
 
 
 def test_ray_march_golden(golden):

@@ -15,8 +15,11 @@ extr = orr.look_at_pose(30, 20)[None, None].cuda(); intr = orr.srn_intrinsics()[
 c, f = coords.cuda(), feats.cuda()
 
 
+VAR = os.environ.get("NPCD_AB_VAR", "NPCD_SHADE_PAIRS8")          # which switch to A/B (NPCD_SHADE_PAIRS8 / NPCD_SHADE_PAIRS16)
+
+
 def render(mode):
-    os.environ["NPCD_SHADE_PAIRS8"] = mode
+    os.environ[VAR] = mode
     with torch.no_grad():
         return model.render(c, f, extr, intr, 128)
 
@@ -33,4 +36,4 @@ for r in range(rounds):
         e0.record()
         for _ in range(40): render(m)
         e1.record(); torch.cuda.synchronize()
-        print(f"round {r} pairs8={m}: {e0.elapsed_time(e1) / 40 * 1000:.1f} us per view", flush=True)
+        print(f"round {r} {VAR}={m}: {e0.elapsed_time(e1) / 40 * 1000:.1f} us per view", flush=True)
