@@ -295,20 +295,23 @@ template <int KS32>
 __device__ __forceinline__ f16x8 wfrag16(wrsrc_t rs, int w_off, int wave, int lane, int s, int mb) {
     return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + mb * kFragBytes, w_off + (wave * KS32 + s) * (4 * kFragBytes), 0));
 }
+// (the first weight fragments of a layer are requested BEFORE the previous layer's write-back, like in the 32x32 form.  The bias --
+//  the C operand of the first step -- is read from an LDS copy of the four layers' biases instead: prefetched through registers it was
+//  spilled across the write-back, with a blocking wait on the load it had just issued)
 template <int KS32>
-__device__ __forceinline__ void layer_prefetch16(wrsrc_t rs, int w_off, int b_off, int wave, int lane, WRing16& ring, f32x4a (&init)[4]) {
-    const int g = lane >> 4;
-#pragma unroll
-    for (int mb = 0; mb < 4; ++mb)      // bias16: [wave][g][mb][4]
-        init[mb] = __builtin_bit_cast(f32x4a, __builtin_amdgcn_raw_buffer_load_b128(rs, g * 64 + mb * 16, b_off + wave * 256, 0));
+__device__ __forceinline__ void layer_prefetch16(wrsrc_t rs, int w_off, int wave, int lane, WRing16& ring) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) ring.a[0][mb] = wfrag16<KS32>(rs, w_off, wave, lane, 0, mb);
 }
 template <int KS32, int NB16>
-__device__ __forceinline__ void layer_mfma16(const unsigned char* H, wrsrc_t rs, int w_off, int wave, int lane, WRing16& ring,
-                                             const f32x4a (&init)[4], f32x4a (&acc)[4][8]) {
+__device__ __forceinline__ void layer_mfma16(const unsigned char* H, const unsigned char* bias_l, wrsrc_t rs, int w_off, int wave, int lane,
+                                             WRing16& ring, f32x4a (&acc)[4][8]) {
     constexpr int NH = NB16 > 4 ? 2 : 1;                     // half-steps per 32 input channels
     const unsigned char* hb = H + (lane & 15) * kRowBytes + (lane >> 4) * 16;
+    f32x4a init[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)      // bias16: [wave][g][mb][4]
+        init[mb] = *reinterpret_cast<const f32x4a*>(bias_l + wave * 256 + (lane >> 4) * 64 + mb * 16);
     f16x8 bc[4], bn[4];
 #pragma unroll
     for (int r = 0; r < (NB16 < 4 ? NB16 : 4); ++r) bc[r] = *reinterpret_cast<const f16x8*>(hb + r * 16 * kRowBytes);
@@ -365,25 +368,24 @@ __device__ __forceinline__ void layer_store16(unsigned char* H, int wave, int la
             *reinterpret_cast<u32x4*>(sb + rb * 16 * kRowBytes + p2 * 64) = u32x4{v[0], v[1], v[2], v[3]};
         }
 }
-struct PairPack16 { wrsrc_t rs; int w[4], b[4]; };
+struct PairPack16 { wrsrc_t rs; int w0, w1; const unsigned char* bias; };      // offsets of A0 / A1 in the pack, the LDS copy of the biases
 template <int FEAT, int NB16>
 __device__ __forceinline__ void pair_layers16(unsigned char* H, const PairPack16& pk, int wave, int lane) {
     constexpr int K0 = FEAT + kEncBlock;
     f32x4a acc[4][8];
     WRing16 ring;
-    f32x4a init[4];
-    layer_prefetch16<K0 / 32>(pk.rs, pk.w[0], pk.b[0], wave, lane, ring, init);
-    layer_mfma16<K0 / 32, NB16>(H, pk.rs, pk.w[0], wave, lane, ring, init, acc);
-    layer_prefetch16<kHidden / 32>(pk.rs, pk.w[1], pk.b[1], wave, lane, ring, init);
+    layer_prefetch16<K0 / 32>(pk.rs, pk.w0, wave, lane, ring);
+    layer_mfma16<K0 / 32, NB16>(H, pk.bias, pk.rs, pk.w0, wave, lane, ring, acc);
+    layer_prefetch16<kHidden / 32>(pk.rs, pk.w1, wave, lane, ring);
     __syncthreads();
     layer_store16<true, NB16>(H, wave, lane, acc);
     __syncthreads();
 #pragma unroll 1
     for (int l = 1; l < 4; ++l) {
-        // (w[1..3] / b[1..3] are equally spaced: offsets in closed form, no indexed struct access -- see pair_layers)
-        const int w_off = pk.w[1] + (l - 1) * (kHidden * kHidden * 2), b_off = pk.b[1] + (l - 1) * (kHidden * 4);
-        layer_mfma16<kHidden / 32, NB16>(H, pk.rs, w_off, wave, lane, ring, init, acc);
-        if (l < 3) layer_prefetch16<kHidden / 32>(pk.rs, w_off + kHidden * kHidden * 2, b_off + kHidden * 4, wave, lane, ring, init);
+        // (A1..A3 are equally spaced: offsets in closed form, no indexed struct access -- see pair_layers)
+        const int w_off = pk.w1 + (l - 1) * (kHidden * kHidden * 2);
+        layer_mfma16<kHidden / 32, NB16>(H, pk.bias + l * (kHidden * 4), pk.rs, w_off, wave, lane, ring, acc);
+        if (l < 3) layer_prefetch16<kHidden / 32>(pk.rs, w_off + kHidden * kHidden * 2, wave, lane, ring);
         __syncthreads();
         layer_store16<true, NB16>(H, wave, lane, acc);
         __syncthreads();
@@ -435,8 +437,14 @@ __global__ __launch_bounds__(256, 2) void shade_pairs_kernel(ShadeArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const ShadeLayout L = shade_layout(FEAT);
     const PairPack pk = {pack_rsrc(a.wpack, L.total), (int)L.w[1], (int)L.bias[0]};
-    const PairPack16 pk16 = {pk.rs, {(int)L.w16[0], (int)L.w16[1], (int)L.w16[2], (int)L.w16[3]},
-                             {(int)L.bias16[0], (int)L.bias16[1], (int)L.bias16[2], (int)L.bias16[3]}};
+    // (FORM 1: the four layers' biases, 4 KiB in the order of their C operands, copied to LDS once per workgroup; first read behind the
+    //  first tile's prologue barrier)
+    unsigned char* bias_lds = reinterpret_cast<unsigned char*>(pcount + 16 + 4);
+    const PairPack16 pk16 = {pk.rs, (int)L.w16[0], (int)L.w16[1], bias_lds};
+    if constexpr (FORM == 1) {
+        for (int i = tid; i < 4 * kHidden / 4; i += 256)
+            reinterpret_cast<f32x4*>(bias_lds)[i] = *reinterpret_cast<const f32x4*>(a.wpack + L.bias16[0] + (int64_t)i * 16);
+    }
     // the count comes from device memory (the compact query's counter); that counter keeps counting past the capacity of the
     // lists when they overflow (the host then retries with larger buffers), so it is clamped to the rows that exist
     const int P = min(*a.n_points, a.max_points);
@@ -1325,6 +1333,7 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
     static const bool static_tiles = getenv("NPCD_SHADE_STATIC_TILES") != nullptr;
     if (!static_tiles) a.tile_counter = tile_ticket_slot();      // (nullptr: tiles strided over the grid)
     const int ldsA = kRows * kRowBytes + kRows * 4 + 32 * 4 + 16;   // activations, row weights, per-point packed-row ranges, next tile
+    const int ldsA16 = ldsA + 4 * kHidden * 4;                       // + the four layers' biases (16x16x32 form)
     const int ldsB = kRows * (kRowBytes + 4 * 4 * 4);
     static DynLds lds_a32, lds_a128, lds_b, lds_bd;
     NPCD_HIP_CHECK(lds_a32.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<32>), ldsA));
@@ -1333,8 +1342,8 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
     NPCD_HIP_CHECK(lds_a8_32.ensure(reinterpret_cast<const void*>(shade_pairs8_kernel<32>), ldsA));
     NPCD_HIP_CHECK(lds_a8_128.ensure(reinterpret_cast<const void*>(shade_pairs8_kernel<128>), ldsA));
     static DynLds lds_a16_32, lds_a16_128;
-    NPCD_HIP_CHECK(lds_a16_32.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<32, 1>), ldsA));
-    NPCD_HIP_CHECK(lds_a16_128.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<128, 1>), ldsA));
+    NPCD_HIP_CHECK(lds_a16_32.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<32, 1>), ldsA16));
+    NPCD_HIP_CHECK(lds_a16_128.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<128, 1>), ldsA16));
     const char* pairs16_env = getenv("NPCD_SHADE_PAIRS16");               // read per call (A/B in one process)
     const bool pairs16 = !(pairs16_env && pairs16_env[0] == '0');         // the default since round 5 (R5.13); 0 = the 32x32x16 layers
     const char* pairs8_env = getenv("NPCD_SHADE_PAIRS8");                 // read per call (A/B in one process)
@@ -1356,8 +1365,8 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
         if (feat_dim == 32) hipLaunchKernelGGL(shade_pairs8_kernel<32>, dim3(gridA), dim3(512), ldsA, st, a);
         else hipLaunchKernelGGL(shade_pairs8_kernel<128>, dim3(gridA), dim3(512), ldsA, st, a);
     } else if (pairs16) {
-        if (feat_dim == 32) hipLaunchKernelGGL((shade_pairs_kernel<32, 1>), dim3(gridA), dim3(256), ldsA, st, a);
-        else hipLaunchKernelGGL((shade_pairs_kernel<128, 1>), dim3(gridA), dim3(256), ldsA, st, a);
+        if (feat_dim == 32) hipLaunchKernelGGL((shade_pairs_kernel<32, 1>), dim3(gridA), dim3(256), ldsA16, st, a);
+        else hipLaunchKernelGGL((shade_pairs_kernel<128, 1>), dim3(gridA), dim3(256), ldsA16, st, a);
     } else if (feat_dim == 32) hipLaunchKernelGGL(shade_pairs_kernel<32>, dim3(gridA), dim3(256), ldsA, st, a);
     else hipLaunchKernelGGL(shade_pairs_kernel<128>, dim3(gridA), dim3(256), ldsA, st, a);
     if (dir_bias) hipLaunchKernelGGL(shade_points_kernel<true>, dim3(gridB), dim3(256), ldsB, st, a);
