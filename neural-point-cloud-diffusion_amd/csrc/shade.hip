@@ -1136,17 +1136,163 @@ __device__ __forceinline__ void points_pass(PointsArgs a, unsigned char* H, floa
     NPCD_PTS(31);
 }
 
+// The same pass on v_mfma_f32_16x16x32_f16 (round 5, R5.13; the layer functions of the pair kernel's 16x16x32 form): a lane holds row
+// rb * 16 + (l & 15) and, per channel block mb, the four channels 64 wave + 32 (mb >> 1) + 8 g + 4 (mb & 1) + b (g = l >> 4) -- the heads'
+// dot products run over those and are summed over the four lane groups g with two lane swaps, then over the waves through `red`.
+// One form for both configurations: the view-direction variant has the registers for the pipelined layers here.
+__device__ __forceinline__ float sum_lane_groups(float x) {       // x summed over lanes l, l ^ 16, l ^ 32, l ^ 48
+    const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+}
+template <bool DIR, int NB>
+__device__ __forceinline__ void points_pass16(PointsArgs a, unsigned char* H, float* red, const unsigned char* bias_lds, int row0, int P, int tid) {
+    asm volatile("" : "+v"(tid));
+    constexpr int NB16 = 2 * NB;
+    const ShadeLayout L = shade_layout(a.feat_dim);
+    const int lane = tid & 63, wave = tid >> 6, n = lane & 15, g = lane >> 4;
+    const float* s1 = reinterpret_cast<const float*>(a.wpack + L.s1);
+    const float* c4 = reinterpret_cast<const float*>(a.wpack + L.c4);
+    constexpr int kLayerBytes = kHidden * kHidden * 2;
+    const wrsrc_t rs = pack_rsrc(a.wpack, L.total);
+    const int wv = __builtin_amdgcn_readfirstlane(wave), w4 = (int)L.w16[4];
+    WRing16 ring;
+    layer_prefetch16<8>(rs, w4, wv, lane, ring);
+#pragma unroll
+    for (int it = 0; it < 4 * NB; ++it) {
+        const int cidx = it * 256 + tid, row = cidx >> 5, chunk = cidx & 31;
+        const int p = row0 + row;
+        u32x4 v = {0, 0, 0, 0};
+        if (p < P) v = *reinterpret_cast<const u32x4*>(a.G + (int64_t)p * kHidden + chunk * 8);
+        *reinterpret_cast<u32x4*>(H + act_off(row, chunk)) = v;
+    }
+    __syncthreads();
+    f32x4a acc[4][8];
+    // ---- last aggregator layer (linear): feat ------------------------------------------
+    layer_mfma16<8, NB16>(H, bias_lds, rs, w4, wv, lane, ring, acc);
+    layer_prefetch16<8>(rs, w4 + kLayerBytes, wv, lane, ring);
+    __syncthreads();
+    layer_store16<false, NB16>(H, wave, lane, acc);
+    __syncthreads();
+    // ---- density head: Linear(256,256) + LeakyReLU + Linear(256,1), softplus(x - 1) ------
+    layer_mfma16<8, NB16>(H, bias_lds + kHidden * 4, rs, w4 + kLayerBytes, wv, lane, ring, acc);
+    layer_prefetch16<8>(rs, w4 + 2 * kLayerBytes, wv, lane, ring);
+    {
+        float part[NB16];
+#pragma unroll
+        for (int rb = 0; rb < NB16; ++rb) part[rb] = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const f32x4 wv4 = *reinterpret_cast<const f32x4*>(s1 + 64 * wave + 32 * (mb >> 1) + 8 * g + 4 * (mb & 1));
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int rb = 0; rb < NB16; ++rb) {
+                    float x = acc[mb][rb][b];
+                    x = x > 0.f ? x : kLeaky * x;
+                    part[rb] += x * wv4[b];
+                }
+        }
+#pragma unroll
+        for (int rb = 0; rb < NB16; ++rb) {
+            const float t = sum_lane_groups(part[rb]);
+            if (g == 0) red[(wave * a.red_rows + rb * 16 + n) * 4 + 3] = t;
+        }
+    }
+    // (H still holds feat: the density pass did not write activations)
+    // ---- colour head: 4 x [Linear(256,256) + LeakyReLU] + Linear(256,3), sigmoid ----------
+#pragma unroll 1
+    for (int l = 0; l < 4; ++l) {
+        const int w_off = w4 + (2 + l) * kLayerBytes;
+        layer_mfma16<8, NB16>(H, bias_lds + (2 + l) * (kHidden * 4), rs, w_off, wv, lane, ring, acc);
+        if (l < 3) layer_prefetch16<8>(rs, w_off + kLayerBytes, wv, lane, ring);
+        if (DIR && l == 0) {       // + the view-direction part of the first colour layer (per ray, fp32)
+#pragma unroll
+            for (int rb = 0; rb < NB16; ++rb) {
+                const int p = row0 + rb * 16 + n;
+                const float* db = a.dir_bias + (int64_t)(p < P ? a.point_ray[p] : 0) * kHidden;
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(db + 64 * wave + 32 * (mb >> 1) + 8 * g + 4 * (mb & 1));
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[mb][rb][b] += v[b];
+                }
+            }
+        }
+        if (l < 3) {
+            __syncthreads();
+            layer_store16<true, NB16>(H, wave, lane, acc);
+            __syncthreads();
+        }
+    }
+    {
+        float pc[NB16][3];
+#pragma unroll
+        for (int rb = 0; rb < NB16; ++rb) pc[rb][0] = pc[rb][1] = pc[rb][2] = 0.f;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb) {
+            const float* cp = c4 + 64 * wave + 32 * (mb >> 1) + 8 * g + 4 * (mb & 1);
+            const f32x4 wr = *reinterpret_cast<const f32x4*>(cp), wg = *reinterpret_cast<const f32x4*>(cp + kHidden),
+                        wb = *reinterpret_cast<const f32x4*>(cp + 2 * kHidden);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int rb = 0; rb < NB16; ++rb) {
+                    float x = acc[mb][rb][b];
+                    x = x > 0.f ? x : kLeaky * x;
+                    pc[rb][0] += x * wr[b];
+                    pc[rb][1] += x * wg[b];
+                    pc[rb][2] += x * wb[b];
+                }
+        }
+#pragma unroll
+        for (int rb = 0; rb < NB16; ++rb) {
+            const float pr = sum_lane_groups(pc[rb][0]), pg = sum_lane_groups(pc[rb][1]), pb = sum_lane_groups(pc[rb][2]);
+            if (g == 0) {
+                float* q = red + (wave * a.red_rows + rb * 16 + n) * 4;
+                q[0] = pr; q[1] = pg; q[2] = pb;
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 32 * NB) {
+        const int p = row0 + tid;
+        if (p < P) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(red + (w * a.red_rows + tid) * 4);
+                t += v;
+            }
+            if (a.status && not_finite_bits(__builtin_fabsf(t[0]) + __builtin_fabsf(t[1]) + __builtin_fabsf(t[2]) + __builtin_fabsf(t[3])))
+                atomicOr(a.status, kShadeNonfiniteHeads);
+            a.sigma[p] = softplus_m1(t[3] + s1[kHidden]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.rgb[(int64_t)p * 3 + c] = 1.f / (1.f + expf(-(t[c] + c4[3 * kHidden + c])));
+        }
+    }
+    __syncthreads();
+}
+
 // kernel B: the point-level layers.  The compact points are cut into 32-row blocks and the blocks are dealt out EVENLY:
 // workgroup i takes the contiguous range [i q + min(i, rem), ...) of q or q + 1 blocks and walks it in passes of at most four blocks
 // (128 rows), the passes of a range as equal as possible (5 blocks = 3 + 2).  (Until round 3 the grid strode over 128-row tiles:
 // 584 tiles of a 128^2 view on 512 resident workgroups are two rounds for 1.14 rounds of work.)
-template <bool DIR>
+template <bool DIR, int FORM = 0>          // FORM 0: 32x32x16 layers, 1: 16x16x32 layers (points_pass16)
 __global__ __launch_bounds__(256, 2) void shade_points_kernel(ShadeArgs a) {
     constexpr int MAXNB = 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
     unsigned char* H = dsmem;
     float* red = reinterpret_cast<float*>(dsmem + MAXNB * 32 * kRowBytes);  // [4 waves][128 rows][4]
     const int tid = threadIdx.x;
+    unsigned char* bias_lds = reinterpret_cast<unsigned char*>(red + 4 * 32 * MAXNB * 4);   // FORM 1: the six layers' biases (6 KiB)
+    if constexpr (FORM == 1) {
+        const ShadeLayout L = shade_layout(a.feat_dim);
+        for (int i = tid; i < 6 * kHidden / 4; i += 256)
+            reinterpret_cast<f32x4*>(bias_lds)[i] = *reinterpret_cast<const f32x4*>(a.wpack + L.bias16[4] + (int64_t)i * 16);
+        __syncthreads();
+    }
     if (blockIdx.x == 0 && tid == 0 && a.tile_counter) *a.tile_counter = 0;      // the pair kernel of this call is done: its ticket word is free again
     const PointsArgs pa{a.wpack, a.G, a.sigma, a.rgb, a.dir_bias, a.point_ray, a.status, a.feat_dim, 32 * MAXNB};
     const int P = min(*a.n_points, a.max_points);
@@ -1155,10 +1301,17 @@ __global__ __launch_bounds__(256, 2) void shade_points_kernel(ShadeArgs a) {
     int left = q + ((int)blockIdx.x < rem ? 1 : 0);
     while (left > 0) {
         const int passes = (left + MAXNB - 1) / MAXNB, nb = (left + passes - 1) / passes;
+        if constexpr (FORM == 1) {
+            if (nb >= 4) points_pass16<DIR, 4>(pa, H, red, bias_lds, b * 32, P, tid);
+            else if (nb == 3) points_pass16<DIR, 3>(pa, H, red, bias_lds, b * 32, P, tid);
+            else if (nb == 2) points_pass16<DIR, 2>(pa, H, red, bias_lds, b * 32, P, tid);
+            else points_pass16<DIR, 1>(pa, H, red, bias_lds, b * 32, P, tid);
+        } else {
         if (nb >= 4) points_pass<DIR, 4>(pa, H, red, b * 32, P, tid);
         else if (nb == 3) points_pass<DIR, 3>(pa, H, red, b * 32, P, tid);
         else if (nb == 2) points_pass<DIR, 2>(pa, H, red, b * 32, P, tid);
         else points_pass<DIR, 1>(pa, H, red, b * 32, P, tid);
+        }
         b += nb;
         left -= nb;
     }
@@ -1279,9 +1432,9 @@ extern "C" int npcd_shade_pack_weights(const float* const* weights_host, const f
         memcpy(out + L.bias[i], biases_host[src[i]], kHidden * 4);
     }
     pack_rows_stream(weights_host, feat_dim, L.k0, out + L.rows);
-    for (int i = 0; i < 4; ++i) {
-        pack_matrix16(weights_host[i], i == 0 ? in0 : kHidden, i == 0 ? L.k0 : kHidden, out + L.w16[i]);
-        pack_bias16(biases_host[i], out + L.bias16[i]);
+    for (int i = 0; i < 10; ++i) {
+        pack_matrix16(weights_host[src[i]], i == 0 ? in0 : kHidden, i == 0 ? L.k0 : kHidden, out + L.w16[i]);
+        pack_bias16(biases_host[src[i]], out + L.bias16[i]);
     }
     float* s1 = reinterpret_cast<float*>(out + L.s1);
     memcpy(s1, weights_host[6], kHidden * 4);
@@ -1344,6 +1497,12 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
     static DynLds lds_a16_32, lds_a16_128;
     NPCD_HIP_CHECK(lds_a16_32.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<32, 1>), ldsA16));
     NPCD_HIP_CHECK(lds_a16_128.ensure(reinterpret_cast<const void*>(shade_pairs_kernel<128, 1>), ldsA16));
+    const int ldsB16 = ldsB + 6 * kHidden * 4;                       // + the six point-level layers' biases: 80 KiB, two workgroups = the CU's LDS
+    static DynLds lds_b16, lds_bd16;
+    NPCD_HIP_CHECK(lds_b16.ensure(reinterpret_cast<const void*>(shade_points_kernel<false, 1>), ldsB16));
+    NPCD_HIP_CHECK(lds_bd16.ensure(reinterpret_cast<const void*>(shade_points_kernel<true, 1>), ldsB16));
+    const char* points16_env = getenv("NPCD_SHADE_POINTS16");             // read per call (A/B in one process)
+    const bool points16 = !(points16_env && points16_env[0] == '0');      // default since round 5; 0 = the 32x32x16 layers
     const char* pairs16_env = getenv("NPCD_SHADE_PAIRS16");               // read per call (A/B in one process)
     const bool pairs16 = !(pairs16_env && pairs16_env[0] == '0');         // the default since round 5 (R5.13); 0 = the 32x32x16 layers
     const char* pairs8_env = getenv("NPCD_SHADE_PAIRS8");                 // read per call (A/B in one process)
@@ -1369,7 +1528,10 @@ static int shade_points_launch(const void* wpack, int feat_dim, int n_freqs, int
         else hipLaunchKernelGGL((shade_pairs_kernel<128, 1>), dim3(gridA), dim3(256), ldsA16, st, a);
     } else if (feat_dim == 32) hipLaunchKernelGGL(shade_pairs_kernel<32>, dim3(gridA), dim3(256), ldsA, st, a);
     else hipLaunchKernelGGL(shade_pairs_kernel<128>, dim3(gridA), dim3(256), ldsA, st, a);
-    if (dir_bias) hipLaunchKernelGGL(shade_points_kernel<true>, dim3(gridB), dim3(256), ldsB, st, a);
+    if (points16) {
+        if (dir_bias) hipLaunchKernelGGL((shade_points_kernel<true, 1>), dim3(gridB), dim3(256), ldsB16, st, a);
+        else hipLaunchKernelGGL((shade_points_kernel<false, 1>), dim3(gridB), dim3(256), ldsB16, st, a);
+    } else if (dir_bias) hipLaunchKernelGGL(shade_points_kernel<true>, dim3(gridB), dim3(256), ldsB, st, a);
     else hipLaunchKernelGGL(shade_points_kernel<false>, dim3(gridB), dim3(256), ldsB, st, a);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;

@@ -31,8 +31,9 @@ struct ShadeLayout {
     int64_t s1, c4;  // fp32 vectors: s1 = [256 w | 1 b | pad], c4 = [3*256 w | 3 b | pad]
     int64_t rows;    // A0..A3 once more, as the slab stream of the rows kernel (shade_rows.hip)
     int rows_slabs;  // its length in 4-KiB slabs: 4 quarters x (k0 / 32 + 3 * 8)
-    // A0..A3 and their biases a third time, in the fragment order of the 16x16x32 form of the pair kernel (shade.hip, pack_matrix16)
-    int64_t w16[4], bias16[4];
+    // all ten matrices and their biases once more, in the fragment order of the 16x16x32 forms of the pair and point kernels
+    // (shade.hip, pack_matrix16 / pack_bias16; the bias blocks lie back to back: copied to LDS in one run)
+    int64_t w16[10], bias16[10];
     int64_t total;
 };
 __host__ __device__ inline ShadeLayout shade_layout(int feat_dim) {
@@ -51,8 +52,8 @@ __host__ __device__ inline ShadeLayout shade_layout(int feat_dim) {
     L.rows = off;
     L.rows_slabs = 4 * (L.k0 / 32 + 3 * (kHidden / 32));
     off += (int64_t)L.rows_slabs * 4096;
-    for (int i = 0; i < 4; ++i) { L.w16[i] = off; off += (int64_t)kHidden * (i == 0 ? L.k0 : kHidden) * 2; }
-    for (int i = 0; i < 4; ++i) { L.bias16[i] = off; off += kHidden * 4; }
+    for (int i = 0; i < 10; ++i) { L.w16[i] = off; off += (int64_t)kHidden * (i == 0 ? L.k0 : kHidden) * 2; }
+    for (int i = 0; i < 10; ++i) { L.bias16[i] = off; off += kHidden * 4; }
     L.total = off;
     return L;
 }

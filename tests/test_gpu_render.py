@@ -218,14 +218,18 @@ def test_grid_capacity_limits_and_batches():
         hg.query_dense(9, 2.0, 5, x=T(x).cuda())
 
 
-@pytest.fixture(params=["tiles", "rows"])
+@pytest.fixture(params=["tiles", "rows", "tiles32"])
 def shade_form(request, monkeypatch):
-    """Both forms of the per-pair shading kernel: LDS tiles of 16 points (default) and NPCD_SHADE_ROWS=1 (csrc/shade_rows.hip:
-    activations in registers, aggregation as a matrix product); the library reads the switch at every call."""
+    """The forms of the shading kernels: LDS tiles of 16 points with the layers on v_mfma_f32_16x16x32_f16 (default since round 5),
+    NPCD_SHADE_ROWS=1 (csrc/shade_rows.hip: activations in registers, aggregation as a matrix product), and the tiles with the
+    32x32x16 layers of rounds 1-4 in both kernels (NPCD_SHADE_PAIRS16=0 NPCD_SHADE_POINTS16=0); the library reads the switches at every call."""
+    for v in ("NPCD_SHADE_ROWS", "NPCD_SHADE_PAIRS16", "NPCD_SHADE_POINTS16"):
+        monkeypatch.delenv(v, raising=False)
     if request.param == "rows":
         monkeypatch.setenv("NPCD_SHADE_ROWS", "1")
-    else:
-        monkeypatch.delenv("NPCD_SHADE_ROWS", raising=False)
+    elif request.param == "tiles32":
+        monkeypatch.setenv("NPCD_SHADE_PAIRS16", "0")
+        monkeypatch.setenv("NPCD_SHADE_POINTS16", "0")
     return request.param
 
 
@@ -541,19 +545,29 @@ def test_pair_layers_on_both_matrix_instruction_shapes(monkeypatch, F_):
     kp = torch.rand(Ntab, 3, device="cuda") - 0.5
     kf = torch.randn(Ntab, F_, device="cuda")
     over = torch.full((1,), 7 * Np, dtype=torch.int32, device="cuda")
-    monkeypatch.setenv("NPCD_SHADE_PAIRS16", "0")
-    s32, c32 = hr.shade_points(wp, F_, nb, pts, kp, kf, n_points=over)
-    monkeypatch.delenv("NPCD_SHADE_PAIRS16")
-    s16, c16 = hr.shade_points(wp, F_, nb, pts, kp, kf, n_points=over)
-    s16b, c16b = hr.shade_points(wp, F_, nb, pts, kp, kf)
-    torch.cuda.synchronize()
-    assert torch.isfinite(s16).all() and torch.isfinite(c16).all()
-    assert float(((s16 - s32).abs() / s32.abs().clamp_min(1.0)).max()) < 3e-3 and float((c16 - c32).abs().max()) < 3e-3
-    assert torch.equal(s16, s16b) and torch.equal(c16, c16b)
+    # with and without view directions (per-ray bias rows of the first colour layer)
+    rays = torch.randint(0, 97, (Np,), dtype=torch.int32, device="cuda")
+    dirb = torch.randn(97, 256, device="cuda") * 0.3
+    for kw in ({}, {"dir_bias": dirb, "point_ray": rays}):
+        monkeypatch.setenv("NPCD_SHADE_PAIRS16", "0")
+        monkeypatch.setenv("NPCD_SHADE_POINTS16", "0")
+        s32, c32 = hr.shade_points(wp, F_, nb, pts, kp, kf, n_points=over, **kw)
+        monkeypatch.delenv("NPCD_SHADE_POINTS16")
+        s32p, c32p = hr.shade_points(wp, F_, nb, pts, kp, kf, n_points=over, **kw)       # only the point kernel on the new shape
+        monkeypatch.delenv("NPCD_SHADE_PAIRS16")
+        s16, c16 = hr.shade_points(wp, F_, nb, pts, kp, kf, n_points=over, **kw)
+        s16b, c16b = hr.shade_points(wp, F_, nb, pts, kp, kf, **kw)
+        torch.cuda.synchronize()
+        assert torch.isfinite(s16).all() and torch.isfinite(c16).all()
+        for sx, cx in ((s16, c16), (s32p, c32p)):
+            assert float(((sx - s32).abs() / s32.abs().clamp_min(1.0)).max()) < 3e-3 and float((cx - c32).abs().max()) < 3e-3
+        assert torch.equal(s16, s16b) and torch.equal(c16, c16b)
+    assert float((c16 - hr.shade_points(wp, F_, nb, pts, kp, kf)[1]).abs().max()) > 1e-3          # (the direction rows do enter)
     big = {kn: (v * 300 if kn.startswith("aggregator.local_field") and kn.endswith("weight") else v) for kn, v in p.items()}
     wpb = hr.pack_field_weights(big, F_, "cuda")
     for mode in ("0", "1"):
         monkeypatch.setenv("NPCD_SHADE_PAIRS16", mode)
+        monkeypatch.setenv("NPCD_SHADE_POINTS16", mode)
         status = torch.zeros(1, dtype=torch.int32, device="cuda")
         hr.shade_points(wpb, F_, nb, pts, kp, kf, status=status)
         torch.cuda.synchronize()
