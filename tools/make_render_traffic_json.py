@@ -54,9 +54,12 @@ res["note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tool
                "(gfx950 tallies 128-B requests at 64 B); every buffer of a view fits the 256-MB Infinity Cache, whose hits these fabric-side counters "
                "appear to include: the ratio says how many bytes the kernels MOVE per algorithmic byte, not how many came from DRAM.  The weights "
                "(1.2 MB) and the point table are re-read from L2 by every workgroup and are not algorithmic HBM bytes.")
+import hashlib
+_csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neural-point-cloud-diffusion_amd", "csrc")
+res["source_sha256"] = {f: hashlib.sha256(open(os.path.join(_csrc, f), "rb").read()).hexdigest() for f in ("geometry.hip", "shade.hip", "shade_common.h", "common.h")}
 json.dump(res, open(out, "w"), indent=1)
 for S, per in res.items():
-    if S != "note":
+    if S not in ("note", "source_sha256"):
         for k, v in per.items():
             if not k.startswith("_"):
                 print(S, k, f"alg {v['algorithmic_bytes'] / 1e6:.2f} MB  hbm {v['hbm_bytes'] / 1e6:.2f} MB  ratio {v['ratio_to_algorithmic']:.2f}")
