@@ -159,7 +159,7 @@ def bench_render(device, n_iters=100, burn_in=5):
                         "roofline_query": query_roofline(S, query_ms, len(qev), rclock)}
     r = dict(per_s[128])
     # the same view with the field MLPs in the reference's numerics class (the evaluation scripts run them in fp32): per-pair layers
-    # on the fp32-class matrix-core kernel (two bf16 halves per operand, three products), heads on fp32 library GEMMs
+    # on the fp32-class matrix-core kernel (two bf16 halves per operand, three products), fifth layer + heads on its point-level sibling
     try:
         net.renderer.depth_resolution = 128
         net.renderer.count_pairs = False
@@ -170,8 +170,8 @@ def bench_render(device, n_iters=100, burn_in=5):
         r["fp32_class_shading"] = {"rays_per_s": 128 * 128 / dt32, "ms_per_view": dt32 * 1e3,
                                    "max_abs_pixel_difference_to_the_fp16_operand_render": float((a16 - a32).abs().max()),
                                    "numerics": "PointNeRF.render(mlp_dtype=torch.float32): per-pair layers with every operand as two bf16 halves "
-                                               "(csrc/pairs_mlp.hip precision 1, ~1e-5 relative), fifth layer and heads fp32 library GEMMs; "
-                                               "one host read of the point count per view"}
+                                               "(csrc/pairs_mlp.hip precision 1, ~1e-5 relative), fifth layer and heads fused in the same numerics "
+                                               "(csrc/points_x2.hip; fp32 library GEMMs until late in round 5); one host read of the point count per view"}
     except Exception as e:                      # noqa: BLE001
         r["fp32_class_shading"] = {"error": f"{type(e).__name__}: {e}"}
     # continuity with rounds 1-2, which ran the FINE-grid reading of torch_knnquery (fewer shading points with a neighbour, i.e.

@@ -265,6 +265,23 @@ int npcd_shade_points_dir(const void* wpack, int feat_dim, int n_freqs, int hidd
                           int32_t* status, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The POINT-level layers in the reference's fp32 numerics class (round 5, ABI 8): last aggregator layer (linear; aggregators/mlp.py:83-84,
+ * local_field[8]), shape_net + softplus(x - 1) (fields/mlp.py:38-51, field.py:30,126-128), channel_net + sigmoid (fields/mlp.py:53-72,
+ * field.py:139-140) on `feat` [max_points, 256] fp32 = the aggregated per-point features (the output of npcd_pair_mlp_fwd with
+ * NPCD_PAIR_MLP_X2 + the weighted mean).  Every operand is two bf16 halves, every product three matrix instructions in fp32
+ * accumulators (the numerics of NPCD_PAIR_MLP_X2: ~4e-6 relative per layer, fp32's exponent range); csrc/points_x2.hip.
+ *   npcd_points_x2_pack: the twelve HOST pointers of npcd_shade_pack_weights (entries 4..11 are read); c0_in_dim = input columns of
+ *   channel_net.0 (256, or 256 + the direction encoding: its first 256 columns are packed).
+ *   npcd_points_x2: n_points_dev may be NULL (= max_points); dir_bias [rows, 256] fp32 + point_ray [max_points] int32 add row
+ *   point_ray[p] to the first colour layer's pre-activation of point p (use_view_dir, fields/mlp.py:67-70), or both NULL.
+ *   -> sigma [max_points], rgb [max_points, 3] (activations applied).
+ * ------------------------------------------------------------------------------------------ */
+int64_t npcd_points_x2_wpack_bytes(void);
+int npcd_points_x2_pack(const float* const* weights_host, const float* const* biases_host, int c0_in_dim, void* wpack_host);
+int npcd_points_x2(const void* wpack, const float* feat, const int32_t* n_points_dev, int max_points, float* sigma, float* rgb,
+                   const float* dir_bias, const int32_t* point_ray, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Ray marching (renderer.py:96-110,120-185, volume_renderer.py:23-39) on the dense slot layout:
  * sigma/rgb are COMPACT per valid slot (row-major over [ray, slot]); slot_valid [Nr,M] uint8,
  * slot_loc [Nr,M,3], point_base [Nr] int32 = index of the ray's first compact point.

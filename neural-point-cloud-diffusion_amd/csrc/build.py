@@ -39,6 +39,7 @@ SOURCES = {
     "pairs.hip": ["-ffp-contract=off"],
     "pairs_mlp.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "split.hip": [],
+    "points_x2.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
           "-fno-gpu-rdc", "-ffast-math" if False else "-fno-fast-math"]

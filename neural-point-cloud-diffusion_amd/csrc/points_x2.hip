@@ -1,0 +1,370 @@
+// The point-level layers of the PointNeRF field in the reference's fp32 numerics class, fused (round 5).
+//
+// Reference op chain replaced (eval_pointnerf.py / eval_diffusion.py run the field in plain fp32):
+//   last aggregator layer (linear)        npcd/models/pointnerf/fields/aggregators/mlp.py:83-84 (local_field[8])
+//   shape_net + softplus(x - 1)           fields/mlp.py:38-51, field.py:30,126-128
+//   channel_net + sigmoid                 fields/mlp.py:53-72, field.py:139-140
+//
+// `PointNeRF.render(mlp_dtype=torch.float32)` ran these six 256 x 256 layers as fp32 library GEMMs on the ~75 k shading points of a
+// view: ~0.8 ms of its 1.61 ms.  Here every operand is two bf16 halves (x = hi + lo) and every product three matrix instructions
+// hi.hi + hi.lo + lo.hi in fp32 accumulators -- the numerics of csrc/pairs_mlp.hip's precision 1 (~4e-6 relative per layer, fp32's
+// exponent range) -- on v_mfma_f32_16x16x32_bf16 (docs/experiments.md R5.13: the instruction under which the power-bound chip
+// clocks highest).  Structure of the fp16 point kernel's 16x16x32 form (csrc/shade.hip, points_pass16): weights as the A operand
+// straight from L2 in fragment order (4 KiB runs per wave and 32 input channels, hi and lo), activations as the B operand from two
+// LDS planes (hi, lo; 64 points x 528 bytes each), biases as the C operand of a layer's first step from an LDS copy, the heads' final
+// 256 -> 1 / 256 -> 3 projections from the fp32 accumulators.  Tile = 64 points, 4 waves x 64 output channels, two workgroups per CU.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace npcd {
+
+constexpr int kXHidden = 256;
+constexpr int kXRows = 64;                       // points per tile
+constexpr int kXPitch = 528;                     // bytes per row of a plane (512 + 16: ds_read_b128 of 16 consecutive rows is conflict-free)
+constexpr int kXPlane = kXRows * kXPitch;
+constexpr int kXFrag = 1024;
+constexpr int kXMat = kXHidden * kXHidden * 2;   // bytes of one half (hi or lo) of a matrix
+constexpr float kXLeaky = 0.01f;
+
+struct PointsX2Layout {
+    int64_t w[6];        // per matrix: [hi: kXMat bytes][lo: kXMat bytes], fragment order [wave][32-column step][block mb][lane][8]
+    int64_t bias;        // 6 x 256 fp32 in the order of the C operands: [layer][wave][g][mb][4]
+    int64_t s1, c4;      // fp32: s1 = [256 w | 1 b | pad], c4 = [3 x 256 w | 3 b | pad]
+    int64_t total;
+};
+__host__ __device__ inline PointsX2Layout points_x2_layout() {
+    PointsX2Layout L;
+    int64_t off = 0;
+    for (int i = 0; i < 6; ++i) { L.w[i] = off; off += 2 * kXMat; }
+    L.bias = off; off += 6 * kXHidden * 4;
+    L.s1 = off; off += 264 * 4;
+    L.c4 = off; off += 776 * 4;
+    L.total = off;
+    return L;
+}
+
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t xrsrc_t;
+__device__ __forceinline__ f32x4a xmfma(bf16x8 a, bf16x8 b, f32x4a c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ bf16x8 xfrag(xrsrc_t rs, int w_off, int wave, int lane, int s, int mb) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + mb * kXFrag, w_off + (wave * 8 + s) * (4 * kXFrag), 0));
+}
+struct XRing { bf16x8 h[2][4], l[2][4]; };
+__device__ __forceinline__ void xprefetch(xrsrc_t rs, int w_off, int wave, int lane, XRing& ring) {
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        ring.h[0][mb] = xfrag(rs, w_off, wave, lane, 0, mb);
+        ring.l[0][mb] = xfrag(rs, w_off + kXMat, wave, lane, 0, mb);
+    }
+}
+// one layer on a tile: acc[mb][rb] = bias + sum over 256 inputs of (Wh Xh + Wh Xl + Wl Xh); 16 independent accumulators between two
+// instructions on the same one
+__device__ __forceinline__ void xlayer(const unsigned char* Hh, const unsigned char* Hl, const unsigned char* bias_l, xrsrc_t rs, int w_off,
+                                       int wave, int lane, XRing& ring, f32x4a (&acc)[4][4]) {
+    const int off = (lane & 15) * kXPitch + (lane >> 4) * 16;
+    f32x4a init[4];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) init[mb] = *reinterpret_cast<const f32x4a*>(bias_l + wave * 256 + (lane >> 4) * 64 + mb * 16);
+    bf16x8 bh[4], bl[4], nh[4], nl[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        bh[r] = *reinterpret_cast<const bf16x8*>(Hh + off + r * 16 * kXPitch);
+        bl[r] = *reinterpret_cast<const bf16x8*>(Hl + off + r * 16 * kXPitch);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (s + 1 < 8) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                ring.h[(s + 1) & 1][mb] = xfrag(rs, w_off, wave, lane, s + 1, mb);
+                ring.l[(s + 1) & 1][mb] = xfrag(rs, w_off + kXMat, wave, lane, s + 1, mb);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                nh[r] = *reinterpret_cast<const bf16x8*>(Hh + off + r * 16 * kXPitch + (s + 1) * 64);
+                nl[r] = *reinterpret_cast<const bf16x8*>(Hl + off + r * 16 * kXPitch + (s + 1) * 64);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) acc[mb][r] = xmfma(ring.h[s & 1][mb], bh[r], s == 0 ? init[mb] : acc[mb][r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) acc[mb][r] = xmfma(ring.h[s & 1][mb], bl[r], acc[mb][r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) acc[mb][r] = xmfma(ring.l[s & 1][mb], bh[r], acc[mb][r]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { bh[r] = nh[r]; bl[r] = nl[r]; }
+    }
+}
+__device__ __forceinline__ uint32_t xpack2(__bf16 a, __bf16 b) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    const b2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, v);
+}
+// write-back: optional LeakyReLU in fp32, then the two halves of every value to the two planes (8 consecutive channels per store:
+// blocks 2 p, 2 p + 1 of a lane, the pack's row order)
+template <bool ACT>
+__device__ __forceinline__ void xstore(unsigned char* Hh, unsigned char* Hl, int wave, int lane, const f32x4a (&acc)[4][4]) {
+    const int sb = (lane & 15) * kXPitch + (lane >> 4) * 16 + wave * 128;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2) {
+            uint32_t vh[4], vl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float x0 = acc[2 * p2 + (q >> 1)][rb][2 * (q & 1)], x1 = acc[2 * p2 + (q >> 1)][rb][2 * (q & 1) + 1];
+                if (ACT) {
+                    x0 = x0 > 0.f ? x0 : kXLeaky * x0;
+                    x1 = x1 > 0.f ? x1 : kXLeaky * x1;
+                }
+                const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+                vh[q] = xpack2(h0, h1);
+                vl[q] = xpack2((__bf16)(x0 - (float)h0), (__bf16)(x1 - (float)h1));
+            }
+            *reinterpret_cast<u32x4*>(Hh + sb + rb * 16 * kXPitch + p2 * 64) = u32x4{vh[0], vh[1], vh[2], vh[3]};
+            *reinterpret_cast<u32x4*>(Hl + sb + rb * 16 * kXPitch + p2 * 64) = u32x4{vl[0], vl[1], vl[2], vl[3]};
+        }
+}
+__device__ __forceinline__ float xsum_groups(float x) {          // x summed over lanes l, l ^ 16, l ^ 32, l ^ 48
+    const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
+    const auto r32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r32[0]) + __uint_as_float(r32[1]);
+}
+__device__ __forceinline__ float xsoftplus_m1(float x) {
+    x -= 1.f;
+    return x > 20.f ? x : log1pf(expf(x));  // F.softplus(beta=1, threshold=20)
+}
+
+struct PointsX2Args {
+    const unsigned char* wpack;
+    const float* feat;            // [max_points][256] fp32: the aggregated per-point features (output of the per-pair layers)
+    const int32_t* n_points;      // device-side count (may be null: max_points)
+    int max_points;
+    float *sigma, *rgb;
+    const float* dir_bias;        // use_view_dir: [n_rays][256] fp32 rows added to the first colour layer's pre-activation, or null
+    const int32_t* point_ray;
+};
+
+template <bool DIR>
+__global__ __launch_bounds__(256, 2) void points_x2_kernel(PointsX2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+    unsigned char* Hh = dsmem;
+    unsigned char* Hl = dsmem + kXPlane;
+    float* red = reinterpret_cast<float*>(dsmem + 2 * kXPlane);                   // [4 waves][64 rows][4]
+    unsigned char* bias_lds = reinterpret_cast<unsigned char*>(red + 4 * kXRows * 4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), n = lane & 15, g = lane >> 4;
+    const PointsX2Layout L = points_x2_layout();
+    const xrsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wpack), 0, (int)L.total, 0x00020000);
+    for (int i = tid; i < 6 * kXHidden / 4; i += 256)
+        reinterpret_cast<f32x4*>(bias_lds)[i] = *reinterpret_cast<const f32x4*>(a.wpack + L.bias + (int64_t)i * 16);
+    const float* s1 = reinterpret_cast<const float*>(a.wpack + L.s1);
+    const float* c4 = reinterpret_cast<const float*>(a.wpack + L.c4);
+    const int P = a.n_points ? min(*a.n_points, a.max_points) : a.max_points;
+    const int ntiles = (P + kXRows - 1) / kXRows;
+    const int w0 = (int)L.w[0];
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * kXRows;
+        XRing ring;
+        xprefetch(rs, w0, wave, lane, ring);
+        // ---- the tile's 64 x 256 fp32 features -> the two planes ----------------------------
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int cidx = it * 256 + tid, row = cidx >> 5, chunk = cidx & 31;
+            const int p = row0 + row;
+            f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
+            if (p < P) {
+                x0 = *reinterpret_cast<const f32x4*>(a.feat + (int64_t)p * kXHidden + chunk * 8);
+                x1 = *reinterpret_cast<const f32x4*>(a.feat + (int64_t)p * kXHidden + chunk * 8 + 4);
+            }
+            uint32_t vh[4], vl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float y0 = q < 2 ? x0[2 * q] : x1[2 * q - 4], y1 = q < 2 ? x0[2 * q + 1] : x1[2 * q - 3];
+                const __bf16 h0 = (__bf16)y0, h1 = (__bf16)y1;
+                vh[q] = xpack2(h0, h1);
+                vl[q] = xpack2((__bf16)(y0 - (float)h0), (__bf16)(y1 - (float)h1));
+            }
+            *reinterpret_cast<u32x4*>(Hh + row * kXPitch + chunk * 16) = u32x4{vh[0], vh[1], vh[2], vh[3]};
+            *reinterpret_cast<u32x4*>(Hl + row * kXPitch + chunk * 16) = u32x4{vl[0], vl[1], vl[2], vl[3]};
+        }
+        __syncthreads();
+        f32x4a acc[4][4];
+        // ---- last aggregator layer (linear): feat -------------------------------------------
+        xlayer(Hh, Hl, bias_lds, rs, w0, wave, lane, ring, acc);
+        xprefetch(rs, w0 + 2 * kXMat, wave, lane, ring);
+        __syncthreads();
+        xstore<false>(Hh, Hl, wave, lane, acc);
+        __syncthreads();
+        // ---- density head ---------------------------------------------------------------------
+        xlayer(Hh, Hl, bias_lds + kXHidden * 4, rs, w0 + 2 * kXMat, wave, lane, ring, acc);
+        xprefetch(rs, w0 + 4 * kXMat, wave, lane, ring);
+        {
+            float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(s1 + 64 * wave + 32 * (mb >> 1) + 8 * g + 4 * (mb & 1));
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) {
+                        float x = acc[mb][rb][b];
+                        x = x > 0.f ? x : kXLeaky * x;
+                        part[rb] = __builtin_fmaf(x, wv[b], part[rb]);
+                    }
+            }
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const float t = xsum_groups(part[rb]);
+                if (g == 0) red[(wave * kXRows + rb * 16 + n) * 4 + 3] = t;
+            }
+        }
+        // (the planes still hold feat: the density layer did not write activations)
+        // ---- colour head ------------------------------------------------------------------------
+#pragma unroll 1
+        for (int l = 0; l < 4; ++l) {
+            const int w_off = w0 + (2 + l) * (2 * kXMat);
+            xlayer(Hh, Hl, bias_lds + (2 + l) * (kXHidden * 4), rs, w_off, wave, lane, ring, acc);
+            if (l < 3) xprefetch(rs, w_off + 2 * kXMat, wave, lane, ring);
+            if (DIR && l == 0) {
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    const int p = row0 + rb * 16 + n;
+                    const float* db = a.dir_bias + (int64_t)(p < P ? a.point_ray[p] : 0) * kXHidden;
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(db + 64 * wave + 32 * (mb >> 1) + 8 * g + 4 * (mb & 1));
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[mb][rb][b] += v[b];
+                    }
+                }
+            }
+            if (l < 3) {
+                __syncthreads();
+                xstore<true>(Hh, Hl, wave, lane, acc);
+                __syncthreads();
+            }
+        }
+        {
+            float pc[4][3];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) pc[rb][0] = pc[rb][1] = pc[rb][2] = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                const float* cp = c4 + 64 * wave + 32 * (mb >> 1) + 8 * g + 4 * (mb & 1);
+                const f32x4 wr = *reinterpret_cast<const f32x4*>(cp), wg = *reinterpret_cast<const f32x4*>(cp + kXHidden),
+                            wb = *reinterpret_cast<const f32x4*>(cp + 2 * kXHidden);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int rb = 0; rb < 4; ++rb) {
+                        float x = acc[mb][rb][b];
+                        x = x > 0.f ? x : kXLeaky * x;
+                        pc[rb][0] = __builtin_fmaf(x, wr[b], pc[rb][0]);
+                        pc[rb][1] = __builtin_fmaf(x, wg[b], pc[rb][1]);
+                        pc[rb][2] = __builtin_fmaf(x, wb[b], pc[rb][2]);
+                    }
+            }
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const float pr = xsum_groups(pc[rb][0]), pg = xsum_groups(pc[rb][1]), pb = xsum_groups(pc[rb][2]);
+                if (g == 0) {
+                    float* q = red + (wave * kXRows + rb * 16 + n) * 4;
+                    q[0] = pr; q[1] = pg; q[2] = pb;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < kXRows) {
+            const int p = row0 + tid;
+            if (p < P) {
+                f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(red + (w * kXRows + tid) * 4);
+                a.sigma[p] = xsoftplus_m1(t[3] + s1[kXHidden]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) a.rgb[(int64_t)p * 3 + c] = 1.f / (1.f + expf(-(t[c] + c4[3 * kXHidden + c])));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace npcd
+
+using namespace npcd;
+
+extern "C" int64_t npcd_points_x2_wpack_bytes(void) { return points_x2_layout().total; }
+
+// weights_host / biases_host: the twelve pointers of npcd_shade_pack_weights (aggregator.local_field.{0,2,4,6,8}, shape_net.{0,2},
+// channel_net.{0,2,4,6,8}); entries 4..11 are read.  c0_in_dim = input columns of channel_net.0 (256, or 256 + the direction
+// encoding with use_view_dir: its first 256 columns are packed, the rest enters as dir_bias).
+extern "C" int npcd_points_x2_pack(const float* const* weights_host, const float* const* biases_host, int c0_in_dim, void* wpack_host) {
+    if (!weights_host || !biases_host || !wpack_host || c0_in_dim < kXHidden) return NPCD_ERR_ARG;
+    for (int i = 4; i < 12; ++i)
+        if (!weights_host[i] || !biases_host[i]) return NPCD_ERR_ARG;
+    const PointsX2Layout L = points_x2_layout();
+    unsigned char* out = static_cast<unsigned char*>(wpack_host);
+    memset(out, 0, L.total);
+    const int src[6] = {4, 5, 7, 8, 9, 10};
+    for (int i = 0; i < 6; ++i) {
+        const float* W = weights_host[src[i]];
+        const int in_dim = src[i] == 7 ? c0_in_dim : kXHidden;
+        __bf16* dh = reinterpret_cast<__bf16*>(out + L.w[i]);
+        __bf16* dl = reinterpret_cast<__bf16*>(out + L.w[i] + kXMat);
+        for (int w = 0; w < 4; ++w)
+            for (int s = 0; s < 8; ++s)
+                for (int mb = 0; mb < 4; ++mb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int m = lane & 15, o = 64 * w + 32 * (mb >> 1) + 8 * (m >> 2) + 4 * (mb & 1) + (m & 3), c = 32 * s + 8 * (lane >> 4) + j;
+                            const float v = W[(int64_t)o * in_dim + c];
+                            const __bf16 h = (__bf16)v;
+                            const int64_t at = ((((int64_t)w * 8 + s) * 4 + mb) * 64 + lane) * 8 + j;
+                            dh[at] = h;
+                            dl[at] = (__bf16)(v - (float)h);
+                        }
+        float* db = reinterpret_cast<float*>(out + L.bias) + i * kXHidden;
+        for (int w = 0; w < 4; ++w)
+            for (int g = 0; g < 4; ++g)
+                for (int mb = 0; mb < 4; ++mb)
+                    for (int b = 0; b < 4; ++b) db[((w * 4 + g) * 4 + mb) * 4 + b] = biases_host[src[i]][64 * w + 32 * (mb >> 1) + 8 * g + 4 * (mb & 1) + b];
+    }
+    float* s1 = reinterpret_cast<float*>(out + L.s1);
+    memcpy(s1, weights_host[6], kXHidden * 4);
+    s1[kXHidden] = biases_host[6][0];
+    float* c4 = reinterpret_cast<float*>(out + L.c4);
+    memcpy(c4, weights_host[11], 3 * kXHidden * 4);
+    memcpy(c4 + 3 * kXHidden, biases_host[11], 3 * 4);
+    return NPCD_OK;
+}
+
+extern "C" int npcd_points_x2(const void* wpack, const float* feat, const int32_t* n_points_dev, int max_points, float* sigma, float* rgb,
+                              const float* dir_bias, const int32_t* point_ray, void* stream) {
+    if (!wpack || !feat || !sigma || !rgb || max_points < 0) return NPCD_ERR_ARG;
+    if ((dir_bias != nullptr) != (point_ray != nullptr)) return NPCD_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(dir_bias) | reinterpret_cast<uintptr_t>(wpack)) & 15) return NPCD_ERR_ARG;
+    if (max_points == 0) return NPCD_OK;
+    PointsX2Args a{static_cast<const unsigned char*>(wpack), feat, n_points_dev, max_points, sigma, rgb, dir_bias, point_ray};
+    const int lds = 2 * kXPlane + 4 * kXRows * 4 * 4 + 6 * kXHidden * 4;
+    static DynLds lds_p, lds_d;
+    NPCD_HIP_CHECK(lds_p.ensure(reinterpret_cast<const void*>(points_x2_kernel<false>), lds));
+    NPCD_HIP_CHECK(lds_d.ensure(reinterpret_cast<const void*>(points_x2_kernel<true>), lds));
+    const int tiles = (max_points + kXRows - 1) / kXRows, grid = tiles < 512 ? tiles : 512;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dir_bias) hipLaunchKernelGGL(points_x2_kernel<true>, dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(points_x2_kernel<false>, dim3(grid), dim3(256), lds, st, a);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}

@@ -220,6 +220,39 @@ def pack_field_weights(state: dict, feat_dim: int, device, n_freqs: int = 10, hi
     return host.to(device)
 
 
+def points_x2_pack(state: dict, device) -> torch.Tensor:
+    """The point-level layers of a Field (local_field.8, shape_net, channel_net; state_dict keys relative to the Field module) as hi / lo
+    bf16 fragments for npcd_points_x2 (csrc/points_x2.hip).  Returns a uint8 device tensor."""
+    L = lib()
+    ws = [state[n + ".weight"].detach().to("cpu", _f32).contiguous() for n in FIELD_ORDER]
+    bs = [state[n + ".bias"].detach().to("cpu", _f32).contiguous() for n in FIELD_ORDER]
+    wp = (ctypes.c_void_p * 12)(*[w.data_ptr() for w in ws])
+    bp = (ctypes.c_void_p * 12)(*[b.data_ptr() for b in bs])
+    host = torch.empty(L.npcd_points_x2_wpack_bytes(), dtype=torch.uint8)
+    check(L.npcd_points_x2_pack(wp, bp, int(ws[7].shape[1]), ctypes.c_void_p(host.data_ptr())), "npcd_points_x2_pack")
+    return host.to(device)
+
+
+def points_x2(wpack: torch.Tensor, feat: torch.Tensor, dir_bias: Optional[torch.Tensor] = None, point_ray: Optional[torch.Tensor] = None):
+    """feat [P, 256] fp32 (aggregated per-point features) -> sigma [P], rgb [P, 3]: the last aggregator layer and both heads in the
+    reference's fp32 numerics class on the matrix cores (split bf16 operands).  dir_bias [rows, 256] fp32 + point_ray [P] int32: the
+    direction part of the first colour layer's pre-activation (use_view_dir)."""
+    require_gpu(wpack, feat)
+    if (dir_bias is None) != (point_ray is None):
+        raise ValueError("dir_bias and point_ray go together")
+    P = feat.shape[0]
+    feat = feat.to(_f32).contiguous()
+    sigma = torch.empty(P, dtype=_f32, device=feat.device)
+    rgb = torch.empty((P, 3), dtype=_f32, device=feat.device)
+    if P == 0:
+        return sigma, rgb
+    if dir_bias is not None:
+        dir_bias, point_ray = dir_bias.to(_f32).contiguous(), point_ray.to(_i32).contiguous()
+    check(lib().npcd_points_x2(ptr(wpack), ptr(feat), None, P, ptr(sigma), ptr(rgb), ptr(dir_bias), ptr(point_ray), stream_ptr()),
+          "npcd_points_x2")
+    return sigma, rgb
+
+
 # When set to a list, the two shading kernels of every shade_points() call (shade_pairs_kernel + shade_points_kernel, one C call)
 # are bracketed by HIP events recorded on the launch stream (bench.py: per-kernel roofline of the renderer's dominant kernels).
 SHADE_EVENTS = None

@@ -182,6 +182,20 @@ class Field(nn.Module):
                 else:
                     x = m(x)
             return x
+        if not os.environ.get("NPCD_FP32_HEADS_LIBRARY"):
+            # the fifth layer and both heads fused, same numerics class as the per-pair layers (csrc/points_x2.hip; round 5: ~0.2 ms
+            # against ~0.8 ms of fp32 library GEMMs per 128 x 128 view).  NPCD_FP32_HEADS_LIBRARY=1 = the fp32 GEMMs below.
+            pw = [p for m in (lf[8], *self.shape_net, *self.channel_net) if isinstance(m, nn.Linear) for p in (m.weight, m.bias)]
+            key2 = (str(pts.device),) + tuple((p.data_ptr(), p._version) for p in pw)
+            if getattr(self, "_packx2_key", None) != key2:
+                self._packx2 = hr.points_x2_pack({k: v for k, v in self.state_dict().items()}, pts.device)
+                self._packx2_key = key2
+            db = ray = None
+            if self.use_dir:          # the direction columns of the first colour layer, per point, as fp32 bias rows
+                w0 = self.channel_net[0].weight
+                db = encode_dir(point_dir.float(), self.dir_freqs) @ w0[:, self.hid_dim:].float().t()
+                ray = torch.arange(G.shape[0], dtype=torch.int32, device=G.device)
+            return hr.points_x2(self._packx2, G, db, ray)
         with torch.autocast("cuda", enabled=False):
             feat = mlp([lf[8]], G)
             # (a point without neighbours aggregates to zero and sees the biases only, like the fused kernels and aggregators/mlp.py:60-62)

@@ -355,6 +355,50 @@ def test_render_surfaces_the_range_guard(monkeypatch):
             assert out["shading_status"] & 1
 
 
+@pytest.mark.parametrize("use_dir", [False, True])
+def test_fused_point_level_layers_in_the_fp32_class(use_dir, monkeypatch):
+    """csrc/points_x2.hip (round 5): the last aggregator layer and both heads on split bf16 operands (three matrix instructions per
+    product, fp32 accumulation) against the same layers as float64 torch modules on the same inputs: sigma to 1e-4 of max(1, |sigma|),
+    rgb to 2e-5 (16 mantissa bits per product on features of O(10) and weights 1.7 x the default scale: pre-activations of O(100) with
+    cancellation; the fp16-operand kernels on such inputs: ~1e-2), a point count that is not a multiple of the 64-point tile, with and
+    without view-direction rows, bitwise repeatable.  Field.shade_fp32 reaches the kernel by default (the fp32-class render test
+    holds its 2e-5 pixel bar through it); NPCD_FP32_HEADS_LIBRARY=1 selects the fp32 library GEMMs it replaces."""
+    from npcd.hip import render as hr
+    torch.manual_seed(5)
+    from npcd.models.pointnerf import PointNeRF
+    p = orr.init_field_params(32, seed=1, dir_dim=51 if use_dir else 0)
+    for kname in p:
+        if kname.endswith("weight"):
+            p[kname] = p[kname] * 1.7
+    m = PointNeRF(1, 32, 64, use_dir)
+    m.field.load_state_dict(p)
+    field = m.cuda().eval().field
+    P = 64 * 37 + 13
+    G = (torch.randn(P, 256, device="cuda") * 4.0).contiguous()
+    pd = torch.nn.functional.normalize(torch.randn(P, 3, device="cuda"), dim=-1) if use_dir else None
+    wp = hr.points_x2_pack(field.state_dict(), "cuda")
+    db = ray = None
+    if use_dir:
+        from npcd.models.pointnerf.field import encode_dir
+        db = encode_dir(pd, field.dir_freqs) @ field.channel_net[0].weight[:, 256:].float().t()
+        ray = torch.arange(P, dtype=torch.int32, device="cuda")
+    sig, rgb = hr.points_x2(wp, G, db, ray)
+    sig2, rgb2 = hr.points_x2(wp, G, db, ray)
+    torch.cuda.synchronize()
+    assert torch.equal(sig, sig2) and torch.equal(rgb, rgb2)
+    import copy
+    f64 = copy.deepcopy(field).double()
+    with torch.no_grad():
+        feat = f64.aggregator.local_field[8](G.double())
+        cin = feat if not use_dir else torch.cat((feat, encode_dir(pd.double(), field.dir_freqs)), dim=-1)
+        want_s = torch.nn.functional.softplus(f64.shape_net(feat) - 1.0)[:, 0]
+        want_c = torch.sigmoid(f64.channel_net(cin))
+    es = float(((sig.double() - want_s).abs() / want_s.abs().clamp_min(1.0)).max())
+    ec = float((rgb.double() - want_c).abs().max())
+    print("points_x2 vs float64: sigma", es, "rgb", ec)
+    assert es < 1e-4 and ec < 2e-5, (es, ec)
+
+
 def test_render_in_the_reference_numerics_class(golden):
     """PointNeRF.render(mlp_dtype=torch.float32) (VERDICT r4 missing 3): the field MLPs in the reference's fp32 class -- per-pair layers
     on the fp32-class matrix-core kernel, heads in fp32 -- against the fp32 CPU oracle: pixels to 2e-5 (the fp16-operand kernels'
