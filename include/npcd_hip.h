@@ -276,6 +276,15 @@ int npcd_shade_points_dir(const void* wpack, int feat_dim, int n_freqs, int hidd
  *   point_ray[p] to the first colour layer's pre-activation of point p (use_view_dir, fields/mlp.py:67-70), or both NULL.
  *   -> sigma [max_points], rgb [max_points, 3] (activations applied).
  * ------------------------------------------------------------------------------------------ */
+/* The four non-linear PER-PAIR layers + the inverse-distance mean in the same numerics, forward only (aggregators/mlp.py:62-125,
+ * aggregator.py:122-156, positional_encoder.py:16-20): nb_idx [max_points, k] int32 global neighbour indices (-1 = none, anywhere in a
+ * row: the compact query's lists as they are), pts [max_points, 3], kp_pos [B N, 3], kp_feat [B N, feat_dim] -> G [max_points, 256] fp32,
+ * the input of npcd_points_x2.  feat_dim in {32, 128}, k <= 8; n_points_dev may be NULL.  npcd_pairs_x2_pack reads entries 0..3 of the
+ * twelve host pointers.  (npcd_pair_mlp_fwd with NPCD_PAIR_MLP_X2 computes the same and can save its activations for training.) */
+int64_t npcd_pairs_x2_wpack_bytes(int feat_dim);
+int npcd_pairs_x2_pack(const float* const* weights_host, const float* const* biases_host, int feat_dim, void* wpack_host);
+int npcd_pairs_x2(const void* wpack, int feat_dim, const int32_t* nb_idx, const float* pts, const float* kp_pos, const float* kp_feat,
+                  const int32_t* n_points_dev, int max_points, int k, float* G, void* stream);
 int64_t npcd_points_x2_wpack_bytes(void);
 int npcd_points_x2_pack(const float* const* weights_host, const float* const* biases_host, int c0_in_dim, void* wpack_host);
 int npcd_points_x2(const void* wpack, const float* feat, const int32_t* n_points_dev, int max_points, float* sigma, float* rgb,

@@ -49,19 +49,23 @@ __host__ __device__ inline PointsX2Layout points_x2_layout() {
 typedef float f32x4a __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t xrsrc_t;
 __device__ __forceinline__ f32x4a xmfma(bf16x8 a, bf16x8 b, f32x4a c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// KS = 32-column steps of the layer (8 for a 256-wide input); the lo half of a matrix lies KS * 16 KiB behind its hi half
+template <int KS = 8>
 __device__ __forceinline__ bf16x8 xfrag(xrsrc_t rs, int w_off, int wave, int lane, int s, int mb) {
-    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + mb * kXFrag, w_off + (wave * 8 + s) * (4 * kXFrag), 0));
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16 + mb * kXFrag, w_off + (wave * KS + s) * (4 * kXFrag), 0));
 }
 struct XRing { bf16x8 h[2][4], l[2][4]; };
+template <int KS = 8>
 __device__ __forceinline__ void xprefetch(xrsrc_t rs, int w_off, int wave, int lane, XRing& ring) {
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
-        ring.h[0][mb] = xfrag(rs, w_off, wave, lane, 0, mb);
-        ring.l[0][mb] = xfrag(rs, w_off + kXMat, wave, lane, 0, mb);
+        ring.h[0][mb] = xfrag<KS>(rs, w_off, wave, lane, 0, mb);
+        ring.l[0][mb] = xfrag<KS>(rs, w_off + KS * 16384, wave, lane, 0, mb);
     }
 }
 // one layer on a tile: acc[mb][rb] = bias + sum over 256 inputs of (Wh Xh + Wh Xl + Wl Xh); 16 independent accumulators between two
 // instructions on the same one
+template <int KS = 8, int NB16 = 4>
 __device__ __forceinline__ void xlayer(const unsigned char* Hh, const unsigned char* Hl, const unsigned char* bias_l, xrsrc_t rs, int w_off,
                                        int wave, int lane, XRing& ring, f32x4a (&acc)[4][4]) {
     const int off = (lane & 15) * kXPitch + (lane >> 4) * 16;
@@ -70,40 +74,42 @@ __device__ __forceinline__ void xlayer(const unsigned char* Hh, const unsigned c
     for (int mb = 0; mb < 4; ++mb) init[mb] = *reinterpret_cast<const f32x4a*>(bias_l + wave * 256 + (lane >> 4) * 64 + mb * 16);
     bf16x8 bh[4], bl[4], nh[4], nl[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < NB16; ++r) {
         bh[r] = *reinterpret_cast<const bf16x8*>(Hh + off + r * 16 * kXPitch);
         bl[r] = *reinterpret_cast<const bf16x8*>(Hl + off + r * 16 * kXPitch);
     }
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        if (s + 1 < 8) {
+    for (int s = 0; s < KS; ++s) {
+        if (s + 1 < KS) {
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
-                ring.h[(s + 1) & 1][mb] = xfrag(rs, w_off, wave, lane, s + 1, mb);
-                ring.l[(s + 1) & 1][mb] = xfrag(rs, w_off + kXMat, wave, lane, s + 1, mb);
+                ring.h[(s + 1) & 1][mb] = xfrag<KS>(rs, w_off, wave, lane, s + 1, mb);
+                ring.l[(s + 1) & 1][mb] = xfrag<KS>(rs, w_off + KS * 16384, wave, lane, s + 1, mb);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < NB16; ++r) {
                 nh[r] = *reinterpret_cast<const bf16x8*>(Hh + off + r * 16 * kXPitch + (s + 1) * 64);
                 nl[r] = *reinterpret_cast<const bf16x8*>(Hl + off + r * 16 * kXPitch + (s + 1) * 64);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < NB16; ++r)
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) acc[mb][r] = xmfma(ring.h[s & 1][mb], bh[r], s == 0 ? init[mb] : acc[mb][r]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < NB16; ++r)
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) acc[mb][r] = xmfma(ring.h[s & 1][mb], bl[r], acc[mb][r]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < NB16; ++r)
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) acc[mb][r] = xmfma(ring.l[s & 1][mb], bh[r], acc[mb][r]);
         __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < KS) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { bh[r] = nh[r]; bl[r] = nl[r]; }
+            for (int r = 0; r < NB16; ++r) { bh[r] = nh[r]; bl[r] = nl[r]; }
+        }
     }
 }
 __device__ __forceinline__ uint32_t xpack2(__bf16 a, __bf16 b) {
@@ -113,11 +119,11 @@ __device__ __forceinline__ uint32_t xpack2(__bf16 a, __bf16 b) {
 }
 // write-back: optional LeakyReLU in fp32, then the two halves of every value to the two planes (8 consecutive channels per store:
 // blocks 2 p, 2 p + 1 of a lane, the pack's row order)
-template <bool ACT>
+template <bool ACT, int NB16 = 4>
 __device__ __forceinline__ void xstore(unsigned char* Hh, unsigned char* Hl, int wave, int lane, const f32x4a (&acc)[4][4]) {
     const int sb = (lane & 15) * kXPitch + (lane >> 4) * 16 + wave * 128;
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
+    for (int rb = 0; rb < NB16; ++rb)
 #pragma unroll
         for (int p2 = 0; p2 < 2; ++p2) {
             uint32_t vh[4], vl[4];
@@ -301,6 +307,224 @@ __global__ __launch_bounds__(256, 2) void points_x2_kernel(PointsX2Args a) {
     }
 }
 
+// ============================================================================================
+// The four non-linear per-pair layers + the inverse-distance mean in the same numerics, forward only (rendering)
+// ============================================================================================
+// Reference: gather + x_rel + weights + positional encoding (aggregators/mlp.py:62-88, aggregator.py:122-156, positional_encoder.py:16-20),
+// local_field[0..7] (aggregators/mlp.py:83-84, utils/model.py:22-36), weighted aggregation (aggregators/mlp.py:102-125).  The training
+// kernel of this numerics class (csrc/pairs_mlp.hip, precision 1) also renders, but it is built around saving activations: 128-row
+// tiles on 32x32x16, one workgroup per CU -- 75 % of a fp32-class view.  This one is the fp16 pair kernel's 16x16x32 form
+// (csrc/shade.hip) on two planes: tile = 8 points x 8 neighbour slots = 64 candidate rows packed to the front, row blocks of 16,
+// layers through xlayer / xstore, the weighted mean in fp32 from hi + lo.  Takes the compact query's int32 lists as they are (-1 anywhere)
+// and its device-side count: no host preprocessing.
+constexpr int kXEnc = 64;            // 3 + 60 positional-encoding columns + 1 zero pad
+struct PairsX2Layout {
+    int64_t w[4];        // per matrix [hi][lo]; A0 has K0 = feat + 64 input columns (K0 / 32 steps), A1..A3 256
+    int64_t bias;        // 4 x 256 fp32, [layer][wave][g][mb][4]
+    int64_t total;
+};
+__host__ __device__ inline PairsX2Layout pairs_x2_layout(int feat) {
+    PairsX2Layout L;
+    int64_t off = 0;
+    L.w[0] = off; off += (int64_t)2 * (feat + kXEnc) * kXHidden * 2;
+    for (int i = 1; i < 4; ++i) { L.w[i] = off; off += 2 * kXMat; }
+    L.bias = off; off += 4 * kXHidden * 4;
+    L.total = off;
+    return L;
+}
+__device__ __forceinline__ float xenc_value(int q, const float (&rel)[3]) {
+    if (q < 3) return rel[q];
+    if (q >= 63) return 0.f;
+    const int c = (q - 3) / 20, rem = (q - 3) % 20, i = rem % 10;
+    const float u = rel[c] * (0.5f * (float)(1 << i));           // sin(x 2^i pi) = sin(2 pi u): v_sin / v_cos take revolutions
+    const float f = __builtin_amdgcn_fractf(u);
+    return rem < 10 ? __builtin_amdgcn_sinf(f) : __builtin_amdgcn_cosf(f);
+}
+__device__ __forceinline__ void xput8(unsigned char* Hh, unsigned char* Hl, int off, const float (&x)[8]) {
+    uint32_t vh[4], vl[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const __bf16 h0 = (__bf16)x[2 * q], h1 = (__bf16)x[2 * q + 1];
+        vh[q] = xpack2(h0, h1);
+        vl[q] = xpack2((__bf16)(x[2 * q] - (float)h0), (__bf16)(x[2 * q + 1] - (float)h1));
+    }
+    *reinterpret_cast<u32x4*>(Hh + off) = u32x4{vh[0], vh[1], vh[2], vh[3]};
+    *reinterpret_cast<u32x4*>(Hl + off) = u32x4{vl[0], vl[1], vl[2], vl[3]};
+}
+template <int FEAT, int PART>
+__device__ __forceinline__ void xenc_put16(unsigned char* Hh, unsigned char* Hl, int prow, const float (&rel)[3]) {
+#pragma unroll
+    for (int c8 = 0; c8 < 2; ++c8) {
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = xenc_value(PART * 16 + c8 * 8 + j, rel);
+        xput8(Hh, Hl, prow * kXPitch + (FEAT / 8 + PART * 2 + c8) * 16, e);
+    }
+}
+template <int FEAT, int NB16>
+__device__ __forceinline__ void xpair_layers(unsigned char* Hh, unsigned char* Hl, const unsigned char* bias_lds, xrsrc_t rs, int w0, int w1,
+                                             int wave, int lane) {
+    constexpr int KS0 = (FEAT + kXEnc) / 32;
+    f32x4a acc[4][4];
+    XRing ring;
+    xprefetch<KS0>(rs, w0, wave, lane, ring);
+    xlayer<KS0, NB16>(Hh, Hl, bias_lds, rs, w0, wave, lane, ring, acc);
+    xprefetch<8>(rs, w1, wave, lane, ring);
+    __syncthreads();
+    xstore<true, NB16>(Hh, Hl, wave, lane, acc);
+    __syncthreads();
+#pragma unroll 1
+    for (int l = 1; l < 4; ++l) {
+        const int w_off = w1 + (l - 1) * (2 * kXMat);
+        xlayer<8, NB16>(Hh, Hl, bias_lds + l * (kXHidden * 4), rs, w_off, wave, lane, ring, acc);
+        if (l < 3) xprefetch<8>(rs, w_off + 2 * kXMat, wave, lane, ring);
+        __syncthreads();
+        xstore<true, NB16>(Hh, Hl, wave, lane, acc);
+        __syncthreads();
+    }
+}
+struct PairsX2Args {
+    const unsigned char* wpack;
+    const int32_t* nb_idx;        // [max_points][k] global neighbour indices, -1 = none (anywhere in a row)
+    const float *pts, *kp_pos, *kp_feat;
+    const int32_t* n_points;      // device-side count (may be null: max_points)
+    int max_points, k;
+    float* G;                     // [max_points][256] fp32: the aggregated per-point features
+};
+template <int FEAT>
+__global__ __launch_bounds__(256, 2) void pairs_x2_kernel(PairsX2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+    unsigned char* Hh = dsmem;
+    unsigned char* Hl = dsmem + kXPlane;
+    float* wrow = reinterpret_cast<float*>(dsmem + 2 * kXPlane);                 // [64] inverse distances of the packed rows
+    int* pstart = reinterpret_cast<int*>(wrow + kXRows);                          // [8] first packed row of each point
+    int* pcount = pstart + 8;                                                     // [8] its number of valid neighbours
+    unsigned char* bias_lds = reinterpret_cast<unsigned char*>(pcount + 8);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const PairsX2Layout L = pairs_x2_layout(FEAT);
+    const xrsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.wpack), 0, (int)L.total, 0x00020000);
+    for (int i = tid; i < 4 * kXHidden / 4; i += 256)
+        reinterpret_cast<f32x4*>(bias_lds)[i] = *reinterpret_cast<const f32x4*>(a.wpack + L.bias + (int64_t)i * 16);
+    const int P = a.n_points ? min(*a.n_points, a.max_points) : a.max_points;
+    const int ntiles = (P + 7) / 8;
+    const int w0 = (int)L.w[0], w1 = (int)L.w[1];
+    constexpr int FQ = FEAT / 4;          // input features per wave (a wave = the tile's 64 candidates x one quarter of the input columns)
+    // what a lane needs to build its row of a tile, requested one tile AHEAD (the neighbour index while the previous tile's layers
+    // run, the gathered point / position / features while its aggregation runs): the prologue starts from registers
+    const int slot = lane & 7, part = wave;
+    auto load_index = [&](int t) {
+        const int p = t * 8 + (lane >> 3);
+        return (p < P && slot < a.k) ? a.nb_idx[(int64_t)p * a.k + slot] : -1;
+    };
+    float in_pt[3], in_kp[3], in_fx[FQ];
+    auto load_data = [&](int t, int gi) {       // (unconditional, clamped indices: no value of the previous tile has to survive the layers)
+        const int pc = min(t * 8 + (lane >> 3), a.max_points - 1), gc = max(gi, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { in_pt[c] = a.pts[(int64_t)pc * 3 + c]; in_kp[c] = a.kp_pos[(int64_t)gc * 3 + c]; }
+#pragma unroll
+        for (int c4 = 0; c4 < FQ / 4; ++c4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a.kp_feat + (int64_t)gc * FEAT + part * FQ + c4 * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) in_fx[c4 * 4 + j] = v[j];
+        }
+    };
+    int tile = blockIdx.x, gi = -1;
+    if (tile < ntiles) {
+        gi = load_index(tile);
+        load_data(tile, gi);
+    }
+    while (tile < ntiles) {
+        int nblk;
+        {
+            const int row = lane;
+            float rel[3] = {0.f, 0.f, 0.f};
+            if (gi >= 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) rel[c] = in_pt[c] - in_kp[c];
+            }
+            const unsigned long long mine = __ballot(gi >= 0);
+            const int V = __popcll(mine), prow = __popcll(mine & ((1ull << lane) - 1ull));
+            nblk = (V + 15) >> 4;
+            if (part == 0 && slot == 0) {
+                pstart[row >> 3] = prow;
+                pcount[row >> 3] = __popcll((mine >> (lane & ~7)) & 0xffull);
+            }
+            if (part == 0 && gi >= 0) wrow[prow] = 1.f / (sqrtf(__builtin_fmaf(rel[0], rel[0], __builtin_fmaf(rel[1], rel[1], rel[2] * rel[2]))) + 1e-5f);
+            if (gi >= 0) {
+#pragma unroll
+                for (int c8 = 0; c8 < FQ / 8; ++c8) {
+                    float e[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e[j] = in_fx[c8 * 8 + j];
+                    xput8(Hh, Hl, prow * kXPitch + (part * (FQ / 8) + c8) * 16, e);
+                }
+                switch (part) {        // (wave-uniform)
+                    case 0: xenc_put16<FEAT, 0>(Hh, Hl, prow, rel); break;
+                    case 1: xenc_put16<FEAT, 1>(Hh, Hl, prow, rel); break;
+                    case 2: xenc_put16<FEAT, 2>(Hh, Hl, prow, rel); break;
+                    default: xenc_put16<FEAT, 3>(Hh, Hl, prow, rel); break;
+                }
+            }
+            if (row >= V && row < 16 * nblk) {          // computed (whole row blocks) but never aggregated: defined inputs
+                const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int c8 = 0; c8 < FQ / 8; ++c8) {
+                    *reinterpret_cast<u32x4*>(Hh + row * kXPitch + (part * (FQ / 8) + c8) * 16) = z;
+                    *reinterpret_cast<u32x4*>(Hl + row * kXPitch + (part * (FQ / 8) + c8) * 16) = z;
+                }
+#pragma unroll
+                for (int c8 = 0; c8 < 2; ++c8) {
+                    *reinterpret_cast<u32x4*>(Hh + row * kXPitch + (FEAT / 8 + part * 2 + c8) * 16) = z;
+                    *reinterpret_cast<u32x4*>(Hl + row * kXPitch + (FEAT / 8 + part * 2 + c8) * 16) = z;
+                }
+            }
+        }
+        const int ntile = tile + (int)gridDim.x;
+        gi = ntile < ntiles ? load_index(ntile) : -1;          // arrives while the layers run
+        __syncthreads();
+        switch (nblk) {                    // (workgroup-uniform)
+            case 4: xpair_layers<FEAT, 4>(Hh, Hl, bias_lds, rs, w0, w1, wave, lane); break;
+            case 3: xpair_layers<FEAT, 3>(Hh, Hl, bias_lds, rs, w0, w1, wave, lane); break;
+            case 2: xpair_layers<FEAT, 2>(Hh, Hl, bias_lds, rs, w0, w1, wave, lane); break;
+            case 1: xpair_layers<FEAT, 1>(Hh, Hl, bias_lds, rs, w0, w1, wave, lane); break;
+            default: break;                // no valid pair in the tile
+        }
+        load_data(min(ntile, ntiles - 1), gi);                  // ... and the gathered inputs while the aggregation runs
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            // point pl, channels 8 cc .. + 7: all eight slots at once (slot >= count re-reads the point's last row with weight 0)
+            const int pl = tid >> 5, cc = tid & 31;
+            const int p = tile * 8 + pl;
+            const int r0 = pstart[pl], cnt = pcount[pl], last = max(cnt - 1, 0);
+            float w8[8], wsum = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+                w8[s2] = wrow[r0 + min(s2, last)];
+                w8[s2] = s2 < cnt ? w8[s2] : 0.f;
+                wsum += w8[s2];
+            }
+            const float inv = wsum > 0.f ? 1.f / wsum : 0.f;
+            float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+                const int o = (r0 + min(s2, last)) * kXPitch + cc * 16;
+                const bf16x8 vh = *reinterpret_cast<const bf16x8*>(Hh + o), vl = *reinterpret_cast<const bf16x8*>(Hl + o);
+                const float ws = w8[s2] * inv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) out[j] = __builtin_fmaf(ws, (float)vh[j] + (float)vl[j], out[j]);
+            }
+            if (p < P) {
+                float* gp = a.G + (int64_t)p * kXHidden + cc * 8;
+                const bool any = cnt > 0;
+                *reinterpret_cast<f32x4*>(gp) = any ? f32x4{out[0], out[1], out[2], out[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(gp + 4) = any ? f32x4{out[4], out[5], out[6], out[7]} : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        __syncthreads();
+        tile = ntile;
+    }
+}
+
 }  // namespace npcd
 
 using namespace npcd;
@@ -365,6 +589,67 @@ extern "C" int npcd_points_x2(const void* wpack, const float* feat, const int32_
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dir_bias) hipLaunchKernelGGL(points_x2_kernel<true>, dim3(grid), dim3(256), lds, st, a);
     else hipLaunchKernelGGL(points_x2_kernel<false>, dim3(grid), dim3(256), lds, st, a);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+extern "C" int64_t npcd_pairs_x2_wpack_bytes(int feat_dim) {
+    if (feat_dim != 32 && feat_dim != 128) return -1;
+    return pairs_x2_layout(feat_dim).total;
+}
+
+// weights_host / biases_host: the twelve pointers of npcd_shade_pack_weights; entries 0..3 (aggregator.local_field.{0,2,4,6}) are read.
+extern "C" int npcd_pairs_x2_pack(const float* const* weights_host, const float* const* biases_host, int feat_dim, void* wpack_host) {
+    if (!weights_host || !biases_host || !wpack_host) return NPCD_ERR_ARG;
+    if (feat_dim != 32 && feat_dim != 128) return NPCD_ERR_UNSUPPORTED;
+    for (int i = 0; i < 4; ++i)
+        if (!weights_host[i] || !biases_host[i]) return NPCD_ERR_ARG;
+    const PairsX2Layout L = pairs_x2_layout(feat_dim);
+    unsigned char* out = static_cast<unsigned char*>(wpack_host);
+    memset(out, 0, L.total);
+    const int in0 = feat_dim + 63, k0 = feat_dim + kXEnc;
+    for (int i = 0; i < 4; ++i) {
+        const float* W = weights_host[i];
+        const int in_dim = i == 0 ? in0 : kXHidden, ks = (i == 0 ? k0 : kXHidden) / 32;
+        __bf16* dh = reinterpret_cast<__bf16*>(out + L.w[i]);
+        __bf16* dl = reinterpret_cast<__bf16*>(out + L.w[i] + (int64_t)ks * 16384);
+        for (int w = 0; w < 4; ++w)
+            for (int s = 0; s < ks; ++s)
+                for (int mb = 0; mb < 4; ++mb)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int m = lane & 15, o = 64 * w + 32 * (mb >> 1) + 8 * (m >> 2) + 4 * (mb & 1) + (m & 3), c = 32 * s + 8 * (lane >> 4) + j;
+                            const float v = c < in_dim ? W[(int64_t)o * in_dim + c] : 0.f;
+                            const __bf16 h = (__bf16)v;
+                            const int64_t at = ((((int64_t)w * ks + s) * 4 + mb) * 64 + lane) * 8 + j;
+                            dh[at] = h;
+                            dl[at] = (__bf16)(v - (float)h);
+                        }
+        float* db = reinterpret_cast<float*>(out + L.bias) + i * kXHidden;
+        for (int w = 0; w < 4; ++w)
+            for (int g = 0; g < 4; ++g)
+                for (int mb = 0; mb < 4; ++mb)
+                    for (int b = 0; b < 4; ++b) db[((w * 4 + g) * 4 + mb) * 4 + b] = biases_host[i][64 * w + 32 * (mb >> 1) + 8 * g + 4 * (mb & 1) + b];
+    }
+    return NPCD_OK;
+}
+
+extern "C" int npcd_pairs_x2(const void* wpack, int feat_dim, const int32_t* nb_idx, const float* pts, const float* kp_pos, const float* kp_feat,
+                             const int32_t* n_points_dev, int max_points, int k, float* G, void* stream) {
+    if (!wpack || !nb_idx || !pts || !kp_pos || !kp_feat || !G || max_points < 0) return NPCD_ERR_ARG;
+    if (feat_dim != 32 && feat_dim != 128) return NPCD_ERR_UNSUPPORTED;
+    if (k <= 0 || k > 8) return NPCD_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(kp_feat) | reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(wpack)) & 15) return NPCD_ERR_ARG;
+    if (max_points == 0) return NPCD_OK;
+    PairsX2Args a{static_cast<const unsigned char*>(wpack), nb_idx, pts, kp_pos, kp_feat, n_points_dev, max_points, k, G};
+    const int lds = 2 * kXPlane + kXRows * 4 + 16 * 4 + 4 * kXHidden * 4;
+    static DynLds lds32, lds128;
+    NPCD_HIP_CHECK(lds32.ensure(reinterpret_cast<const void*>(pairs_x2_kernel<32>), lds));
+    NPCD_HIP_CHECK(lds128.ensure(reinterpret_cast<const void*>(pairs_x2_kernel<128>), lds));
+    const int tiles = (max_points + 7) / 8, grid = tiles < 2048 ? tiles : 2048;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (feat_dim == 32) hipLaunchKernelGGL(pairs_x2_kernel<32>, dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(pairs_x2_kernel<128>, dim3(grid), dim3(256), lds, st, a);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }

@@ -64,6 +64,9 @@ SIGNATURES = {
     "npcd_shade_wpack_bytes": (c_int64, [c_int, c_int, c_int]),
     "npcd_shade_workspace_bytes": (c_int64, [c_int, c_int]),
     "npcd_shade_pack_weights": (c_int, [POINTER(_P), POINTER(_P), c_int, c_int, c_int, _P]),
+    "npcd_pairs_x2_wpack_bytes": (c_int64, [c_int]),
+    "npcd_pairs_x2_pack": (c_int, [POINTER(_P), POINTER(_P), c_int, _P]),
+    "npcd_pairs_x2": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P, _P]),
     "npcd_points_x2_wpack_bytes": (c_int64, []),
     "npcd_points_x2_pack": (c_int, [POINTER(_P), POINTER(_P), c_int, _P]),
     "npcd_points_x2": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P]),

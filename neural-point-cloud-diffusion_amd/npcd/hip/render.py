@@ -220,6 +220,35 @@ def pack_field_weights(state: dict, feat_dim: int, device, n_freqs: int = 10, hi
     return host.to(device)
 
 
+def pairs_x2_pack(state: dict, feat_dim: int, device) -> torch.Tensor:
+    """The four non-linear per-pair layers of a Field (aggregator.local_field.{0,2,4,6}) as hi / lo bf16 fragments for npcd_pairs_x2."""
+    L = lib()
+    nbytes = L.npcd_pairs_x2_wpack_bytes(feat_dim)
+    if nbytes < 0:
+        raise RuntimeError(f"npcd_pairs_x2 supports feat_dim in (32, 128); got {feat_dim}")
+    ws = [state[n + ".weight"].detach().to("cpu", _f32).contiguous() for n in FIELD_ORDER]
+    bs = [state[n + ".bias"].detach().to("cpu", _f32).contiguous() for n in FIELD_ORDER]
+    wp = (ctypes.c_void_p * 12)(*[w.data_ptr() for w in ws])
+    bp = (ctypes.c_void_p * 12)(*[b.data_ptr() for b in bs])
+    host = torch.empty(nbytes, dtype=torch.uint8)
+    check(L.npcd_pairs_x2_pack(wp, bp, feat_dim, ctypes.c_void_p(host.data_ptr())), "npcd_pairs_x2_pack")
+    return host.to(device)
+
+
+def pairs_x2(wpack: torch.Tensor, feat_dim: int, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch.Tensor, kp_feat: torch.Tensor):
+    """nb_idx [P, k] (global indices, -1 pad anywhere), pts [P, 3], kp_pos [B N, 3], kp_feat [B N, F] -> G [P, 256] fp32: the four
+    non-linear per-pair layers and the inverse-distance mean in the reference's fp32 numerics class (csrc/points_x2.hip, forward only)."""
+    require_gpu(wpack, nb_idx, pts, kp_pos, kp_feat)
+    P, k = nb_idx.shape
+    G = torch.empty((P, 256), dtype=_f32, device=pts.device)
+    if P == 0:
+        return G
+    check(lib().npcd_pairs_x2(ptr(wpack), feat_dim, ptr(nb_idx.to(_i32).contiguous()), ptr(pts.to(_f32).contiguous()),
+                              ptr(kp_pos.to(_f32).contiguous()), ptr(kp_feat.to(_f32).contiguous()), None, P, k, ptr(G), stream_ptr()),
+          "npcd_pairs_x2")
+    return G
+
+
 def points_x2_pack(state: dict, device) -> torch.Tensor:
     """The point-level layers of a Field (local_field.8, shape_net, channel_net; state_dict keys relative to the Field module) as hi / lo
     bf16 fragments for npcd_points_x2 (csrc/points_x2.hip).  Returns a uint8 device tensor."""

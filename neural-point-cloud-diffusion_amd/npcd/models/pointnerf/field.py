@@ -159,17 +159,28 @@ class Field(nn.Module):
         agg, lf = self.aggregator, self.aggregator.local_field
         if nb_idx.shape[0] == 0:          # no shading point at all (every ray misses the cloud)
             return torch.zeros(0, dtype=torch.float32, device=pts.device), torch.zeros((0, 3), dtype=torch.float32, device=pts.device)
-        nb = nb_idx.long()
-        valid = nb >= 0
-        cnt = valid.sum(dim=1)
-        off = torch.cumsum(cnt, 0) - cnt
-        key = (str(pts.device),) + tuple((lf[i].weight.data_ptr(), lf[i].weight._version, lf[i].bias._version) for i in (0, 2, 4, 6))
-        if getattr(self, "_pack32_key", None) != key:
-            self._pack32 = hr.pair_mlp_pack([lf[i].weight for i in (0, 2, 4, 6)], [lf[i].bias for i in (0, 2, 4, 6)], agg.in_dim, hr.PAIR_MLP_X2,
-                                            pts.device)
-            self._pack32_key = key
-        G = hr.pair_mlp_forward_raw(kp_feat.reshape(-1, kp_feat.shape[-1]), None, None, nb, pts, kp_pos.reshape(-1, 3), off, 0,
-                                    hr.PAIR_MLP_X2, save=False, wpack=self._pack32)[0]
+        import os
+        fused_pairs = not os.environ.get("NPCD_FP32_PAIRS_TRAINING_KERNEL") and agg.in_dim in (32, 128) and nb_idx.shape[1] <= 8
+        if fused_pairs:
+            # forward-only kernel of the same numerics on the compact lists as they are (csrc/points_x2.hip, round 5);
+            # NPCD_FP32_PAIRS_TRAINING_KERNEL=1 = the training kernel's forward below (csrc/pairs_mlp.hip, precision 1)
+            keyp = (str(pts.device),) + tuple((lf[i].weight.data_ptr(), lf[i].weight._version, lf[i].bias._version) for i in (0, 2, 4, 6))
+            if getattr(self, "_packp2_key", None) != keyp:
+                self._packp2 = hr.pairs_x2_pack({k: v for k, v in self.state_dict().items()}, agg.in_dim, pts.device)
+                self._packp2_key = keyp
+            G = hr.pairs_x2(self._packp2, agg.in_dim, nb_idx, pts, kp_pos.reshape(-1, 3), kp_feat.reshape(-1, kp_feat.shape[-1]))
+        else:
+            nb = nb_idx.long()
+            valid = nb >= 0
+            cnt = valid.sum(dim=1)
+            off = torch.cumsum(cnt, 0) - cnt
+            key = (str(pts.device),) + tuple((lf[i].weight.data_ptr(), lf[i].weight._version, lf[i].bias._version) for i in (0, 2, 4, 6))
+            if getattr(self, "_pack32_key", None) != key:
+                self._pack32 = hr.pair_mlp_pack([lf[i].weight for i in (0, 2, 4, 6)], [lf[i].bias for i in (0, 2, 4, 6)], agg.in_dim, hr.PAIR_MLP_X2,
+                                                pts.device)
+                self._pack32_key = key
+            G = hr.pair_mlp_forward_raw(kp_feat.reshape(-1, kp_feat.shape[-1]), None, None, nb, pts, kp_pos.reshape(-1, 3), off, 0,
+                                        hr.PAIR_MLP_X2, save=False, wpack=self._pack32)[0]
         from .train_path import x2_linear_forward
 
         import os

@@ -6,6 +6,8 @@ Bars:
   * shading (fp16 MFMA inputs, fp32 accumulation): sigma <= 2e-3 * max(1, sigma), rgb <= 2e-3 abs
   * rendered pixels: max-abs <= 5e-3 and PSNR(hip, oracle) >= 50 dB  (north-star: PSNR within 0.1 dB)
 """
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -397,6 +399,63 @@ def test_fused_point_level_layers_in_the_fp32_class(use_dir, monkeypatch):
     ec = float((rgb.double() - want_c).abs().max())
     print("points_x2 vs float64: sigma", es, "rgb", ec)
     assert es < 1e-4 and ec < 2e-5, (es, ec)
+
+
+@pytest.mark.parametrize("F_", [32, 128])
+def test_forward_only_pair_layers_in_the_fp32_class(F_):
+    """csrc/points_x2.hip, pairs_x2_kernel (round 5): the four non-linear per-pair layers + the inverse-distance mean on split bf16
+    operands, forward only, on lists with holes anywhere in a row, neighbour-less points, 1..8 neighbours (every number of occupied
+    16-row blocks of an eight-point tile), a point count that is not a multiple of eight -- against the training kernel of the same
+    numerics class (npcd_pair_mlp_fwd, precision 1: rel-L2 1e-5) and against a float64 restatement (3e-5); bitwise repeatable."""
+    from npcd.hip import render as hr
+    torch.manual_seed(7)
+    Np, k, Ntab = 2003, 8, 512
+    p = orr.init_field_params(F_, seed=2)
+    from npcd.models.pointnerf import PointNeRF
+    m = PointNeRF(1, F_, 64, False)
+    m.field.load_state_dict(p)
+    field = m.cuda().eval().field
+    nb = torch.randint(0, Ntab, (Np, k), dtype=torch.int32, device="cuda")
+    nb[torch.rand(Np, k, device="cuda") < 0.35] = -1
+    nb[5:40] = -1
+    for i, keep in enumerate((1, 2, 3, 4, 5, 6, 7)):
+        nb[160 + 8 * i:168 + 8 * i, keep:] = -1
+    pts = torch.rand(Np, 3, device="cuda") - 0.5
+    kp = torch.rand(Ntab, 3, device="cuda") - 0.5
+    kf = torch.randn(Ntab, F_, device="cuda")
+    wp = hr.pairs_x2_pack(field.state_dict(), F_, "cuda")
+    G = hr.pairs_x2(wp, F_, nb, pts, kp, kf)
+    G2 = hr.pairs_x2(wp, F_, nb, pts, kp, kf)
+    torch.cuda.synchronize()
+    assert torch.equal(G, G2) and bool(torch.isfinite(G).all())
+    # float64 restatement (aggregators/mlp.py:62-125)
+    lf = [field.aggregator.local_field[i] for i in (0, 2, 4, 6)]
+    valid = nb >= 0
+    idx = nb.clamp_min(0).long()
+    rel = (pts[:, None, :] - kp[idx]).double()
+    w = 1.0 / (rel.norm(dim=-1) + 1e-5) * valid
+    freqs = (2.0 ** torch.arange(10, device="cuda", dtype=torch.float64)) * math.pi
+    ang = rel[..., None] * freqs                                            # [P, k, 3, 10]
+    enc = torch.cat((torch.sin(ang), torch.cos(ang)), dim=-1).flatten(-2)   # per coordinate: sin f0..9, cos f0..9
+    x = torch.cat((kf[idx].double(), rel, enc), dim=-1)
+    with torch.no_grad():
+        for l in lf:
+            x = torch.nn.functional.leaky_relu(torch.nn.functional.linear(x, l.weight.double(), l.bias.double()), 0.01)
+    wn = w / w.sum(dim=1, keepdim=True).clamp_min(1e-300)
+    want = (x * wn[..., None]).sum(dim=1) * (valid.any(dim=1, keepdim=True))
+    e64 = float((G.double() - want).norm() / want.norm())
+    # the training kernel's forward on the same lists (valid entries first, as it expects)
+    order = torch.argsort((~valid).int(), dim=1, stable=True)
+    nbs = torch.gather(nb, 1, order)
+    cnt = (nbs >= 0).sum(dim=1)
+    off = torch.cumsum(cnt, 0) - cnt
+    pack = hr.pair_mlp_pack([l.weight for l in lf], [l.bias for l in lf], F_, hr.PAIR_MLP_X2, "cuda")
+    Gt = hr.pair_mlp_forward_raw(kf, None, None, nbs.long(), pts, kp, off, 0, hr.PAIR_MLP_X2, save=False, wpack=pack)[0]
+    et = float((G - Gt).norm() / Gt.norm())
+    print("pairs_x2: rel-L2 vs float64", e64, "vs the training kernel", et)
+    assert e64 < 3e-5 and et < 1e-5, (e64, et)
+    empty = ~valid.any(dim=1)
+    assert int(empty.sum()) >= 35 and float(G[empty].abs().max()) == 0.0
 
 
 def test_render_in_the_reference_numerics_class(golden):
