@@ -52,11 +52,19 @@ _OWN_WGRAD = bool(os.environ.get("NPCD_OWN_WGRAD"))
 _OWN_DGELU = bool(os.environ.get("NPCD_OWN_DGELU"))
 
 
-def _split_gemm(fn, T):
+# Below _SPLIT_MIN only the products whose OUTPUT is at least this wide are split (round 5, R5.18): at T = 4,104 / 8,208 the left-over
+# row of 256-row tiles turns the 4,096-wide products (c_fc forward, mlp.c_proj data gradient) from 256 / 512 tiles = one / two full
+# rounds into 272 / 528.  Same box, alternating processes: a rank's step at per-GPU batch 8 18.51-18.57 -> 18.18-18.36 ms, at 16
+# 28.71-28.75 -> 27.96-27.99 ms; with 3,072 (c_qkv too) 18.34.  NPCD_GEMM_SPLIT_WIDE_N=0 switches it off.
+_SPLIT_WIDE_N = int(os.environ.get("NPCD_GEMM_SPLIT_WIDE_N", "4096"))
+
+
+def _split_gemm(fn, T, N=0):
     """fn(rows) enqueues the product for a row range into a shared output."""
     # below ~16 k tokens the large call is short enough that the extra launch costs what the quarter tile did (measured at
     # per-GPU batch 8 and 16: 19.9 vs 20.2 ms and 30.8 vs 31.1 ms per step; at per-GPU batch 32 the split wins: 50.4 -> 48.9 ms)
-    Tm = T - T % _SPLIT if (_SPLIT and T >= _SPLIT_MIN) else T
+    wide = _SPLIT_WIDE_N > 0 and N >= _SPLIT_WIDE_N and T > _SPLIT
+    Tm = T - T % _SPLIT if (_SPLIT and (T >= _SPLIT_MIN or wide)) else T
     if Tm == 0 or Tm == T:
         fn(slice(0, T))
         return
@@ -85,7 +93,7 @@ def _linear(bias, x, w16):
             and bias.is_contiguous() and x.dtype == w16.dtype == bias.dtype and hlin.supported128(T, N, K)):
         return hlin.linear128_fwd(x, w16, bias, out)
     wt = w16.t()
-    _split_gemm(lambda r: torch.addmm(bias, x[r], wt, out=out[r]), T)
+    _split_gemm(lambda r: torch.addmm(bias, x[r], wt, out=out[r]), T, N)
     return out
 
 
@@ -93,7 +101,7 @@ def _dgrad(dy, w16):
     """dy [T, N] bf16, w16 [N, K] bf16 -> dy @ w16, [T, K] bf16."""
     T = dy.shape[0]
     out = torch.empty((T, w16.shape[1]), dtype=dy.dtype, device=dy.device)
-    _split_gemm(lambda r: torch.mm(dy[r], w16, out=out[r]), T)
+    _split_gemm(lambda r: torch.mm(dy[r], w16, out=out[r]), T, w16.shape[1])
     return out
 
 

@@ -16,7 +16,8 @@ if rot and hasattr(tun, "set_rotating_buffer_size"):
     tun.set_rotating_buffer_size(rot)
 tun.set_filename(out)
 dev = torch.device("cuda", 0)
-for B in (64, 32, 16, 8):                       # per-GPU batches of the 1/2/4/8-GPU strong-scaling runs
+# NPCD_TUNE_BATCHES="8,16": only those per-GPU batches (e.g. to add the shapes of a new switch to an existing file: tools/merge_tuned.py)
+for B in tuple(int(b) for b in os.environ.get("NPCD_TUNE_BATCHES", "64,32,16,8").split(",")):      # per-GPU batches of the 1/2/4/8-GPU strong-scaling runs
     tr = bench.build_trainer(dev, B)
     coords, feats = bench.synthetic_batch(64, 0, 64 // B, dev)
     for _ in range(2):
