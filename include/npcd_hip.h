@@ -289,6 +289,14 @@ int64_t npcd_points_x2_wpack_bytes(void);
 int npcd_points_x2_pack(const float* const* weights_host, const float* const* biases_host, int c0_in_dim, void* wpack_host);
 int npcd_points_x2(const void* wpack, const float* feat, const int32_t* n_points_dev, int max_points, float* sigma, float* rgb,
                    const float* dir_bias, const int32_t* point_ray, void* stream);
+/* The same layers as the stage-1 TRAINING forward (published configuration, no view directions): save [6][max_points][256] fp32 = feat, s0, c0,
+ * c1, c2, c3 (every hidden activation, after its LeakyReLU where the layer has one: what the backward of the eight Linear layers
+ * needs), pre [max_points][4] = the heads' pre-activations (r, g, b, sigma) with their biases -- softplus(x - 1) / sigmoid are the
+ * caller's (autograd's). */
+int npcd_points_x2_train(const void* wpack, const float* feat, int max_points, float* save, float* pre, void* stream);
+/* npcd_points_x2_pack from DEVICE tensors (training packs once per optimizer step): weights_dev / biases_dev = a host array of the eight
+ * device pointers of local_field.8, shape_net.{0,2}, channel_net.{0,2,4,6,8}. */
+int npcd_points_x2_pack_dev(const float* const* weights_dev, const float* const* biases_dev, int c0_in_dim, void* wpack_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Ray marching (renderer.py:96-110,120-185, volume_renderer.py:23-39) on the dense slot layout:

@@ -142,6 +142,27 @@ __device__ __forceinline__ void xstore(unsigned char* Hh, unsigned char* Hl, int
             *reinterpret_cast<u32x4*>(Hl + sb + rb * 16 * kXPitch + p2 * 64) = u32x4{vl[0], vl[1], vl[2], vl[3]};
         }
 }
+// the same values in fp32, straight from the accumulators, to a row-major [rows][256] array (training: the backward's activations)
+template <bool ACT>
+__device__ __forceinline__ void xsave(float* dst, int row0, int P, int wave, int lane, const f32x4a (&acc)[4][4]) {
+    const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        const int p = row0 + rb * 16 + n;
+        if (p < P) {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                f32x4 v;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float x = acc[mb][rb][b];
+                    v[b] = (ACT && !(x > 0.f)) ? kXLeaky * x : x;
+                }
+                *reinterpret_cast<f32x4*>(dst + (int64_t)p * kXHidden + 64 * wave + 32 * (mb >> 1) + 8 * g + 4 * (mb & 1)) = v;
+            }
+        }
+    }
+}
 __device__ __forceinline__ float xsum_groups(float x) {          // x summed over lanes l, l ^ 16, l ^ 32, l ^ 48
     const auto r16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     x = __uint_as_float(r16[0]) + __uint_as_float(r16[1]);
@@ -161,9 +182,13 @@ struct PointsX2Args {
     float *sigma, *rgb;
     const float* dir_bias;        // use_view_dir: [n_rays][256] fp32 rows added to the first colour layer's pre-activation, or null
     const int32_t* point_ray;
+    // training forward (SAVE): the six hidden activations [6][max_points][256] fp32 -- feat, s0, c0, c1, c2, c3 (after LeakyReLU where
+    // the layer has one) -- and the heads' PRE-activations [max_points][4] = (r, g, b, sigma), biases added; sigma / rgb are not written
+    float* save;
+    float* pre;
 };
 
-template <bool DIR>
+template <bool DIR, bool SAVE = false>
 __global__ __launch_bounds__(256, 2) void points_x2_kernel(PointsX2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
     unsigned char* Hh = dsmem;
@@ -210,12 +235,15 @@ __global__ __launch_bounds__(256, 2) void points_x2_kernel(PointsX2Args a) {
         // ---- last aggregator layer (linear): feat -------------------------------------------
         xlayer(Hh, Hl, bias_lds, rs, w0, wave, lane, ring, acc);
         xprefetch(rs, w0 + 2 * kXMat, wave, lane, ring);
+        const int64_t plane = (int64_t)a.max_points * kXHidden;        // (SAVE) one saved activation
+        if (SAVE) xsave<false>(a.save, row0, P, wave, lane, acc);
         __syncthreads();
         xstore<false>(Hh, Hl, wave, lane, acc);
         __syncthreads();
         // ---- density head ---------------------------------------------------------------------
         xlayer(Hh, Hl, bias_lds + kXHidden * 4, rs, w0 + 2 * kXMat, wave, lane, ring, acc);
         xprefetch(rs, w0 + 4 * kXMat, wave, lane, ring);
+        if (SAVE) xsave<true>(a.save + plane, row0, P, wave, lane, acc);
         {
             float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -256,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void points_x2_kernel(PointsX2Args a) {
                     }
                 }
             }
+            if (SAVE) xsave<true>(a.save + (2 + l) * plane, row0, P, wave, lane, acc);
             if (l < 3) {
                 __syncthreads();
                 xstore<true>(Hh, Hl, wave, lane, acc);
@@ -298,9 +327,14 @@ __global__ __launch_bounds__(256, 2) void points_x2_kernel(PointsX2Args a) {
                 f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int w = 0; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(red + (w * kXRows + tid) * 4);
-                a.sigma[p] = xsoftplus_m1(t[3] + s1[kXHidden]);
+                if (SAVE) {
+                    *reinterpret_cast<f32x4*>(a.pre + (int64_t)p * 4) =
+                        f32x4{t[0] + c4[3 * kXHidden], t[1] + c4[3 * kXHidden + 1], t[2] + c4[3 * kXHidden + 2], t[3] + s1[kXHidden]};
+                } else {
+                    a.sigma[p] = xsoftplus_m1(t[3] + s1[kXHidden]);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) a.rgb[(int64_t)p * 3 + c] = 1.f / (1.f + expf(-(t[c] + c4[3 * kXHidden + c])));
+                    for (int c = 0; c < 3; ++c) a.rgb[(int64_t)p * 3 + c] = 1.f / (1.f + expf(-(t[c] + c4[3 * kXHidden + c])));
+                }
             }
         }
         __syncthreads();
@@ -525,6 +559,40 @@ __global__ __launch_bounds__(256, 2) void pairs_x2_kernel(PairsX2Args a) {
     }
 }
 
+// device-side packing of the point-level pack (training: the weights change every step; the host packer costs ~5 ms per call)
+struct PointsX2PackArgs {
+    const float* w[8];      // local_field.8, shape_net.0, shape_net.2, channel_net.0, .2, .4, .6, .8 (row-major [out][in])
+    const float* b[8];
+    unsigned char* out;
+    int c0_in_dim;
+};
+__global__ __launch_bounds__(256) void points_x2_pack_kernel(PointsX2PackArgs a) {
+    const PointsX2Layout L = points_x2_layout();
+    const int wide[6] = {0, 1, 3, 4, 5, 6};              // the six 256 x 256 matrices among the eight
+    const int i = blockIdx.y;                             // matrix
+    const int e = blockIdx.x * 256 + threadIdx.x;         // element of its fragment stream: [wave][s][mb][lane][8]
+    if (i < 6) {
+        const int j = e & 7, lane = (e >> 3) & 63, mb = (e >> 9) & 3, s2 = (e >> 11) & 7, w = e >> 14;
+        const int m = lane & 15, o = 64 * w + 32 * (mb >> 1) + 8 * (m >> 2) + 4 * (mb & 1) + (m & 3), c = 32 * s2 + 8 * (lane >> 4) + j;
+        const int in_dim = wide[i] == 3 ? a.c0_in_dim : kXHidden;
+        const float v = a.w[wide[i]][(int64_t)o * in_dim + c];
+        const __bf16 h = (__bf16)v;
+        reinterpret_cast<__bf16*>(a.out + L.w[i])[e] = h;
+        reinterpret_cast<__bf16*>(a.out + L.w[i] + kXMat)[e] = (__bf16)(v - (float)h);
+        if (e < kXHidden) {                                // bias: [w][g][mb][b]
+            const int b = e & 3, mb2 = (e >> 2) & 3, g = (e >> 4) & 3, w2 = e >> 6;
+            reinterpret_cast<float*>(a.out + L.bias)[i * kXHidden + e] = a.b[wide[i]][64 * w2 + 32 * (mb2 >> 1) + 8 * g + 4 * (mb2 & 1) + b];
+        }
+    } else if (e < kXHidden) {                             // the heads' last layers, fp32
+        float* s1 = reinterpret_cast<float*>(a.out + L.s1);
+        float* c4 = reinterpret_cast<float*>(a.out + L.c4);
+        s1[e] = a.w[2][e];
+        c4[e] = a.w[7][e]; c4[kXHidden + e] = a.w[7][kXHidden + e]; c4[2 * kXHidden + e] = a.w[7][2 * kXHidden + e];
+        if (e == 0) s1[kXHidden] = a.b[2][0];
+        if (e < 3) c4[3 * kXHidden + e] = a.b[7][e];
+    }
+}
+
 }  // namespace npcd
 
 using namespace npcd;
@@ -580,7 +648,7 @@ extern "C" int npcd_points_x2(const void* wpack, const float* feat, const int32_
     if ((dir_bias != nullptr) != (point_ray != nullptr)) return NPCD_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(dir_bias) | reinterpret_cast<uintptr_t>(wpack)) & 15) return NPCD_ERR_ARG;
     if (max_points == 0) return NPCD_OK;
-    PointsX2Args a{static_cast<const unsigned char*>(wpack), feat, n_points_dev, max_points, sigma, rgb, dir_bias, point_ray};
+    PointsX2Args a{static_cast<const unsigned char*>(wpack), feat, n_points_dev, max_points, sigma, rgb, dir_bias, point_ray, nullptr, nullptr};
     const int lds = 2 * kXPlane + 4 * kXRows * 4 * 4 + 6 * kXHidden * 4;
     static DynLds lds_p, lds_d;
     NPCD_HIP_CHECK(lds_p.ensure(reinterpret_cast<const void*>(points_x2_kernel<false>), lds));
@@ -650,6 +718,40 @@ extern "C" int npcd_pairs_x2(const void* wpack, int feat_dim, const int32_t* nb_
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (feat_dim == 32) hipLaunchKernelGGL(pairs_x2_kernel<32>, dim3(grid), dim3(256), lds, st, a);
     else hipLaunchKernelGGL(pairs_x2_kernel<128>, dim3(grid), dim3(256), lds, st, a);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+// Training forward of the same layers: `save` [6][max_points][256] fp32 = feat, s0, c0, c1, c2, c3 (the activations the backward needs, after
+// LeakyReLU where the layer has one), `pre` [max_points][4] = the heads' pre-activations (r, g, b, sigma) with their biases.
+extern "C" int npcd_points_x2_train(const void* wpack, const float* feat, int max_points, float* save, float* pre, void* stream) {
+    if (!wpack || !feat || !save || !pre || max_points < 0) return NPCD_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(feat) | reinterpret_cast<uintptr_t>(save) | reinterpret_cast<uintptr_t>(pre) | reinterpret_cast<uintptr_t>(wpack)) & 15)
+        return NPCD_ERR_ARG;
+    if (max_points == 0) return NPCD_OK;
+    PointsX2Args a{static_cast<const unsigned char*>(wpack), feat, nullptr, max_points, nullptr, nullptr, nullptr, nullptr, save, pre};
+    const int lds = 2 * kXPlane + 4 * kXRows * 4 * 4 + 6 * kXHidden * 4;
+    static DynLds lds_s;
+    NPCD_HIP_CHECK(lds_s.ensure(reinterpret_cast<const void*>(points_x2_kernel<false, true>), lds));
+    const int tiles = (max_points + kXRows - 1) / kXRows, grid = tiles < 512 ? tiles : 512;
+    hipLaunchKernelGGL((points_x2_kernel<false, true>), dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+// The same pack from DEVICE tensors (training: once per optimizer step): weights_dev / biases_dev = the eight device pointers of
+// local_field.8, shape_net.{0,2}, channel_net.{0,2,4,6,8} in that order (a host array of pointers).
+extern "C" int npcd_points_x2_pack_dev(const float* const* weights_dev, const float* const* biases_dev, int c0_in_dim, void* wpack_dev, void* stream) {
+    if (!weights_dev || !biases_dev || !wpack_dev || c0_in_dim < kXHidden) return NPCD_ERR_ARG;
+    PointsX2PackArgs a;
+    for (int i = 0; i < 8; ++i) {
+        if (!weights_dev[i] || !biases_dev[i]) return NPCD_ERR_ARG;
+        a.w[i] = weights_dev[i];
+        a.b[i] = biases_dev[i];
+    }
+    a.out = static_cast<unsigned char*>(wpack_dev);
+    a.c0_in_dim = c0_in_dim;
+    hipLaunchKernelGGL(points_x2_pack_kernel, dim3(kXHidden * kXHidden / 256, 7), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
 }

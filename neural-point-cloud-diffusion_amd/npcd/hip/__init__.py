@@ -70,6 +70,8 @@ SIGNATURES = {
     "npcd_points_x2_wpack_bytes": (c_int64, []),
     "npcd_points_x2_pack": (c_int, [POINTER(_P), POINTER(_P), c_int, _P]),
     "npcd_points_x2": (c_int, [_P, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    "npcd_points_x2_train": (c_int, [_P, _P, c_int, _P, _P, _P]),
+    "npcd_points_x2_pack_dev": (c_int, [POINTER(_P), POINTER(_P), c_int, _P, _P]),
     "npcd_shade_points": (c_int, [_P, c_int, c_int, c_int] + [_P] * 5 + [c_int, c_int] + [_P] * 3 + [_P] + [_P]),
     "npcd_shade_points_dir": (c_int, [_P, c_int, c_int, c_int] + [_P] * 5 + [c_int, c_int] + [_P] * 3 + [_P, _P] + [_P] + [_P]),
     "npcd_ray_march_ws_floats": (c_int64, [c_int]),

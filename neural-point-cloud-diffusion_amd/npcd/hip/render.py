@@ -262,7 +262,23 @@ def points_x2_pack(state: dict, device) -> torch.Tensor:
     return host.to(device)
 
 
-def points_x2(wpack: torch.Tensor, feat: torch.Tensor, dir_bias: Optional[torch.Tensor] = None, point_ray: Optional[torch.Tensor] = None):
+def points_x2_pack_device(mods, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The same pack from the eight Linear modules on the device (local_field.8, shape_net.{0,2}, channel_net.{0,2,4,6,8}), one
+    launch; `out`: a pack to overwrite (training re-packs after every optimizer step)."""
+    L = lib()
+    ws = [m.weight.detach().to(_f32).contiguous() for m in mods]
+    bs = [m.bias.detach().to(_f32).contiguous() for m in mods]
+    require_gpu(*ws)
+    if out is None:
+        out = torch.zeros(L.npcd_points_x2_wpack_bytes(), dtype=torch.uint8, device=ws[0].device)      # (the pad words stay zero)
+    wp = (ctypes.c_void_p * 8)(*[w.data_ptr() for w in ws])
+    bp = (ctypes.c_void_p * 8)(*[b.data_ptr() for b in bs])
+    check(L.npcd_points_x2_pack_dev(wp, bp, int(ws[3].shape[1]), ptr(out), stream_ptr()), "npcd_points_x2_pack_dev")
+    return out
+
+
+def points_x2(wpack: torch.Tensor, feat: torch.Tensor, dir_bias: Optional[torch.Tensor] = None, point_ray: Optional[torch.Tensor] = None,
+              save: bool = False):
     """feat [P, 256] fp32 (aggregated per-point features) -> sigma [P], rgb [P, 3]: the last aggregator layer and both heads in the
     reference's fp32 numerics class on the matrix cores (split bf16 operands).  dir_bias [rows, 256] fp32 + point_ray [P] int32: the
     direction part of the first colour layer's pre-activation (use_view_dir)."""
@@ -271,6 +287,15 @@ def points_x2(wpack: torch.Tensor, feat: torch.Tensor, dir_bias: Optional[torch.
         raise ValueError("dir_bias and point_ray go together")
     P = feat.shape[0]
     feat = feat.to(_f32).contiguous()
+    if save:
+        # training forward: (pre [P, 4] = the heads' pre-activations r, g, b, sigma; saved [6, P, 256] = feat, s0, c0, c1, c2, c3)
+        if dir_bias is not None:
+            raise ValueError("the training forward covers the published configuration (no view directions)")
+        pre = torch.empty((P, 4), dtype=_f32, device=feat.device)
+        saved = torch.empty((6, P, 256), dtype=_f32, device=feat.device)
+        if P:
+            check(lib().npcd_points_x2_train(ptr(wpack), ptr(feat), P, ptr(saved), ptr(pre), stream_ptr()), "npcd_points_x2_train")
+        return pre, saved
     sigma = torch.empty(P, dtype=_f32, device=feat.device)
     rgb = torch.empty((P, 3), dtype=_f32, device=feat.device)
     if P == 0:

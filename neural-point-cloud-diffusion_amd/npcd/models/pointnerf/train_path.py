@@ -73,16 +73,22 @@ class _RowSplitLinear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         xx, ww = ctx.saved_tensors[:2]
+        z = ctx.saved_tensors[2] if ctx.slope is not None else None
+        dx, dw, db = _RowSplitLinear.linear_backward(dy, xx, ww, z, ctx.slope, ctx.in_dtype, ctx.needs_input_grad[0])
+        return dx, dw, db, None, None
+
+    @staticmethod
+    def linear_backward(dy, xx, ww, z, slope, in_dtype, need_dx=True):
+        """(dx, dW, db) of y = leaky(x W^T + b) given dy, the layer's input xx, weight ww and (with a slope) its OUTPUT z."""
         dy = dy.to(xx.dtype).contiguous()
         db = None
-        if ctx.slope is not None:
-            z = ctx.saved_tensors[2]
-            fused = hr.leaky_bwd_colsum(dy, z, ctx.slope) if dy.is_cuda else None    # activation backward + bias gradient: one pass
+        if slope is not None:
+            fused = hr.leaky_bwd_colsum(dy, z, slope) if dy.is_cuda else None    # activation backward + bias gradient: one pass
             if fused is not None:
                 dy, db = fused
             else:
-                dy = dy * torch.where(z > 0, 1.0, ctx.slope).to(dy.dtype)
-        dx = torch.mm(dy, ww).to(ctx.in_dtype) if ctx.needs_input_grad[0] else None
+                dy = dy * torch.where(z > 0, 1.0, slope).to(dy.dtype)
+        dx = torch.mm(dy, ww).to(in_dtype) if need_dx else None
         rows, c = dy.shape[0], _RowSplitLinear.SLICE
         S = rows // c
         f32 = torch.float32
@@ -113,7 +119,39 @@ class _RowSplitLinear(torch.autograd.Function):
             dw = torch.mm(dy.t(), xx, out_dtype=f32) if mixed else torch.mm(dy.t(), xx)
         if db is None:
             db = dy.sum(dim=0, dtype=f32)
-        return dx, dw, db, None, None
+        return dx, dw, db
+
+
+class _PointLayersX2(torch.autograd.Function):
+    """The point-level layers of the stage-1 forward -- last aggregator layer, shape_net, channel_net (8 Linear layers) -- as ONE launch
+    in the fp32-class numerics of the per-pair kernels (csrc/points_x2.hip, `save` mode: every hidden activation is written out in
+    fp32 for the backward), where the fp32 library path runs eight GEMMs + activation passes over ~2 x 10^5 points.  The backward is
+    the chain the separate layers had (_RowSplitLinear.linear_backward: fp32 library GEMMs, fused LeakyReLU backward + bias sums).
+    Inputs: G [P, 256] and the 16 parameters in module order; outputs: the heads' PRE-activations [P], [P, 3]."""
+
+    @staticmethod
+    def forward(ctx, G, wpack, *params):
+        pre, saved = hr.points_x2(wpack, G, save=True)
+        ctx.save_for_backward(G, saved, *params[0::2])
+        ctx.need_dG = G.requires_grad
+        return pre[:, 3].contiguous(), pre[:, :3].contiguous()
+
+    @staticmethod
+    def backward(ctx, d_sig, d_rgb):
+        G, saved, w8, ws0, ws1, wc0, wc1, wc2, wc3, wc4 = ctx.saved_tensors
+        feat, s0, c0, c1, c2, c3 = saved.unbind(0)
+        lb, f32, slope = _RowSplitLinear.linear_backward, torch.float32, 0.01
+        # colour head: C4 (linear), C3..C0 (LeakyReLU)
+        d3, dwc4, dbc4 = lb(d_rgb, c3, wc4, None, None, f32)
+        d2, dwc3, dbc3 = lb(d3, c2, wc3, c3, slope, f32)
+        d1, dwc2, dbc2 = lb(d2, c1, wc2, c2, slope, f32)
+        d0, dwc1, dbc1 = lb(d1, c0, wc1, c1, slope, f32)
+        dfc, dwc0, dbc0 = lb(d0, feat, wc0, c0, slope, f32)
+        # density head: S1 (linear), S0 (LeakyReLU)
+        ds0, dws1, dbs1 = lb(d_sig[:, None], s0, ws1, None, None, f32)
+        dfs, dws0, dbs0 = lb(ds0, feat, ws0, s0, slope, f32)
+        dG, dw8, db8 = lb(dfc + dfs, G, w8, None, None, f32, ctx.need_dG)
+        return (dG, None, dw8, db8, dws0, dbs0, dws1, dbs1, dwc0, dbc0, dwc1, dbc1, dwc2, dbc2, dwc3, dbc3, dwc4, dbc4)
 
 
 def split2(t: torch.Tensor):
@@ -244,6 +282,17 @@ def fused_pair_mlp_precision(field, mlp_dtype):
     return None
 
 
+def _point_layers_fusable(field) -> bool:
+    """shape_net = Linear(256, 256), LeakyReLU(0.01), Linear(256, 1); channel_net = 4 x [Linear(256, 256), LeakyReLU(0.01)], Linear(256, 3)
+    (pointnerf.py:161-162): what csrc/points_x2.hip is built for."""
+    def ok(seq, widths):
+        lin = [m for m in seq if isinstance(m, torch.nn.Linear)]
+        act = [m for m in seq if isinstance(m, torch.nn.LeakyReLU)]
+        return ([(m.in_features, m.out_features) for m in lin] == widths and len(act) == len(lin) - 1 and len(seq) == 2 * len(lin) - 1
+                and all(a.negative_slope == 0.01 for a in act))
+    return ok(field.shape_net, [(256, 256), (256, 1)]) and ok(field.channel_net, [(256, 256)] * 4 + [(256, 3)])
+
+
 def fused_pair_mlp_ok(field, mlp_dtype) -> bool:
     return fused_pair_mlp_precision(field, mlp_dtype) is not None
 
@@ -278,6 +327,19 @@ def shade_autograd(field, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch
         lf = agg.local_field
         G = hr.pair_mlp(kp_feat.reshape(-1, kp_feat.shape[-1]), [(lf[i].weight, lf[i].bias) for i in (0, 2, 4, 6)], nb_idx, pts,
                         kp_pos.detach().reshape(-1, 3), off, owner, flat, precision)
+        if (precision == hr.PAIR_MLP_X2 and lib_dtype is None and not field.use_dir and G.is_cuda and G.shape[0] >= 4096
+                and not os.environ.get("NPCD_STAGE1_LIBRARY_HEADS") and _point_layers_fusable(field)):
+            # the eight point-level layers in one launch of the same numerics class (csrc/points_x2.hip), activations saved for the
+            # backward; NPCD_STAGE1_LIBRARY_HEADS=1 = the fp32 library layers below
+            mods = ([lf[8]] + [m for m in field.shape_net if isinstance(m, torch.nn.Linear)]
+                    + [m for m in field.channel_net if isinstance(m, torch.nn.Linear)])
+            params = [t for m in mods for t in (m.weight, m.bias)]
+            key = (str(G.device),) + tuple((t.data_ptr(), t._version) for t in params)
+            if getattr(field, "_train_packx2_key", None) != key:          # (every optimizer step: packed on the device, one launch)
+                field._train_packx2 = hr.points_x2_pack_device(mods, getattr(field, "_train_packx2", None))
+                field._train_packx2_key = key
+            shape_pre, chan_pre = _PointLayersX2.apply(G, field._train_packx2, *params)
+            return F.softplus(shape_pre - 1.0), torch.sigmoid(chan_pre)
         if precision == hr.PAIR_MLP_BF16:
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 agg_feat = lf[8](G).float()

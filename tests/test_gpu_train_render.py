@@ -172,6 +172,54 @@ def test_losses_match_reference_golden_and_oracle(golden):
     assert isinstance(PointNeRFLoss(net), torch.nn.Module)
 
 
+def test_fused_point_level_layers_of_the_training_forward(monkeypatch):
+    """train_path._PointLayersX2 (round 5): the eight point-level Linear layers of the stage-1 forward as one launch of the fp32-class
+    kernel (csrc/points_x2.hip, npcd_points_x2_train: activations saved in fp32), backward = the separate layers' chain.  Against the
+    same layers as fp32 library GEMMs (NPCD_STAGE1_LIBRARY_HEADS=1) through shade_autograd on the same compact lists: sigma / rgb to
+    3e-5, the gradient of every field parameter and of the point features to 2e-3 relative L2 (measured 6e-4: the LeakyReLU units whose
+    tiny pre-activation falls on the other side of zero under the forward's 1e-5 -- two fp32 implementations differ by ~3e-4 the same
+    way, docs/experiments.md R5.4)."""
+    from npcd.models.pointnerf import PointNeRF, train_path as tp
+    torch.manual_seed(11)
+    F_, Ntab, P, k = 32, 512, 6000, 8
+    p = orr.init_field_params(F_, seed=4)
+    m = PointNeRF(1, F_, Ntab, False)
+    m.field.load_state_dict(p)
+    field = m.cuda().train().field
+    nb = torch.randint(0, Ntab, (P, k), dtype=torch.int64, device="cuda")
+    nb[torch.rand(P, k, device="cuda") < 0.3] = -1
+    nb = torch.gather(nb, 1, torch.argsort((nb < 0).int(), dim=1, stable=True))          # valid entries first
+    nb[:, 0] = nb[:, 0].clamp_min(0)                                                       # every compact point has a pair
+    pts = torch.rand(P, 3, device="cuda") - 0.5
+    kp = torch.rand(1, Ntab, 3, device="cuda") - 0.5
+    gs, gc = torch.randn(P, device="cuda"), torch.randn(P, 3, device="cuda")
+    res = {}
+    for mode in ("fused", "library"):
+        if mode == "library":
+            monkeypatch.setenv("NPCD_STAGE1_LIBRARY_HEADS", "1")
+        else:
+            monkeypatch.delenv("NPCD_STAGE1_LIBRARY_HEADS", raising=False)
+        kf = torch.randn(1, Ntab, F_, device="cuda", generator=torch.Generator("cuda").manual_seed(3)).requires_grad_(True)
+        for q in field.parameters():
+            q.grad = None
+        sig, rgb = tp.shade_autograd(field, nb, pts, kp, kf)
+        ((sig * gs).sum() + (rgb * gc).sum()).backward()
+        res[mode] = (sig.detach(), rgb.detach(), kf.grad.clone(), {n: q.grad.clone() for n, q in field.named_parameters() if q.grad is not None})
+    # the device-side packer (training re-packs after every optimizer step) writes the same bytes as the host packer
+    from npcd.hip import render as hr
+    mods = ([field.aggregator.local_field[8]] + [q for q in field.shape_net if isinstance(q, torch.nn.Linear)]
+            + [q for q in field.channel_net if isinstance(q, torch.nn.Linear)])
+    assert torch.equal(hr.points_x2_pack_device(mods).cpu(), hr.points_x2_pack(field.state_dict(), "cuda").cpu())
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    (s1, c1, g1, p1), (s0, c0, g0, p0) = res["fused"], res["library"]
+    assert float((s1 - s0).abs().max()) < 3e-5 * max(1.0, float(s0.abs().max())) and float((c1 - c0).abs().max()) < 3e-5
+    assert rel(g1, g0) < 2e-3, rel(g1, g0)
+    assert set(p1) == set(p0) and len(p1) == 24
+    worst = max((rel(p1[n], p0[n]), n) for n in p0)
+    print("fused point-level layers: worst parameter-gradient rel-L2", worst, "d kp_feat", rel(g1, g0))
+    assert worst[0] < 2e-3, worst
+
+
 @pytest.mark.parametrize("mlp_dtype", [None, "library", torch.bfloat16])
 def test_stage1_training_step_reduces_the_loss(mlp_dtype):
     """PointNeRFTrainer on a synthetic target: images rendered from a 'teacher' feature table; the student starts from zeros.
