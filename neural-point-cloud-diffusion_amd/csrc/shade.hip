@@ -330,7 +330,6 @@ __device__ __forceinline__ void layer_mfma16(const unsigned char* H, const unsig
         }
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            constexpr int dummy = 0; (void)dummy;
             const int r0 = h * 4, nr = (NB16 - r0) < 4 ? (NB16 - r0) : 4;                       // this half-step's row blocks
             const int ns = (h + 1 < NH) ? s : s + 1, nr0 = (h + 1 < NH) ? 4 : 0;                 // the next half-step
             const int nnr = (NB16 - nr0) < 4 ? (NB16 - nr0) : 4;
