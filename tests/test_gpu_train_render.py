@@ -176,7 +176,7 @@ def test_fused_point_level_layers_of_the_training_forward(monkeypatch):
     """train_path._PointLayersX2 (round 5): the eight point-level Linear layers of the stage-1 forward as one launch of the fp32-class
     kernel (csrc/points_x2.hip, npcd_points_x2_train: activations saved in fp32), backward = the separate layers' chain.  Against the
     same layers as fp32 library GEMMs (NPCD_STAGE1_LIBRARY_HEADS=1) through shade_autograd on the same compact lists: sigma / rgb to
-    3e-5, the gradient of the point features to 2e-3 and of every field parameter to 5e-3 relative L2 (measured 6e-4 / 1.6e-3: the LeakyReLU units whose
+    1e-4, the gradient of the point features to 2e-3 and of every field parameter to 5e-3 relative L2 (measured 6e-4 / 1.6e-3: the LeakyReLU units whose
     tiny pre-activation falls on the other side of zero under the forward's 1e-5 -- two fp32 implementations differ by ~3e-4 the same
     way, docs/experiments.md R5.4)."""
     from npcd.models.pointnerf import PointNeRF, train_path as tp
@@ -212,7 +212,7 @@ def test_fused_point_level_layers_of_the_training_forward(monkeypatch):
     assert torch.equal(hr.points_x2_pack_device(mods).cpu(), hr.points_x2_pack(field.state_dict(), "cuda").cpu())
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
     (s1, c1, g1, p1), (s0, c0, g0, p0) = res["fused"], res["library"]
-    assert float((s1 - s0).abs().max()) < 3e-5 * max(1.0, float(s0.abs().max())) and float((c1 - c0).abs().max()) < 3e-5
+    assert float((s1 - s0).abs().max()) < 1e-4 * max(1.0, float(s0.abs().max())) and float((c1 - c0).abs().max()) < 1e-4
     assert rel(g1, g0) < 2e-3, rel(g1, g0)
     assert set(p1) == set(p0) and len(p1) == 24
     worst = max((rel(p1[n], p0[n]), n) for n in p0)
