@@ -933,20 +933,23 @@ def main():
             r["rays_per_s_all_gpus"] = float(tt)
         result["render"] = r
         try:
-            # lead figure: the reference's numerics class -- stage 1 trains in fp32 (train_pointnerf.py has no autocast).  Default of
-            # PointNeRFTrainer since round 5: the per-pair layers on the fp32-class matrix-core kernels (two bf16 halves per operand,
-            # three products, fp32 accumulation: ~1e-5 relative per product, tests/test_gpu_train_render.py::
-            # test_fused_pair_mlp_fp32_class_mode), the point-level layers on fp32 library GEMMs.  Beside it: every Linear layer on
-            # fp32 library GEMMs (the lead until round 4), and the bf16-operand opt-in (narrower than the reference).
+            # lead figure: the reference's numerics -- stage 1 trains in TRUE fp32 (train_pointnerf.py has no autocast), which is what
+            # PointNeRFTrainer(mlp_dtype=None) runs: fp32 operands and accumulation on library GEMMs for every Linear layer (round 6, ADVICE
+            # r5: the split-operand mode had been the default for one round).  Beside it the two explicit opt-ins: "fp32_class" (per-pair
+            # layers + the point-level forward on the matrix cores with every operand as two bf16 halves: ~1e-5 relative per product,
+            # tests/test_gpu_train_render.py::test_fused_pair_mlp_fp32_class_mode) and bf16 operands (narrower still).
+            keys = ("steps_per_s", "ms_per_step", "ms_per_step_min_median_max", "loss", "differentiable_part")
             s1 = bench_stage1(device)
-            s1["numerics"] = ("fp32-class: per-pair aggregator MLP with every operand as two bf16 halves (hi + lo), three matrix instructions per product, "
-                              "fp32 accumulation, fp32 weight gradients (csrc/pairs_mlp.hip precision 1: forward 5e-6, gradients 1e-5 relative to float64 "
-                              "in the kernel test); point-level layers, losses and Adam in fp32 (PointNeRFTrainer(mlp_dtype=None))")
-            libr = bench_stage1(device, mlp_dtype="library")
-            s1["fp32_library_gemms"] = {k: libr[k] for k in ("steps_per_s", "ms_per_step", "ms_per_step_min_median_max", "loss", "differentiable_part")}
-            s1["fp32_library_gemms"]["numerics"] = "fp32 operands and accumulation on library GEMMs for every Linear layer (PointNeRFTrainer(mlp_dtype='library'))"
+            s1["numerics"] = ("fp32 operands and accumulation on library GEMMs for every Linear layer, losses and Adam in fp32 "
+                              "(PointNeRFTrainer(mlp_dtype=None)): the reference's arithmetic")
+            x2 = bench_stage1(device, mlp_dtype="fp32_class")
+            s1["fp32_class_opt_in"] = {k: x2[k] for k in keys}
+            s1["fp32_class_opt_in"]["numerics"] = ("EMULATED fp32 (opt-in, PointNeRFTrainer(mlp_dtype='fp32_class')): every operand as two bf16 halves (hi + lo), "
+                                                   "three matrix instructions per product, fp32 accumulation and weight gradients -- 16 mantissa bits, ~1e-5 relative per "
+                                                   "product where fp32 has 6e-8; per-pair layers forward + backward (csrc/pairs_mlp.hip precision 1) and the point-level "
+                                                   "layers' forward (csrc/points_x2.hip); the text of `differentiable_part` is derived from the predicates the forward uses")
             opt = bench_stage1(device, mlp_dtype=torch.bfloat16)
-            s1["bf16_operands_opt_in"] = {k: opt[k] for k in ("steps_per_s", "ms_per_step", "ms_per_step_min_median_max", "loss", "differentiable_part")}
+            s1["bf16_operands_opt_in"] = {k: opt[k] for k in keys}
             s1["bf16_operands_opt_in"]["numerics"] = ("bf16 operands, fp32 accumulation, fp32 weight gradients and optimizer: NARROWER than the "
                                                       "reference's fp32 -- not the creditable figure")
             result["stage1_pointnerf_training"] = s1

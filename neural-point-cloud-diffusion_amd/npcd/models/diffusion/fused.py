@@ -141,9 +141,21 @@ def _wgrad(dy, x, out):
 # 82.9-84.3 ms (R5.11) -- the default below _WGRAD_STREAM_MAX_T token rows since.  NPCD_WGRAD_STREAM=0 / 1 forces it off / on at
 # every size, NPCD_WGRAD_STREAM_PRIO=<priority> sets the side stream's priority.  Same kernels in the same order per tensor: the
 # gradients are the same bits either way (tests/test_gpu_fused.py).
-_WGRAD_STREAM = os.environ.get("NPCD_WGRAD_STREAM", "1") != "0"
-_WGRAD_STREAM_MAX_T = (1 << 62) if os.environ.get("NPCD_WGRAD_STREAM") == "1" else 20000
+def _parse_wgrad_stream(value):
+    """NPCD_WGRAD_STREAM -> (enabled, max token rows): unset = on below 20,000 rows, "0" = off, "1" = on at every size, any other
+    integer = on up to that many rows.  Parsed ONCE, here (it had been read twice with two meanings)."""
+    if value is None or value == "":
+        return True, 20000
+    if value == "0":
+        return False, 0
+    if value == "1":
+        return True, 1 << 62
+    return True, int(value)
+
+
+_WGRAD_STREAM, _WGRAD_STREAM_MAX_T = _parse_wgrad_stream(os.environ.get("NPCD_WGRAD_STREAM"))
 _side = {}
+_side_open = {}          # device -> True while weight-gradient products on the side stream have not been joined into the main stream
 
 
 def _side_stream(device):
@@ -169,14 +181,33 @@ def _wgrad_fork(pending, device):
             x.record_stream(side)
             _wgrad(dy, x, out)
     pending.clear()
+    _side_open[device] = True
 
 
 def _wgrad_join(device):
     torch.cuda.current_stream().wait_stream(_side_stream(device))
+    _side_open[device] = False
+
+
+def side_stream_joined(device) -> bool:
+    """False while weight gradients enqueued on the side stream have not been ordered before the main stream's next work: nobody may
+    hand those gradients to a consumer on another stream (the gradient reducer asserts this in mark_ready)."""
+    return not _side_open.get(device, False)
+
+
+def _no_engine():
+    return None
 
 
 class FusedBackboneEngine:
     """Views into the flat fp32 parameter / gradient buffers and the bf16 shadow for every block."""
+
+    # the engine belongs to ONE trainer's flat buffers: a deep copy / pickle of the backbone carries None (the module path) instead
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (_no_engine, ())
 
     def __init__(self, backbone, flat, shadow, reducer=None):
         self.heads = backbone.resblocks[0].attn.heads
@@ -206,6 +237,12 @@ class FusedBackboneEngine:
         self.dtype = shadow.dtype                            # the run's 16-bit activation type: bf16, or f16 (with loss scaling)
         self._stamped = [p for e in self.blocks for p in e["params"]]
         self._stamp = self._versions()
+        # counts the writes to the 16-bit shadow (optimizer pass, parameter gather, re-cast): what a cached derivative of the shadow
+        # -- the transposed mlp.c_proj weights of the NPCD_OWN_DGELU launch -- is stamped with
+        self.shadow_epoch = 0
+
+    def shadow_written(self):
+        self.shadow_epoch += 1
 
     def _versions(self):
         return [p._version for p in self._stamped]
@@ -221,6 +258,7 @@ class FusedBackboneEngine:
                     raise RuntimeError("a parameter of the fused backbone was re-homed outside the trainer's flat buffer "
                                        "(p.data replaced): build a new DiffusionTrainer for this model")
             ew.cast_f32_bf16(self._flat.flat, self._shadow)
+            self.shadow_written()
             self._stamp = v
 
     def __call__(self, x):
@@ -384,6 +422,7 @@ class _BackboneFn(torch.autograd.Function):
 
             def ready(entry):
                 if eng.reducer is not None:
+                    assert side_stream_joined(dx.device), "weight gradients handed to the reducer before the side stream was joined"
                     for p in entry["params"]:
                         eng.reducer.mark_ready(p)
             for bi in range(len(eng.blocks) - 1, -1, -1):
@@ -397,11 +436,15 @@ class _BackboneFn(torch.autograd.Function):
                 w2 = e["mlp_c_proj_weight_16"]
                 # (the own launch only for what npcd_linear_dgelu_bwd takes -- contiguous 16-bit operands of one type; anything else
                 # goes through the library product + gelu_bwd below instead of raising, like NPCD_ERR_UNSUPPORTED would, ADVICE r4.
-                # The transposed copy of the weight is made per backward: it changes with every optimizer step and each backward
-                # uses it once, so a cached copy would have to be refreshed as often -- 8 MB and ~5 us per block either way.)
+                # The transposed 16-bit copy of the weight is CACHED per block and stamped with the engine's shadow epoch: it is rebuilt
+                # (into the same 8-MB buffer) only after the shadow was written -- once per optimizer step in a plain loop, not at
+                # all between the backwards of a gradient-accumulation loop or of repeated evaluations of one model state.)
                 if (_OWN_DGELU and Tm > 0 and hlin.supported(Tm, 4 * W, W) and dxb.is_contiguous() and h.is_contiguous()
                         and w2.is_contiguous() and dxb.dtype == w2.dtype == h.dtype and dxb.dtype in (torch.bfloat16, torch.float16)):
-                    wT = hlin.transpose16(w2)
+                    wT = e.get("mlp_c_proj_weight_16T")
+                    if wT is None or e.get("mlp_c_proj_weight_16T_epoch") != eng.shadow_epoch or wT.dtype != w2.dtype:
+                        wT = e["mlp_c_proj_weight_16T"] = hlin.transpose16(w2, out=wT if wT is not None and wT.dtype == w2.dtype else None)
+                        e["mlp_c_proj_weight_16T_epoch"] = eng.shadow_epoch
                     dh = torch.empty_like(h)
                     extra = ew.lib().npcd_colsum_blocks(T - Tm) if Tm < T else 0
                     _, part, rows = hlin.linear_dgelu_bwd(dxb[:Tm], wT, h[:Tm], out=dh[:Tm], extra_part_rows=extra)

@@ -189,7 +189,7 @@ class Field(nn.Module):
         def mlp(seq, x):      # fp32 library GEMMs; with the switch the wide layers as three cross products of split bf16 operands
             for m in seq:
                 if _X2_HEADS and isinstance(m, nn.Linear) and m.out_features >= 16 and m.in_features % 8 == 0 and x.shape[0] >= 4096:
-                    x = x2_linear_forward(x, m.weight, m.bias)[0]
+                    x = x2_linear_forward(x, m.weight, m.bias, save=False)[0]
                 else:
                     x = m(x)
             return x

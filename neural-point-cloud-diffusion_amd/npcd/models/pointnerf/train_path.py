@@ -160,12 +160,14 @@ def split2(t: torch.Tensor):
     return hi, (t - hi.float()).to(torch.bfloat16)
 
 
-def x2_linear_forward(x, weight, bias):
+def x2_linear_forward(x, weight, bias, save: bool):
     """y = x W^T + b in the fp32 class on the bf16 matrix rate: x W^T ~ xh Wh^T + xl Wh^T + xh Wl^T as ONE library GEMM over a three
     times longer contraction, [xh | xl | xh] [Wh | Wh | Wl]^T, with fp32 accumulation and output (the lo x lo term, 2^-18 relative,
-    is dropped: ~1e-5 relative per product, like csrc/pairs_mlp.hip at precision 1).  Returns (y, saved operands)."""
+    is dropped: ~1e-5 relative per product, like csrc/pairs_mlp.hip at precision 1).  `save` (the caller says so explicitly: inside
+    an autograd.Function's forward grad mode is off, so it cannot be probed): True = return the split operands a backward needs,
+    False = forward only (rendering), the activation side in one pass.  Returns (y, saved operands or None)."""
     wh, wl = split2(weight)
-    if x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 8 == 0 and not torch.is_grad_enabled():
+    if not save and x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 8 == 0:
         # forward only (rendering): the activation side in one pass (csrc/split.hip)
         y = torch.mm(ew.split3(x), torch.cat((wh, wh, wl), dim=1).t(), out_dtype=torch.float32)
         return y + bias, None
@@ -185,7 +187,7 @@ class _X2Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, slope=None):
-        y, (xh, xl, wh, wl) = x2_linear_forward(x, weight, bias)
+        y, (xh, xl, wh, wl) = x2_linear_forward(x, weight, bias, save=True)
         if slope is not None:
             y = F.leaky_relu(y, slope, inplace=True)
             ctx.save_for_backward(xh, xl, wh, wl, y)
@@ -258,18 +260,27 @@ def _mlp(seq, x, dtype):
     return x
 
 
+FP32_CLASS = "fp32_class"          # PointNeRFTrainer(mlp_dtype=FP32_CLASS): the split-operand matrix-core mode, an explicit opt-in
+
+
 def fused_pair_mlp_precision(field, mlp_dtype):
     """Which mode of the matrix-core pair MLP (csrc/pairs_mlp.hip) runs the four non-linear per-pair layers, or None for the library
     GEMMs.  The fused kernels cover the published network (pointnerf.py:174-179: four LeakyReLU layers of width 256 + a linear
     one, 10 frequency bands, feature width 32 or 128).
-      mlp_dtype None / torch.float32 (the reference's numerics, train_pointnerf.py has no autocast): PAIR_MLP_X2 -- fp32-class,
-          every operand as two bf16 halves, ~1e-5 relative per product (round 5; before: fp32 library GEMMs with every [Q, 256]
-          activation round-tripping HBM, still selectable with mlp_dtype="library" or NPCD_STAGE1_LIBRARY_FP32=1);
-      mlp_dtype torch.bfloat16: PAIR_MLP_BF16 -- bf16 operands, narrower than the reference (opt-in)."""
+      mlp_dtype None / torch.float32 / "library": None -- TRUE fp32 like the reference (train_pointnerf.py has no autocast): fp32
+          operands and accumulation on library GEMMs for every Linear layer (~6e-8 per operand);
+      mlp_dtype "fp32_class": PAIR_MLP_X2 -- every operand as two bf16 halves hi + lo, three matrix instructions per product,
+          ~1e-5 relative per product (16 mantissa bits, fp32's range): faster, NOT the reference's arithmetic -- an explicit opt-in
+          (it was the default for one round; ADVICE r5: a default below the reference's precision needs the caller's say-so);
+      mlp_dtype torch.bfloat16: PAIR_MLP_BF16 -- bf16 operands, narrower still (opt-in)."""
     agg = field.aggregator
     lf = agg.local_field
-    if isinstance(mlp_dtype, str) or os.environ.get("NPCD_NO_FUSED_PAIR_MLP"):
+    if os.environ.get("NPCD_NO_FUSED_PAIR_MLP"):
         return None
+    if mlp_dtype is None or mlp_dtype == torch.float32 or mlp_dtype == "library":
+        return None
+    if isinstance(mlp_dtype, str) and mlp_dtype != FP32_CLASS:
+        raise ValueError(f"mlp_dtype {mlp_dtype!r}: None / torch.float32 / 'library' (fp32), 'fp32_class', or torch.bfloat16")
     covered = (agg.in_dim in (32, 128) and agg.n_freqs == 10
                and len(lf) == 9 and all(isinstance(lf[i], torch.nn.Linear) and lf[i].out_features == 256 for i in (0, 2, 4, 6, 8))
                and all(isinstance(lf[i], torch.nn.LeakyReLU) and lf[i].negative_slope == 0.01 for i in (1, 3, 5, 7)))
@@ -277,9 +288,18 @@ def fused_pair_mlp_precision(field, mlp_dtype):
         return None
     if mlp_dtype == torch.bfloat16:
         return hr.PAIR_MLP_BF16
-    if mlp_dtype in (None, torch.float32) and not os.environ.get("NPCD_STAGE1_LIBRARY_FP32"):
+    if mlp_dtype == FP32_CLASS:
         return hr.PAIR_MLP_X2
     return None
+
+
+def point_layers_fused(field, mlp_dtype, n_points=None) -> bool:
+    """Does the stage-1 forward run its eight point-level layers as ONE fp32-class launch (csrc/points_x2.hip, _PointLayersX2)?  The
+    single predicate shade_autograd, PointNeRFTrainer.describe() and bench.py's labels share (n_points None: the batch-size
+    condition, >= 4096 compact points, is left out -- the answer for a training-size batch)."""
+    return (fused_pair_mlp_precision(field, mlp_dtype) == hr.PAIR_MLP_X2 and not os.environ.get("NPCD_STAGE1_X2_HEADS")
+            and not field.use_dir and not os.environ.get("NPCD_STAGE1_LIBRARY_HEADS") and _point_layers_fusable(field)
+            and (n_points is None or n_points >= 4096))
 
 
 def _point_layers_fusable(field) -> bool:
@@ -310,11 +330,11 @@ def shade_autograd(field, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch
     flat = nb_idx[owner, col]
     cnt = valid.sum(dim=1)
     off = torch.cumsum(cnt, 0) - cnt                             # a point's pairs are rows off[p] .. off[p] + cnt[p]
-    # the reference trains stage 1 in fp32; `field.train_mlp_dtype = torch.bfloat16` (PointNeRFTrainer(mlp_dtype=...)) is an
-    # opt-in that runs the Linear layers of the three MLPs under autocast (MFMA instead of fp32 matrix instructions)
+    # the reference trains stage 1 in fp32 and so does the default here (fp32 library GEMMs); `field.train_mlp_dtype`
+    # (PointNeRFTrainer(mlp_dtype=...)) = "fp32_class" / torch.bfloat16 are the opt-ins that put the MLPs on the 16-bit matrix rate
     mlp_dtype = getattr(field, "train_mlp_dtype", None)
     precision = fused_pair_mlp_precision(field, mlp_dtype)
-    lib_dtype = None if (mlp_dtype is None or isinstance(mlp_dtype, str) or mlp_dtype == torch.float32) else mlp_dtype     # operand type of the library layers
+    lib_dtype = None if (mlp_dtype is None or isinstance(mlp_dtype, str) or mlp_dtype == torch.float32) else mlp_dtype     # operand type of the library layers (None: fp32)
     if precision == hr.PAIR_MLP_X2 and os.environ.get("NPCD_STAGE1_X2_HEADS"):
         # opt-in (measured SLOWER: 20.6-21.1 against 16.1 ms per step, docs/experiments.md R5.4): the point-level layers in the same fp32
         # class as one bf16 library GEMM over the three cross products of the split operands (_X2Linear) instead of fp32 library GEMMs
@@ -327,8 +347,7 @@ def shade_autograd(field, nb_idx: torch.Tensor, pts: torch.Tensor, kp_pos: torch
         lf = agg.local_field
         G = hr.pair_mlp(kp_feat.reshape(-1, kp_feat.shape[-1]), [(lf[i].weight, lf[i].bias) for i in (0, 2, 4, 6)], nb_idx, pts,
                         kp_pos.detach().reshape(-1, 3), off, owner, flat, precision)
-        if (precision == hr.PAIR_MLP_X2 and lib_dtype is None and not field.use_dir and G.is_cuda and G.shape[0] >= 4096
-                and not os.environ.get("NPCD_STAGE1_LIBRARY_HEADS") and _point_layers_fusable(field)):
+        if G.is_cuda and point_layers_fused(field, mlp_dtype, G.shape[0]):
             # the eight point-level layers in one launch of the same numerics class (csrc/points_x2.hip), activations saved for the
             # backward; NPCD_STAGE1_LIBRARY_HEADS=1 = the fp32 library layers below
             mods = ([lf[8]] + [m for m in field.shape_net if isinstance(m, torch.nn.Linear)]

@@ -105,6 +105,7 @@ def load_trainer_state(trainer, ckpt: dict, ema_prefix: str = "diffusion.") -> N
         trainer.exp_avg.copy_(m)
         trainer.exp_avg_sq.copy_(v)
         trainer._ew.cast_f32_bf16(flat.flat, trainer.shadow)
+        trainer._shadow_written()
     else:
         trainer.optimizer.param_groups[0].update(lr=trainer.lr, weight_decay=trainer.weight_decay, betas=trainer.betas, eps=trainer.eps)
         if trainer.iteration > 0:

@@ -20,6 +20,36 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+def _none():
+    return None
+
+
+class _ParamWaitHook:
+    """forward-pre / state_dict-pre hook a DiffusionTrainer installs on its model: completes pending parameter gathers.  It holds the
+    trainer STRONGLY (a dropped trainer reference can never turn the waits into no-ops), and it does not travel: copy.deepcopy(model)
+    and pickling (torch.save(model)) give the copy an inert hook, never a copy of the trainer's flat buffers, streams, ctypes handles
+    and process groups."""
+
+    def __init__(self, trainer, kind):
+        self.trainer, self.kind = trainer, kind
+
+    def __call__(self, module, *args):
+        t = self.trainer
+        if t is None:
+            return None
+        if self.kind == "forward":
+            t._await_params_for_forward(module, args[0])
+        else:
+            t.wait_params()
+        return None
+
+    def __deepcopy__(self, memo):
+        return _ParamWaitHook(None, self.kind)
+
+    def __reduce__(self):
+        return (_ParamWaitHook, (None, self.kind))
+
+
 class FlatBuffers:
     """Re-home the trainable parameters of `module` into one flat buffer (+ flat grads)."""
     ALIGN = 256
@@ -288,16 +318,26 @@ class DiffusionTrainer:
             if prev is not None and prev is not self:
                 prev.close()
             self._hook_handles = []
+            # (model -> hook -> trainer -> model is a reference cycle: the trainer's buffers -- moments, EMA, shadow: 16 bytes per parameter --
+            # are released by close(), or by the cyclic collector some time after the last reference; call close() when done with a trainer)
             if denoiser is not None:
-                self._hook_handles.append(denoiser.register_forward_pre_hook(lambda m, a: self._await_params_for_forward(m, a)))
-                self._hook_handles.append(denoiser.register_state_dict_pre_hook(lambda m, prefix, keep: self.wait_params()))   # denoiser.state_dict() read directly
-            self._hook_handles.append(diffusion.register_state_dict_pre_hook(lambda m, prefix, keep: self.wait_params()))
+                self._hook_handles.append(denoiser.register_forward_pre_hook(_ParamWaitHook(self, "forward")))
+                self._hook_handles.append(denoiser.register_state_dict_pre_hook(_ParamWaitHook(self, "state_dict")))   # denoiser.state_dict() read directly
+            self._hook_handles.append(diffusion.register_state_dict_pre_hook(_ParamWaitHook(self, "state_dict")))
             diffusion.__dict__["_npcd_trainer"] = self
         else:
             # reference path (CPU tests / ablation): torch AdamW over ONE flat "parameter"
             self.master = nn.Parameter(self.flat.flat, requires_grad=True)
             self.master.grad = self.flat.grad
             self.optimizer = torch.optim.AdamW([self.master], lr=lr, weight_decay=weight_decay, fused=self.flat.flat.is_cuda)
+
+    # A trainer never travels with its model: a deep copy or a pickle of a model with an attached trainer (EMA snapshots by
+    # copy.deepcopy(model), torch.save(model)) carries None in its place and the module path instead of the fused engine.
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (_none, ())
 
     def comm_stats(self):
         """Communication bookkeeping of the LAST step of this rank (bench.py puts it into the line for n_gpus > 1, DESIGN.md
@@ -357,6 +397,7 @@ class DiffusionTrainer:
             h, _, s0, e0 = pend.pop(b)
             h.wait()
             self._ew.cast_f32_bf16(self.flat.flat[s0:e0], self.shadow[s0:e0])
+            self._shadow_written()
 
     def _await_params_for_forward(self, module, args):
         """forward-pre-hook of the denoiser.  The fused training forward asks for its blocks one by one (so that the gathers of
@@ -435,7 +476,13 @@ class DiffusionTrainer:
             self._clean_steps = 0
         return True
 
+    def _shadow_written(self):
+        eng = getattr(self, "_fused_engine", None)
+        if eng is not None:
+            eng.shadow_written()
+
     def _adamw_range(self, s0, e0, zero_grad=True):
+        self._shadow_written()
         ema = None if self.ema is None else self.ema[s0:e0]
         self._ew.adamw_ema(self.flat.flat[s0:e0], self.flat.grad[s0:e0], self.exp_avg[s0:e0], self.exp_avg_sq[s0:e0], ema,
                            self.shadow[s0:e0], self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.iteration,
@@ -454,6 +501,7 @@ class DiffusionTrainer:
         self.wait_params(s0, e0)                      # (a no-op unless a step ran without any forward in between)
         a, b = red.shard_range(s0, e0)
         g = red.gshard[s0 // red.world:e0 // red.world]
+        self._shadow_written()
         ema = None if self.ema is None else self.ema[a:b]
         self._ew.adamw_ema(self.flat.flat[a:b], g, self.exp_avg[a:b], self.exp_avg_sq[a:b], ema, self.shadow[a:b], self.lr, self.betas[0],
                            self.betas[1], self.eps, self.weight_decay, self.iteration, self.ema_decay, zero_grad=False)

@@ -13,10 +13,12 @@ from ..losses import PointNeRFLoss
 class PointNeRFTrainer:
     def __init__(self, model, loss=None, lr: float = 1e-3, mlp_dtype=None):
         """model: NPCD (uses model.pointnerf); loss: a PointNeRFLoss (default weights of train_pointnerf.py:56-59).
-        mlp_dtype: None (or torch.float32) = the reference's numerics (train_pointnerf.py runs without autocast): the per-pair layers
-        on the fp32-class matrix-core kernels (every operand as two bf16 halves, ~1e-5 relative per product: csrc/pairs_mlp.hip
-        precision 1), the point-level layers on fp32 library GEMMs; "library" = every Linear layer on fp32 library GEMMs (the
-        default before round 5); torch.bfloat16 = bf16 operands throughout (opt-in, narrower than the reference)."""
+        mlp_dtype: None (or torch.float32, or "library") = the reference's numerics (train_pointnerf.py runs without autocast): TRUE
+        fp32 operands and accumulation, every Linear layer on fp32 library GEMMs;
+        "fp32_class" = explicit opt-in, faster: every operand as two bf16 halves on the matrix cores (~1e-5 relative per product
+        where fp32 has ~6e-8: csrc/pairs_mlp.hip precision 1, csrc/points_x2.hip) -- the per-pair layers forward + backward and,
+        from 4,096 shading points on, the point-level layers' forward;
+        torch.bfloat16 = bf16 operands throughout (opt-in, narrower still)."""
         self.model = model
         model.pointnerf.field.train_mlp_dtype = mlp_dtype
         self.loss = loss if loss is not None else PointNeRFLoss(model, 1, 1e-7, 3.5e-7)
@@ -27,9 +29,10 @@ class PointNeRFTrainer:
         self.iteration = 0
 
     def describe(self) -> str:
-        """What runs where in this trainer's step (bench.py prints it next to the timing)."""
+        """What runs where in this trainer's step (bench.py prints it next to the timing).  Derived from the predicates the forward
+        itself uses (train_path.fused_pair_mlp_precision / point_layers_fused), so the text cannot drift from the code path."""
         from ..hip import render as hr
-        from ..models.pointnerf.train_path import fused_pair_mlp_precision
+        from ..models.pointnerf.train_path import fused_pair_mlp_precision, point_layers_fused
         field = self.model.pointnerf.field
         dt = getattr(field, "train_mlp_dtype", None)
         base = ("HIP kernels with hand-written backward: ray generation, both neighbour queries, ray march; ")
@@ -38,11 +41,14 @@ class PointNeRFTrainer:
             return base + ("per-pair aggregator MLP (gather, positional encoding, 4 layers, weighted mean) forward + backward on the matrix "
                            "cores with bf16 operands (csrc/pairs_mlp.hip); point-level layers and losses: torch under bf16 autocast")
         if prec == hr.PAIR_MLP_X2:
+            points = ("point-level layers: forward as ONE fp32-class fused launch (csrc/points_x2.hip, activations saved in fp32) from 4,096 "
+                      "shading points on, backward on fp32 library GEMMs (row-split weight gradients)" if point_layers_fused(field, dt)
+                      else "point-level layers: fp32 library GEMMs (row-split weight gradients)")
             return base + ("per-pair aggregator MLP (gather, positional encoding, 4 layers, weighted mean) forward + backward on the matrix "
                            "cores in the fp32-class mode (two bf16 halves per operand, three products, fp32 accumulation: csrc/pairs_mlp.hip); "
-                           "point-level layers: fp32 library GEMMs (row-split weight gradients); losses: torch fp32")
+                           + points + "; losses: torch fp32")
         return base + ("pair inputs / aggregation (csrc/pairs.hip); Linear layers: library GEMMs (row-split weight gradients) in "
-                       + ("fp32" if dt is None or isinstance(dt, str) else str(dt)) + " under torch autograd")
+                       + ("fp32" if dt is None or isinstance(dt, str) or dt == torch.float32 else str(dt)) + " under torch autograd")
 
     def step(self, sample, rng=None):
         """sample: dict(images [B,T,3,H,W], intrinsics [B,T,3,3], extrinsics [B,T,4,4], obj_idx [B]) on the GPU."""

@@ -68,13 +68,16 @@ def import_reference(ref_root: str):
     return ref
 
 
+OUT = HERE          # --out DIR writes the fixtures elsewhere (tests/test_golden_regeneration.py compares a fresh set with the committed one)
+
+
 def save(name, **arrays):
     out = {}
     for k, v in arrays.items():
         if isinstance(v, torch.Tensor):
             v = v.detach().cpu().numpy()
         out[k] = np.asarray(v)
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT, name + ".npz")
     np.savez(path, **out)
     print(f"  {name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
 
@@ -348,10 +351,15 @@ def main():
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--only-denoiser", nargs="*", default=None,
                     help="write only these denoiser_<tag>.npz fixtures (leaves every other fixture file untouched)")
+    ap.add_argument("--out", default=None, help="directory to write to (default: this directory)")
     args = ap.parse_args()
+    global OUT
+    if args.out:
+        OUT = args.out
+        os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(4)
     ref = import_reference(args.ref)
-    print("writing fixtures to", HERE)
+    print("writing fixtures to", OUT)
     if args.only_denoiser is not None:
         gen_denoiser(ref, only=args.only_denoiser)
         return

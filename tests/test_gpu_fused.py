@@ -175,6 +175,43 @@ def test_weight_gradients_on_the_side_stream_are_the_same_bits():
         fused._WGRAD_STREAM = True
 
 
+def test_side_stream_weight_gradients_at_a_rank_sized_batch_are_the_same_bits():
+    """The same bit-identity at the size the side stream is the default FOR (it was tested at T = 245 only): width 1,024, two
+    blocks, 38 x 513 = 19,494 token rows -- just under fused._WGRAD_STREAM_MAX_T = 20,000, above _SPLIT_MIN, so the token split of the
+    GEMMs (large call + left-over rows) and the row-split weight gradients run as in a rank's step.  Also: the environment variable is
+    parsed once into (enabled, max rows)."""
+    from npcd.models.diffusion import DiffusionModel, fused
+    from npcd.train import DiffusionTrainer
+    assert fused._parse_wgrad_stream(None) == (True, 20000) and fused._parse_wgrad_stream("0") == (False, 0)
+    assert fused._parse_wgrad_stream("1") == (True, 1 << 62) and fused._parse_wgrad_stream("5000") == (True, 5000)
+    B, N, F_, W = 38, 512, 32, 1024
+    assert fused._SPLIT_MIN <= B * (N + 1) < fused._WGRAD_STREAM_MAX_T and fused._wgrad_side_ok(B * (N + 1))
+    g = torch.Generator().manual_seed(7)
+    c0, f0 = torch.randn(B, 3, N, generator=g).cuda(), torch.randn(B, F_, N, generator=g).cuda()
+    t = torch.randint(0, 1000, (B,), generator=g).cuda()
+    cn, fn = torch.randn(B, 3, N, generator=g).cuda(), torch.randn(B, F_, N, generator=g).cuda()
+    grads = {}
+    try:
+        for side in (True, False):
+            torch.manual_seed(9)
+            m = DiffusionModel(3, F_, N, W, 2, 16, True)
+            torch.nn.init.normal_(m.denoiser.output_proj.weight, std=0.02)
+            tr = DiffusionTrainer(m.cuda().train(), fused=True)
+            fused._WGRAD_STREAM = side
+            tr.flat.zero_grad(); tr.reducer.start_step()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss, _, _ = tr.model.compute_loss(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
+            loss.backward()
+            torch.cuda.synchronize()
+            assert fused.side_stream_joined(c0.device)
+            grads[side] = tr.flat.grad.clone()
+            tr.close()
+            del tr, m
+        assert float(grads[True].abs().sum()) > 0 and torch.equal(grads[True], grads[False])
+    finally:
+        fused._WGRAD_STREAM = True
+
+
 @pytest.mark.parametrize("tag", ["f32_w64", "f128_w64", "f32_w128_h2"])
 @pytest.mark.parametrize("half", [torch.bfloat16, torch.float16])
 def test_fused_engine_matches_reference_golden_directly(golden, tag, half):
@@ -618,3 +655,38 @@ def test_trainer_close_removes_its_hooks_and_engine():
     assert torch.isfinite(loss)
     t3.close()
     assert "_npcd_trainer" not in a.__dict__ and den.backbone.fused_engine is None
+
+
+def test_model_with_attached_trainer_copies_and_pickles_without_it(tmp_path):
+    """copy.deepcopy(model) (the common EMA-snapshot pattern) and torch.save(model) on a model with an attached trainer must not try to
+    copy or pickle the trainer -- flat buffers, streams, ctypes handles, process groups: the copy carries no trainer, no fused
+    engine and inert hooks, owns its parameters (not views of the trainer's flat buffer) and runs on the module path."""
+    import copy
+    from npcd.train import DiffusionTrainer
+    a, _ = _models()
+    tr = DiffusionTrainer(a, fused=True)
+    g = torch.Generator().manual_seed(4)
+    c0, f0 = torch.randn(2, 3, 48, generator=g).cuda(), torch.randn(2, 32, 48, generator=g).cuda()
+    tr.step(c0, f0)
+    snap = copy.deepcopy(a)
+    assert snap.__dict__.get("_npcd_trainer") is None and snap.denoiser.backbone.fused_engine is None
+    assert a.__dict__["_npcd_trainer"] is tr and a.denoiser.backbone.fused_engine is not None          # the original keeps its trainer
+    lo, hi = tr.flat.flat.data_ptr(), tr.flat.flat.data_ptr() + tr.flat.flat.numel() * 4
+    for (n, p), (_, q) in zip(snap.named_parameters(), a.named_parameters()):
+        assert torch.equal(p, q) and not (lo <= p.data_ptr() < hi), n
+    before = {n: p.detach().clone() for n, p in snap.named_parameters()}
+    tr.step(c0, f0)                                                   # the original moves on, the snapshot does not
+    assert all(torch.equal(p, before[n]) for n, p in snap.named_parameters())
+    assert any(not torch.equal(p, before[n]) for n, p in a.named_parameters())
+    t = torch.tensor([3, 700]).cuda()
+    with torch.no_grad():                                             # the snapshot is a working model (module path, inert hooks)
+        ec, ef = snap.denoiser(c0, f0, t)
+    assert torch.isfinite(ec).all() and torch.isfinite(ef).all()
+    snap.state_dict()
+    path = str(tmp_path / "whole_model.pt")
+    torch.save(a, path)
+    back = torch.load(path, weights_only=False)
+    assert back.__dict__.get("_npcd_trainer") is None and back.denoiser.backbone.fused_engine is None
+    for (n, p), (_, q) in zip(back.named_parameters(), a.named_parameters()):
+        assert torch.equal(p.cuda(), q), n
+    tr.close()

@@ -173,12 +173,17 @@ def test_losses_match_reference_golden_and_oracle(golden):
 
 
 def test_fused_point_level_layers_of_the_training_forward(monkeypatch):
-    """train_path._PointLayersX2 (round 5): the eight point-level Linear layers of the stage-1 forward as one launch of the fp32-class
-    kernel (csrc/points_x2.hip, npcd_points_x2_train: activations saved in fp32), backward = the separate layers' chain.  Against the
-    same layers as fp32 library GEMMs (NPCD_STAGE1_LIBRARY_HEADS=1) through shade_autograd on the same compact lists: sigma / rgb to
-    1e-4, the gradient of the point features to 2e-3 and of every field parameter to 5e-3 relative L2 (measured 6e-4 / 1.6e-3: the LeakyReLU units whose
-    tiny pre-activation falls on the other side of zero under the forward's 1e-5 -- two fp32 implementations differ by ~3e-4 the same
-    way, docs/experiments.md R5.4)."""
+    """train_path._PointLayersX2: the eight point-level Linear layers of the stage-1 forward (mlp_dtype="fp32_class") as one launch of
+    the fp32-class kernel (csrc/points_x2.hip, npcd_points_x2_train: activations saved in fp32), backward = the separate layers' chain;
+    beside it the same layers as fp32 library GEMMs (NPCD_STAGE1_LIBRARY_HEADS=1) through shade_autograd on the same compact lists.
+    BOTH sides are compared with a float64 evaluation of the same eight layers on the per-pair kernels' own output G (recorded from
+    the call; it is the same bits on both sides), so that "which one is off" is visible: each side earns its own
+    bar.  fp32 library side: sigma / rgb 5e-6, gradients 2e-4 rel-L2 (what is left above fp32 round-off are LeakyReLU units whose
+    tiny pre-activation falls on the other side of zero); fused fp32-class forward: sigma / rgb 1e-4, the gradient w.r.t. G 2e-3, every
+    parameter gradient 5e-3 (the same units, ~100 x more of them under the forward's 1e-5: docs/experiments.md R5.4, R6)."""
+    import copy
+    import torch.nn.functional as F
+    from npcd.hip import render as hr
     from npcd.models.pointnerf import PointNeRF, train_path as tp
     torch.manual_seed(11)
     F_, Ntab, P, k = 32, 512, 6000, 8
@@ -186,6 +191,7 @@ def test_fused_point_level_layers_of_the_training_forward(monkeypatch):
     m = PointNeRF(1, F_, Ntab, False)
     m.field.load_state_dict(p)
     field = m.cuda().train().field
+    field.train_mlp_dtype = tp.FP32_CLASS
     nb = torch.randint(0, Ntab, (P, k), dtype=torch.int64, device="cuda")
     nb[torch.rand(P, k, device="cuda") < 0.3] = -1
     nb = torch.gather(nb, 1, torch.argsort((nb < 0).int(), dim=1, stable=True))          # valid entries first
@@ -193,38 +199,100 @@ def test_fused_point_level_layers_of_the_training_forward(monkeypatch):
     pts = torch.rand(P, 3, device="cuda") - 0.5
     kp = torch.rand(1, Ntab, 3, device="cuda") - 0.5
     gs, gc = torch.randn(P, device="cuda"), torch.randn(P, 3, device="cuda")
+    rec = {}
+    pair_mlp = hr.pair_mlp
+
+    def spy(*a, **kw):                       # the per-pair kernels' output and its incoming gradient, as this call saw them
+        G = pair_mlp(*a, **kw)
+        rec["G"] = G.detach().clone()
+        G.register_hook(lambda g: rec.__setitem__("dG", g.detach().clone()))
+        return G
+    monkeypatch.setattr(hr, "pair_mlp", spy)
+    point_names = [n for n, _ in field.named_parameters() if not (n.startswith("aggregator.local_field.") and n.split(".")[2] in "0246")]
     res = {}
     for mode in ("fused", "library"):
         if mode == "library":
             monkeypatch.setenv("NPCD_STAGE1_LIBRARY_HEADS", "1")
         else:
             monkeypatch.delenv("NPCD_STAGE1_LIBRARY_HEADS", raising=False)
+        assert tp.point_layers_fused(field, field.train_mlp_dtype, P) == (mode == "fused")
         kf = torch.randn(1, Ntab, F_, device="cuda", generator=torch.Generator("cuda").manual_seed(3)).requires_grad_(True)
         for q in field.parameters():
             q.grad = None
         sig, rgb = tp.shade_autograd(field, nb, pts, kp, kf)
         ((sig * gs).sum() + (rgb * gc).sum()).backward()
-        res[mode] = (sig.detach(), rgb.detach(), kf.grad.clone(), {n: q.grad.clone() for n, q in field.named_parameters() if q.grad is not None})
+        res[mode] = (sig.detach(), rgb.detach(), rec.pop("dG"), {n: q.grad.clone() for n, q in field.named_parameters() if q.grad is not None},
+                     rec.pop("G"))
+    assert torch.equal(res["fused"][4], res["library"][4])            # same per-pair kernels in front of both: G is the same bits
     # the device-side packer (training re-packs after every optimizer step) writes the same bytes as the host packer
-    from npcd.hip import render as hr
     mods = ([field.aggregator.local_field[8]] + [q for q in field.shape_net if isinstance(q, torch.nn.Linear)]
             + [q for q in field.channel_net if isinstance(q, torch.nn.Linear)])
     assert torch.equal(hr.points_x2_pack_device(mods).cpu(), hr.points_x2_pack(field.state_dict(), "cuda").cpu())
+    # ---- float64 evaluation of the eight point-level layers on that G
+    f64 = copy.deepcopy(field).double()
+    for q in f64.parameters():
+        q.grad = None
+    G64 = res["fused"][4].double().requires_grad_(True)
+    feat = f64.aggregator.local_field[8](G64)
+    s64, c64 = F.softplus(f64.shape_net(feat) - 1.0)[:, 0], torch.sigmoid(f64.channel_net(feat))
+    ((s64 * gs.double()).sum() + (c64 * gc.double()).sum()).backward()
+    p64 = {n: q.grad for n, q in f64.named_parameters() if q.grad is not None}
+    assert set(p64) == set(point_names) and len(point_names) == 16
     rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
-    (s1, c1, g1, p1), (s0, c0, g0, p0) = res["fused"], res["library"]
+    bars = {"library": (5e-6, 2e-4, 2e-4), "fused": (1e-4, 2e-3, 5e-3)}
+    for mode in ("library", "fused"):
+        s1, c1, dG, p1, _ = res[mode]
+        assert set(p1) >= set(point_names) and len(p1) == 24
+        fwd = max(float((s1.double() - s64).abs().max()) / max(1.0, float(s64.abs().max())), float((c1.double() - c64).abs().max()))
+        worst = max((rel(p1[n], p64[n]), n) for n in point_names)
+        print(f"point-level layers [{mode}] vs float64: forward {fwd:.2e}, dG rel-L2 {rel(dG, G64.grad):.2e}, worst parameter gradient {worst}")
+        bf, bg, bp = bars[mode]
+        assert fwd < bf, (mode, fwd)
+        assert rel(dG, G64.grad) < bg, (mode, rel(dG, G64.grad))
+        assert worst[0] < bp, (mode, worst)
+
+
+def test_x2_heads_opt_in_trains(monkeypatch):
+    """NPCD_STAGE1_X2_HEADS=1 (train_path._X2Linear, opt-in): the point-level layers as split-operand library GEMMs with their own backward.
+    ADVICE r5: the forward crashed on the GPU (x2_linear_forward probed grad mode inside autograd.Function.forward, where it is off) and no
+    test covered the switch.  sigma / rgb and the gradients against the fp32 library layers of the same call."""
+    from npcd.models.pointnerf import PointNeRF, train_path as tp
+    torch.manual_seed(5)
+    F_, Ntab, P, k = 32, 256, 4500, 8
+    m = PointNeRF(1, F_, Ntab, False)
+    m.field.load_state_dict(orr.init_field_params(F_, seed=2))
+    field = m.cuda().train().field
+    field.train_mlp_dtype = tp.FP32_CLASS
+    nb = torch.randint(0, Ntab, (P, k), dtype=torch.int64, device="cuda")
+    nb[:, 4:] = -1
+    pts = torch.rand(P, 3, device="cuda") - 0.5
+    kp = torch.rand(1, Ntab, 3, device="cuda") - 0.5
+    gs, gc = torch.randn(P, device="cuda"), torch.randn(P, 3, device="cuda")
+    res = {}
+    for mode in ("x2", "library"):
+        monkeypatch.setenv("NPCD_STAGE1_X2_HEADS" if mode == "x2" else "NPCD_STAGE1_LIBRARY_HEADS", "1")
+        if mode == "library":
+            monkeypatch.delenv("NPCD_STAGE1_X2_HEADS")
+        kf = torch.randn(1, Ntab, F_, device="cuda", generator=torch.Generator("cuda").manual_seed(3)).requires_grad_(True)
+        for q in field.parameters():
+            q.grad = None
+        sig, rgb = tp.shade_autograd(field, nb, pts, kp, kf)
+        ((sig * gs).sum() + (rgb * gc).sum()).backward()
+        res[mode] = (sig.detach(), rgb.detach(), kf.grad.clone(), {n: q.grad.clone() for n, q in field.named_parameters()})
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    (s1, c1, g1, p1), (s0, c0, g0, p0) = res["x2"], res["library"]
     assert float((s1 - s0).abs().max()) < 1e-4 * max(1.0, float(s0.abs().max())) and float((c1 - c0).abs().max()) < 1e-4
-    assert rel(g1, g0) < 2e-3, rel(g1, g0)
-    assert set(p1) == set(p0) and len(p1) == 24
+    assert rel(g1, g0) < 5e-3, rel(g1, g0)
     worst = max((rel(p1[n], p0[n]), n) for n in p0)
-    print("fused point-level layers: worst parameter-gradient rel-L2", worst, "d kp_feat", rel(g1, g0))
-    assert worst[0] < 5e-3, worst
+    assert worst[0] < 1e-2, worst
 
 
-@pytest.mark.parametrize("mlp_dtype", [None, "library", torch.bfloat16])
+@pytest.mark.parametrize("mlp_dtype", [None, "fp32_class", torch.bfloat16])
 def test_stage1_training_step_reduces_the_loss(mlp_dtype):
     """PointNeRFTrainer on a synthetic target: images rendered from a 'teacher' feature table; the student starts from zeros.
-    mlp_dtype None = the reference's numerics on the fp32-class matrix-core pair MLP (csrc/pairs_mlp.hip precision 1), "library" = fp32
-    library GEMMs for every layer, torch.bfloat16 = the bf16-operand pair MLP; the fused kernels must be engaged where they are named."""
+    mlp_dtype None = the reference's numerics, true fp32 on library GEMMs for every layer (the default again since round 6);
+    "fp32_class" = the explicit opt-in on the fp32-class matrix-core pair MLP (csrc/pairs_mlp.hip precision 1), torch.bfloat16 = the
+    bf16-operand pair MLP; the fused kernels must be engaged exactly where they are named."""
     from npcd.train import PointNeRFTrainer
     B, Tn, N, F_, res = 2, 2, 512, 32, 32
     coords, feats = orr.synthetic_cloud(N, F_, B, seed=8)
@@ -248,8 +316,9 @@ def test_stage1_training_step_reduces_the_loss(mlp_dtype):
         pn.feats.get_emb().weight.view(B, N, 2 * F_)[..., F_:] = -6.0                                      # small variance
     coords_before = pn.get_all_coords().clone()
     trainer = PointNeRFTrainer(net, lr=2e-3, mlp_dtype=mlp_dtype)
-    assert ("csrc/pairs_mlp.hip" in trainer.describe()) == (mlp_dtype != "library")
-    assert ("fp32-class" in trainer.describe()) == (mlp_dtype is None)
+    assert ("csrc/pairs_mlp.hip" in trainer.describe()) == (mlp_dtype is not None)
+    assert ("fp32-class" in trainer.describe()) == (mlp_dtype == "fp32_class")
+    assert ("csrc/points_x2.hip" in trainer.describe()) == (mlp_dtype == "fp32_class")
     sample = {"images": images, "intrinsics": intr, "extrinsics": extr, "obj_idx": torch.arange(B, device="cuda")}
     torch.manual_seed(0)
     losses = [float(trainer.step(sample)[0]) for _ in range(40)]
