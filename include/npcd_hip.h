@@ -389,6 +389,12 @@ int npcd_cast_f32_dt(const float* src, void* dst, int64_t numel, int dtype, void
  * reproducible.  NPCD_ERR_UNSUPPORTED for other shapes (the caller then uses the library). */
 int npcd_wgrad_slices(int T, int N, int K);
 int npcd_wgrad(const void* dy, const void* x, float* out, float* workspace, int T, int N, int K, int dtype, void* stream);
+/* (ABI 9) `count` (1..8) such weight gradients over the SAME token range in one launch: dW_g [N_g, K_g] = dy_g[T, N_g]^T x_g[T, K_g].
+ * One workgroup per 256 x 256 output tile over all T tokens: no slices, no workspace, one fixed summation order.  Meant for the token
+ * count of one rank of the strong-scaling job (T = 4,104: the four Linear layers of a block are 192 tiles = one round on 192 of 256
+ * CUs, beside the backward's critical path on another stream).  dy / x / out / N / K: host arrays of `count` entries. */
+int npcd_wgrad_group(int count, const void* const* dy, const void* const* x, float* const* out, const int* N, const int* K, int T,
+                     int dtype, void* stream);
 
 /* Linear layers of the residual block as own NT products with fused epilogues (csrc/gemm_nt.hip): 16-bit `dtype` operands
  * (NPCD_BF16 / NPCD_F16), fp32 accumulation, 16-bit outputs; x [M, K], w [N, K] row-major (the nn.Linear weight as stored), any

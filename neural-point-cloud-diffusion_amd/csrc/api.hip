@@ -11,7 +11,7 @@ void set_hip_error(hipError_t e) {
 }
 }  // namespace npcd
 
-extern "C" int npcd_abi_version(void) { return 8; }
+extern "C" int npcd_abi_version(void) { return 9; }
 
 extern "C" const char* npcd_error_string(int code) {
     switch (code) {

@@ -25,6 +25,7 @@
 
 #include <type_traits>
 
+#include "attention_gen.h"
 #include "common.h"
 
 namespace npcd {
@@ -3024,11 +3025,16 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* ou
         NPCD_HIP_CHECK(hipGetLastError());
         return NPCD_OK;
     }
-    int rc = check_common(B, n, H, d, dtype);
+    // head dims 32 and 128 (the reference's attention works for any width / heads, transformer.py:68-84): the kernels of
+    // attention_gen.hip; NPCD_ATTN_GEN=1 sends d = 64 there too (tests: the two kernel families against each other)
+    const bool force_gen = getenv("NPCD_ATTN_GEN") != nullptr;      // (read at every call, like NPCD_ATTN_FWD)
+    const bool gen = d != 64 || force_gen;
+    int rc = check_common(B, n, H, gen && attn_gen_supported(d) ? 64 : d, dtype);
     if (rc != NPCD_OK) return rc;
     if (!q || !k || !v || !out || !lse) return NPCD_ERR_ARG;
     if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out)) return NPCD_ERR_ARG;
     if (!strides_ok(qkv_sb, qkv_sn, qkv_sh) || !strides_ok(out_sb, out_sn, out_sh)) return NPCD_ERR_ARG;
+    if (gen) return attn_gen_fwd(q, k, v, out, lse, B, n, H, d, qkv_sb, qkv_sn, qkv_sh, out_sb, out_sn, out_sh, scale, dtype, stream);
     AttnParams p{};
     p.q = q; p.k = k; p.v = v; p.o_w = out; p.lse = lse;
     p.B = B; p.n = n; p.H = H;
@@ -3211,7 +3217,9 @@ static int attn_bwd_launch(int passes, const void* q, const void* k, const void*
         NPCD_HIP_CHECK(hipGetLastError());
         return NPCD_OK;
     }
-    int rc = check_common(B, n, H, d, dtype);
+    const bool force_gen = getenv("NPCD_ATTN_GEN") != nullptr;      // (read at every call, like NPCD_ATTN_FWD)
+    const bool gen = d != 64 || (force_gen && !colsum);
+    int rc = check_common(B, n, H, gen && attn_gen_supported(d) ? 64 : d, dtype);
     if (rc != NPCD_OK) return rc;
     if (!q || !k || !v || !out || !dout || !lse || !delta) return NPCD_ERR_ARG;
     if ((passes & 1) && !dq) return NPCD_ERR_ARG;
@@ -3220,6 +3228,11 @@ static int attn_bwd_launch(int passes, const void* q, const void* k, const void*
         !aligned16(dk) || !aligned16(dv))
         return NPCD_ERR_ARG;
     if (!strides_ok(qkv_sb, qkv_sn, qkv_sh) || !strides_ok(out_sb, out_sn, out_sh) || !strides_ok(g_sb, g_sn, g_sh)) return NPCD_ERR_ARG;
+    if (gen) {
+        if (colsum) return NPCD_ERR_UNSUPPORTED;        // the column-sum by-product belongs to the d = 64 kernels (the fused backbone)
+        return attn_gen_bwd(passes, q, k, v, out, dout, lse, dq, dk, dv, delta, B, n, H, d, qkv_sb, qkv_sn, qkv_sh, out_sb, out_sn, out_sh,
+                            g_sb, g_sn, g_sh, scale, dtype, stream);
+    }
     AttnParams p{};
     p.q = q; p.k = k; p.v = v; p.out = out; p.dout = dout; p.lse = const_cast<float*>(lse); p.delta = delta;
     p.dq = dq; p.dk = dk; p.dv = dv;

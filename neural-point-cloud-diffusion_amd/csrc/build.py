@@ -28,6 +28,7 @@ SOURCES = {
     # -fno-slp-vectorize: packed fp32 VALU (v_pk_mul/add_f32) is slower than two scalar ops beside MFMAs and
     # mis-pairs the 16-bit packing (MI355X_MICROARCH.md, per-instruction cycle constants)
     "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans", "-fno-slp-vectorize"],
+    "attention_gen.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "geometry.hip": ["-ffp-contract=off"],
     "shade.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     # the rows kernel runs one wave per SIMD on the whole register file: accumulators (which the epilogues read) in VGPRs, the

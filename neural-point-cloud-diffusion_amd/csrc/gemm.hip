@@ -104,19 +104,14 @@ __device__ unsigned char g_zero_page[128];      // (zero-initialised device memo
 // (Tried: touching the 32 cache lines of a sub-tile a few stages ahead of its LDS-DMA with one plain load per wave and stage, so that
 //  the DMA finds them in the XCD's L2.  c_fc 269 -> 360 us at every distance tried (4, 6, 10 stages): vmcnt retires in order, and the
 //  far-ahead loads that miss the L2 hold the counted waits of the ring behind them.  Removed.)
+// one 256 x 256 output tile at (n0, k0) over the ring stages [s_lo, s_hi) of the token range, written to `out` (row pitch p.K)
 template <class TR>
-__global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
+__device__ __forceinline__ void wgrad_tile(const WgradParams& p, float* out, int n0, int k0, int s_lo, int s_hi) {
     using E = typename TR::elem;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];      // kRing stages x 32 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;                                   // wave tile: rows [128 wm, +128) x columns [64 wn, +64)
-    // workgroup -> (n tile, slice, k tile): k fastest, so that the workgroups of one XCD chunk share dy panels
-    const int w = xcd_remap(blockIdx.x, gridDim.x);
-    const int tk = w % p.tiles_k, s = (w / p.tiles_k) % p.S, tn = w / (p.tiles_k * p.S);
-    const int n0 = tn * 256, k0 = tk * 256;
-    const int steps = (p.T + 31) >> 5;                                         // ring stages of 32 tokens
-    const int s_lo = (int)((int64_t)steps * s / p.S), s_hi = (int)((int64_t)steps * (s + 1) / p.S);
     const E* dy = static_cast<const E*>(p.dy);
     const E* xx = static_cast<const E*>(p.x);
     const E* zeros = reinterpret_cast<const E*>(g_zero_page);
@@ -209,8 +204,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
 #undef NPCD_G_MMA
 #undef NPCD_G_WAIT
 #undef NPCD_G_VMWAIT
-    // ---- slab of this slice: row n0 + 128 wm + 32 mi + acc_row(i, hh), column k0 + 64 wn + 32 ni + (lane & 31)
-    float* out = p.out + (int64_t)s * p.N * p.K;
+    // ---- row n0 + 128 wm + 32 mi + acc_row(i, hh), column k0 + 64 wn + 32 ni + (lane & 31)
     const int r = lane & 31, hh = lane >> 5;
     if (NPCD_WGRAD_DIAG == 3 && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
@@ -221,6 +215,45 @@ __global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[(int64_t)acc_row(i, hh) * p.K] = acc[mi][ni][i];
         }
+}
+
+template <class TR>
+__global__ __launch_bounds__(512, 2) void wgrad_kernel(WgradParams p) {
+    // workgroup -> (n tile, slice, k tile): k fastest, so that the workgroups of one XCD chunk share dy panels
+    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    const int tk = w % p.tiles_k, s = (w / p.tiles_k) % p.S, tn = w / (p.tiles_k * p.S);
+    const int steps = (p.T + 31) >> 5;                                         // ring stages of 32 tokens
+    const int s_lo = (int)((int64_t)steps * s / p.S), s_hi = (int)((int64_t)steps * (s + 1) / p.S);
+    wgrad_tile<TR>(p, p.out + (int64_t)s * p.N * p.K, tn * 256, tk * 256, s_lo, s_hi);      // the slab of this slice
+}
+
+// Several weight gradients over the SAME token range in one launch (the four Linear layers of a residual block at the token count of
+// one rank of the 8-GPU job): every 256 x 256 output tile of every product is ONE workgroup over the whole token range -- no slices,
+// no slabs, no second kernel, one fixed summation order per element.  4,104 tokens x (3072 + 1024 + 4096 + 1024) x 1024: 192 tiles,
+// i.e. one round on 192 of the 256 CUs; the launch runs on a side stream beside the backward's critical path, which takes the rest.
+constexpr int kWgradGroupMax = 8;
+struct WgradGroup {
+    const void* dy[kWgradGroupMax];
+    const void* x[kWgradGroupMax];
+    float* out[kWgradGroupMax];
+    int N[kWgradGroupMax], K[kWgradGroupMax];
+    int first[kWgradGroupMax + 1];      // first tile of product g in the launch's tile order
+    int T, count;
+};
+
+template <class TR>
+__global__ __launch_bounds__(512, 2) void wgrad_group_kernel(WgradGroup gp) {
+    const int w = xcd_remap(blockIdx.x, gridDim.x);
+    int g = 0;
+#pragma unroll
+    for (int i = 1; i < kWgradGroupMax; ++i)
+        if (i < gp.count && w >= gp.first[i]) g = i;
+    WgradParams p;
+    p.dy = gp.dy[g]; p.x = gp.x[g]; p.out = gp.out[g];
+    p.T = gp.T; p.N = gp.N[g]; p.K = gp.K[g]; p.S = 1;
+    p.tiles_n = p.N / 256; p.tiles_k = p.K / 256;
+    const int t = w - gp.first[g];
+    wgrad_tile<TR>(p, p.out, (t / p.tiles_k) * 256, (t % p.tiles_k) * 256, 0, (gp.T + 31) >> 5);
 }
 
 // out[i] = slab[0][i] + slab[1][i] + ... in slice order (fp32, 16 bytes per thread and trip)
@@ -276,6 +309,38 @@ extern "C" int npcd_wgrad(const void* dy, const void* x, float* out, float* work
         const int64_t n4 = (int64_t)N * K / 4;
         const int rgrid = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rgrid), dim3(256), 0, st, reinterpret_cast<const f32x4*>(workspace), reinterpret_cast<f32x4*>(out), S, n4);
+    }
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
+}
+
+// count (<= 8) weight gradients dW_g [N_g, K_g] fp32 = dy_g[T, N_g]^T x_g[T, K_g] over one token range in ONE launch: one workgroup per
+// 256 x 256 output tile over all T tokens (no slices, no workspace); meant for token counts of a few thousand, where the tiles of all
+// products together are about one round of the chip.  Same shape rules as npcd_wgrad per product.
+extern "C" int npcd_wgrad_group(int count, const void* const* dy, const void* const* x, float* const* out, const int* N, const int* K, int T,
+                                int dtype, void* stream) {
+    if (count < 1 || count > kWgradGroupMax || !dy || !x || !out || !N || !K || T <= 0) return NPCD_ERR_ARG;
+    if (dtype != NPCD_BF16 && dtype != NPCD_F16) return NPCD_ERR_UNSUPPORTED;
+    WgradGroup gp{};
+    gp.T = T; gp.count = count;
+    int tiles = 0;
+    for (int g = 0; g < count; ++g) {
+        if (!dy[g] || !x[g] || !out[g] || N[g] <= 0 || K[g] <= 0) return NPCD_ERR_ARG;
+        if (N[g] % 256 || K[g] % 256) return NPCD_ERR_UNSUPPORTED;
+        if ((reinterpret_cast<uintptr_t>(dy[g]) & 15) || (reinterpret_cast<uintptr_t>(x[g]) & 15) || (reinterpret_cast<uintptr_t>(out[g]) & 15)) return NPCD_ERR_ARG;
+        gp.dy[g] = dy[g]; gp.x[g] = x[g]; gp.out[g] = out[g]; gp.N[g] = N[g]; gp.K[g] = K[g];
+        gp.first[g] = tiles;
+        tiles += (N[g] / 256) * (K[g] / 256);
+    }
+    gp.first[count] = tiles;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static DynLds lds_b, lds_h;
+    if (dtype == NPCD_BF16) {
+        NPCD_HIP_CHECK(lds_b.ensure(reinterpret_cast<const void*>(wgrad_group_kernel<BF16>), kRing * kStage));
+        hipLaunchKernelGGL(wgrad_group_kernel<BF16>, dim3(tiles), dim3(512), kRing * kStage, st, gp);
+    } else {
+        NPCD_HIP_CHECK(lds_h.ensure(reinterpret_cast<const void*>(wgrad_group_kernel<F16>), kRing * kStage));
+        hipLaunchKernelGGL(wgrad_group_kernel<F16>, dim3(tiles), dim3(512), kRing * kStage, st, gp);
     }
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;

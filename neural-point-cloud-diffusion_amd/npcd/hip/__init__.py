@@ -99,6 +99,7 @@ SIGNATURES = {
     "npcd_cast_f32_dt": (c_int, [_P, _P, c_int64, c_int, _P]),
     "npcd_wgrad_slices": (c_int, [c_int, c_int, c_int]),
     "npcd_wgrad": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "npcd_wgrad_group": (c_int, [c_int, POINTER(_P), POINTER(_P), POINTER(_P), POINTER(c_int), POINTER(c_int), c_int, c_int, _P]),
     "npcd_sum_slices": (c_int, [_P, _P, c_int, c_int64, _P]),
     "npcd_linear_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "npcd_linear128_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),

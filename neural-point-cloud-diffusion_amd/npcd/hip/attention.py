@@ -110,6 +110,9 @@ def _check_input(x):
 
 def _fwd_f32(q, k, v, scale, want_lse=False):
     B, n, H, d = q.shape
+    if d != 64:
+        raise RuntimeError(f"HIP fp32 attention is built for head dim 64 (got {d}); the 16-bit kernels (bf16 / f16 autocast, the reference's "
+                           "training and sampling precision options) cover head dims 32, 64 and 128")
     out = torch.empty((B, n, H, d), dtype=torch.float32, device=q.device)
     lse = torch.empty((B, H, n), dtype=torch.float32, device=q.device) if want_lse else None
     check(lib().npcd_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), B, n, H, d, q.stride(0), q.stride(1), q.stride(2),

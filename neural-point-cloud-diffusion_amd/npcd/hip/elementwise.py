@@ -167,6 +167,28 @@ def wgrad(dy, x, out):
     return True
 
 
+def wgrad_group(triples):
+    """[(dy [T, N_g], x [T, K_g], out [N_g, K_g] fp32), ...] (<= 8, one T and one 16-bit dtype): all weight gradients in ONE launch of the
+    own kernel, one workgroup per 256 x 256 tile over the whole token range (csrc/gemm.hip, npcd_wgrad_group); False if a shape is not
+    covered (the caller's per-product path then runs)."""
+    import ctypes
+    n = len(triples)
+    if not 1 <= n <= 8:
+        return False
+    T, dt = triples[0][0].shape[0], triples[0][0].dtype
+    for dy, x, out in triples:
+        if (dy.shape[0] != T or x.shape[0] != T or dy.dtype != dt or x.dtype != dt or dt not in (_bf16, _f16) or dy.shape[1] % 256 or x.shape[1] % 256
+                or not dy.is_contiguous() or not x.is_contiguous() or not out.is_contiguous() or out.dtype != _f32
+                or tuple(out.shape) != (dy.shape[1], x.shape[1])):
+            return False
+    P = ctypes.c_void_p * n
+    I = ctypes.c_int * n
+    check(lib().npcd_wgrad_group(n, P(*[ptr(t[0]) for t in triples]), P(*[ptr(t[1]) for t in triples]), P(*[ptr(t[2]) for t in triples]),
+                                 I(*[t[0].shape[1] for t in triples]), I(*[t[1].shape[1] for t in triples]), T, dtype_code(triples[0][0]), stream_ptr()),
+          "npcd_wgrad_group")
+    return True
+
+
 def sum_slices(part, out):
     """out = part.sum(dim=0) for fp32 part [S, ...] (S in 2, 4, 8), slices added in order; False if the shape is not covered."""
     S, n = part.shape[0], out.numel()

@@ -155,7 +155,6 @@ def _parse_wgrad_stream(value):
 
 _WGRAD_STREAM, _WGRAD_STREAM_MAX_T = _parse_wgrad_stream(os.environ.get("NPCD_WGRAD_STREAM"))
 _side = {}
-_side_open = {}          # device -> True while weight-gradient products on the side stream have not been joined into the main stream
 
 
 def _side_stream(device):
@@ -169,30 +168,41 @@ def _wgrad_side_ok(T):
     return _WGRAD_STREAM and T <= _WGRAD_STREAM_MAX_T
 
 
-def _wgrad_fork(pending, device):
+# Round 6: below _WGRAD_GROUP_MAX_T token rows the four weight gradients of a block are ONE launch of the own kernel (csrc/gemm.hip,
+# npcd_wgrad_group: a workgroup per 256 x 256 tile over the whole token range; 192 tiles at width 1,024), beside the critical path on the
+# side stream.  NPCD_WGRAD_GROUP=0 switches it off (the library's products), NPCD_WGRAD_GROUP_MAX_T sets the size limit.
+_WGRAD_GROUP = os.environ.get("NPCD_WGRAD_GROUP", "1") != "0"
+_WGRAD_GROUP_MAX_T = int(os.environ.get("NPCD_WGRAD_GROUP_MAX_T", "17000"))
+# Round 6: the main stream no longer waits for the side stream once per block (a cross-queue dependency costs ~10 us of an idle chip per
+# block even when it is already satisfied: tools/step_timeline.py on the rank step).  A block's gradients are handed to the reducer FROM the
+# side stream instead -- behind the block's weight gradients in that stream's order, and behind the block's critical path through the fork's
+# wait -- so a collective launched there depends on exactly what it reads; the main stream joins the side stream once, at the end of the
+# backward.  NPCD_WGRAD_JOIN_PER_BLOCK=1 restores the per-block join (A/B).
+_JOIN_PER_BLOCK = bool(os.environ.get("NPCD_WGRAD_JOIN_PER_BLOCK"))
+
+
+def _wgrad_fork(pending, device, before=None):
     """The weight-gradient products of ONE block -- (dy, x, out) triples -- on the side stream, behind everything the current stream has
     been given so far: one fork per block (per product it cost the host ~40 us of stream bookkeeping, 3.8 ms of a rank's step at
-    per-GPU batch 8, which is host-bound: tools/probes/gpu_dev_b8_hostprofile.py)."""
+    per-GPU batch 8, which is host-bound: tools/probes/gpu_dev_b8_hostprofile.py).  `before()`: called on the side stream ahead of the
+    products (the hand-over of the block above to the reducer)."""
     side = _side_stream(device)
+    with torch.cuda.stream(side):
+        if before is not None:
+            before()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for dy, x, out in pending:
             dy.record_stream(side)
             x.record_stream(side)
-            _wgrad(dy, x, out)
+        if not (_WGRAD_GROUP and pending and pending[0][0].shape[0] <= _WGRAD_GROUP_MAX_T and ew.wgrad_group(pending)):
+            for dy, x, out in pending:
+                _wgrad(dy, x, out)
     pending.clear()
-    _side_open[device] = True
 
 
 def _wgrad_join(device):
     torch.cuda.current_stream().wait_stream(_side_stream(device))
-    _side_open[device] = False
-
-
-def side_stream_joined(device) -> bool:
-    """False while weight gradients enqueued on the side stream have not been ordered before the main stream's next work: nobody may
-    hand those gradients to a consumer on another stream (the gradient reducer asserts this in mark_ready)."""
-    return not _side_open.get(device, False)
 
 
 def _no_engine():
@@ -420,9 +430,10 @@ class _BackboneFn(torch.autograd.Function):
             last["mlp_c_proj_bias_g"].copy_(dx.sum(dim=0))
             side, pending = _wgrad_side_ok(T), []
 
+            reducing = eng.reducer is not None and eng.reducer.active
+
             def ready(entry):
-                if eng.reducer is not None:
-                    assert side_stream_joined(dx.device), "weight gradients handed to the reducer before the side stream was joined"
+                if reducing:
                     for p in entry["params"]:
                         eng.reducer.mark_ready(p)
             for bi in range(len(eng.blocks) - 1, -1, -1):
@@ -488,13 +499,19 @@ class _BackboneFn(torch.autograd.Function):
                                     prev_bias_g, want_bf16=bi > 0, batch=sums)
                 del dy1, dx2
                 sums.flush()
-                if side:
-                    # the block ABOVE had this block's critical path to finish its weight gradients beside: join them, hand its
-                    # gradients on, then start this block's four products on the side stream
+                if side and _JOIN_PER_BLOCK:
+                    # (the round-5 order, A/B) the block ABOVE had this block's critical path to finish its weight gradients beside: join
+                    # them, hand its gradients on, then start this block's four products on the side stream
                     if bi + 1 < len(eng.blocks):
                         _wgrad_join(dx.device)
                         ready(eng.blocks[bi + 1])
                     _wgrad_fork(pending, dx.device)
+                elif side:
+                    # the block ABOVE is handed to the reducer ON the side stream, behind its own weight gradients (and, through the
+                    # wait of the fork that started them, behind its critical path): the main stream does not wait; then this block's
+                    # four products start there
+                    above = eng.blocks[bi + 1] if (reducing and bi + 1 < len(eng.blocks)) else None
+                    _wgrad_fork(pending, dx.device, before=None if above is None else (lambda: ready(above)))
                 else:
                     ready(e)       # this block's gradients are final (mlp.c_proj.bias was finished by the block above / the tail)
             if side:

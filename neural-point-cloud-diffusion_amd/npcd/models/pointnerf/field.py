@@ -145,8 +145,8 @@ class Field(nn.Module):
 
     def fp32_class_ok(self) -> bool:
         """Can shade_fp32 run this field?  (the published aggregator network: pointnerf.py:174-179)"""
-        from .train_path import fused_pair_mlp_precision
-        return fused_pair_mlp_precision(self, torch.float32) == hr.PAIR_MLP_X2
+        from .train_path import FP32_CLASS, fused_pair_mlp_precision
+        return fused_pair_mlp_precision(self, FP32_CLASS) == hr.PAIR_MLP_X2
 
     @torch.no_grad()
     def shade_fp32(self, nb_idx, pts, kp_pos, kp_feat, point_dir=None):

@@ -24,7 +24,11 @@ class VolumeRenderer(nn.Module):
         # fp16 range guard of the fused shading kernels (include/npcd_hip.h): the kernels raise bits in a device word when an
         # activation left the fp16 range (the reference shades in fp32).  The word comes back as out["shading_status"] -- a host
         # int where the call reads the point count from the device anyway, a device scalar on the sync-free path -- and
-        # `check_shading_status` turns a raised bit into a FloatingPointError ("raise"), a RuntimeWarning ("warn") or nothing.
+        # `check_shading_status` turns a raised bit into a FloatingPointError ("raise"), a RuntimeWarning ("warn") or nothing ("off").
+        # "promote" (round 6): the call reads the word (one host read per call, like the point count) and, if a bit is raised,
+        # shades the SAME compact lists again in the fp32-class kernels on the GPU (csrc/points_x2.hip: fp32's exponent range,
+        # nothing overflows) and marches again -- the caller gets reference-class pixels plus out["shading_promoted"] = True; no CPU
+        # path is involved.  Needs the published field architecture (Field.fp32_class_ok()).
         self.range_guard = "warn"
         # None: the fused fp16-operand shading kernels (csrc/shade.hip).  torch.float32: the reference's numerics class -- per-pair
         # layers on the fp32-class matrix-core kernel, heads on fp32 library GEMMs (Field.shade_fp32); one host read of the point
@@ -61,6 +65,7 @@ class VolumeRenderer(nn.Module):
         B, T = extr.shape[:2]
         field, agg = self.field, self.field.aggregator
         grid = agg.voxel_grid
+        promoted = False
         o, d, t0, t1 = hr.ray_gen(extr.flatten(0, 1), intr.flatten(0, 1), resolution, self.cube_scale)
         t0, t1 = self.limits(t0, t1)
         R = o.shape[1]
@@ -75,7 +80,8 @@ class VolumeRenderer(nn.Module):
             if dir_bias is not None and not hr.COMPACT_ORDERED:
                 raise RuntimeError("use_view_dir needs the ray-ordered compact lists (NPCD_COMPACT_ORDERED=0 is set)")
             worst = B * T * R * M                              # every slot of every ray valid
-            sync_free = worst <= self.sync_free_points
+            # ("promote" decides on the host what to launch next: it takes the path that reads the counters)
+            sync_free = worst <= self.sync_free_points and not (self.range_guard == "promote" and self.shade_dtype is None)
             capacity = worst if sync_free else max(4096, int(worst * self.capacity_fraction))
             while True:
                 counter, ray_base, _, ray_bits, nb, pts = grid.query_compact(agg.k, agg.r, M, rays, self.depth_resolution, capacity,
@@ -106,9 +112,19 @@ class VolumeRenderer(nn.Module):
                     P, shading_status = counter[0], counter[2]
                     break
                 P, overflow, shading_status, _ = counter.tolist()      # (the range-guard word rides on the read of the point count)
-                if not overflow:
-                    break
-                capacity = worst
+                if overflow:
+                    capacity = worst
+                    continue
+                if shading_status and self.range_guard == "promote" and self.shade_dtype is None:
+                    self._require_promotable()
+                    s32, c32 = field.shade_fp32(nb[:P], pts[:P], kp_pos, kp_feat,
+                                                None if point_ray is None else d.view(-1, 3)[point_ray[:P].long()])
+                    sigma, rgb = torch.zeros_like(sigma), torch.zeros_like(rgb)
+                    sigma[:P], rgb[:P] = s32, c32
+                    mask, depth, chan = hr.ray_march_compact(sigma, rgb, ray_bits, pts, ray_base, o.view(-1, 3), d.view(-1, 3), t1.reshape(-1),
+                                                             M, self.white_back)
+                    promoted = True
+                break
             n_pairs = int((nb[:int(P)] >= 0).sum()) if self.count_pairs else -1
         else:
             # dense path: the reference's voxel_grid=None branch (knn_mode 1), explicit sample positions (disparity-space sampling)
@@ -133,10 +149,14 @@ class VolumeRenderer(nn.Module):
                 sigma, rgb = field.shade_fp32(nb, pts, kp_pos, kp_feat, None if dir_bias is None else d.view(-1, 3)[point_ray.long()])
             else:
                 sigma, rgb = field.shade(nb, pts, kp_pos, kp_feat, dir_bias, None if dir_bias is None else point_ray, status=status)
+            shading_status = int(status)
+            if shading_status and self.range_guard == "promote" and self.shade_dtype is None:
+                self._require_promotable()
+                sigma, rgb = field.shade_fp32(nb, pts, kp_pos, kp_feat, None if dir_bias is None else d.view(-1, 3)[point_ray.long()])
+                promoted = True
             march = (valid, loc.view(Nr, M, 3), base, o.view(-1, 3), d.view(-1, 3), t1.reshape(-1), self.white_back)
             mask, depth, chan = hr.ray_march(sigma, rgb, *march)
             P, n_pairs = int(nb.shape[0]), int((nb >= 0).sum())
-            shading_status = int(status)
             if return_kp_weights:
                 kp_weights = self._kp_weights(sigma, rgb, march, nb, pts, point_ray, kp_pos).view(B, T, R, kp_pos.shape[1])
         out = AttrDict(mask=mask.view(B, T, R, 1), depth=depth.view(B, T, R, 1))
@@ -147,25 +167,35 @@ class VolumeRenderer(nn.Module):
         out["num_shading_points"] = P
         out["num_pairs"] = n_pairs
         out["shading_status"] = shading_status
-        out["shading_numerics"] = "fp32-class (two bf16 halves per operand; heads fp32)" if self.shade_dtype == torch.float32 else "fp16 operands, fp32 accumulation"
-        if not torch.is_tensor(shading_status):
+        out["shading_promoted"] = promoted
+        out["shading_numerics"] = ("fp32-class (EMULATED fp32: two bf16 halves per operand, 16 mantissa bits, fp32's range)"
+                                   if (self.shade_dtype == torch.float32 or promoted) else "fp16 operands, fp32 accumulation")
+        if not torch.is_tensor(shading_status) and not promoted:
             self.check_shading_status(shading_status)
         # which neighbour search produced this render: the reading of the (absent) torch_knnquery source, or
         # the reference's in-repo brute-force branch -- so that evaluation logs and saved renders say what they were made with
         out["grid_level"] = "brute_force" if knn_mode else getattr(grid, "grid_level", None)
         return out
 
+    def _require_promotable(self):
+        if not self.field.fp32_class_ok():
+            raise FloatingPointError("fused fp16 shading left the fp16 range and range_guard='promote' cannot re-shade this field: the "
+                                     "fp32-class kernels cover the published architecture only (Field.fp32_class_ok())")
+
     def check_shading_status(self, status) -> int:
         """The range-guard word of a render (out["shading_status"]: int, or a device scalar after a sync-free call -- reading it
         here waits for that call).  Non-zero: an fp16 activation of the fused shading MLPs overflowed, the pixels are not the
         reference's (fp32) pixels.  Acts as `range_guard` says and returns the word."""
         status = int(status)
+        if self.range_guard not in ("warn", "raise", "off", "promote"):
+            raise ValueError(f"range_guard {self.range_guard!r}: 'warn', 'raise', 'off' or 'promote'")
         if status and self.range_guard != "off":
             where = [n for bit, n in ((hr.SHADE_NONFINITE_PAIRS, "per-pair aggregator layers"), (hr.SHADE_NONFINITE_HEADS, "density / colour heads"))
                      if status & bit]
             msg = ("fused fp16 shading left the fp16 range (|activation| >= 65,520 -> inf / NaN) in the " + " and the ".join(where) +
-                   ": these pixels differ from the reference's fp32 shading; render with mlp_dtype=torch.float32")
-            if self.range_guard == "raise":
+                   ": these pixels differ from the reference's fp32 shading; render with mlp_dtype=torch.float32 "
+                   "or set renderer.range_guard = 'promote'")
+            if self.range_guard in ("raise", "promote"):      # ("promote" reaches here only for a word read AFTER a call: too late to re-shade)
                 raise FloatingPointError(msg)
             import warnings
             warnings.warn(msg, RuntimeWarning, stacklevel=3)

@@ -173,6 +173,9 @@ class GradReducer:
                 h = dist.reduce_scatter_tensor(out16, wire, op=op, group=self.group, async_op=True)
 
                 def post(o=out, o16=out16, w=wire):          # (w: keeps the send buffer alive until the collective is done)
+                    # (a bucket may be launched from the backward's side stream: tell the allocator this stream reads the buffers too)
+                    if o16.is_cuda:
+                        o16.record_stream(torch.cuda.current_stream())
                     o.copy_(o16)
                     if scale is not None:
                         o.mul_(scale)
@@ -183,6 +186,8 @@ class GradReducer:
             post = (lambda t=buf: t.mul_(scale)) if scale is not None else None
         else:
             def post(t=buf, w=wire):
+                if w.is_cuda:
+                    w.record_stream(torch.cuda.current_stream())
                 t.copy_(w)
                 if scale is not None:
                     t.mul_(scale)

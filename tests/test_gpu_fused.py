@@ -203,7 +203,6 @@ def test_side_stream_weight_gradients_at_a_rank_sized_batch_are_the_same_bits():
                 loss, _, _ = tr.model.compute_loss(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
             loss.backward()
             torch.cuda.synchronize()
-            assert fused.side_stream_joined(c0.device)
             grads[side] = tr.flat.grad.clone()
             tr.close()
             del tr, m
@@ -435,6 +434,35 @@ def test_own_weight_gradient_kernel(T, N, K, dtype):
     out2 = torch.empty_like(out)
     assert ew.wgrad(dy, x, out2) and torch.equal(out, out2)
     assert not ew.wgrad(dy[:, :100].contiguous(), x, torch.empty(100, K, device="cuda"))      # shapes it does not cover: the caller's fallback
+
+
+@pytest.mark.parametrize("T", [513 * 8, 700])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_grouped_weight_gradient_launch(T, dtype):
+    """npcd_wgrad_group (round 6): the four weight gradients of a residual block at width 1,024 -- (3072, 1024), (1024, 1024), (4096, 1024),
+    (1024, 4096) -- over one token range in ONE launch, a workgroup per 256 x 256 tile over all T tokens.  T = 4,104 is one rank's token
+    count at per-GPU batch 8 (VERDICT r5 next 1a).  Against the fp64 product of the same 16-bit operands: 1e-5 of the largest entry;
+    bitwise reproducible; equal to the single-product launch's bits wherever that one does not split the token range."""
+    from npcd.hip import elementwise as ew
+    g = torch.Generator().manual_seed(T)
+    shapes = [(3072, 1024), (1024, 1024), (4096, 1024), (1024, 4096)]
+    trip = []
+    for N, K in shapes:
+        dy = torch.randn(T, N, generator=g).to(dtype).cuda()
+        x = torch.randn(T, K, generator=g).to(dtype).cuda()
+        trip.append((dy, x, torch.full((N, K), float("nan"), device="cuda")))
+    assert ew.wgrad_group(trip)
+    for dy, x, out in trip:
+        ref = dy.double().t() @ x.double()
+        assert float((out.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    again = [(dy, x, torch.empty_like(out)) for dy, x, out in trip]
+    assert ew.wgrad_group(again)
+    assert all(torch.equal(a[2], b[2]) for a, b in zip(trip, again))
+    if ew.lib().npcd_wgrad_slices(T, 1024, 1024) == 1:
+        one = torch.empty_like(trip[1][2])
+        assert ew.wgrad(trip[1][0], trip[1][1], one) and torch.equal(one, trip[1][2])
+    assert not ew.wgrad_group([(trip[0][0][:, :100].contiguous(), trip[0][1], torch.empty(100, 1024, device="cuda"))])
+    assert not ew.wgrad_group(trip + trip + [trip[0]])           # more than eight products: the caller's per-product path
 
 
 def test_float16_training_with_dynamic_loss_scale():

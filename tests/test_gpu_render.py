@@ -357,6 +357,45 @@ def test_render_surfaces_the_range_guard(monkeypatch):
             assert out["shading_status"] & 1
 
 
+def test_range_guard_promotes_to_the_fp32_class_on_the_gpu():
+    """VolumeRenderer.range_guard = "promote" (VERDICT r5 next 2a): with weights that overflow fp16 the call re-shades the same compact
+    lists in the fp32-class kernels (npcd_pairs_x2 / npcd_points_x2) on the GPU and returns THAT -- finite pixels equal to the explicit
+    mlp_dtype=torch.float32 render bit for bit and within the fp32-class bar of the fp32 oracle; with ordinary weights nothing is promoted
+    and the fp16 kernels' pixels come back unchanged.  Sync-free and counter-reading paths, the dense (brute-force) path, and the
+    module's own record of what happened (out["shading_promoted"], out["shading_numerics"])."""
+    import warnings
+    res = 32
+    coords, feats, extr, intr = _scene(res, 1, 512, 32, seed=1)
+    args = (coords.cuda(), feats.cuda(), extr.cuda(), intr.cuda(), res)
+    p = orr.init_field_params(32, seed=0)
+    p["aggregator.local_field.2.weight"] = p["aggregator.local_field.2.weight"] * 3.0e5
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")                            # a promoted render must not warn: its pixels ARE reference-class
+        good = _model(32, 512, orr.init_field_params(32, seed=0))
+        plain = good.render(*args)["channels"]
+        good.renderer.range_guard = "promote"
+        out = good.render(*args)
+        assert out["shading_promoted"] is False and out["shading_status"] == 0 and "fp16" in out["shading_numerics"]
+        assert torch.equal(out["channels"], plain)
+        bad = _model(32, 512, p)
+        ref32 = bad.render(*args, mlp_dtype=torch.float32)
+        bad.renderer.shade_dtype = None
+        bad.renderer.range_guard = "promote"
+        for sync_free_points in (1 << 23, 0):
+            bad.renderer.sync_free_points = sync_free_points
+            out = bad.render(*args)
+            assert out["shading_promoted"] is True and out["shading_status"] & 1 and "fp32-class" in out["shading_numerics"]
+            assert torch.isfinite(out["channels"]).all() and torch.isfinite(out["mask"]).all()
+            assert torch.equal(out["channels"], ref32["channels"]) and torch.equal(out["mask"], ref32["mask"])
+        ref = orr.render(p, coords, feats, extr, intr, res=res)
+        assert float((out["channels"].cpu() - ref["channels"]).abs().max()) < 1e-3          # (activations of O(1e5): the bar of the fp32-class test)
+        dense = bad.renderer(coords.cuda(), feats.cuda(), extr.cuda(), intr.cuda(), res, False, knn_mode=1)
+        assert dense["shading_promoted"] is True and torch.isfinite(dense["channels"]).all()
+        bad.renderer.range_guard = "nonsense"
+        with pytest.raises(ValueError):
+            bad.renderer.check_shading_status(1)
+
+
 @pytest.mark.parametrize("use_dir", [False, True])
 def test_fused_point_level_layers_in_the_fp32_class(use_dir, monkeypatch):
     """csrc/points_x2.hip (round 5): the last aggregator layer and both heads on split bf16 operands (three matrix instructions per

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"libnpcd_hip.so does not export {name}"
     assert declared == set(hip.SIGNATURES), (declared ^ set(hip.SIGNATURES))
     assert L.npcd_missing == (), f"stale library, missing {L.npcd_missing}"
-    assert L.npcd_abi_version() == 8
+    assert L.npcd_abi_version() == 9
     assert L.npcd_ray_march_ws_floats(16384) >= 2 and L.npcd_ray_march_ws_floats(0) == -1
     assert L.npcd_ray_gen_ws_floats(1, 128, 0) == 4 + 2 * 64 and L.npcd_ray_gen_ws_floats(2, 128, 100) == 4 + 2 and L.npcd_ray_gen_ws_floats(0, 128, 0) == -1
     assert L.npcd_error_string(-2).decode() == "unsupported shape or dtype"
