@@ -159,21 +159,28 @@ def bench_render(device, n_iters=100, burn_in=5):
                         "roofline_query": query_roofline(S, query_ms, len(qev), rclock)}
     r = dict(per_s[128])
     # the same view with the field MLPs in the reference's numerics class (the evaluation scripts run them in fp32): per-pair layers
-    # on the fp32-class matrix-core kernel (two bf16 halves per operand, three products), fifth layer + heads on its point-level sibling
-    try:
-        net.renderer.depth_resolution = 128
-        net.renderer.count_pairs = False
-        with torch.no_grad():
-            dt32 = timed(lambda: net.render(c, f, extr, intr, 128, mlp_dtype=torch.float32), 30, 3)
-            a16 = net.render(c, f, extr, intr, 128)["channels"]
-            a32 = net.render(c, f, extr, intr, 128, mlp_dtype=torch.float32)["channels"]
-        r["fp32_class_shading"] = {"rays_per_s": 128 * 128 / dt32, "ms_per_view": dt32 * 1e3,
-                                   "max_abs_pixel_difference_to_the_fp16_operand_render": float((a16 - a32).abs().max()),
-                                   "numerics": "PointNeRF.render(mlp_dtype=torch.float32): per-pair layers with every operand as two bf16 halves "
-                                               "(csrc/pairs_mlp.hip precision 1, ~1e-5 relative), fifth layer and heads fused in the same numerics "
-                                               "(csrc/points_x2.hip; fp32 library GEMMs until late in round 5); one host read of the point count per view"}
-    except Exception as e:                      # noqa: BLE001
-        r["fp32_class_shading"] = {"error": f"{type(e).__name__}: {e}"}
+    # on the fp32-class matrix-core kernel (two bf16 halves per operand, three products), fifth layer + heads on its point-level sibling.
+    # At both depth resolutions: 128 is the reference's code, 64 what BASELINE.json configs[2] names.
+    for S in (128, 64):
+        try:
+            net.renderer.depth_resolution = S
+            net.renderer.count_pairs = False
+            with torch.no_grad():
+                dt32 = timed(lambda: net.render(c, f, extr, intr, 128, mlp_dtype=torch.float32), 30, 3)
+                a16 = net.render(c, f, extr, intr, 128)["channels"]
+                a32 = net.render(c, f, extr, intr, 128, mlp_dtype=torch.float32)["channels"]
+            entry = {"rays_per_s": 128 * 128 / dt32, "ms_per_view": dt32 * 1e3, "depth_samples": S,
+                     "max_abs_pixel_difference_to_the_fp16_operand_render": float((a16 - a32).abs().max()),
+                     "numerics": "PointNeRF.render(mlp_dtype=torch.float32): EMULATED fp32 -- per-pair layers with every operand as two bf16 halves "
+                                 "(16 mantissa bits, fp32's exponent range; three matrix instructions per product, ~4e-6 relative per product; "
+                                 "csrc/points_x2.hip pairs_x2_kernel), fifth layer and heads fused in the same numerics (points_x2_kernel); "
+                                 "7e-7 max pixel error against the fp32 oracle in the tests; one host read of the point count per view"}
+        except Exception as e:                      # noqa: BLE001
+            entry = {"error": f"{type(e).__name__}: {e}"}
+        if S == 128:
+            r["fp32_class_shading"] = entry
+        else:
+            per_s[64]["fp32_class_shading"] = entry
     # continuity with rounds 1-2, which ran the FINE-grid reading of torch_knnquery (fewer shading points with a neighbour, i.e.
     # less work per view): the same view at grid_level "fine" (DESIGN.md section 3 has the evidence for the default)
     level = net.voxel_grid.grid_level

@@ -265,6 +265,7 @@ struct QueryArgs {
     float* sample_loc;
     int32_t* slot_sample;
     int32_t* nsel;
+    int rpw;                // rays per wave of grid_query_wave_kernel (0 / 1: one)
 };
 
 // position of depth sample s of a ray: renderer.py:49-77 (eval) + volume_renderer.py:70
@@ -453,8 +454,13 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
     }
     for (int w = tid; w < a.nwords; w += blockDim.x) bitmap[w] = a.occ[(int64_t)b * a.nwords + w];
     __syncthreads();
-    const int r = rb * 4 + wave;
-    if (r >= a.R) return;
+    // a.rpw rays per wave, one after the other (round 6): a workgroup stages the cloud and the occupancy bitmap ONCE for 4 x rpw rays
+    // instead of once for 4 -- at 16,384 rays per view that was 4,096 workgroups staging 12 KB each.  Every ray is computed by the same
+    // code on wave-private LDS: the lists are the same bits whatever rpw is.
+    const int rpw = a.rpw > 0 ? a.rpw : 1;
+    for (int rr = 0; rr < rpw; ++rr) {
+    const int r = (rb * rpw + rr) * 4 + wave;
+    if (r >= a.R) break;
     const int64_t ray = (int64_t)b * a.R + r;
     float o[3] = {0, 0, 0}, d[3] = {0, 0, 0}, t0 = 0, t1 = 0;
     if (!a.x) {
@@ -774,6 +780,7 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
         }
         if (lane == 0) a.nsel[ray] = nsel;
     }
+    }   // rays of this wave
 }
 
 // Ordered compaction (second launch of npcd_grid_query_compact_ordered).  Workgroup j owns the 64 rays [64 j, 64 j + 64).  Its
@@ -1409,7 +1416,13 @@ static int grid_query_compact_launch(const npcd_grid_params* g_in, const void* w
     CompactOut co{};
     co.counter = counter; co.capacity = capacity; co.ray_base = ray_base; co.ray_nsel = ray_nsel;
     co.ray_bits = reinterpret_cast<unsigned long long*>(ray_bits); co.nb = nb_idx; co.pts = pts;
-    const int bpe = (R + 3) / 4;
+    // rays per wave: enough workgroups to fill the chip a few times over, few enough that the per-workgroup staging of the cloud stops
+    // dominating (NPCD_QUERY_RPW overrides; 1 = the round-1..5 decomposition)
+    static const int rpw_env = [] { const char* e = getenv("NPCD_QUERY_RPW"); return e ? atoi(e) : 0; }();
+    int rpw = rpw_env > 0 ? rpw_env : 4;
+    while (rpw > 1 && (int64_t)B * ((R + 4 * rpw - 1) / (4 * rpw)) < 1024) rpw >>= 1;      // keep >= 1,024 workgroups
+    a.rpw = rpw;
+    const int bpe = (R + 4 * rpw - 1) / (4 * rpw);
     const size_t lds = (size_t)N * 16 + (size_t)a.nwords * 4 + 4 * 64 * 4 + 16 + 4 * 64 * 16 + 4 * 64 * 8 + 4 * 64 * 8 * 4 + 4 * 64 * 4 * 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
     static DynLds lds_attr;

@@ -8,13 +8,13 @@ import math
 
 import torch
 
-from . import check, dtype_code, lib, ptr, require_gpu, stream_ptr
+from . import arena, check, dtype_code, lib, ptr, require_gpu, stream_ptr
 
 
 def _fwd(q, k, v, scale):
     B, n, H, d = q.shape
-    out = torch.empty((B, n, H, d), dtype=q.dtype, device=q.device)
-    lse = torch.empty((B, H, n), dtype=torch.float32, device=q.device)
+    out = arena.empty((B, n, H, d), q.dtype, q.device)
+    lse = arena.empty((B, H, n), torch.float32, q.device)
     assert q.stride() == k.stride() == v.stride() and q.stride(3) == 1
     if FWD_FP8 and q.dtype == torch.bfloat16:
         # opt-in: e4m3 operands on the block-scaled matrix instruction (csrc/attention.hip, attn_fwd_fp8_kernel); lengths it does not
@@ -27,7 +27,7 @@ def _fwd(q, k, v, scale):
                                                                 out.stride(2), scale, dtype_code(q), stream_ptr())), "npcd_attn_fwd_fp8")
             return out, lse
     nws = lib().npcd_attn_fwd_workspace_floats(B, n, H) if FWD_WS else 0
-    ws = torch.empty(nws, dtype=torch.float32, device=q.device) if nws > 0 else None
+    ws = arena.empty(nws, torch.float32, q.device) if nws > 0 else None
     check(_timed("fwd", lambda: lib().npcd_attn_fwd_ws(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), ptr(ws), B, n, H, d,
                                                        q.stride(0), q.stride(1), q.stride(2), out.stride(0), out.stride(1),
                                                        out.stride(2), scale, dtype_code(q), stream_ptr())), "npcd_attn_fwd_ws")
@@ -68,13 +68,13 @@ def colsum_part_for(dq):
         return None
     B, n, H, d = dq.shape
     rows = lib().npcd_attn_bwd_colsum_rows(B, n, H)
-    return torch.empty((rows + lib().npcd_colsum_scratch_rows(), 3 * H * d), dtype=torch.float32, device=dq.device), rows
+    return arena.empty((rows + lib().npcd_colsum_scratch_rows(), 3 * H * d), torch.float32, dq.device), rows
 
 
 def _bwd(q, k, v, out, dout, lse, dq, dk, dv, scale, colsum_part=None):
     B, n, H, d = q.shape
     # row constants handed from pass 1 to pass 2 (+ the partial sums of the edge token's three gradient rows when n = 128 j + 1)
-    delta = torch.empty(lib().npcd_attn_bwd_workspace_floats(B, n, H), dtype=torch.float32, device=q.device)
+    delta = arena.empty(lib().npcd_attn_bwd_workspace_floats(B, n, H), torch.float32, q.device)
     assert dq.stride() == dk.stride() == dv.stride() and dout.stride() == out.stride()
     if BWD_MODE == "fused":
         nslab = lib().npcd_attn_bwd_fused_slab_floats(B, n, H)

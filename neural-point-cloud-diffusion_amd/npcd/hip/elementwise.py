@@ -3,7 +3,7 @@ import ctypes
 
 import torch
 
-from . import check, dtype_code, lib, ptr, require_gpu, stream_ptr
+from . import arena, check, dtype_code, lib, ptr, require_gpu, stream_ptr
 
 _f32, _bf16, _f16 = torch.float32, torch.bfloat16, torch.float16
 MAX_JOBS = 8          # NPCD_COLSUM_MAX_JOBS
@@ -65,10 +65,10 @@ def add_ln_fwd(x_in, delta, gamma, beta, eps=1e-5, want_sum=True, dtype=_bf16):
     dev = x_in.device
     if delta is not None:
         dtype = delta.dtype
-    x_out = torch.empty_like(x_in) if (delta is not None and want_sum) else None
-    y = torch.empty((T, W), dtype=dtype, device=dev)
-    mean = torch.empty(T, dtype=_f32, device=dev)
-    rstd = torch.empty(T, dtype=_f32, device=dev)
+    x_out = arena.empty_like(x_in) if (delta is not None and want_sum) else None
+    y = arena.empty((T, W), dtype, dev)
+    mean = arena.empty(T, _f32, dev)
+    rstd = arena.empty(T, _f32, dev)
     check(_timed("add_ln_fwd" if delta is not None and want_sum else "ln_fwd",
                  lambda: lib().npcd_add_ln_fwd_dt(ptr(x_in), ptr(delta), ptr(gamma), ptr(beta), ptr(x_out), ptr(y), ptr(mean), ptr(rstd), T, W,
                                                   float(eps), dtype_code(y), stream_ptr())), "npcd_add_ln_fwd")
@@ -82,9 +82,9 @@ def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma_out, dbeta_out, dcol_out=None,
     dev = x.device
     L = lib()
     nblk = L.npcd_ln_bwd_blocks(T)
-    dx = torch.empty((T, W), dtype=_f32, device=dev)
-    dxb = torch.empty((T, W), dtype=dy.dtype, device=dev) if want_bf16 else None          # (the run's 16-bit type)
-    parts = torch.empty((3, nblk + L.npcd_colsum_scratch_rows(), W), dtype=_f32, device=dev)
+    dx = arena.empty((T, W), _f32, dev)
+    dxb = arena.empty((T, W), dy.dtype, dev) if want_bf16 else None          # (the run's 16-bit type)
+    parts = arena.empty((3, nblk + L.npcd_colsum_scratch_rows(), W), _f32, dev)
     full = dres is not None and want_bf16          # the shape bench.py prices: dy, x, dres read; dx, dx(bf16) written
     check(_timed("ln_bwd" if full else "ln_bwd_partial",
                  lambda: L.npcd_ln_bwd_dt(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(dxb), ptr(parts[0]),
@@ -98,7 +98,7 @@ def ln_bwd(dy, x, mean, rstd, gamma, dres, dgamma_out, dbeta_out, dcol_out=None,
 
 
 def gelu_fwd(h):
-    g = torch.empty_like(h)
+    g = arena.empty_like(h)
     check(_timed("gelu_fwd", lambda: lib().npcd_gelu_fwd_dt(ptr(h), ptr(g), h.numel(), dtype_code(h), stream_ptr())), "npcd_gelu_fwd")
     return g
 
@@ -109,11 +109,11 @@ def gelu_bwd(dg, h, dbias_out, batch=None, out=None, part_rows=None):
     T, N = h.shape
     L = lib()
     nblk = L.npcd_colsum_blocks(T)
-    dh = torch.empty_like(h) if out is None else out
+    dh = arena.empty_like(h) if out is None else out
     if part_rows is not None:
         check(_timed("gelu_bwd", lambda: L.npcd_gelu_bwd_dt(ptr(dg), ptr(h), ptr(dh), ptr(part_rows), T, N, dtype_code(h), stream_ptr())), "npcd_gelu_bwd")
         return dh, nblk
-    part = torch.empty((nblk + L.npcd_colsum_scratch_rows(), N), dtype=_f32, device=h.device)
+    part = arena.empty((nblk + L.npcd_colsum_scratch_rows(), N), _f32, h.device)
     check(_timed("gelu_bwd", lambda: L.npcd_gelu_bwd_dt(ptr(dg), ptr(h), ptr(dh), ptr(part), T, N, dtype_code(h), stream_ptr())), "npcd_gelu_bwd")
     _finish(batch, part, nblk, N, dbias_out)
     return dh
@@ -124,7 +124,7 @@ def colsum_bf16(a, out, batch=None):
     T, N = a.shape
     L = lib()
     nblk = L.npcd_colsum_blocks(T)
-    part = torch.empty((nblk + L.npcd_colsum_scratch_rows(), N), dtype=_f32, device=a.device)
+    part = arena.empty((nblk + L.npcd_colsum_scratch_rows(), N), _f32, a.device)
     check(L.npcd_colsum_dt(ptr(a), ptr(part), T, N, dtype_code(a), stream_ptr()), "npcd_colsum")
     _finish(batch, part, nblk, N, out)
     return out
@@ -146,8 +146,8 @@ def small_wgrad(dy, x):
         return None
     L = lib()
     nblk = L.npcd_small_wgrad_blocks(T)
-    part = torch.empty((nblk + L.npcd_colsum_scratch_rows(), J * K), dtype=_f32, device=x.device)
-    out = torch.empty((J, K), dtype=_f32, device=x.device)
+    part = arena.empty((nblk + L.npcd_colsum_scratch_rows(), J * K), _f32, x.device)
+    out = arena.empty((J, K), _f32, x.device)
     check(L.npcd_small_wgrad(ptr(dy), ptr(x), ptr(part), T, J, K, stream_ptr()), "npcd_small_wgrad")
     check(L.npcd_colsum_finalize(ptr(part), nblk, J * K, ptr(out), 0, stream_ptr()), "npcd_colsum_finalize")
     return out
@@ -162,7 +162,7 @@ def wgrad(dy, x, out):
         return False
     L = lib()
     S = L.npcd_wgrad_slices(T, N, K)
-    ws = torch.empty((S, N, K), dtype=_f32, device=dy.device) if S > 1 else None
+    ws = arena.empty((S, N, K), _f32, dy.device) if S > 1 else None
     check(L.npcd_wgrad(ptr(dy), ptr(x), ptr(out), ptr(ws), T, N, K, dtype_code(dy), stream_ptr()), "npcd_wgrad")
     return True
 
@@ -210,7 +210,7 @@ def split3(x, bias=None, gelu=False):
     require_gpu(x)
     x = x.contiguous()
     T, K = x.shape
-    out = torch.empty((T, 3 * K), dtype=torch.bfloat16, device=x.device)
+    out = arena.empty((T, 3 * K), torch.bfloat16, x.device)
     b = None if bias is None else bias.to(torch.float32).contiguous()
     check(lib().npcd_split3_bf16(ptr(x), ptr(b), ptr(out), T, K, 1 if gelu else 0, stream_ptr()), "npcd_split3_bf16")
     return out
@@ -224,12 +224,12 @@ def add_ln_split3(x, gamma, beta, o=None, bias=None, eps=1e-5):
     if W % 256 or W // 256 not in (1, 2, 3, 4, 8, 16):
         return None
     x = x.contiguous()
-    out = torch.empty((T, 3 * W), dtype=torch.bfloat16, device=x.device)
+    out = arena.empty((T, 3 * W), torch.bfloat16, x.device)
     xnew = None
     if o is not None:
         o = o.contiguous()
         bias = bias.to(torch.float32).contiguous()
-        xnew = torch.empty_like(x)
+        xnew = arena.empty_like(x)
     check(lib().npcd_add_ln_split3_bf16(ptr(x), ptr(o), ptr(bias), ptr(gamma.contiguous()), ptr(beta.contiguous()), ptr(xnew), ptr(out), T, W,
                                         float(eps), stream_ptr()), "npcd_add_ln_split3_bf16")
     return (x if xnew is None else xnew), out
@@ -242,8 +242,8 @@ def ddpm_reverse_step(x_t, eps, noise, t, tables, clip=None, want_x0=False):
     require_gpu(x_t)
     x_t, noise, eps = x_t.contiguous(), noise.contiguous(), eps.contiguous()
     B = x_t.shape[0]
-    out = torch.empty_like(x_t)
-    x0 = torch.empty_like(x_t) if want_x0 else None
+    out = arena.empty_like(x_t)
+    x0 = arena.empty_like(x_t) if want_x0 else None
     code = {torch.float32: 2, torch.bfloat16: 0}[eps.dtype]
     lo, hi = (float(clip[0]), float(clip[1])) if clip is not None else (0.0, 0.0)
     check(lib().npcd_ddpm_reverse_step(ptr(x_t), ptr(eps), code, ptr(noise), ptr(out), ptr(x0), ptr(t), B, x_t.numel() // B,
@@ -255,7 +255,7 @@ def q_sample(x0, noise, t, tab_sqrt_acp, tab_sqrt_1macp):
     """x_t = sqrt(acp[t]) x_0 + sqrt(1 - acp[t]) noise in one launch (coefficients looked up on the device).  fp32 [B, ...]."""
     require_gpu(x0, noise, t)
     x0, noise = x0.contiguous(), noise.contiguous()
-    out = torch.empty_like(x0)
+    out = arena.empty_like(x0)
     B = x0.shape[0]
     check(lib().npcd_q_sample(ptr(x0), ptr(noise), ptr(t.contiguous()), ptr(tab_sqrt_acp), ptr(tab_sqrt_1macp), ptr(out), B, x0.numel() // B,
                               stream_ptr()), "npcd_q_sample")
@@ -271,9 +271,9 @@ class _EpsMSE(torch.autograd.Function):
         L = lib()
         eps_c, noise_c = eps.contiguous(), noise.contiguous()
         n = eps_c.numel()
-        pw = torch.empty(eps_c.shape, dtype=_f32, device=eps.device) if want_pointwise else None
-        part = torch.empty(L.npcd_eps_mse_blocks(), dtype=_f32, device=eps.device)
-        loss = torch.empty(1, dtype=_f32, device=eps.device)
+        pw = arena.empty(eps_c.shape, _f32, eps.device) if want_pointwise else None
+        part = arena.empty(L.npcd_eps_mse_blocks(), _f32, eps.device)
+        loss = arena.empty(1, _f32, eps.device)
         check(L.npcd_eps_mse_fwd(ptr(noise_c), ptr(eps_c), dtype_code(eps_c), n, ptr(pw), ptr(part), ptr(loss), stream_ptr()), "npcd_eps_mse_fwd")
         ctx.save_for_backward(eps_c, noise_c)
         if pw is None:
@@ -285,7 +285,7 @@ class _EpsMSE(torch.autograd.Function):
     def backward(ctx, g, _gpw):
         from . import dtype_code
         eps, noise = ctx.saved_tensors
-        grad = torch.empty_like(eps)
+        grad = arena.empty_like(eps)
         up = g.reshape(1).to(_f32).contiguous()
         check(lib().npcd_eps_mse_bwd(ptr(noise), ptr(eps), dtype_code(eps), eps.numel(), ptr(up), ptr(grad), stream_ptr()), "npcd_eps_mse_bwd")
         return grad, None, None

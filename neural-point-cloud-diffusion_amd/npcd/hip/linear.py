@@ -2,7 +2,7 @@
 (reference transformer.py:67, :107-115, :118-137) and their data gradients."""
 import torch
 
-from . import check, dtype_code, lib, ptr, require_gpu, stream_ptr
+from . import arena, check, dtype_code, lib, ptr, require_gpu, stream_ptr
 
 _f32 = torch.float32
 
@@ -38,7 +38,7 @@ def linear_fwd(x, w, bias=None, out=None):
     _check_operands(x, w)
     M, K = x.shape
     N = w.shape[0]
-    y = torch.empty((M, N), dtype=x.dtype, device=x.device) if out is None else out
+    y = arena.empty((M, N), x.dtype, x.device) if out is None else out
     check(_timed("fwd", lambda: lib().npcd_linear_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), M, N, K, dtype_code(x), stream_ptr())), "npcd_linear_fwd")
     return y
 
@@ -52,7 +52,7 @@ def linear128_fwd(x, w, bias=None, out=None):
     _check_operands(x, w)
     M, K = x.shape
     N = w.shape[0]
-    y = torch.empty((M, N), dtype=x.dtype, device=x.device) if out is None else out
+    y = arena.empty((M, N), x.dtype, x.device) if out is None else out
     check(_timed("fwd128", lambda: lib().npcd_linear128_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), M, N, K, dtype_code(x), stream_ptr())), "npcd_linear128_fwd")
     return y
 
@@ -62,8 +62,8 @@ def linear_gelu_fwd(x, w, bias):
     _check_operands(x, w)
     M, K = x.shape
     N = w.shape[0]
-    h = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    g = torch.empty_like(h)
+    h = arena.empty((M, N), x.dtype, x.device)
+    g = arena.empty_like(h)
     check(_timed("gelu_fwd", lambda: lib().npcd_linear_gelu_fwd(ptr(x), ptr(w), ptr(bias), ptr(h), ptr(g), M, N, K, dtype_code(x), stream_ptr())),
           "npcd_linear_gelu_fwd")
     return h, g
@@ -78,8 +78,8 @@ def linear_dgelu_bwd(dy, wt, h, out=None, extra_part_rows=0):
     N = wt.shape[0]
     L = lib()
     rows = L.npcd_linear_dgelu_rows(M)
-    dh = torch.empty((M, N), dtype=dy.dtype, device=dy.device) if out is None else out
-    part = torch.empty((rows + extra_part_rows + L.npcd_colsum_scratch_rows(), N), dtype=_f32, device=dy.device)
+    dh = arena.empty((M, N), dy.dtype, dy.device) if out is None else out
+    part = arena.empty((rows + extra_part_rows + L.npcd_colsum_scratch_rows(), N), _f32, dy.device)
     check(_timed("dgelu_bwd", lambda: L.npcd_linear_dgelu_bwd(ptr(dy), ptr(wt), ptr(h), ptr(dh), ptr(part), M, N, K, dtype_code(dy), stream_ptr())),
           "npcd_linear_dgelu_bwd")
     return dh, part, rows
@@ -89,6 +89,6 @@ def transpose16(w, out=None):
     """[R, C] 16-bit -> [C, R]."""
     require_gpu(w)
     R, C = w.shape
-    o = torch.empty((C, R), dtype=w.dtype, device=w.device) if out is None else out
+    o = arena.empty((C, R), w.dtype, w.device) if out is None else out
     check(lib().npcd_transpose_16(ptr(w), ptr(o), R, C, stream_ptr()), "npcd_transpose_16")
     return o

@@ -16,6 +16,7 @@ import math
 
 import torch
 
+from ...hip import arena as harena
 from ...hip import attention as hattn
 from ...hip import elementwise as ew
 from ...hip import linear as hlin
@@ -87,7 +88,7 @@ _LIN128_MAX_T = int(os.environ.get("NPCD_LIN128_MAX_T", "4200"))
 def _linear(bias, x, w16):
     """x [T, K] bf16, w16 [N, K] bf16, bias [N] bf16 -> x @ w16^T + bias, [T, N] bf16."""
     T = x.shape[0]
-    out = torch.empty((T, w16.shape[0]), dtype=x.dtype, device=x.device)
+    out = harena.empty((T, w16.shape[0]), x.dtype, x.device)
     N, K = w16.shape
     if (_LIN128 and N == 1024 and K == 1024 and T <= _LIN128_MAX_T and x.is_cuda and x.is_contiguous() and w16.is_contiguous()
             and bias.is_contiguous() and x.dtype == w16.dtype == bias.dtype and hlin.supported128(T, N, K)):
@@ -100,7 +101,7 @@ def _linear(bias, x, w16):
 def _dgrad(dy, w16):
     """dy [T, N] bf16, w16 [N, K] bf16 -> dy @ w16, [T, K] bf16."""
     T = dy.shape[0]
-    out = torch.empty((T, w16.shape[1]), dtype=dy.dtype, device=dy.device)
+    out = harena.empty((T, w16.shape[1]), dy.dtype, dy.device)
     _split_gemm(lambda r: torch.mm(dy[r], w16, out=out[r]), T, w16.shape[1])
     return out
 
@@ -179,6 +180,11 @@ _WGRAD_GROUP_MAX_T = int(os.environ.get("NPCD_WGRAD_GROUP_MAX_T", "17000"))
 # wait -- so a collective launched there depends on exactly what it reads; the main stream joins the side stream once, at the end of the
 # backward.  NPCD_WGRAD_JOIN_PER_BLOCK=1 restores the per-block join (A/B).
 _JOIN_PER_BLOCK = bool(os.environ.get("NPCD_WGRAD_JOIN_PER_BLOCK"))
+# Round 6: below _STEP_ARENA_MAX_T token rows the ~740 buffers a step of the fused node allocates are kept and handed out again in the
+# same order by the next step (npcd/hip/arena.py): 1.6 ms of host time per step at per-GPU batch 8.  The memory of a step then stays
+# allocated between steps (at 4,104 rows ~8 GB; the caching allocator would keep most of it anyway).  NPCD_STEP_ARENA=0: off.
+_STEP_ARENA = os.environ.get("NPCD_STEP_ARENA", "1") != "0"
+_STEP_ARENA_MAX_T = int(os.environ.get("NPCD_STEP_ARENA_MAX_T", "20000"))
 
 
 def _wgrad_fork(pending, device, before=None):
@@ -207,6 +213,11 @@ def _wgrad_join(device):
 
 def _no_engine():
     return None
+
+
+import contextlib
+
+_NULL = contextlib.nullcontext()
 
 
 class FusedBackboneEngine:
@@ -250,6 +261,9 @@ class FusedBackboneEngine:
         # counts the writes to the 16-bit shadow (optimizer pass, parameter gather, re-cast): what a cached derivative of the shadow
         # -- the transposed mlp.c_proj weights of the NPCD_OWN_DGELU launch -- is stamped with
         self.shadow_epoch = 0
+        # the buffers of a step, reused by the next one (npcd.hip.arena) -- for the token counts of a rank of the strong-scaling job,
+        # where the host side of a step is as long as its GPU side; NPCD_STEP_ARENA=0 switches it off
+        self.arena = harena.StepArena() if _STEP_ARENA else None
 
     def shadow_written(self):
         self.shadow_epoch += 1
@@ -392,6 +406,25 @@ class _BackboneFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, eng):
         B, n, W = x.shape
+        T = B * n
+        arena = eng.arena if (eng.arena is not None and x.is_cuda and T <= _STEP_ARENA_MAX_T) else None
+        token = arena.begin() if arena is not None else 0
+        if not token:
+            arena = None                       # (another step of this engine still holds its buffers: plain allocations for this one)
+        ctx.arena, ctx.arena_token = arena, token
+        if arena is None:
+            return _BackboneFn._forward(ctx, x, eng)
+        ctx.arena_guard = harena.StepGuard(arena, token)      # ends the step if the graph is dropped without a backward
+        try:
+            with arena.active():
+                return _BackboneFn._forward(ctx, x, eng)
+        except BaseException:
+            arena.end(token)
+            raise
+
+    @staticmethod
+    def _forward(ctx, x, eng):
+        B, n, W = x.shape
         T, H = B * n, eng.heads
         d = W // H
         scale = 1.0 / math.sqrt(d)
@@ -415,12 +448,23 @@ class _BackboneFn(torch.autograd.Function):
                 delta = _linear(e["mlp_c_proj_bias_16"], g, e["mlp_c_proj_weight_16"])
                 saved.append((x_cur, mean1, rstd1, y1, qkv, a, lse, x2, mean2, rstd2, y2, h, g))
                 xs = x2
-            out = xs + delta                       # fp32 + bf16 -> fp32
+            out = xs + delta                       # fp32 + bf16 -> fp32  (a torch operator: the node's output is never an arena buffer)
         ctx.eng, ctx.saved, ctx.dims, ctx.scale = eng, saved, (B, n, W, H, d), scale
         return out.view(B, n, W)
 
     @staticmethod
     def backward(ctx, dout):
+        arena = ctx.arena
+        if arena is None:
+            return _BackboneFn._backward(ctx, dout)
+        try:
+            with arena.active():           # (the engine's worker thread: the arena context is per thread)
+                return _BackboneFn._backward(ctx, dout)
+        finally:
+            arena.end(ctx.arena_token)
+
+    @staticmethod
+    def _backward(ctx, dout):
         eng, (B, n, W, H, d), scale = ctx.eng, ctx.dims, ctx.scale
         T = B * n
         with torch.autocast("cuda", enabled=False):
@@ -456,7 +500,7 @@ class _BackboneFn(torch.autograd.Function):
                     if wT is None or e.get("mlp_c_proj_weight_16T_epoch") != eng.shadow_epoch or wT.dtype != w2.dtype:
                         wT = e["mlp_c_proj_weight_16T"] = hlin.transpose16(w2, out=wT if wT is not None and wT.dtype == w2.dtype else None)
                         e["mlp_c_proj_weight_16T_epoch"] = eng.shadow_epoch
-                    dh = torch.empty_like(h)
+                    dh = harena.empty_like(h)
                     extra = ew.lib().npcd_colsum_blocks(T - Tm) if Tm < T else 0
                     _, part, rows = hlin.linear_dgelu_bwd(dxb[:Tm], wT, h[:Tm], out=dh[:Tm], extra_part_rows=extra)
                     if Tm < T:       # remainder rows: library product + the separate kernel, partial rows behind the own kernel's
@@ -480,7 +524,7 @@ class _BackboneFn(torch.autograd.Function):
                 # ---- attention branch: x2 = x + c_proj(attn(c_qkv(ln_1(x)))) ---------------------------
                 da = _dgrad(dx2b, e["attn_c_proj_weight_16"])
                 wg((dx2b, a, e["attn_c_proj_weight_g"]))
-                dqkv = torch.empty_like(qkv)
+                dqkv = harena.empty_like(qkv)
                 q4, g4 = qkv.view(B, n, H, 3 * d), dqkv.view(B, n, H, 3 * d)
                 # the c_qkv bias gradient (column sums of dqkv) is a by-product of the attention backward's row stores
                 cpart = hattn.colsum_part_for(g4[..., :d]) if _ATTN_COLSUM else None
@@ -495,8 +539,10 @@ class _BackboneFn(torch.autograd.Function):
                 wg((dqkv, y1, e["attn_c_qkv_weight_g"]))
                 del dqkv, y1
                 prev_bias_g = eng.blocks[bi - 1]["mlp_c_proj_bias_g"] if bi > 0 else None
-                dx, dxb = ew.ln_bwd(dy1, x_cur, mean1, rstd1, e["ln_1_weight"], dx2, e["ln_1_weight_g"], e["ln_1_bias_g"],
-                                    prev_bias_g, want_bf16=bi > 0, batch=sums)
+                # (the last block's dx is what the node returns: allocated outside the arena, like everything that outlives the step)
+                with (harena.paused() if bi == 0 else _NULL):
+                    dx, dxb = ew.ln_bwd(dy1, x_cur, mean1, rstd1, e["ln_1_weight"], dx2, e["ln_1_weight_g"], e["ln_1_bias_g"],
+                                        prev_bias_g, want_bf16=bi > 0, batch=sums)
                 del dy1, dx2
                 sums.flush()
                 if side and _JOIN_PER_BLOCK:

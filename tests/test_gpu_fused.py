@@ -175,6 +175,83 @@ def test_weight_gradients_on_the_side_stream_are_the_same_bits():
         fused._WGRAD_STREAM = True
 
 
+def test_step_arena_reuses_buffers_and_changes_no_bits():
+    """npcd/hip/arena.py (round 6): the buffers a fused step allocates are handed out again, in order, by the next step.  Same kernels on
+    the same values: parameters after four steps on four different batches are bit-identical to a trainer without the arena; the second
+    step allocates nothing new; a forward whose graph is dropped without a backward releases the arena; two forwards before their
+    backwards (the second one falls back to plain allocations) still give the gradients of two separate steps; what leaves the node
+    (its output, the gradient of its input) is never an arena buffer."""
+    import gc
+    from npcd.models.diffusion import fused
+    from npcd.train import DiffusionTrainer
+    a, b = _models()
+    ta = DiffusionTrainer(a, fused=True)
+    eng = a.denoiser.backbone.fused_engine
+    assert eng.arena is not None
+    old = fused._STEP_ARENA
+    fused._STEP_ARENA = False
+    try:
+        tb = DiffusionTrainer(b, fused=True)
+    finally:
+        fused._STEP_ARENA = old
+    assert b.denoiser.backbone.fused_engine.arena is None
+    g = torch.Generator().manual_seed(11)
+    B, N, F_ = 3, 48, 32
+    batches = [(torch.randn(B, 3, N, generator=g).cuda(), torch.randn(B, F_, N, generator=g).cuda(), torch.randint(0, 1000, (B,), generator=g).cuda(),
+                torch.randn(B, 3, N, generator=g).cuda(), torch.randn(B, F_, N, generator=g).cuda()) for _ in range(4)]
+    for i, (c0, f0, t, cn, fn) in enumerate(batches):
+        la, _ = ta.step(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
+        lb, _ = tb.step(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
+        assert torch.equal(la, lb), i
+        if i == 0:
+            recorded = len(eng.arena.slots)
+            assert recorded > 20 and not eng.arena.busy
+        else:
+            assert len(eng.arena.slots) == recorded                  # nothing new after the first step
+    torch.cuda.synchronize()
+    assert torch.equal(ta.flat.flat, tb.flat.flat) and eng.arena.hits >= 3 * recorded
+    # a dropped graph releases the arena
+    c0, f0, t, cn, fn = batches[0]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss, _, _ = ta.model.compute_loss(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
+    assert eng.arena.busy
+    del loss
+    gc.collect()
+    assert not eng.arena.busy
+    # two forwards, then their backwards: gradients of each equal those of the same forward + backward on its own
+    def grads(batch_list, interleaved):
+        outs = []
+        ta.flat.zero_grad(); ta.reducer.start_step()
+        losses = []
+        for c0, f0, t, cn, fn in batch_list:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                l, _, _ = ta.model.compute_loss(c0, f0, t=t, coords_noise=cn, feats_noise=fn)
+            if interleaved:
+                losses.append(l)
+            else:
+                l.backward()
+                outs.append(ta.flat.grad.clone())
+        for l in losses:
+            l.backward()
+            outs.append(ta.flat.grad.clone())
+        torch.cuda.synchronize()
+        return outs
+    sep = grads(batches[:2], interleaved=False)
+    both = grads(batches[:2], interleaved=True)
+    # (the fused node OVERWRITES its gradient ranges: after the second backward the block gradients are those of the second batch)
+    lo, hi = eng.block_ranges[0][0] if eng.block_ranges else 0, eng.block_ranges[-1][1] if eng.block_ranges else ta.flat.numel
+    assert torch.equal(sep[1][lo:hi], both[1][lo:hi]) and torch.equal(sep[0][lo:hi], both[0][lo:hi])
+    assert not eng.arena.busy
+    # the node's output and input gradient are not arena buffers
+    x = torch.randn(2, N + 1, a.denoiser.backbone.width, device="cuda", requires_grad=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = a.denoiser.backbone(x)
+    y.float().sum().backward()
+    ptrs = {s.data_ptr() for s in eng.arena.slots}
+    assert y.data_ptr() not in ptrs and x.grad.data_ptr() not in ptrs
+    ta.close(); tb.close()
+
+
 def test_side_stream_weight_gradients_at_a_rank_sized_batch_are_the_same_bits():
     """The same bit-identity at the size the side stream is the default FOR (it was tested at T = 245 only): width 1,024, two
     blocks, 38 x 513 = 19,494 token rows -- just under fused._WGRAD_STREAM_MAX_T = 20,000, above _SPLIT_MIN, so the token split of the
