@@ -458,6 +458,26 @@ int npcd_ray_march_compact(const float* sigma, const float* rgb, const uint64_t*
                            int Nr, int M, int capacity, int white_back, float* mask, float* depth, float* channels,
                            float* depth_ws, void* stream);
 
+/* Fused render (ABI 9): two launches per view fewer, the same bits (Renderer.forward, renderer.py:202-268, for every pixel of
+ * `views` views per example; ray_sampler.py:10-49 + renderer.py:36-47 + aggregator.py:63-73 + renderer.py:120-185).
+ *   npcd_render_rays_query     = npcd_ray_gen + npcd_grid_query_compact_ordered in one query launch: the query kernel computes its ray
+ *       from extr [B * views, 4, 4] (world2cam) / intr [B * views, 3, 3] and writes rays_o / rays_d [B, R, 3], t0 / t1 [B, R]
+ *       (R = views * res^2) for the later stages.  t0 / t1 of a ray that misses the cube keep the raw -1 / -2; lim_part
+ *       [npcd_render_lim_words(B, R)] receives per-group (min start, max end) keys of the rays that hit.  Needs the ordered form
+ *       (order_ws) and box >= the grid's range on every axis (a missing ray then has no sample inside the grid: nothing is lost by not
+ *       sampling it between the global limits); NPCD_ERR_UNSUPPORTED otherwise -- the caller then uses the separate entry points.
+ *   npcd_ray_march_compact_fused = npcd_ray_march_compact that ends a missing ray at the global end taken from lim_part (the
+ *       renderer.py:40-43 fix-up): t0 [Nr] as written by the query, lim_part / lim_pairs = npcd_render_lim_words(B, R) / 2. */
+int64_t npcd_render_lim_words(int B, int R);
+int npcd_render_rays_query(const npcd_grid_params* grid, const void* workspace, const float* points, int B, int N, const float* extr,
+                           const float* intr, int views, int res, float box, int S, int M, int k, float r, float* rays_o, float* rays_d,
+                           float* t0, float* t1, int32_t* counter, int32_t capacity, int32_t* ray_base, int32_t* ray_nsel,
+                           uint64_t* ray_bits, int32_t* nb_idx, float* pts, void* order_ws, uint32_t* lim_part, void* stream);
+int npcd_ray_march_compact_fused(const float* sigma, const float* rgb, const uint64_t* ray_bits, const float* pts, const int32_t* ray_base,
+                                 const float* rays_o, const float* rays_d, const float* t0, const float* t1, const uint32_t* lim_part,
+                                 int lim_pairs, int Nr, int M, int capacity, int white_back, float* mask, float* depth,
+                                 float* channels, float* depth_ws, void* stream);
+
 /* ---- stage-1 training path: the data movement around the per-pair MLP (aggregators/mlp.py:36-125,
  * positional_encoder.py:16-20, aggregator.py:122-144).  Pairs (shading point, neighbour) are compact and ordered by point:
  * flat [Q] = global neighbour index, owner [Q] = shading-point index, off / cnt [P] = first pair and number of pairs of a point.

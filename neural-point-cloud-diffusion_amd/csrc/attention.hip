@@ -541,9 +541,51 @@ __device__ __forceinline__ void kv_idle_loop(unsigned char* smem, const E* kb, c
     __builtin_amdgcn_s_barrier();       // the one before the row stores
 }
 
-// online-softmax update of one 32-key half from its raw scores; returns the 16-bit P operands
+// online-softmax update of one 32-key half from its raw scores; returns the 16-bit P operands.
+// Round 6 (NPCD_FWD32_TRIGGER, default on): the form of the 64-row kernel's blk_softmax -- P = exp2(c S - m) and its lane sum FIRST, against
+// the stored maximum; only when a lane sum leaves (0, 128] (a score more than ~2^7 above the stored maximum, or the very first tile of
+// an unseeded row: exp2(+inf)) the exact row maximum is taken, O / l are rescaled and P is recomputed.  The steady-state stage loses the
+// eight v_max3, the half-wave exchange, the multiply and the compare-with-margin of the per-tile maximum: ~60 instead of ~72 vector
+// instructions per 32 x 32 score block (the kernel is bound by vector issue).  P <= 128 on the fast path; 16-bit relative
+// precision is scale-free.  NPCD_FWD32_TRIGGER=0 builds the round-1..5 form (maximum per tile, advanced when exceeded by 2^8).
+#ifndef NPCD_FWD32_TRIGGER
+#define NPCD_FWD32_TRIGGER 1
+#endif
+constexpr float kTrigger32 = 128.f;
+template <class TR>
+__device__ __forceinline__ float fwd_exp_block(const f32x16& s0, float m, float c, u32x4 (&pw)[2]) {
+    float pr[16];
+    float rs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        pr[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[j], c, -m));
+        rs += pr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pw[j >> 2][j & 3] = pack2<TR>(pr[2 * j], pr[2 * j + 1]);
+    return rs;
+}
 template <class TR>
 __device__ __forceinline__ void fwd_softmax(const f32x16& s0, f32x16& o0, f32x16& o1, float& m, float& l, float c, u32x4 (&pw)[2]) {
+#if NPCD_FWD32_TRIGGER
+    float rs = fwd_exp_block<TR>(s0, m, c, pw);
+    if (__any(!(rs <= kTrigger32))) {                 // wave-uniform; !(<=) also catches inf / nan
+        float mx = fmaxf(s0[0], s0[1]);
+#pragma unroll
+        for (int i = 2; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s0[i]), s0[i + 1]);
+        const float mn = fmaxf(m, half_max(mx) * c);  // c = scale * log2(e) > 0: m lives in the exp2 domain
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            o0[i] *= alpha;
+            o1[i] *= alpha;
+        }
+        rs = fwd_exp_block<TR>(s0, m, c, pw);
+    }
+    l += rs;
+#else
     float mx = fmaxf(s0[0], s0[1]);
 #pragma unroll
     for (int i = 2; i < 16; i += 2) mx = fmaxf(fmaxf(mx, s0[i]), s0[i + 1]);
@@ -567,6 +609,7 @@ __device__ __forceinline__ void fwd_softmax(const f32x16& s0, f32x16& o0, f32x16
         pw[j >> 2][j & 3] = pack2<TR>(a, b2);
     }
     l += rs;
+#endif
 }
 
 // One pipelined stage of the forward over FULL key tiles: the score products of half (SLOT, KB), then -- behind them on

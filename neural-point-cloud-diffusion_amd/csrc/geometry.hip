@@ -32,6 +32,50 @@ __device__ __forceinline__ float fkey_inv(uint32_t k) {
 // rays
 // ============================================================================================
 
+// One camera ray and its limits against the cube [-box, box]^3: E = world2cam [4 x 4], K = intrinsics [3 x 3], `ray` = row-major pixel
+// number.  tmin = -1, tmax = -2 for a ray that misses.  Shared by ray_gen_kernel and the fused query of a render
+// (grid_query_wave_kernel with QueryArgs::extr): the same operations in the same order, i.e. the same bits.
+__device__ __forceinline__ void gen_ray(const float* __restrict__ E, const float* __restrict__ K, int res, float box, int ray, float (&o)[3],
+                                        float (&d)[3], float& tmin, float& tmax) {
+    tmin = -1.f;
+    tmax = -2.f;
+    const float fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
+    const float x = (float)(ray % res) + 0.5f, y = (float)(ray / res) + 0.5f;
+    // ray_sampler.py:27-28
+    const float xl = (x - cx + cy * sk / fy - sk * y / fy) / fx;
+    const float yl = (y - cy) / fy;
+    // cam2world = [R^T | -R^T t]  (ray_sampler.py:35-39); world = cam2world * (xl, yl, 1, 1)
+    float w[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float r0 = E[0 * 4 + a], r1 = E[1 * 4 + a], r2 = E[2 * 4 + a];  // row a of R^T
+        o[a] = -(r0 * E[3] + r1 * E[7] + r2 * E[11]);
+        w[a] = r0 * xl + r1 * yl + r2 * 1.f + o[a] * 1.f;
+    }
+    d[0] = w[0] - o[0]; d[1] = w[1] - o[1]; d[2] = w[2] - o[2];
+    const float nrm = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);  // F.normalize eps
+#pragma unroll
+    for (int a = 0; a < 3; ++a) d[a] = d[a] / nrm;
+    // slab test (math_utils.py:46-97)
+    float lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float inv = 1.f / d[a];
+        const bool neg = inv < 0.f;
+        lo[a] = ((neg ? box : -box) - o[a]) * inv;
+        hi[a] = ((neg ? -box : box) - o[a]) * inv;
+    }
+    bool ok = true;
+    float a0 = lo[0], a1 = hi[0];
+    if (a0 > hi[1] || lo[1] > a1) ok = false;
+    a0 = fmaxf(a0, lo[1]);   // torch.max/min propagate NaN; NaN only arises for degenerate rays
+    a1 = fminf(a1, hi[1]);
+    if (a0 > hi[2] || lo[2] > a1) ok = false;
+    a0 = fmaxf(a0, lo[2]);
+    a1 = fminf(a1, hi[2]);
+    if (ok) { tmin = a0; tmax = a1; }
+}
+
 // pixel_ids (may be NULL): the n_ids pixels (row-major ids, the same for every view) to generate rays for -- the training
 // path renders ~100 random pixels per view; without it all res^2 pixels of every view are generated
 __global__ __launch_bounds__(256) void ray_gen_kernel(const float* __restrict__ extr, const float* __restrict__ intr, int V, int res,
@@ -44,43 +88,8 @@ __global__ __launch_bounds__(256) void ray_gen_kernel(const float* __restrict__ 
     if (gid < (int64_t)V * R) {
         const int v = (int)(gid / R);
         const int ray = pixel_ids ? pixel_ids[gid % R] : (int)(gid % R);
-        const float* E = extr + v * 16;
-        const float* K = intr + v * 9;
-        const float fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
-        const float x = (float)(ray % res) + 0.5f, y = (float)(ray / res) + 0.5f;
-        // ray_sampler.py:27-28
-        const float xl = (x - cx + cy * sk / fy - sk * y / fy) / fx;
-        const float yl = (y - cy) / fy;
-        // cam2world = [R^T | -R^T t]  (ray_sampler.py:35-39); world = cam2world * (xl, yl, 1, 1)
-        float o[3], w[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float r0 = E[0 * 4 + a], r1 = E[1 * 4 + a], r2 = E[2 * 4 + a];  // row a of R^T
-            o[a] = -(r0 * E[3] + r1 * E[7] + r2 * E[11]);
-            w[a] = r0 * xl + r1 * yl + r2 * 1.f + o[a] * 1.f;
-        }
-        float d[3] = {w[0] - o[0], w[1] - o[1], w[2] - o[2]};
-        const float nrm = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);  // F.normalize eps
-#pragma unroll
-        for (int a = 0; a < 3; ++a) d[a] = d[a] / nrm;
-        // slab test (math_utils.py:46-97)
-        float lo[3], hi[3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float inv = 1.f / d[a];
-            const bool neg = inv < 0.f;
-            lo[a] = ((neg ? box : -box) - o[a]) * inv;
-            hi[a] = ((neg ? -box : box) - o[a]) * inv;
-        }
-        bool ok = true;
-        float a0 = lo[0], a1 = hi[0];
-        if (a0 > hi[1] || lo[1] > a1) ok = false;
-        a0 = fmaxf(a0, lo[1]);   // torch.max/min propagate NaN; NaN only arises for degenerate rays
-        a1 = fminf(a1, hi[1]);
-        if (a0 > hi[2] || lo[2] > a1) ok = false;
-        a0 = fmaxf(a0, lo[2]);
-        a1 = fminf(a1, hi[2]);
-        if (ok) { tmin = a0; tmax = a1; }
+        float o[3], d[3];
+        gen_ray(extr + v * 16, intr + v * 9, res, box, ray, o, d, tmin, tmax);
         hit = tmax > tmin;
         rays_o[gid * 3 + 0] = o[0]; rays_o[gid * 3 + 1] = o[1]; rays_o[gid * 3 + 2] = o[2];
         rays_d[gid * 3 + 0] = d[0]; rays_d[gid * 3 + 1] = d[1]; rays_d[gid * 3 + 2] = d[2];
@@ -266,6 +275,13 @@ struct QueryArgs {
     int32_t* slot_sample;
     int32_t* nsel;
     int rpw;                // rays per wave of grid_query_wave_kernel (0 / 1: one)
+    // fused ray generation (npcd_render_rays_query; round 6): when extr is set the kernel computes its ray from the camera of view
+    // r / (res res) of example b instead of reading rays_o / rays_d / t0 / t1, and lane 0 writes it to gen_* for the later stages
+    // (t0 = -1, t1 = -2 for a ray that misses the cube: the march substitutes the global end, see ray_march_wave_kernel)
+    const float *extr, *intr;
+    int res, views;         // pixels per image edge, views per example (R = views * res * res)
+    float box;
+    float *gen_o, *gen_d, *gen_t0, *gen_t1;
 };
 
 // position of depth sample s of a ray: renderer.py:49-77 (eval) + volume_renderer.py:70
@@ -431,6 +447,11 @@ struct CompactOut {
     int32_t* ray_cnt;     // [B*R] or nullptr (atomic form)
     int32_t* st_nb;       // [B*R][M][k]
     float* st_pts;        // [B*R][M][3]
+    // fused render (round 6): compact_ordered_kernel also reduces the start / end of the rays that hit the cube over its 64 rays into
+    // lim_part[2 j], lim_part[2 j + 1] (monotone keys; 0xffffffff / 0 when none hit) -- what ray_limits_fix_kernel did in a launch of
+    // its own; the march combines the pairs (renderer.py:40-43)
+    const float *lim_t0, *lim_t1;
+    uint32_t* lim_part;   // [2 * ceil(B R / 64)] or nullptr
 };
 
 template <bool COMPACT>
@@ -454,16 +475,27 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
     }
     for (int w = tid; w < a.nwords; w += blockDim.x) bitmap[w] = a.occ[(int64_t)b * a.nwords + w];
     __syncthreads();
-    // a.rpw rays per wave, one after the other (round 6): a workgroup stages the cloud and the occupancy bitmap ONCE for 4 x rpw rays
-    // instead of once for 4 -- at 16,384 rays per view that was 4,096 workgroups staging 12 KB each.  Every ray is computed by the same
-    // code on wave-private LDS: the lists are the same bits whatever rpw is.
+    // a.rpw rays per wave, one after the other (round 6 experiment, default 1: more than one measured slower, see the launch code).
+    // Every ray is computed by the same code on wave-private LDS: the lists are the same bits whatever rpw is.
     const int rpw = a.rpw > 0 ? a.rpw : 1;
     for (int rr = 0; rr < rpw; ++rr) {
     const int r = (rb * rpw + rr) * 4 + wave;
     if (r >= a.R) break;
     const int64_t ray = (int64_t)b * a.R + r;
     float o[3] = {0, 0, 0}, d[3] = {0, 0, 0}, t0 = 0, t1 = 0;
-    if (!a.x) {
+    bool ray_hits = true;
+    if (a.extr) {
+        // the ray of pixel r % (res res) of view r / (res res) of this example, computed by every lane (wave-uniform values)
+        const int rv = a.res * a.res, view = b * a.views + r / rv;
+        gen_ray(a.extr + view * 16, a.intr + view * 9, a.res, a.box, r % rv, o, d, t0, t1);
+        ray_hits = t1 > t0;           // a ray that misses the cube has no sample inside the grid's range (the launch checks box >= range)
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { a.gen_o[ray * 3 + c] = o[c]; a.gen_d[ray * 3 + c] = d[c]; }
+            a.gen_t0[ray] = t0;
+            a.gen_t1[ray] = t1;
+        }
+    } else if (!a.x) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) { o[c] = a.rays_o[ray * 3 + c]; d[c] = a.rays_d[ray * 3 + c]; }
         t0 = a.t0[ray];
@@ -473,7 +505,7 @@ __global__ __launch_bounds__(256) void grid_query_wave_kernel(QueryArgs a, Compa
     float4* myselp = selp + wave * 64;
     const bool unit_scale = (a.g.voxel_scale[0] | a.g.voxel_scale[1] | a.g.voxel_scale[2]) == 1;      // the scaled reading
     int nsel = 0;
-    for (int s0 = 0; s0 < a.S && nsel < a.M; s0 += 64) {
+    for (int s0 = 0; ray_hits && s0 < a.S && nsel < a.M; s0 += 64) {
         const int s = s0 + lane;
         bool occ = false;
         float p[3] = {0.f, 0.f, 0.f};
@@ -844,6 +876,19 @@ __global__ __launch_bounds__(256) void compact_ordered_kernel(CompactOut co, int
         scan[lane] = base;
         if (lane == 63) scan[64] = base0 + inc;
         if (ray < nrays) co.ray_base[ray] = base;
+        if (co.lim_part) {          // (kernel-uniform) limits of this workgroup's rays that hit the cube
+            uint32_t kmin = 0xffffffffu, kmax = 0u;
+            if (ray < nrays) {
+                const float a0 = co.lim_t0[ray], a1 = co.lim_t1[ray];
+                if (a1 > a0) { kmin = fkey(a0); kmax = fkey(a1); }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, off, 64));
+                kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+            }
+            if (lane == 0) { co.lim_part[2 * blockIdx.x] = kmin; co.lim_part[2 * blockIdx.x + 1] = kmax; }
+        }
         if (ray == nrays - 1) {
             co.counter[0] = base + cnt;
             co.counter[1] = (base + cnt > co.capacity) ? 1 : 0;
@@ -994,16 +1039,38 @@ __device__ __forceinline__ float wave_total(float x) {                  // sum o
 #define NPCD_MARCH_RAYS 1
 #endif
 constexpr int kMarchRays = NPCD_MARCH_RAYS;
+// the fused render's extras of the march (null / 0 otherwise): the start of every ray + the per-workgroup limit pairs of the compaction
+// kernel (a ray that misses the cube ends at the global end)
+struct MarchFused {
+    const float* t0;
+    const uint32_t* lim_part;
+    int lim_n;
+};
 template <bool COMPACT>
 __global__ __launch_bounds__(256) void ray_march_wave_kernel(const float* __restrict__ sigma, const float* __restrict__ rgb,
                                                              const uint8_t* __restrict__ slot_valid, const float* __restrict__ slot_loc,
                                                              const int32_t* __restrict__ point_base, const float* __restrict__ rays_o,
                                                              const float* __restrict__ rays_d, const float* __restrict__ t1, int Nr, int M,
                                                              int capacity, int white_back, float* __restrict__ mask, float* __restrict__ depth,
-                                                             float* __restrict__ channels, uint32_t* ws) {
+                                                             float* __restrict__ channels, uint32_t* ws, MarchFused mf) {
     __shared__ uint32_t wg_min[4], wg_max[4];
+    __shared__ uint32_t lim_hi[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool in = lane < M;
+    // fused render: the global end of the rays that hit the cube, from the pairs compact_ordered_kernel left (a few hundred words)
+    float global_end = 0.f;
+    bool any_hit = false;
+    if (mf.lim_part) {
+        uint32_t kmax = 0u;
+        for (int i = threadIdx.x; i < mf.lim_n; i += 256) kmax = max(kmax, mf.lim_part[2 * i + 1]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, off, 64));
+        if (lane == 0) lim_hi[wave] = kmax;
+        __syncthreads();
+        kmax = max(max(lim_hi[0], lim_hi[1]), max(lim_hi[2], lim_hi[3]));
+        any_hit = kmax != 0u;
+        global_end = fkey_inv(kmax);
+    }
     float dmin = INFINITY, dmax = -INFINITY;           // this lane's slot depths over the wave's rays
     bool any = false;
 #pragma unroll 1
@@ -1012,7 +1079,8 @@ __global__ __launch_bounds__(256) void ray_march_wave_kernel(const float* __rest
         if (ray >= Nr) break;
         const float o[3] = {rays_o[ray * 3], rays_o[ray * 3 + 1], rays_o[ray * 3 + 2]};
         const float d[3] = {rays_d[ray * 3], rays_d[ray * 3 + 1], rays_d[ray * 3 + 2]};
-        const float ray_end = t1[ray];
+        float ray_end = t1[ray];
+        if (mf.lim_part && any_hit && !(ray_end > mf.t0[ray])) ray_end = global_end;      // a ray that misses the cube (renderer.py:40-43)
         unsigned long long bits;
         if (COMPACT) bits = reinterpret_cast<const unsigned long long*>(slot_valid)[ray];
         else bits = __ballot(in && slot_valid[(int64_t)ray * M + lane] != 0);
@@ -1066,6 +1134,10 @@ __global__ __launch_bounds__(256) void ray_march_wave_kernel(const float* __rest
         ws[2 + 2 * blockIdx.x] = min(min(wg_min[0], wg_min[1]), min(wg_min[2], wg_min[3]));
         ws[3 + 2 * blockIdx.x] = max(max(wg_max[0], wg_max[1]), max(wg_max[2], wg_max[3]));
     }
+    // (Round 6 tried the depth clamp HERE -- the last workgroup to finish, found through a ticket counter behind a device-scope fence,
+    //  combining the limits and clamping all depths -- to save depth_clamp_kernel's launch: a view went from 0.354 to 0.626 ms.  The march
+    //  is 4,096 workgroups of four rays; a device-scope release fence on gfx950 writes the XCD's L2 back, once per workgroup.  Removed:
+    //  docs/experiments.md R6.6.)
 }
 
 // Backward of the ray march w.r.t. the compact densities and colours (stage-1 training; slot positions, ray geometry and hence
@@ -1357,7 +1429,7 @@ extern "C" int npcd_ray_march(const float* sigma, const float* rgb, const uint8_
     if (M <= 64 && !getenv("NPCD_MARCH_PER_THREAD")) {        // (A/B switch: the thread-per-ray form)
         nparts = march_parts(Nr);
         hipLaunchKernelGGL(ray_march_wave_kernel<false>, dim3(nparts), dim3(256), 0, st, sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d,
-                           t1, Nr, M, 0, white_back, mask, depth, channels, ws);
+                           t1, Nr, M, 0, white_back, mask, depth, channels, ws, MarchFused{});
     } else {
         hipLaunchKernelGGL(march_init_kernel, dim3(1), dim3(1), 0, st, ws);
         hipLaunchKernelGGL(ray_march_kernel<false>, dim3(grid), dim3(256), 0, st, sigma, rgb, slot_valid, slot_loc, point_base, rays_o, rays_d, t1,
@@ -1388,10 +1460,16 @@ extern "C" int npcd_ray_march_bwd(const float* sigma, const float* rgb, const ui
 // arrays.  counter [4]: counter[0] receives the number of compact points, counter[1] an overflow flag (capacity too small;
 // nothing is written for the overflowing rays), counter[2] and [3] are zeroed (ABI 8: [2] is the word the caller hands to the
 // shading kernels as their range-guard `status`, zeroed here so that it costs no launch of its own).  Rows of one ray are contiguous and in slot order.
+struct RenderRays {          // fused ray generation of npcd_render_rays_query
+    const float *extr, *intr;
+    int views, res;
+    float box;
+    uint32_t* lim_part;
+};
 static int grid_query_compact_launch(const npcd_grid_params* g_in, const void* workspace, const float* points, int B, int N, int R, int S,
                                      int M, int k, float r, const float* rays_o, const float* rays_d, const float* t0, const float* t1,
                                      int32_t* counter, int32_t capacity, int32_t* ray_base, int32_t* ray_nsel, uint64_t* ray_bits,
-                                     int32_t* nb_idx, float* pts, void* order_ws, void* stream) {
+                                     int32_t* nb_idx, float* pts, void* order_ws, void* stream, const RenderRays* rr = nullptr) {
     int rc = grid_check(g_in, B, N);
     if (rc != NPCD_OK) return rc;
     const npcd_grid_params ge = effective_grid(*g_in);
@@ -1416,11 +1494,18 @@ static int grid_query_compact_launch(const npcd_grid_params* g_in, const void* w
     CompactOut co{};
     co.counter = counter; co.capacity = capacity; co.ray_base = ray_base; co.ray_nsel = ray_nsel;
     co.ray_bits = reinterpret_cast<unsigned long long*>(ray_bits); co.nb = nb_idx; co.pts = pts;
-    // rays per wave: enough workgroups to fill the chip a few times over, few enough that the per-workgroup staging of the cloud stops
-    // dominating (NPCD_QUERY_RPW overrides; 1 = the round-1..5 decomposition)
+    if (rr) {       // the rays are OUTPUTS of the query kernel here
+        a.extr = rr->extr; a.intr = rr->intr; a.views = rr->views; a.res = rr->res; a.box = rr->box;
+        a.gen_o = const_cast<float*>(rays_o); a.gen_d = const_cast<float*>(rays_d);
+        a.gen_t0 = const_cast<float*>(t0); a.gen_t1 = const_cast<float*>(t1);
+        co.lim_t0 = t0; co.lim_t1 = t1; co.lim_part = rr->lim_part;
+    }
+    // rays per wave (NPCD_QUERY_RPW, an A/B switch; default 1).  Round 6 measured 2 / 4 / 8 rays per wave on the bench view: the kernel
+    // got SLOWER -- 63.4 -> 70.4 / 103.5 / 102.7 us at 128 depth samples, 40.7 -> 40.9 / 58.5 / 58.8 at 64: the rays of a view differ by
+    // an order of magnitude in cost, a wave that draws several long ones finishes last, and the 12 KB of staging per workgroup it saves
+    // were never the limit (docs/experiments.md R6.7).
     static const int rpw_env = [] { const char* e = getenv("NPCD_QUERY_RPW"); return e ? atoi(e) : 0; }();
-    int rpw = rpw_env > 0 ? rpw_env : 4;
-    while (rpw > 1 && (int64_t)B * ((R + 4 * rpw - 1) / (4 * rpw)) < 1024) rpw >>= 1;      // keep >= 1,024 workgroups
+    int rpw = rpw_env > 0 ? rpw_env : 1;
     a.rpw = rpw;
     const int bpe = (R + 4 * rpw - 1) / (4 * rpw);
     const size_t lds = (size_t)N * 16 + (size_t)a.nwords * 4 + 4 * 64 * 4 + 16 + 4 * 64 * 16 + 4 * 64 * 8 + 4 * 64 * 8 * 4 + 4 * 64 * 4 * 4;
@@ -1473,9 +1558,9 @@ extern "C" int npcd_grid_query_compact_ordered(const npcd_grid_params* g_in, con
 }
 
 // Ray march on the compact layout produced by npcd_grid_query_compact.
-extern "C" int npcd_ray_march_compact(const float* sigma, const float* rgb, const uint64_t* ray_bits, const float* pts, const int32_t* ray_base,
-                                      const float* rays_o, const float* rays_d, const float* t1, int Nr, int M, int capacity, int white_back,
-                                      float* mask, float* depth, float* channels, float* depth_ws, void* stream) {
+static int ray_march_compact_launch(const float* sigma, const float* rgb, const uint64_t* ray_bits, const float* pts, const int32_t* ray_base,
+                                    const float* rays_o, const float* rays_d, const float* t1, int Nr, int M, int capacity, int white_back,
+                                    float* mask, float* depth, float* channels, float* depth_ws, const MarchFused& mf, void* stream) {
     if (!sigma || !rgb || !ray_bits || !pts || !ray_base || !rays_o || !rays_d || !t1 || !mask || !depth || !channels || !depth_ws)
         return NPCD_ERR_ARG;
     if (Nr <= 0 || M <= 0 || M > 64 || capacity <= 0) return NPCD_ERR_ARG;
@@ -1483,10 +1568,12 @@ extern "C" int npcd_ray_march_compact(const float* sigma, const float* rgb, cons
     uint32_t* ws = reinterpret_cast<uint32_t*>(depth_ws);
     const int grid = (Nr + 255) / 256;
     int nparts = 0;
-    if (!getenv("NPCD_MARCH_PER_THREAD")) {
+    const bool per_thread = getenv("NPCD_MARCH_PER_THREAD") != nullptr;
+    if (per_thread && mf.lim_part) return NPCD_ERR_UNSUPPORTED;
+    if (!per_thread) {
         nparts = march_parts(Nr);
         hipLaunchKernelGGL(ray_march_wave_kernel<true>, dim3(nparts), dim3(256), 0, st, sigma, rgb, reinterpret_cast<const uint8_t*>(ray_bits), pts,
-                           ray_base, rays_o, rays_d, t1, Nr, M, capacity, white_back, mask, depth, channels, ws);
+                           ray_base, rays_o, rays_d, t1, Nr, M, capacity, white_back, mask, depth, channels, ws, mf);
     } else {
         hipLaunchKernelGGL(march_init_kernel, dim3(1), dim3(1), 0, st, ws);
         hipLaunchKernelGGL(ray_march_kernel<true>, dim3(grid), dim3(256), 0, st, sigma, rgb, reinterpret_cast<const uint8_t*>(ray_bits), pts, ray_base,
@@ -1495,4 +1582,44 @@ extern "C" int npcd_ray_march_compact(const float* sigma, const float* rgb, cons
     hipLaunchKernelGGL(depth_clamp_kernel, dim3(grid), dim3(256), 0, st, Nr, depth, ws, nparts);
     NPCD_HIP_CHECK(hipGetLastError());
     return NPCD_OK;
+}
+extern "C" int npcd_ray_march_compact(const float* sigma, const float* rgb, const uint64_t* ray_bits, const float* pts, const int32_t* ray_base,
+                                      const float* rays_o, const float* rays_d, const float* t1, int Nr, int M, int capacity, int white_back,
+                                      float* mask, float* depth, float* channels, float* depth_ws, void* stream) {
+    return ray_march_compact_launch(sigma, rgb, ray_bits, pts, ray_base, rays_o, rays_d, t1, Nr, M, capacity, white_back, mask, depth, channels,
+                                    depth_ws, MarchFused{}, stream);
+}
+
+// ---- fused render (round 6, ABI 9): ray generation inside the neighbour query, the box-limit fix-up inside the march -- two launches
+// per view fewer (ray_gen_kernel, ray_limits_fix_kernel), the same bits.
+// npcd_render_rays_query = npcd_ray_gen + npcd_grid_query_compact_ordered for all views * res^2 pixels of every example, except that
+// t0 / t1 of a ray that misses the cube keep their raw values (-1, -2) and lim_part [npcd_render_lim_words(B, R)] receives per-group
+// (min start, max end) keys; npcd_ray_march_compact_fused takes those.  Needs box >= the grid's range on every axis (a ray that misses
+// the cube then has no sample in the grid).
+extern "C" int64_t npcd_render_lim_words(int B, int R) {
+    if (B <= 0 || R <= 0) return -1;
+    return 2 * (((int64_t)B * R + kOrdRays - 1) / kOrdRays);
+}
+extern "C" int npcd_render_rays_query(const npcd_grid_params* g_in, const void* workspace, const float* points, int B, int N, const float* extr,
+                                      const float* intr, int views, int res, float box, int S, int M, int k, float r, float* rays_o,
+                                      float* rays_d, float* t0, float* t1, int32_t* counter, int32_t capacity, int32_t* ray_base,
+                                      int32_t* ray_nsel, uint64_t* ray_bits, int32_t* nb_idx, float* pts, void* order_ws, uint32_t* lim_part,
+                                      void* stream) {
+    if (!g_in || !extr || !intr || !lim_part || views <= 0 || res <= 0) return NPCD_ERR_ARG;
+    if (!order_ws || (reinterpret_cast<uintptr_t>(order_ws) & 15) || (reinterpret_cast<uintptr_t>(nb_idx) & 15)) return NPCD_ERR_ARG;
+    if ((int64_t)views * res * res > (1 << 28)) return NPCD_ERR_UNSUPPORTED;
+    for (int a = 0; a < 3; ++a)
+        if (!(box >= g_in->range_max[a]) || !(-box <= g_in->range_min[a])) return NPCD_ERR_UNSUPPORTED;
+    RenderRays rr{extr, intr, views, res, box, lim_part};
+    return grid_query_compact_launch(g_in, workspace, points, B, N, views * res * res, S, M, k, r, rays_o, rays_d, t0, t1, counter, capacity,
+                                     ray_base, ray_nsel, ray_bits, nb_idx, pts, order_ws, stream, &rr);
+}
+extern "C" int npcd_ray_march_compact_fused(const float* sigma, const float* rgb, const uint64_t* ray_bits, const float* pts,
+                                            const int32_t* ray_base, const float* rays_o, const float* rays_d, const float* t0, const float* t1,
+                                            const uint32_t* lim_part, int lim_pairs, int Nr, int M, int capacity,
+                                            int white_back, float* mask, float* depth, float* channels, float* depth_ws, void* stream) {
+    if (!t0 || !lim_part || lim_pairs <= 0) return NPCD_ERR_ARG;
+    MarchFused mf{t0, lim_part, lim_pairs};
+    return ray_march_compact_launch(sigma, rgb, ray_bits, pts, ray_base, rays_o, rays_d, t1, Nr, M, capacity, white_back, mask, depth, channels,
+                                    depth_ws, mf, stream);
 }

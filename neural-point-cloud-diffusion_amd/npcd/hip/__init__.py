@@ -59,6 +59,10 @@ SIGNATURES = {
                                         + [_P, _P]),
     "npcd_grid_query_order_ws_bytes": (c_int64, [c_int] * 4),
     "npcd_ray_march_compact": (c_int, [_P] * 8 + [c_int, c_int, c_int, c_int] + [_P] * 4 + [_P]),
+    "npcd_render_lim_words": (c_int64, [c_int, c_int]),
+    "npcd_render_rays_query": (c_int, [POINTER(GridParams), _P, _P, c_int, c_int, _P, _P, c_int, c_int, c_float, c_int, c_int, c_int, c_float]
+                               + [_P] * 5 + [c_int32] + [_P] * 7 + [_P]),
+    "npcd_ray_march_compact_fused": (c_int, [_P] * 10 + [c_int, c_int, c_int, c_int, c_int] + [_P] * 4 + [_P]),
     "npcd_ray_gen": (c_int, [_P, _P, c_int, c_int, c_float] + [_P] * 5 + [_P]),
     "npcd_ray_gen_subset": (c_int, [_P, _P, c_int, c_int, c_float, _P, c_int] + [_P] * 5 + [_P]),
     "npcd_shade_wpack_bytes": (c_int64, [c_int, c_int, c_int]),

@@ -75,6 +75,12 @@ QUERY_EVENTS = None
 # which the rays' waves reach an atomic counter (same per-ray content, ~2 % faster, last bits of the image vary between runs
 # through the order of the float atomics in the weight gradients only -- the forward is order-independent either way).
 COMPACT_ORDERED = os.environ.get("NPCD_COMPACT_ORDERED", "1") != "0"
+# Round 6 (OPT-IN, NPCD_RENDER_FUSED_RAYS=1): the fused render can generate its rays inside the query launch and fix the limits of missing
+# rays inside the march (npcd_render_rays_query / npcd_ray_march_compact_fused: two launches per view fewer, the same bits --
+# tests/test_gpu_render.py::test_rays_generated_inside_the_query_launch_are_the_same_bits).  Measured: 0.353 against 0.351-0.352 ms per view
+# at 128 depth samples, 0.210 against 0.207 at 64 -- what the two 5-us launches cost, the per-wave ray arithmetic and the limit pairs cost
+# again inside the 4,096-workgroup kernels (docs/experiments.md R6.6).  Not the default.
+FUSED_RAYS = os.environ.get("NPCD_RENDER_FUSED_RAYS", "0") == "1"
 
 
 class HipVoxelGrid:
@@ -189,6 +195,50 @@ class HipVoxelGrid:
             ev[1].record()
             QUERY_EVENTS.append(ev)
         return counter, ray_base, ray_nsel, ray_bits, nb, cpts
+
+    def query_compact_rays(self, k: int, r: float, M: int, extr: torch.Tensor, intr: torch.Tensor, res: int, box: float, S: int,
+                           capacity: int, points: Optional[torch.Tensor] = None):
+        """Fused render form (npcd_render_rays_query, round 6): ray generation inside the query launch.  extr [B, T, 4, 4], intr [B, T, 3, 3]
+        -> (rays (o [B, T R, 3], d, t0 [B, T R], t1 -- t0 / t1 RAW for rays that miss the cube), lim_part, counter, ray_base, ray_nsel,
+        ray_bits, nb, pts) or None when the configuration is not covered (cube smaller than the grid's range, unordered lists): the
+        caller then generates the rays with ray_gen and calls query_compact."""
+        if not COMPACT_ORDERED or not FUSED_RAYS:
+            return None
+        g = self.params
+        if any(not (box >= g.range_max[a] and -box <= g.range_min[a]) for a in range(3)):
+            return None
+        pts_t = self.points if points is None else points.detach().to(_f32).contiguous()
+        B, N, _ = pts_t.shape
+        T = extr.shape[1]
+        R = T * res * res
+        dev = pts_t.device
+        extr = extr.to(_f32).contiguous()
+        intr = intr.to(_f32).contiguous()
+        o = torch.empty((B, R, 3), dtype=_f32, device=dev)
+        d = torch.empty((B, R, 3), dtype=_f32, device=dev)
+        t0 = torch.empty((B, R), dtype=_f32, device=dev)
+        t1 = torch.empty((B, R), dtype=_f32, device=dev)
+        counter = torch.empty(4, dtype=_i32, device=dev)
+        ray_base = torch.empty(B * R, dtype=_i32, device=dev)
+        ray_nsel = torch.empty(B * R, dtype=_i32, device=dev)
+        ray_bits = torch.empty(B * R, dtype=torch.int64, device=dev)
+        nb = torch.empty((capacity, k), dtype=_i32, device=dev)
+        cpts = torch.empty((capacity, 3), dtype=_f32, device=dev)
+        L = lib()
+        order_ws = torch.empty(L.npcd_grid_query_order_ws_bytes(B, R, int(M), int(k)), dtype=torch.uint8, device=dev)
+        lim = torch.empty(L.npcd_render_lim_words(B, R), dtype=_i32, device=dev)
+        ev = None
+        if QUERY_EVENTS is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        check(L.npcd_render_rays_query(ctypes.byref(self.params), ptr(self.workspace), ptr(pts_t), B, N, ptr(extr), ptr(intr), T, int(res),
+                                       float(box), int(S), int(M), int(k), float(r), ptr(o), ptr(d), ptr(t0), ptr(t1), ptr(counter),
+                                       int(capacity), ptr(ray_base), ptr(ray_nsel), ptr(ray_bits), ptr(nb), ptr(cpts), ptr(order_ws), ptr(lim),
+                                       stream_ptr()), "npcd_render_rays_query")
+        if ev is not None:
+            ev[1].record()
+            QUERY_EVENTS.append(ev)
+        return (o, d, t0, t1), lim, counter, ray_base, ray_nsel, ray_bits, nb, cpts
 
     def query(self, x: torch.Tensor, k: int, r: float, max_shading_pts: int):
         """torch_knnquery.VoxelGrid.query contract (aggregator.py:63-73):
@@ -362,14 +412,22 @@ def shade_points(wpack: torch.Tensor, feat_dim: int, nb_idx: torch.Tensor, pts: 
     return sigma, rgb
 
 
-def ray_march_compact(sigma, rgb, ray_bits, pts, ray_base, rays_o, rays_d, t1, M, white_back=True):
-    """Ray march on the compact layout of HipVoxelGrid.query_compact."""
+def ray_march_compact(sigma, rgb, ray_bits, pts, ray_base, rays_o, rays_d, t1, M, white_back=True, fused=None):
+    """Ray march on the compact layout of HipVoxelGrid.query_compact.  `fused` = (t0, lim_part) of query_compact_rays: the march then
+    ends rays that miss the cube at the global end itself (npcd_ray_march_compact_fused)."""
     Nr = ray_base.shape[0]
     dev = ray_base.device
     mask = torch.empty(Nr, dtype=_f32, device=dev)
     depth = torch.empty(Nr, dtype=_f32, device=dev)
     chan = torch.empty((Nr, 3), dtype=_f32, device=dev)
     ws = torch.empty(lib().npcd_ray_march_ws_floats(Nr), dtype=_f32, device=dev)
+    if fused is not None:
+        t0, lim = fused
+        check(lib().npcd_ray_march_compact_fused(ptr(sigma), ptr(rgb), ptr(ray_bits), ptr(pts), ptr(ray_base), ptr(rays_o.contiguous()),
+                                                 ptr(rays_d.contiguous()), ptr(t0.contiguous()), ptr(t1.contiguous()), ptr(lim), lim.numel() // 2,
+                                                 Nr, int(M), int(sigma.shape[0]), int(bool(white_back)), ptr(mask), ptr(depth),
+                                                 ptr(chan), ptr(ws), stream_ptr()), "npcd_ray_march_compact_fused")
+        return mask, depth, chan
     check(lib().npcd_ray_march_compact(ptr(sigma), ptr(rgb), ptr(ray_bits), ptr(pts), ptr(ray_base), ptr(rays_o.contiguous()),
                                        ptr(rays_d.contiguous()), ptr(t1.contiguous()), Nr, int(M), int(sigma.shape[0]), int(bool(white_back)), ptr(mask),
                                        ptr(depth), ptr(chan), ptr(ws), stream_ptr()), "npcd_ray_march_compact")

@@ -66,13 +66,24 @@ class VolumeRenderer(nn.Module):
         field, agg = self.field, self.field.aggregator
         grid = agg.voxel_grid
         promoted = False
-        o, d, t0, t1 = hr.ray_gen(extr.flatten(0, 1), intr.flatten(0, 1), resolution, self.cube_scale)
-        t0, t1 = self.limits(t0, t1)
-        R = o.shape[1]
-        Nr = B * T * R
-        rays = (o.view(B, T * R, 3), d.view(B, T * R, 3), t0.view(B, T * R), t1.view(B, T * R))
         M = agg.max_shading_pts
-        dir_bias = field.dir_bias(d.view(-1, 3))           # None unless use_view_dir
+        R = resolution * resolution
+        Nr = B * T * R
+        # Round 6, opt-in (hr.FUSED_RAYS, NPCD_RENDER_FUSED_RAYS=1; measured no faster: docs/experiments.md R6.6): in the published
+        # configuration the rays can be generated INSIDE the neighbour-query launch and the limits of rays that miss the cube fixed inside
+        # the march (hr.query_compact_rays / ray_march_compact(fused=...)): two launches per view fewer, bit-identical results.  Fixed ray
+        # limits, view directions (their bias table needs the directions before the query) and the dense option paths always generate
+        # the rays with the separate kernel.
+        rays_in_query = (knn_mode == 0 and not self.disparity_space_sampling and not return_kp_weights and self.ray_limits is None
+                         and not field.use_dir and hr.FUSED_RAYS and hr.COMPACT_ORDERED)
+        fused_pack = None
+        if not rays_in_query:
+            o, d, t0, t1 = hr.ray_gen(extr.flatten(0, 1), intr.flatten(0, 1), resolution, self.cube_scale)
+            t0, t1 = self.limits(t0, t1)
+            rays = (o.view(B, T * R, 3), d.view(B, T * R, 3), t0.view(B, T * R), t1.view(B, T * R))
+            dir_bias = field.dir_bias(d.view(-1, 3))           # None unless use_view_dir
+        else:
+            rays, dir_bias = None, None
         kp_weights = None
         if knn_mode == 0 and not self.disparity_space_sampling and not return_kp_weights:
             # fused path: compact shading-point lists are produced on the device; the shading kernels read the
@@ -84,8 +95,20 @@ class VolumeRenderer(nn.Module):
             sync_free = worst <= self.sync_free_points and not (self.range_guard == "promote" and self.shade_dtype is None)
             capacity = worst if sync_free else max(4096, int(worst * self.capacity_fraction))
             while True:
-                counter, ray_base, _, ray_bits, nb, pts = grid.query_compact(agg.k, agg.r, M, rays, self.depth_resolution, capacity,
-                                                                           points=kp_pos)
+                got = None
+                if rays_in_query:
+                    got = grid.query_compact_rays(agg.k, agg.r, M, extr, intr, resolution, self.cube_scale, self.depth_resolution, capacity,
+                                                  points=kp_pos)
+                    if got is None:            # (a cube smaller than the grid's range: the separate ray kernel after all)
+                        rays_in_query = False
+                        o, d, t0, t1 = hr.ray_gen(extr.flatten(0, 1), intr.flatten(0, 1), resolution, self.cube_scale)
+                        rays = (o.view(B, T * R, 3), d.view(B, T * R, 3), t0.view(B, T * R), t1.view(B, T * R))
+                if got is not None:
+                    (o, d, t0, t1), lim, counter, ray_base, _, ray_bits, nb, pts = got
+                    fused_pack = (t0.view(-1), lim)
+                else:
+                    counter, ray_base, _, ray_bits, nb, pts = grid.query_compact(agg.k, agg.r, M, rays, self.depth_resolution, capacity,
+                                                                               points=kp_pos)
                 point_ray = None
                 if dir_bias is not None:       # lists are in ray order: row p belongs to the last ray whose base is <= p
                     point_ray = (torch.searchsorted(ray_base, torch.arange(capacity, dtype=torch.int32, device=ray_base.device),
@@ -105,7 +128,7 @@ class VolumeRenderer(nn.Module):
                                                  kp_feat.reshape(-1, kp_feat.shape[-1]), n_points=counter[:1], n_freqs=agg.n_freqs,
                                                  hidden=field.hid_dim, dir_bias=dir_bias, point_ray=point_ray, status=counter[2:3])
                 mask, depth, chan = hr.ray_march_compact(sigma, rgb, ray_bits, pts, ray_base, o.view(-1, 3), d.view(-1, 3), t1.reshape(-1),
-                                                         M, self.white_back)
+                                                         M, self.white_back, fused=fused_pack)
                 if sync_free:
                     # buffers sized for the worst case cannot overflow: nothing to check, the call returns without a host
                     # round trip (the point count stays a device scalar) and the next call's launches overlap this one
@@ -122,7 +145,7 @@ class VolumeRenderer(nn.Module):
                     sigma, rgb = torch.zeros_like(sigma), torch.zeros_like(rgb)
                     sigma[:P], rgb[:P] = s32, c32
                     mask, depth, chan = hr.ray_march_compact(sigma, rgb, ray_bits, pts, ray_base, o.view(-1, 3), d.view(-1, 3), t1.reshape(-1),
-                                                             M, self.white_back)
+                                                             M, self.white_back, fused=fused_pack)
                     promoted = True
                 break
             n_pairs = int((nb[:int(P)] >= 0).sum()) if self.count_pairs else -1

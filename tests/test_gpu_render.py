@@ -996,17 +996,23 @@ def test_compact_list_overflow_retries_without_out_of_bounds_access(ordered, mon
         m.renderer.capacity_fraction = 0.25 * P / (2 * res * res * 50)          # a quarter of what is needed
         calls = []
         grid = m.field.aggregator.voxel_grid
-        orig = grid.query_compact
+        orig, orig_rays = grid.query_compact, grid.query_compact_rays
 
         def spy(*a, **k):
             out = orig(*a, **k)
             calls.append(int(out[4].shape[0]))
             return out
-        grid.query_compact = spy
+
+        def spy_rays(*a, **k):           # (the ordered form can generate its rays inside the query launch: NPCD_RENDER_FUSED_RAYS=1)
+            out = orig_rays(*a, **k)
+            if out is not None:
+                calls.append(int(out[6].shape[0]))
+            return out
+        grid.query_compact, grid.query_compact_rays = spy, spy_rays
         try:
             out = m.render(*args)
         finally:
-            grid.query_compact = orig
+            grid.query_compact, grid.query_compact_rays = orig, orig_rays
     assert len(calls) == 2 and calls[0] < P <= calls[1], (calls, P)              # overflowed once, then the worst case
     assert int(out["num_shading_points"]) == P
     for key in ("mask", "depth", "channels"):
@@ -1233,3 +1239,50 @@ def test_generate_then_render_loop_of_the_diffusion_evaluation():
         assert float(im.min()) >= 0.0 and float(im.max()) <= 1.0
         assert torch.equal(torch.round(im * 255), im * 255) or float((torch.round(im * 255) - im * 255).abs().max()) < 1e-4
     assert res["views_per_s"] > 0 and res["generate_seconds"] > 0
+
+
+@pytest.mark.parametrize("S", [128, 64])
+def test_rays_generated_inside_the_query_launch_are_the_same_bits(S, monkeypatch):
+    """Round 6: the fused render generates its rays inside the neighbour-query launch and ends rays that miss the cube
+    at the global end inside the march (npcd_render_rays_query / npcd_ray_march_compact_fused) -- two
+    launches per view fewer.  Against the separate launches (NPCD_RENDER_FUSED_RAYS=0: ray_gen + limits fix-up, query, march): image,
+    mask, depth, point count BIT for bit -- every ray hitting the cube, some rays missing it (their depth comes from the
+    global limits), all rays missing, two examples x three views per call, the counter-reading path and the sync-free one, a second
+    render through the same objects."""
+    from npcd.hip import render as hr
+    res = 40
+    coords, feats, extr, intr = _scene(res, 3, 512, 32, seed=2, B=2)
+    p = orr.init_field_params(32, seed=3)
+    for name in p:
+        if "shape_net.2" in name:
+            p[name] = p[name] * 8 + 1.0
+    m = _model(32, 512, p)
+    m.renderer.depth_resolution = S
+    intr_some = intr.clone()
+    intr_some[..., 0, 0] = intr_some[..., 1, 1] = 131.25 * res / 128 * 0.45          # zoomed out: the corner rays miss the cube
+    intr_none = intr.clone()
+    intr_none[..., 0, 2] = 1.0e5                                                       # every ray misses
+    for tag, K in (("hit", intr), ("some miss", intr_some), ("all miss", intr_none)):
+        for sync_free_points in (1 << 23, 0):
+            m.renderer.sync_free_points = sync_free_points
+            outs = {}
+            for fused in (True, False, True):
+                monkeypatch.setattr(hr, "FUSED_RAYS", fused)
+                with torch.no_grad():
+                    outs.setdefault(fused, []).append(m.render(coords.cuda(), feats.cuda(), extr.cuda(), K.cuda(), res))
+            a, b, a2 = outs[True][0], outs[False][0], outs[True][1]
+            assert int(a["num_shading_points"]) == int(b["num_shading_points"]), tag
+            if tag == "some miss":
+                o_, d_, t0_, t1_ = hr.ray_gen(extr.flatten(0, 1).cuda(), K.flatten(0, 1).cuda(), res, 1.0)
+                assert 0 < int((t1_ > t0_).sum()) and torch.isfinite(t0_).all()          # (the fix-up gave the missing rays finite limits)
+                assert int(a["num_shading_points"]) > 0
+            for key in ("channels", "mask", "depth"):
+                assert torch.equal(a[key], b[key]), (tag, sync_free_points, key, float((a[key] - b[key]).abs().max()))
+                assert torch.equal(a[key], a2[key]), (tag, key)
+    # the oracle agrees with the opt-in path too
+    ref = orr.render(p, coords, feats, extr, intr_some, res=res, S=S)
+    monkeypatch.setattr(hr, "FUSED_RAYS", True)
+    with torch.no_grad():
+        out = m.render(coords.cuda(), feats.cuda(), extr.cuda(), intr_some.cuda(), res)
+    assert float((out["channels"].cpu() - ref["channels"]).abs().max()) < 5e-3
+    assert float((out["depth"].cpu() - ref["depth"]).abs().max()) < 1e-3

@@ -20,3 +20,9 @@ PY
 done
 done
 cd $GRAFT_REPO_ROOT; grep -v amdgpu.ids $O | tail -40
+echo "== attention forward forms at per-GPU batch 8" >> $O
+for cfg in "X=1" "NPCD_ATTN_ROWX32=1" "NPCD_ATTN_FWD=64"; do
+echo "-- $cfg" >> $O
+env $cfg python tools/probes/gpu_dev_b8.py 8 30 2>&1 | grep "wall" >> $O
+done
+tail -8 $O
