@@ -75,7 +75,7 @@ def query_roofline(S, query_ms, launches, clock_ghz=None):
     predates that record) the counts belong to another binary -- `stale_counters` says so and `achieved` / `frac` are None."""
     import hashlib
     base = {"kernel": "grid_query_wave_kernel", "avg_ms": query_ms, "launches": launches, "bound": "valu-issue", "achieved": None}
-    fp = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r5_render_sq_pmc.json", "r4_render_sq_pmc.json", "r3_render_sq_pmc.json")) if os.path.exists(f)), None)
+    fp = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r6_render_sq_pmc.json", "r5_render_sq_pmc.json", "r4_render_sq_pmc.json", "r3_render_sq_pmc.json")) if os.path.exists(f)), None)
     if fp is None:
         return base
     doc = json.load(open(fp))
@@ -844,8 +844,8 @@ def main():
                 return nm, doc, stale
         return None, {}, True
     attn_src = ("attention.hip", "common.h")
-    tname, tjson, tstale = newest("r5_attention_hbm_traffic_pmc.json", "r4_attention_hbm_traffic_pmc.json", "r3_attention_hbm_traffic_pmc.json", sources=attn_src)
-    sname, sjson, sstale = newest("r5_attention_sq_pmc.json", "r4_attention_sq_pmc.json", "r3_attention_sq_pmc.json", sources=attn_src)
+    tname, tjson, tstale = newest("r6_attention_hbm_traffic_pmc.json", "r5_attention_hbm_traffic_pmc.json", "r4_attention_hbm_traffic_pmc.json", "r3_attention_hbm_traffic_pmc.json", sources=attn_src)
+    sname, sjson, sstale = newest("r6_attention_sq_pmc.json", "r5_attention_sq_pmc.json", "r4_attention_sq_pmc.json", "r3_attention_sq_pmc.json", sources=attn_src)
     traffic = None
     # sequences of 128 j + 1 tokens: the last token's three gradient rows are finished by a small third kernel, launched (and
     # timed here) with the dK/dV pass
@@ -885,7 +885,7 @@ def main():
         dom = max(ew_ms, key=lambda k: ew_ms[k] * len(ew_events[k]))
         gbs = {k: ew_bytes[k] / (ew_ms[k] * 1e-3) / 1e9 for k in ew_ms}
         hname = {"add_ln_fwd": "add_ln_fwd_kernel", "ln_bwd": "ln_bwd_kernel", "gelu_fwd": "gelu_fwd_kernel", "gelu_bwd": "colsum_kernel<true>"}[dom]
-        hfile, hjson, hstale = newest("r5_elementwise_hbm_traffic_pmc.json", "r2_elementwise_hbm_traffic_pmc.json", sources=("elementwise.hip", "common.h"))
+        hfile, hjson, hstale = newest("r6_elementwise_hbm_traffic_pmc.json", "r5_elementwise_hbm_traffic_pmc.json", "r2_elementwise_hbm_traffic_pmc.json", sources=("elementwise.hip", "common.h"))
         htraffic = hjson.get(hname, {}).get("hbm_bytes") if per == 64 and not hstale else None   # PMC-measured bytes per launch at exactly this shape
         hbm = {"kernel": hname,
                "bound": "hbm", "achieved": gbs[dom], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs[dom] / PEAK_HBM_GBS,
