@@ -647,6 +647,38 @@ extern "C" int npcd_ln_bwd(const void* dy, const float* x, const float* mean, co
     return npcd_ln_bwd_dt(dy, x, mean, rstd, gamma, dres, dx, dxb, part_gamma, part_beta, part_col, T, W, NPCD_BF16, stream);
 }
 
+// One-launch form (round 6): a workgroup of 1,024 threads = 64 columns x 16 row lanes; lane r adds rows r, r + 16, ... of its column
+// (two accumulators), the 16 lane sums are added through LDS in a fixed tree.  One launch instead of two, no stage buffer; the
+// summation order differs from the two-stage form (both are fixed: bitwise reproducible either way).  For the token counts of a rank
+// of the strong-scaling job, where the finalisation of a block's eight sums sits on the backward's critical path (16 us of ~400).
+__global__ __launch_bounds__(1024) void colsum_onepass_kernel(FinBatch fb) {
+    __shared__ float red[16][64];
+    const int j = fin_job(fb.first1, fb.njobs, blockIdx.x);
+    const float* __restrict__ part = fb.job[j].part;
+    const int nblk = fb.job[j].nblk, N = fb.job[j].N;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = (blockIdx.x - fb.first1[j]) * 64 + tx;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < N) {
+        int b = ty;
+        for (; b + 16 < nblk; b += 32) {
+            s0 += part[(int64_t)b * N + c];
+            s1 += part[(int64_t)(b + 16) * N + c];
+        }
+        if (b < nblk) s0 += part[(int64_t)b * N + c];
+    }
+    red[ty][tx] = s0 + s1;
+    __syncthreads();
+    if (ty == 0 && c < N) {
+        float q[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) q[g] = (red[4 * g][tx] + red[4 * g + 1][tx]) + (red[4 * g + 2][tx] + red[4 * g + 3][tx]);
+        const float s = (q[0] + q[1]) + (q[2] + q[3]);
+        float* __restrict__ out = fb.job[j].out;
+        out[c] = fb.job[j].accumulate ? out[c] + s : s;
+    }
+}
+
 // `part` must have room for kFinSlices extra rows after its nblk rows (npcd_colsum_scratch_rows()):
 // they are used as the stage buffer.
 extern "C" int npcd_colsum_scratch_rows(void) { return kFinSlices; }
@@ -668,6 +700,15 @@ extern "C" int npcd_colsum_finalize_batch(const NpcdColsumJob* jobs, int njobs, 
     }
     for (int j = njobs; j <= NPCD_COLSUM_MAX_JOBS; ++j) { fb.first1[j] = n1; fb.first2[j] = n2; }
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // NPCD_COLSUM_ONEPASS=1: the one-launch form (A/B switch; default off).  Measured in the rank step at per-GPU batch 8, three
+    // alternating rounds: 17.13 / 17.24 / 17.19 ms with the two launches, 17.14 / 17.38 / 17.05 with one; batch 64: 82.71 against 82.61 --
+    // inside the noise, like deferring the finalisation to the end of the backward in round 5 (docs/experiments.md R5.19, R6.12).
+    static const bool onepass = [] { const char* e = getenv("NPCD_COLSUM_ONEPASS"); return e && atoi(e) > 0; }();
+    if (onepass) {
+        hipLaunchKernelGGL(colsum_onepass_kernel, dim3(n1), dim3(1024), 0, st, fb);
+        NPCD_HIP_CHECK(hipGetLastError());
+        return NPCD_OK;
+    }
     if (any_two_stage) hipLaunchKernelGGL(colsum_stage1_kernel, dim3(n1, kFinSlices), dim3(256), 0, st, fb);
     hipLaunchKernelGGL(colsum_stage2_kernel, dim3(n2), dim3(256), 0, st, fb);
     NPCD_HIP_CHECK(hipGetLastError());
