@@ -2500,45 +2500,52 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_fused_kernel(AttnParams p, fl
 // tiles in LDS (rows padded to 65 floats: the per-lane row reads are conflict-free); pass 1 has the key on
 // the lane (scores), pass 2 the feature dimension on the lane (P.V with P broadcast from LDS).
 // ============================================================================================
-constexpr int kF32Pad = 65;
-
+// Round 6: templated over the head dim (32 / 64 / 128) -- the fp32 sampler (the reference's default sampling precision) then covers
+// every head dim the 16-bit kernels take.  D = 128 needs 77 KB of LDS (dynamic); pass 2 gives a lane the features lane, lane + 64.
+template <int D>
 __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                            float* __restrict__ out, float* __restrict__ lse, int B, int n, int H, int64_t sb,
                                                            int64_t sn, int64_t sh, int64_t osb, int64_t osn, int64_t osh, float scale) {
-    __shared__ float Ks[64 * kF32Pad];
-    __shared__ float Vs[64 * 64];
-    __shared__ float Qs[16 * 64];
-    __shared__ float Ps[16 * 64];
+    constexpr int PAD = D + 1, DF = (D + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char f32smem[];
+    float* Ks = reinterpret_cast<float*>(f32smem);      // [64][D + 1]
+    float* Vs = Ks + 64 * PAD;                          // [64][D]
+    float* Qs = Vs + 64 * D;                            // [16][D]
+    float* Ps = Qs + 16 * D;                            // [16][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nqt = (n + 15) / 16;
     const int qt = blockIdx.x % nqt, bh = blockIdx.x / nqt, h = bh % H, b = bh / H;
     const float* qb = q + b * sb + h * sh;
     const float* kb = k + b * sb + h * sh;
     const float* vb = v + b * sb + h * sh;
-    for (int i = tid; i < 16 * 64; i += 256) {
-        const int row = min(qt * 16 + (i >> 6), n - 1);
-        Qs[i] = qb[row * sn + (i & 63)] * scale;
+    for (int i = tid; i < 16 * D; i += 256) {
+        const int row = min(qt * 16 + i / D, n - 1);
+        Qs[i] = qb[row * sn + (i % D)] * scale;
     }
-    float m[4], l[4], acc[4];
+    float m[4], l[4], acc[4][DF];
 #pragma unroll
-    for (int rq = 0; rq < 4; ++rq) { m[rq] = -INFINITY; l[rq] = 0.f; acc[rq] = 0.f; }
+    for (int rq = 0; rq < 4; ++rq) {
+        m[rq] = -INFINITY; l[rq] = 0.f;
+#pragma unroll
+        for (int f = 0; f < DF; ++f) acc[rq][f] = 0.f;
+    }
     const int nt = (n + 63) / 64;
     for (int t = 0; t < nt; ++t) {
         __syncthreads();
-        for (int i = tid; i < 64 * 64; i += 256) {
-            const int row = min(t * 64 + (i >> 6), n - 1);
-            Ks[(i >> 6) * kF32Pad + (i & 63)] = kb[row * sn + (i & 63)];
-            Vs[i] = vb[row * sn + (i & 63)];
+        for (int i = tid; i < 64 * D; i += 256) {
+            const int row = min(t * 64 + i / D, n - 1);
+            Ks[(i / D) * PAD + (i % D)] = kb[row * sn + (i % D)];
+            Vs[i] = vb[row * sn + (i % D)];
         }
         __syncthreads();
         float s[4] = {0.f, 0.f, 0.f, 0.f};
-        const float* krow = Ks + lane * kF32Pad;
-        const float* qrow = Qs + wave * 4 * 64;
+        const float* krow = Ks + lane * PAD;
+        const float* qrow = Qs + wave * 4 * D;
 #pragma unroll 8
-        for (int d = 0; d < 64; ++d) {
+        for (int d = 0; d < D; ++d) {
             const float kv = krow[d];
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) s[rq] = fmaf(qrow[rq * 64 + d], kv, s[rq]);
+            for (int rq = 0; rq < 4; ++rq) s[rq] = fmaf(qrow[rq * D + d], kv, s[rq]);
         }
         const bool key_ok = t * 64 + lane < n;
 #pragma unroll
@@ -2554,25 +2561,47 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float* __restri
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) ps += __shfl_xor(ps, off, 64);
             l[rq] = l[rq] * alpha + ps;
-            acc[rq] *= alpha;
+#pragma unroll
+            for (int f = 0; f < DF; ++f) acc[rq][f] *= alpha;
             m[rq] = mn;
             Ps[(wave * 4 + rq) * 64 + lane] = pe;
         }
         // same-wave LDS write -> read: ordered within the wave
         const float* prow = Ps + wave * 4 * 64;
-#pragma unroll 8
-        for (int kk = 0; kk < 64; ++kk) {
-            const float vv = Vs[kk * 64 + lane];
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) acc[rq] = fmaf(prow[rq * 64 + kk], vv, acc[rq]);
+        for (int f = 0; f < DF; ++f) {
+            const int col = lane + 64 * f;
+            if (col < D) {
+#pragma unroll 8
+                for (int kk = 0; kk < 64; ++kk) {
+                    const float vv = Vs[kk * D + col];
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) acc[rq][f] = fmaf(prow[rq * 64 + kk], vv, acc[rq][f]);
+                }
+            }
         }
     }
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
         const int row = qt * 16 + wave * 4 + rq;
-        if (row < n) out[b * osb + row * osn + h * osh + lane] = acc[rq] / l[rq];
+#pragma unroll
+        for (int f = 0; f < DF; ++f) {
+            const int col = lane + 64 * f;
+            if (row < n && col < D) out[b * osb + row * osn + h * osh + col] = acc[rq][f] / l[rq];
+        }
         if (lse && row < n && lane == 0) lse[(int64_t)(b * H + h) * n + row] = m[rq] + logf(l[rq]);     // natural log, scaled scores
     }
+}
+template <int D>
+static int launch_f32_valu(const float* q, const float* k, const float* v, float* out, float* lse, int B, int n, int H, int64_t sb, int64_t sn,
+                           int64_t sh, int64_t osb, int64_t osn, int64_t osh, float scale, hipStream_t st) {
+    constexpr size_t lds = (size_t)(64 * (D + 1) + 64 * D + 16 * D + 16 * 64) * sizeof(float);
+    static DynLds attr;
+    if (lds > 65536) NPCD_HIP_CHECK(attr.ensure(reinterpret_cast<const void*>(attn_fwd_f32_kernel<D>), lds));
+    hipLaunchKernelGGL(attn_fwd_f32_kernel<D>, dim3(B * H * ceil_div(n, 16)), dim3(256), lds, st, q, k, v, out, lse, B, n, H, sb, sn, sh, osb, osn,
+                       osh, scale);
+    NPCD_HIP_CHECK(hipGetLastError());
+    return NPCD_OK;
 }
 
 // ============================================================================================
@@ -3047,6 +3076,12 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* ou
                            float scale, int dtype, void* stream) {
     if (dtype == NPCD_F32) {   // exact fp32 path (lse [B, H, n] written when given: natural log of the row sums of exp(scaled scores))
         if (B <= 0 || n <= 0 || H <= 0 || !q || !k || !v || !out) return NPCD_ERR_ARG;
+        if (d == 32 || d == 128) {        // (round 6) the exact vector-ALU form covers the other head dims: forward only (sampling / inference)
+            hipStream_t sv = static_cast<hipStream_t>(stream);
+            const float *fq = static_cast<const float*>(q), *fk = static_cast<const float*>(k), *fv = static_cast<const float*>(v);
+            return d == 32 ? launch_f32_valu<32>(fq, fk, fv, static_cast<float*>(out), lse, B, n, H, qkv_sb, qkv_sn, qkv_sh, out_sb, out_sn, out_sh, scale, sv)
+                           : launch_f32_valu<128>(fq, fk, fv, static_cast<float*>(out), lse, B, n, H, qkv_sb, qkv_sn, qkv_sh, out_sb, out_sn, out_sh, scale, sv);
+        }
         if (d != 64) return NPCD_ERR_UNSUPPORTED;
         static const bool valu_form = getenv("NPCD_ATTN_F32_VALU") != nullptr;
         const bool vec_ok = !(qkv_sb % 4 || qkv_sn % 4 || qkv_sh % 4 || out_sb % 4 || out_sn % 4 || out_sh % 4) && aligned16(q) &&
@@ -3061,12 +3096,8 @@ static int attn_fwd_launch(const void* q, const void* k, const void* v, void* ou
             NPCD_HIP_CHECK(hipGetLastError());
             return NPCD_OK;
         }
-        const int grid32 = B * H * ceil_div(n, 16);
-        hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(grid32), dim3(256), 0, static_cast<hipStream_t>(stream), static_cast<const float*>(q),
-                           static_cast<const float*>(k), static_cast<const float*>(v), static_cast<float*>(out), lse, B, n, H, qkv_sb,
-                           qkv_sn, qkv_sh, out_sb, out_sn, out_sh, scale);
-        NPCD_HIP_CHECK(hipGetLastError());
-        return NPCD_OK;
+        return launch_f32_valu<64>(static_cast<const float*>(q), static_cast<const float*>(k), static_cast<const float*>(v), static_cast<float*>(out),
+                                   lse, B, n, H, qkv_sb, qkv_sn, qkv_sh, out_sb, out_sn, out_sh, scale, static_cast<hipStream_t>(stream));
     }
     // head dims 32 and 128 (the reference's attention works for any width / heads, transformer.py:68-84): the kernels of
     // attention_gen.hip; NPCD_ATTN_GEN=1 sends d = 64 there too (tests: the two kernel families against each other)

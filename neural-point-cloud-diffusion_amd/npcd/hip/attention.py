@@ -110,9 +110,8 @@ def _check_input(x):
 
 def _fwd_f32(q, k, v, scale, want_lse=False):
     B, n, H, d = q.shape
-    if d != 64:
-        raise RuntimeError(f"HIP fp32 attention is built for head dim 64 (got {d}); the 16-bit kernels (bf16 / f16 autocast, the reference's "
-                           "training and sampling precision options) cover head dims 32, 64 and 128")
+    if d not in (32, 64, 128):
+        raise RuntimeError(f"HIP attention is built for head dims 32, 64 and 128 (got head dim {d})")
     out = torch.empty((B, n, H, d), dtype=torch.float32, device=q.device)
     lse = torch.empty((B, H, n), dtype=torch.float32, device=q.device) if want_lse else None
     check(lib().npcd_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(lse), B, n, H, d, q.stride(0), q.stride(1), q.stride(2),
@@ -133,6 +132,9 @@ class _AttnF32(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, scale):
+        if q.shape[-1] != 64:
+            raise RuntimeError(f"HIP fp32 attention WITH GRADIENTS (--dtype float32 training) is built for head dim 64 (got head dim {q.shape[-1]}); "
+                               "fp32 inference / sampling and the 16-bit kernels (bf16 / f16 autocast training) cover head dims 32, 64 and 128")
         if not _f32_layout_ok(q, k, v):
             q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         out, lse = _fwd_f32(q, k, v, scale, want_lse=True)

@@ -164,6 +164,11 @@ def test_denoiser_with_other_head_dims_vs_oracle(W, H):
     assert rel_l2(ec, ec_r.detach()) < 2e-2 and rel_l2(ef, ef_r.detach()) < 2e-2
     worst = max((rel_l2(p.grad, leaves[k].grad), k) for k, p in net.named_parameters() if float(leaves[k].grad.abs().max()) > 1e-3)
     assert worst[0] < 5e-2, worst
+    # the sampler's precision: fp32, no autocast, no gradients (diffusion_model.py:108-133) -- the exact fp32 attention forward at this head dim
+    with torch.no_grad():
+        ec32, ef32 = net(c.cuda(), f.cuda(), t.cuda())
+    assert ec32.dtype == torch.float32
+    assert rel_l2(ec32, ec_r.detach()) < 1e-4 and rel_l2(ef32, ef_r.detach()) < 1e-4
 
 
 def test_attention_forced_rescale(fwd_form):
@@ -319,7 +324,9 @@ def test_unsupported_shapes_fail_loudly():
     with pytest.raises(RuntimeError, match="unsupported"):
         attention_qkvpacked(torch.zeros(1, 8, 3 * 2 * 16, device="cuda", dtype=torch.bfloat16), 2)   # d = 16 (32, 64, 128 are built)
     with pytest.raises(RuntimeError, match="head dim"):
-        attention_qkvpacked(torch.zeros(1, 8, 3 * 2 * 32, device="cuda", dtype=torch.float32), 2)    # fp32 kernels: d = 64 only
+        attention_qkvpacked(torch.zeros(1, 8, 3 * 2 * 16, device="cuda", dtype=torch.float32), 2)    # fp32: 32, 64, 128 as well
+    with pytest.raises(RuntimeError, match="WITH GRADIENTS"):                                        # fp32 TRAINING at other head dims: not built
+        attention_qkvpacked(torch.zeros(1, 8, 3 * 2 * 32, device="cuda", dtype=torch.float32, requires_grad=True), 2)
     with pytest.raises(RuntimeError, match="supports"):
         attention_qkvpacked(torch.zeros(1, 8, 192, device="cuda", dtype=torch.float64), 1)
 
@@ -406,6 +413,24 @@ def test_denoiser_fp32_training_matches_reference_golden(golden, tag):
         if k.startswith("g:") and np.abs(v).max() > 1e-3:
             worst = max(worst, rel_l2(dict(net.named_parameters())[k[2:]].grad, T(v)))
     assert worst < 1e-4, f"worst param-grad rel-L2 {worst:.3e}"
+
+
+@pytest.mark.parametrize("d", [32, 128])
+@pytest.mark.parametrize("n,H", [(1, 1), (17, 2), (65, 1), (130, 3), (513, 2)])
+def test_attention_fp32_inference_other_head_dims(n, H, d):
+    """The exact fp32 forward (the reference samples in fp32, diffusion_model.py:108-133) at head dims 32 and 128 (round 6: the vector-ALU
+    kernel templated over the head dim): against float64 softmax attention on the same inputs, 2e-6 relative."""
+    from npcd.hip.attention import attention_qkvpacked
+    g = torch.Generator().manual_seed(100 * d + n)
+    qkv = torch.randn(2, n, 3 * H * d, generator=g) * 1.2
+    with torch.no_grad():
+        out = attention_qkvpacked(qkv.cuda(), H)
+    x = qkv.double().view(2, n, H, 3 * d)
+    q, k, v = (x[..., i * d:(i + 1) * d].permute(0, 2, 1, 3) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(d), -1) @ v).permute(0, 2, 1, 3).reshape(2, n, H * d)
+    assert out.dtype == torch.float32
+    err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
 
 
 @pytest.mark.parametrize("n,H", [(1, 1), (17, 2), (64, 1), (130, 3), (513, 2)])
