@@ -1,12 +1,12 @@
 """Dev probe: per-kernel time of the attention kernels at cfg-D (B=64, n=513, H=16, d=64) + error vs an fp32 reference.
-usage: python3 tools/probes/gpu_dev_attn_time.py [reps]"""
+usage: python3 tools/probes/gpu_dev_attn_time.py [reps [n [B [head dim]]]]"""
 import sys, os, math
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "neural-point-cloud-diffusion_amd"))
 import torch
 from npcd.hip import attention as A
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-B, n, H, d = (int(sys.argv[3]) if len(sys.argv) > 3 else 64), (int(sys.argv[2]) if len(sys.argv) > 2 else 513), 16, 64
+B, n, H, d = (int(sys.argv[3]) if len(sys.argv) > 3 else 64), (int(sys.argv[2]) if len(sys.argv) > 2 else 513), 16, (int(sys.argv[4]) if len(sys.argv) > 4 else 64)
 torch.manual_seed(0)
 qkv = torch.randn(B, n, H, 3 * d, device="cuda").bfloat16()
 if os.environ.get("NPCD_ZERO_DATA"):      # clock check: all-zero operands draw less power (MI355X_MICROARCH.md, DVFS give-back)
