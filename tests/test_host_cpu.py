@@ -153,3 +153,65 @@ def test_bench_without_launcher_starts_ranks_as_a_child_and_returns_their_exit_c
     assert "starting 2 ranks" in out.stderr and "--nproc-per-node 2" in out.stderr and "--master-addr 127.0.0.1" in out.stderr
     assert out.returncode != 0                                   # no GPU -> the ranks fail -> so does bench.py, loudly
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_step_arena_hands_out_the_same_buffers_in_order():
+    """npcd/hip/arena.py (round 6) on CPU tensors: the i-th request of a step gets the i-th buffer of the previous step when shape, dtype
+    and device match; a changed shape replaces the slot; one step at a time (begin() refuses while a step is out, a StepGuard dropped with
+    the graph ends it); paused() allocates outside and does not advance; outside an active arena empty() is torch.empty."""
+    from npcd.hip import arena
+    dev = torch.device("cpu")
+    a = arena.StepArena()
+    assert arena.empty((2, 3), torch.float32, dev).shape == (2, 3)           # no active arena: plain allocation
+    tok = a.begin()
+    assert tok > 0 and a.begin() == 0                                          # busy: a second step has to do without
+    with a.active():
+        x = arena.empty((4, 5), torch.float32, dev)
+        y = arena.empty_like(x)
+        with arena.paused():
+            z = arena.empty((7,), torch.float32, dev)
+        w = arena.empty(6, torch.int32, dev)
+    a.end(tok)
+    assert len(a.slots) == 3 and not a.busy and all(z is not s for s in a.slots)
+    tok2 = a.begin()
+    with a.active():
+        x2, y2 = arena.empty((4, 5), torch.float32, dev), arena.empty((4, 5), torch.float32, dev)
+        w2 = arena.empty((9,), torch.int32, dev)                               # another shape: the slot is replaced
+    assert x2 is x and y2 is y and w2 is not w and w2.shape == (9,) and a.slots[2] is w2
+    a.end(tok)                                                                 # a stale token does nothing
+    assert a.busy
+    a.end(tok2)
+    assert not a.busy
+    g = arena.StepGuard(a, a.begin())
+    assert a.busy
+    del g
+    assert not a.busy                                                          # the guard ended the step its graph never ran
+    tok3 = a.begin()
+    with a.active():
+        arena.empty((4, 5), torch.float32, dev)
+    a.end(tok3)
+    assert len(a.slots) == 1                                                   # a shorter step drops the tail
+
+
+def test_stage1_numerics_selection_defaults_to_true_fp32():
+    """PointNeRFTrainer's default must be the reference's fp32, the split-operand mode an explicit opt-in."""
+    from npcd.hip import render as hr
+    from npcd.models.pointnerf import PointNeRF, train_path as tp
+    field = PointNeRF(1, 32, 64, False).field
+    assert tp.fused_pair_mlp_precision(field, None) is None
+    assert tp.fused_pair_mlp_precision(field, torch.float32) is None
+    assert tp.fused_pair_mlp_precision(field, "library") is None
+    assert tp.fused_pair_mlp_precision(field, "fp32_class") == hr.PAIR_MLP_X2
+    assert tp.fused_pair_mlp_precision(field, torch.bfloat16) == hr.PAIR_MLP_BF16
+    assert tp.point_layers_fused(field, "fp32_class") and not tp.point_layers_fused(field, None)
+    assert tp.point_layers_fused(field, "fp32_class", 5000) and not tp.point_layers_fused(field, "fp32_class", 100)
+    with pytest.raises(ValueError):
+        tp.fused_pair_mlp_precision(field, "fp64")
+    assert field.fp32_class_ok()
+
+
+def test_weight_gradient_stream_switch_is_parsed_once():
+    from npcd.models.diffusion import fused
+    assert fused._parse_wgrad_stream(None) == (True, 20000) and fused._parse_wgrad_stream("") == (True, 20000)
+    assert fused._parse_wgrad_stream("0") == (False, 0) and fused._parse_wgrad_stream("1") == (True, 1 << 62)
+    assert fused._parse_wgrad_stream("12345") == (True, 12345)
