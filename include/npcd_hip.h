@@ -47,7 +47,11 @@ const char* npcd_last_hip_error(void);
  * Attention over points: out = softmax(q k^T * scale) v, non-causal, no mask, no dropout.
  * Replaces flash_attn_func(q, k, v, causal=False, dropout_p=0) (transformer.py:75) and its
  * autograd backward.  q/k/v are [B, n, H, d] views (typically of one interleaved [B,n,H,3d]
- * buffer, transformer.py:71-72) sharing the stride triple (sb, sn, sh); d must be 64.
+ * buffer, transformer.py:71-72) sharing the stride triple (sb, sn, sh).  Head dims: d = 64 runs the specialised kernels of
+ * csrc/attention.hip; d = 32 and d = 128 (ABI 9; the reference's attention takes any width / heads, transformer.py:68-84) run
+ * csrc/attention_gen.hip in the 16-bit types, forward and backward (for those the first B H n floats of `delta` hold
+ * rowsum(dout * out); no edge scratch is used) and the vector-ALU form of the exact fp32 FORWARD; anything else, and the fp32
+ * backward at d != 64, is NPCD_ERR_UNSUPPORTED.
  * lse [B, H, n] fp32 receives log(sum_j exp(scale * <q_i, k_j>)).
  * dtype NPCD_F32 selects the exact-fp32 kernels on the fp32 matrix instruction (the reference's fp32 sampling path,
  * diffusion_model.py:108-133, and `--dtype float32` training through its einsum attention, transformer.py:76-81): nothing is rounded
